@@ -1,0 +1,112 @@
+"""ORACLE (test infrastructure, never imported by the product path).
+
+numpy restatement of the integer side of
+``LlavaForConditionalGeneration._merge_input_ids_with_image_features``
+(/root/reference/mantis/models/mllava/modeling_llava.py:293-360), in the
+index-only formulation of SURVEY.md appendix A.  Pinned against the merged
+attention-mask / labels / position-ids recorded from the reference in
+tests/golden/*.npz (tests/test_oracle_vs_golden.py), including the
+unequal-image-count quirk case.
+
+Outputs a *source map* instead of copying embeddings, so the same plan drives
+the bf16 row copies (bit-exact by construction, a copy is a copy):
+  src_kind[b, p]  0 = padding slot (zero row), 1 = text token, 2 = image-feature row
+  src_idx[b, p]   text: t (column of input_ids)    image: global feature row (batch-major)
+"""
+import numpy as np
+
+PAD_SLOT, TEXT, IMAGE = 0, 1, 2
+
+
+class PackCountError(ValueError):
+    """same class of failure as modeling_llava.py:347-351 (ValueError)."""
+
+
+def pack_plan(input_ids, attention_mask, labels, num_images, num_patches, image_token_index, pad_token_id,
+              ignore_index=-100):
+    ids = np.asarray(input_ids, dtype=np.int64)
+    attn = np.asarray(attention_mask, dtype=np.int64)
+    B, T = ids.shape
+    N = int(num_patches)
+    # :296  left_padding = not any(ids[:, -1] == pad)
+    left_padding = not bool(np.sum(ids[:, -1] == pad_token_id))
+    # :298-301
+    m = ids == image_token_index
+    k = m.sum(-1)
+    L = int(k.max()) * (N - 1) + T
+    # :309-312
+    p = np.cumsum(m * (N - 1) + 1, -1) - 1
+    nb_image_pad = L - 1 - p[:, -1]
+    if left_padding:
+        p = p + nb_image_pad[:, None]
+    src_kind = np.zeros((B, L), dtype=np.int32)
+    src_idx = np.zeros((B, L), dtype=np.int64)
+    out_mask = np.zeros((B, L), dtype=np.int64)
+    out_lab = np.full((B, L), ignore_index, dtype=np.int64)
+    # :338-341 scatter text
+    bi, ti = np.nonzero(~m)
+    tp = p[bi, ti]
+    src_kind[bi, tp] = TEXT
+    src_idx[bi, tp] = ti
+    out_mask[bi, tp] = attn[bi, ti]
+    if labels is not None:
+        out_lab[bi, tp] = np.asarray(labels, dtype=np.int64)[bi, ti]
+    # :344-345 image slots = unwritten rows minus the first nb_image_pad of them, per sample
+    unwritten = src_kind == 0
+    rank = np.cumsum(unwritten, -1) - 1
+    slots = unwritten & (rank >= nb_image_pad[:, None])
+    # :347-351
+    if int(slots.sum()) != int(num_images) * N:
+        raise PackCountError(
+            f"The input provided to the model are wrong. The number of image tokens is {int(m.sum())} while"
+            f" the number of image given to the model is {int(num_images)}.")
+    # :353 fill in row-major order
+    sb, sp = np.nonzero(slots)
+    src_kind[sb, sp] = IMAGE
+    src_idx[sb, sp] = np.arange(sb.size, dtype=np.int64)
+    # :354-355
+    out_mask |= slots.astype(np.int64)
+    pos = np.cumsum(out_mask, -1) - 1
+    pos[out_mask == 0] = 1
+    return dict(L=L, src_kind=src_kind, src_idx=src_idx, attention_mask=out_mask,
+                labels=out_lab if labels is not None else None, position_ids=pos, text_pos=p,
+                left_padding=left_padding, nb_image_pad=nb_image_pad)
+
+
+def pack_rows(plan, text_embeds, image_features):
+    """Apply the plan to numpy arrays: text_embeds [B,T,d], image_features [I,N,d] -> [B,L,d]."""
+    B, L = plan["src_kind"].shape
+    d = text_embeds.shape[-1]
+    out = np.zeros((B, L, d), dtype=text_embeds.dtype)
+    feats = image_features.reshape(-1, d)
+    for b in range(B):
+        tk = plan["src_kind"][b] == TEXT
+        out[b, tk] = text_embeds[b, plan["src_idx"][b, tk]]
+        ik = plan["src_kind"][b] == IMAGE
+        out[b, ik] = feats[plan["src_idx"][b, ik]]
+    return out
+
+
+def llama3_label_mask(ids, sep_id, ignore_index=-100):
+    """Label rule of ChatDataset.getitem for SeparatorStyle.LLAMA_3 / SINGLE
+    (/root/reference/mantis/train/data.py:415,432-442)."""
+    ids = np.asarray(ids, dtype=np.int64)
+    target = np.full_like(ids, ignore_index)
+    sep = np.nonzero(ids == sep_id)[0].tolist()
+    for i in range(len(sep)):
+        if i % 2 == 0:
+            continue
+        if i == len(sep) - 1:
+            target[sep[i] + 1:] = ids[sep[i] + 1:]
+        else:
+            target[sep[i] + 1:sep[i + 1] + 1] = ids[sep[i] + 1:sep[i + 1] + 1]
+    return target
+
+
+def plain_label_mask(ids, image_token_id, ignore_index=-100):
+    """SeparatorStyle.PLAIN branch (/root/reference/mantis/train/data.py:457-461)."""
+    ids = np.asarray(ids, dtype=np.int64)
+    target = np.full_like(ids, ignore_index)
+    keep = ids != image_token_id
+    target[keep] = ids[keep]
+    return target

@@ -1,0 +1,122 @@
+"""Pin the oracle (oracle/llava_ref.py, oracle/pack_ref.py) against outputs recorded from the reference itself
+(tests/golden/*.npz, written by tests/golden/make_golden.py which imports /root/reference in the build container).
+
+Tolerances (fp32 restatement vs fp32 reference): integers exact; logits atol 1e-5;
+loss rtol 1e-6 (+1e-6 abs); grads rtol 1e-4 relative-L2."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pack_ref
+from oracle.llava_ref import LlavaRef
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(G, "*.npz"))
+               if not os.path.basename(p).startswith(("weights_", "label_rule", "siglip_training_step")))
+
+
+def _pixels(z):
+    if "pixel_values" not in z.files:
+        return None
+    counts = z["pixel_counts"]
+    pv = torch.from_numpy(z["pixel_values"])
+    return list(torch.split(pv, counts.tolist()))
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_forward_backward_matches_reference(case):
+    flavour = case.split("_")[0]
+    z = np.load(os.path.join(G, case + ".npz"))
+    m = LlavaRef.from_npz(os.path.join(G, f"weights_{flavour}.npz"))
+    rec = {}
+    loss, logits = m.forward(z["input_ids"], _pixels(z), z["attention_mask"], z["labels"], record=rec)
+    loss.backward()
+    # integers: exact
+    for k in ("merged_attention_mask", "merged_labels", "merged_position_ids"):
+        if k in z.files:
+            assert np.array_equal(rec[k].numpy(), z[k]), k
+    if "merged_embeds" in z.files:
+        assert np.array_equal(rec["merged_embeds"].detach().numpy(), z["merged_embeds"]) or \
+            np.allclose(rec["merged_embeds"].detach().numpy(), z["merged_embeds"], atol=1e-6)
+    for k in ("projector_in", "projector_out"):
+        if k in z.files:
+            assert np.allclose(rec[k].detach().numpy(), z[k], atol=2e-5), k
+    # decoder activations are compared where the merged mask is 1 (fully-masked query rows are don't-care)
+    if "merged_attention_mask" in z.files:
+        am = z["merged_attention_mask"].astype(bool)
+    else:
+        am = z["attention_mask"].astype(bool)
+    for k in [f for f in z.files if f.startswith("llm_")]:
+        assert np.allclose(rec[k].detach().numpy()[am], z[k][am], atol=3e-5), k
+    assert np.allclose(logits.detach().numpy()[am], z["logits"][am], atol=1e-5 * max(1.0, np.abs(z["logits"]).max()))
+    assert abs(float(loss) - float(z["loss"])) <= 1e-6 * abs(float(z["loss"])) + 1e-6
+    ngrads = 0
+    for k in z.files:
+        if not k.startswith("grad."):
+            continue
+        g = m.w[k[5:]].grad
+        assert g is not None, k
+        assert rel_l2(g.numpy(), z[k]) < 1e-4, (k, rel_l2(g.numpy(), z[k]))
+        ngrads += 1
+    assert ngrads >= 20
+    for k, v in m.w.items():
+        if k.startswith("vision_tower."):
+            assert v.grad is None        # frozen tower, train_mllava.py:240-242
+
+
+def test_count_mismatch_raises_value_error():
+    z = np.load(os.path.join(G, "siglip_b1_img2_adjacent.npz"))
+    m = LlavaRef.from_npz(os.path.join(G, "weights_siglip.npz"))
+    pv = torch.from_numpy(z["pixel_values"])[:1]
+    with pytest.raises(ValueError):
+        m.forward(z["input_ids"], [pv], z["attention_mask"], z["labels"])
+
+
+@pytest.mark.parametrize("ga", [1, 4])
+def test_training_step_matches_reference(ga):
+    z = np.load(os.path.join(G, f"siglip_training_step_ga{ga}.npz"))
+    m = LlavaRef.from_npz(os.path.join(G, "weights_siglip.npz"))
+    m.zero_grad()
+    losses = []
+    for i in range(ga):
+        counts = z[f"mb{i}.pixel_counts"].tolist()
+        batch = dict(input_ids=z[f"mb{i}.input_ids"], attention_mask=z[f"mb{i}.attention_mask"], labels=z[f"mb{i}.labels"],
+                     pixel_values=list(torch.split(torch.from_numpy(z[f"mb{i}.pixel_values"]), counts)))
+        out = m.training_step(batch, gradient_accumulation_steps=ga)
+        assert out.dim() == 0 and not out.requires_grad
+        losses.append(float(out))
+    assert np.allclose(losses, z["returned_losses"], rtol=1e-6)
+    for k in z.files:
+        if k.startswith("grad."):
+            assert rel_l2(m.w[k[5:]].grad.numpy(), z[k]) < 1e-4, k
+
+
+def test_label_rule_matches_reference_fixture():
+    z = np.load(os.path.join(G, "label_rule.npz"))
+    sep, img = int(z["sep_id"]), int(z["image_id"])
+    n = len([k for k in z.files if k.endswith(".ids")])
+    assert n >= 5
+    for c in range(n):
+        ids = z[f"c{c}.ids"]
+        assert np.array_equal(pack_ref.llama3_label_mask(ids, sep), z[f"c{c}.llama3"])
+        assert np.array_equal(pack_ref.plain_label_mask(ids, img), z[f"c{c}.plain"])
+
+
+def test_pack_rows_copy_is_bit_exact():
+    z = np.load(os.path.join(G, "siglip_b2_unequal_quirk.npz"))
+    m = LlavaRef.from_npz(os.path.join(G, "weights_siglip.npz"))
+    emb = m.w["language_model.model.embed_tokens.weight"].detach().numpy()[z["input_ids"]]
+    plan = pack_ref.pack_plan(z["input_ids"], z["attention_mask"], z["labels"], 3, 16, 298, 299)
+    out = pack_ref.pack_rows(plan, emb, z["projector_out"])
+    assert np.array_equal(out, z["merged_embeds"])
+    assert np.array_equal(plan["attention_mask"], z["merged_attention_mask"])
+    assert np.array_equal(plan["position_ids"], z["merged_position_ids"])
+    assert np.array_equal(plan["labels"], z["merged_labels"])
