@@ -1,0 +1,119 @@
+/* libmantis_hip.so -- C-ABI of the MI355X (gfx950) hot path for Mantis' multi-image LLaVA training step.
+ *
+ * Boundary.  The reference (TIGER-AI-Lab/Mantis) is 100 % Python; its hot path -- transformers.Trainer.training_step
+ * driving mantis/models/mllava/modeling_llava.py:364-549 -- reaches native code only through torch/ATen, flash-attn and
+ * NCCL.  There is no reference FFI to mirror, so this header DEFINES the operator boundary a maintainer binds from Python
+ * (ctypes): plain device pointers, sizes, element strides and a hipStream_t passed as void*.  No torch
+ * types, no allocation inside (workspaces are passed in), no hidden global state, re-entrant per stream.
+ * Every function returns 0 on success, MANTIS_EINVAL (-1) for invalid arguments, MANTIS_EUNSUPPORTED (-2) for a shape or
+ * alignment the kernels do not cover, MANTIS_ELAUNCH (-3) if the HIP launch failed.  All tensors are bf16 (raw 16-bit)
+ * unless stated, row-major, 16-byte aligned; "ld*" are row strides in ELEMENTS.
+ *
+ * Each entry cites the reference interface (file:line) it replaces; `HF:` = the transformers copy the reference runs on.
+ */
+#ifndef MANTIS_HIP_H
+#define MANTIS_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MANTIS_OK 0
+#define MANTIS_EINVAL (-1)
+#define MANTIS_EUNSUPPORTED (-2)
+#define MANTIS_ELAUNCH (-3)
+
+/* ---- multi-image token packing --------------------------------------------------------------------------------------
+ * replaces LlavaForConditionalGeneration._merge_input_ids_with_image_features
+ *   /root/reference/mantis/models/mllava/modeling_llava.py:293-360 (integer plan, bit-exact) and the loss row filter
+ *   of :521-527.  L = max_b (#<image> in row b) * (num_patches-1) + T is computed by the caller (:301).
+ * src[B,L]: -1 padding slot | t (text token column) | (1<<30)|r (image-feature row r).
+ * status[0]: 0 ok, 1 image-slot count mismatch (reference raises ValueError :347-351), 2 L mismatch;
+ * status[1] = slots found, status[2] = #<image> tokens, status[3] = left_padding (:296). */
+int mantis_pack_plan(const int64_t* input_ids, const int64_t* attention_mask, const int64_t* labels /*nullable*/, int B,
+                     int T, int num_patches, int num_images, int64_t image_token_index, int64_t pad_token_id,
+                     int64_t ignore_index, int L, int32_t* src, int64_t* out_mask, int64_t* out_labels, int64_t* out_pos,
+                     int32_t* kmask, int32_t* text_pos, int32_t* img_slot, int32_t* ce_row, int32_t* ce_tgt,
+                     int32_t* status, void* stream);
+/* merged[b,p,:] = embed_weight[ids[b,src]] | image_features[src & ~(1<<30)] | 0     (modeling_llava.py:427,338,353) */
+int mantis_pack_rows_fwd(const int32_t* src, const int64_t* input_ids, const void* embed_weight, const void* image_features,
+                         void* out, int B, int T, int L, int d, int64_t vocab, void* stream);
+/* out[r] = idx[r] >= 0 ? in[idx[r]] : 0   /   out[idx[r]] = in[r]  (unique idx) -- autograd of the index_put at :338,:353 */
+int mantis_gather_rows(const void* in, const int32_t* idx, void* out, int64_t nrows, int d, void* stream);
+int mantis_scatter_rows(const void* in, const int32_t* idx, void* out, int64_t nrows, int d, void* stream);
+/* embedding backward of modeling_llava.py:427 (nn.Embedding), deterministic: grad_weight[id] (+)= sum dmerged[b,text_pos] */
+int mantis_embed_grad(const void* dmerged, const int64_t* input_ids, const int32_t* text_pos, int32_t* leader_ws,
+                      int32_t* next_ws, void* grad_weight, int B, int T, int L, int d, int64_t vocab, int accumulate,
+                      void* stream);
+
+/* ---- norms: HF:models/llama/modeling_llama.py:53-67 (LlamaRMSNorm) + autograd; HF:models/siglip/modeling_siglip.py:325-358 */
+int mantis_rmsnorm_fwd(const void* x, const void* weight, void* y, float* rstd /*[rows], nullable*/, int64_t rows, int d,
+                       float eps, void* stream);
+int mantis_rmsnorm_bwd_partials(int64_t rows); /* workspace rows: floats needed = partials * d */
+int mantis_rmsnorm_bwd(const void* dy, const void* x, const void* weight, const float* rstd, const void* dres /*nullable*/,
+                       void* dx, void* grad_weight /*nullable*/, int accumulate, float* workspace, int64_t rows, int d,
+                       void* stream);
+int mantis_layernorm_fwd(const void* x, const void* weight, const void* bias, void* y, int64_t rows, int d, float eps,
+                         void* stream);
+
+/* ---- activations: HF:models/llama/modeling_llama.py:163-176 (SwiGLU), modeling_llava.py:106-118 (GELU), siglip MLP acts.
+ * kind: 0 gelu(erf) 1 gelu(tanh) 2 quick_gelu 3 silu.  gate_up is [M, 2I] = (gate | up). */
+int mantis_swiglu_fwd(const void* gate_up, void* out, int64_t M, int I, int64_t ld_gate_up, void* stream);
+int mantis_swiglu_bwd(const void* dact, const void* gate_up, void* dgate_up, int64_t M, int I, int64_t ld_gate_up,
+                      void* stream);
+int mantis_act_fwd(const void* x, void* y, int64_t n, int kind, void* stream);
+int mantis_act_bwd(const void* dy, const void* x, void* dx, int64_t n, int kind, void* stream);
+int mantis_add(const void* a, const void* b, void* y, int64_t n, void* stream);
+int mantis_colsum_partials(int64_t M);
+int mantis_colsum(const void* x, void* grad, int accumulate, float* workspace, int64_t M, int N, int64_t ld, void* stream);
+
+/* ---- RoPE: HF:models/llama/modeling_llama.py:113-160 on the position_ids of modeling_llava.py:355 */
+int mantis_rope_table(const int64_t* position_ids, const float* inv_freq, void* cos_out, void* sin_out, int64_t R,
+                      int half_dim, void* stream);
+int mantis_rope_apply(void* x, const void* cos_tab, const void* sin_tab, int64_t R, int nheads, int head_dim, int64_t ld,
+                      int backward, void* stream);
+/* out[b][h][c][r] = in[b][h][r][c], zero for R <= r < Rpad (operand layouts for dX/dW GEMMs and attention) */
+int mantis_transpose(const void* in, void* out, int R, int C, int Rpad, int64_t ld_in, int64_t ld_out, int nb, int nh,
+                     int64_t in_stride_b, int64_t in_stride_h, int64_t out_stride_b, int64_t out_stride_h, void* stream);
+
+/* ---- GEMM: every nn.Linear of the path (see csrc/gemm.hip).  C = epi(A[M,K] . B[N,K]^T).
+ * flags: 1 bias | act<<1 (1 gelu-erf, 2 gelu-tanh, 3 quick-gelu) | 16 residual add | 32 accumulate into C */
+int mantis_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
+                        const void* bias, const void* residual, int64_t ldr, int flags, void* stream);
+
+/* ---- attention: HF:models/llama/modeling_llama.py:191-214,262-276; HF:models/siglip/modeling_siglip.py:227-247 */
+int mantis_attn_fwd(const void* Q, const void* K, const void* Vt, const int32_t* kmask, void* O, float* LSE, int B, int L,
+                    int Lp, int H, int Hkv, int hd, int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal,
+                    void* stream);
+int mantis_attn_dsum(const void* dO, const void* O, float* Dsum, int B, int L, int H, int hd, int64_t ldo, void* stream);
+int mantis_attn_bwd(const void* Q, const void* K, const void* V, const void* Qt, const void* Kt, const void* dO,
+                    const void* dOt, const int32_t* kmask, const float* LSE, const float* Dsum, void* dQ, void* dK, void* dV,
+                    int B, int L, int Lp, int H, int Hkv, int hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                    int64_t lddq, int64_t lddk, int64_t lddv, float scale, int causal, void* stream);
+
+/* ---- loss: modeling_llava.py:521-537 (shift + mask filter resolved by mantis_pack_plan into ce_row / ce_tgt) */
+int mantis_ce_fwd_bwd(void* logits, const int32_t* targets, int R, int V, int64_t ld, float grad_scale, float loss_scale,
+                      int write_grad, float* row_loss_ws, float* row_lse_out /*nullable*/, int32_t* count_out,
+                      float* loss_out, void* stream);
+
+/* ---- ViT front end: modeling_llava.py:434-435 + HF Siglip/CLIP VisionEmbeddings; feature select modeling_llava.py:460-461 */
+int mantis_im2col(const float* pixels, void* patches, int I, int C, int H, int W, int P, int Kp, void* stream);
+int mantis_vit_assemble(const void* patch_out, const void* pos_emb, const void* cls_emb /*nullable*/, void* out, int I, int N,
+                        int d, void* stream);
+int mantis_drop_cls(const void* in, void* out, int I, int N, int d, void* stream);
+
+/* ---- optimizer: HF:trainer.py:1785-1796 + clip :2535-2545, AdamW over flat buffers */
+int mantis_adamw(void* param_bf16, const void* grad_bf16, float* master, float* exp_avg, float* exp_avg_sq, int64_t n,
+                 float lr, float beta1, float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2,
+                 const float* grad_scale_dev /*nullable: multiply grads by *grad_scale_dev (clip)*/, void* stream);
+int mantis_sumsq_partials(int64_t n);
+int mantis_sumsq(const void* x_bf16, int64_t n, float* partials_ws, float* out /*[1], += */, int accumulate, void* stream);
+int mantis_clip_scale(const float* sumsq, float max_norm, float* scale_out, float* norm_out, void* stream);
+
+/* library / device info */
+int mantis_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,545 @@
+// Fused softmax attention for gfx950 (flash-style, MFMA, online softmax in fp32) -- forward (ViT windows + Llama causal
+// GQA with key-padding mask) and backward (Llama).
+//
+// Replaces (reference path): the attention call inside SiglipAttention / CLIPAttention / LlamaAttention
+//   transformers/models/siglip/modeling_siglip.py:227-247,267-305 (non-causal, one window per image)
+//   transformers/models/llama/modeling_llama.py:191-214,262-276 (causal + padding mask, GQA repeat_kv)
+// reached from /root/reference/mantis/models/mllava/modeling_llava.py:456 and :510, where the reference calls the
+// flash-attn CUDA extension (train_mllava.py:79-82) or the eager softmax.  Never materialises the LxL score matrix.
+//
+// Layout choices (CDNA4):
+//  * scores are computed TRANSPOSED, S^T = K.Q^T via v_mfma_f32_32x32x16_bf16 with K rows as the A operand, so a lane owns ONE
+//    query column (lane & 31) and 16 keys per 32-key block: the row max / row sum are in-lane reductions plus a single
+//    lane <-> lane+32 exchange, and the rescale factor is lane-uniform.
+//  * the P (or dS) accumulator registers feed the next MFMA's B operand DIRECTLY: the contraction order over keys is
+//    permuted to match the accumulator layout (keys {4h+e+8c}), and the A operand (V^T / K^T / dO^T / Q^T, read from a
+//    key-contiguous LDS image) follows the same permutation -- no cross-lane shuffles, no LDS round trip for P.
+//  * operands whose contraction index is not their contiguous axis (V for P.V, K for dS.K, Q and dO for the dK/dV products)
+//    are consumed from pre-transposed global copies [B, heads, hd, Lp] (rope.hip: mantis_transpose), staged in LDS with a
+//    144-byte pitch (2-way worst case on ds_read_b64).
+// Algorithmic FLOPs: forward 4*L*Lk*hd per head (half for causal); backward 2.5x forward (+1x recompute of S and dP here).
+#include "common.h"
+
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
+
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) {
+    union { u32x4 u; bf16x8 b; } c;
+    c.u = v;
+    return c.b;
+}
+
+// Cooperative global -> LDS tile load through registers (16 B per lane).  Tile = ROWS x NCH chunks(8 bf16); element (r, c*8)
+// comes from g[r*gstride + c*8]; rows >= rows_valid or chunk start >= cols_valid are zero-filled.
+template <int ROWS, int NCH, int PITCH>
+__device__ __forceinline__ void load_tile(const bf16_t* __restrict__ g, long gstride, int rows_valid, int cols_valid,
+                                          char* lds) {
+    for (int idx = threadIdx.x; idx < ROWS * NCH; idx += 256) {
+        const int r = idx / NCH, c = idx - r * NCH;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (r < rows_valid && c * 8 < cols_valid) v = *reinterpret_cast<const u32x4*>(g + (long)r * gstride + c * 8);
+        *reinterpret_cast<u32x4*>(lds + r * PITCH + c * 16) = v;
+    }
+}
+
+// A-operand fragment from a key-contiguous (transposed) LDS image: row = d, 8 "slots" = keys {o, o+1, o+2, o+3, o+8, .., o+11}
+__device__ __forceinline__ bf16x8 read_tfrag(const char* lds, int pitch, int row, int col0) {
+    const u32x2 a = *reinterpret_cast<const u32x2*>(lds + row * pitch + col0 * 2);
+    const u32x2 b = *reinterpret_cast<const u32x2*>(lds + row * pitch + col0 * 2 + 16);
+    return as_bf16x8(u32x4{a[0], a[1], b[0], b[1]});
+}
+
+__device__ __forceinline__ bf16x8 pack_frag(const f32x16& s, int cp) {
+    u32x4 u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) u[e] = pack_bf2(s[8 * cp + 2 * e], s[8 * cp + 2 * e + 1]);
+    return as_bf16x8(u);
+}
+
+template <int HD>
+struct AttnCfg {
+    static constexpr int KP = (HD + 15) / 16 * 16;   // contraction length of Q.K^T, zero padded
+    static constexpr int DP = (HD + 31) / 32 * 32;   // output width of P.V, padded to MFMA blocks
+    static constexpr int NKS = KP / 16;
+    static constexpr int NDB = DP / 32;
+    static constexpr int NCK = KP / 8;
+    static constexpr int KPITCH = KP * 2 + 16;
+    static constexpr int TPITCH = 144;                // 64 keys * 2 B + 16
+};
+
+// ------------------------------------------------------------------------------------------------ forward
+// grid (ceil(L/128), H, B); 4 waves x 32 query rows; KV tiles of 64 keys.
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                       const bf16_t* __restrict__ Vt, const int* __restrict__ kmask,
+                                                       bf16_t* __restrict__ O, float* __restrict__ LSE, int L, int Lp, int H,
+                                                       int Hkv, long ldq, long ldk, long ldo, float scale) {
+    using C = AttnCfg<HD>;
+    __shared__ __attribute__((aligned(16))) char smem[64 * C::KPITCH + C::DP * C::TPITCH + 64 * 4];
+    char* sK = smem;
+    char* sV = smem + 64 * C::KPITCH;
+    float* sBias = reinterpret_cast<float*>(smem + 64 * C::KPITCH + C::DP * C::TPITCH);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hh = lane >> 5, lq = lane & 31;
+    const int b = blockIdx.z, h = blockIdx.y, hk = h / (H / Hkv);
+    const int qblk0 = blockIdx.x * 128, q0 = qblk0 + wave * 32, q = q0 + lq;
+    const int qc = q < L ? q : L - 1;
+    const float c = scale * LOG2E;
+
+    bf16x8 qf[C::NKS];
+#pragma unroll
+    for (int ks = 0; ks < C::NKS; ++ks) {
+        const int ch = ks * 2 + hh;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (ch * 8 < HD) v = *reinterpret_cast<const u32x4*>(Q + ((long)b * L + qc) * ldq + (long)h * HD + ch * 8);
+        qf[ks] = as_bf16x8(v);
+    }
+    f32x16 oacc[C::NDB];
+#pragma unroll
+    for (int d = 0; d < C::NDB; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int kend = CAUSAL ? (qblk0 + 128 < L ? qblk0 + 128 : L) : L;
+    const int ntiles = (kend + 63) / 64;
+    const bf16_t* Kb = K + (long)b * L * ldk + (long)hk * HD;
+    const bf16_t* Vb = Vt + ((long)b * Hkv + hk) * HD * Lp;
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int key0 = t * 64;
+        __syncthreads();
+        load_tile<64, C::NCK, C::KPITCH>(Kb + (long)key0 * ldk, ldk, L - key0, HD, sK);
+        load_tile<HD, 8, C::TPITCH>(Vb + key0, Lp, HD, Lp - key0, sV);
+        if (threadIdx.x < 64) {
+            const int key = key0 + threadIdx.x;
+            const bool ok = key < L && (kmask == nullptr || kmask[(long)b * L + key] != 0);
+            sBias[threadIdx.x] = ok ? 0.f : -INFINITY;
+        }
+        __syncthreads();
+        if (CAUSAL && key0 > q0 + 31) continue;  // wave-uniform: whole tile is in this wave's future
+
+        f32x16 s[2];
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[sb][e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < C::NKS; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (sb * 32 + lq) * C::KPITCH + (ks * 2 + hh) * 16);
+                s[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[sb], 0, 0, 0);
+            }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kl = sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                float v = s[sb][r] * c + sBias[kl];
+                if (CAUSAL && key0 + kl > q) v = -INFINITY;
+                s[sb][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float msafe = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = (m_new == -INFINITY) ? 1.f : exp2f(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = exp2f(s[sb][r] - msafe);
+                s[sb][r] = p;
+                psum += p;
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < C::NDB; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+            for (int cp = 0; cp < 2; ++cp) {
+                const bf16x8 pf = pack_frag(s[sb], cp);
+#pragma unroll
+                for (int d = 0; d < C::NDB; ++d) {
+                    const bf16x8 vf = read_tfrag(sV, C::TPITCH, d * 32 + lq, sb * 32 + 16 * cp + 4 * hh);
+                    oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[d], 0, 0, 0);
+                }
+            }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
+    if (q < L) {
+        bf16_t* op = O + ((long)b * L + q) * ldo + (long)h * HD;
+#pragma unroll
+        for (int d = 0; d < C::NDB; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int dd = d * 32 + 8 * g4 + 4 * hh;
+                if (dd < HD) {
+                    u32x2 o;
+                    o[0] = pack_bf2(oacc[d][4 * g4] * inv, oacc[d][4 * g4 + 1] * inv);
+                    o[1] = pack_bf2(oacc[d][4 * g4 + 2] * inv, oacc[d][4 * g4 + 3] * inv);
+                    *reinterpret_cast<u32x2*>(op + dd) = o;
+                }
+            }
+        if (hh == 0 && LSE) LSE[((long)b * H + h) * L + q] = l_tot > 0.f ? m_run * LN2 + logf(l_tot) : INFINITY;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: D = rowsum(dO * O)
+__global__ void attn_dsum_kernel(const bf16_t* __restrict__ dO, const bf16_t* __restrict__ O, float* __restrict__ Dsum, long rows,
+                                 int H, int HD, int L, long ldo) {
+    // one wave per (token row, head); Dsum layout [B, H, L]
+    const int lane = threadIdx.x & 63;
+    const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= rows * H) return;
+    const long row = w / H;
+    const int h = (int)(w - row * H);
+    float s = 0.f;
+    for (int c = lane; c < HD / 8; c += 64) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(dO + row * ldo + (long)h * HD + c * 8);
+        const u32x4 o = *reinterpret_cast<const u32x4*>(O + row * ldo + (long)h * HD + c * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += bf2f_lo(a[e]) * bf2f_lo(o[e]) + bf2f_hi(a[e]) * bf2f_hi(o[e]);
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+        const long b = row / L, l = row - b * L;
+        Dsum[(b * H + h) * L + l] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dQ
+// Same walk as the forward: grid (ceil(L/128), H, B), KV tiles of 64 keys.  dQ^T[d][q] += K^T[d][key] . dS^T[key][q].
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                          const bf16_t* __restrict__ V, const bf16_t* __restrict__ Kt,
+                                                          const bf16_t* __restrict__ dO, const int* __restrict__ kmask,
+                                                          const float* __restrict__ LSE, const float* __restrict__ Dsum,
+                                                          bf16_t* __restrict__ dQ, int L, int Lp, int H, int Hkv, long ldq,
+                                                          long ldk, long ldv, long ldo, long lddq, float scale) {
+    using C = AttnCfg<HD>;
+    __shared__ __attribute__((aligned(16))) char smem[2 * 64 * C::KPITCH + C::DP * C::TPITCH + 64 * 4];
+    char* sK = smem;
+    char* sV = smem + 64 * C::KPITCH;
+    char* sKt = smem + 2 * 64 * C::KPITCH;
+    float* sBias = reinterpret_cast<float*>(smem + 2 * 64 * C::KPITCH + C::DP * C::TPITCH);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hh = lane >> 5, lq = lane & 31;
+    const int b = blockIdx.z, h = blockIdx.y, hk = h / (H / Hkv);
+    const int qblk0 = blockIdx.x * 128, q0 = qblk0 + wave * 32, q = q0 + lq;
+    const int qc = q < L ? q : L - 1;
+    const float c = scale * LOG2E;
+
+    bf16x8 qf[C::NKS], dof[C::NKS];
+#pragma unroll
+    for (int ks = 0; ks < C::NKS; ++ks) {
+        const int ch = ks * 2 + hh;
+        u32x4 v = {0u, 0u, 0u, 0u}, w = {0u, 0u, 0u, 0u};
+        if (ch * 8 < HD) {
+            v = *reinterpret_cast<const u32x4*>(Q + ((long)b * L + qc) * ldq + (long)h * HD + ch * 8);
+            w = *reinterpret_cast<const u32x4*>(dO + ((long)b * L + qc) * ldo + (long)h * HD + ch * 8);
+        }
+        qf[ks] = as_bf16x8(v);
+        dof[ks] = as_bf16x8(w);
+    }
+    const float lse2 = LSE[((long)b * H + h) * L + qc] * LOG2E;
+    const float dsum = Dsum[((long)b * H + h) * L + qc];
+    f32x16 acc[C::NDB];
+#pragma unroll
+    for (int d = 0; d < C::NDB; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[d][e] = 0.f;
+
+    const int kend = CAUSAL ? (qblk0 + 128 < L ? qblk0 + 128 : L) : L;
+    const int ntiles = (kend + 63) / 64;
+    const bf16_t* Kb = K + (long)b * L * ldk + (long)hk * HD;
+    const bf16_t* Vb = V + (long)b * L * ldv + (long)hk * HD;
+    const bf16_t* Ktb = Kt + ((long)b * Hkv + hk) * HD * Lp;
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int key0 = t * 64;
+        __syncthreads();
+        load_tile<64, C::NCK, C::KPITCH>(Kb + (long)key0 * ldk, ldk, L - key0, HD, sK);
+        load_tile<64, C::NCK, C::KPITCH>(Vb + (long)key0 * ldv, ldv, L - key0, HD, sV);
+        load_tile<HD, 8, C::TPITCH>(Ktb + key0, Lp, HD, Lp - key0, sKt);
+        if (threadIdx.x < 64) {
+            const int key = key0 + threadIdx.x;
+            const bool ok = key < L && (kmask == nullptr || kmask[(long)b * L + key] != 0);
+            sBias[threadIdx.x] = ok ? 0.f : -INFINITY;
+        }
+        __syncthreads();
+        if (CAUSAL && key0 > q0 + 31) continue;
+
+        f32x16 s[2], dp[2];
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { s[sb][e] = 0.f; dp[sb][e] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < C::NKS; ++ks) {
+                const int off = (sb * 32 + lq) * C::KPITCH + (ks * 2 + hh) * 16;
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + off);
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sV + off);
+                s[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[sb], 0, 0, 0);
+                dp[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp[sb], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kl = sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                float v = s[sb][r] * c + sBias[kl];
+                if (CAUSAL && key0 + kl > q) v = -INFINITY;
+                const float p = exp2f(v - lse2);  // lse = +inf for fully masked rows -> p = 0
+                s[sb][r] = p * (dp[sb][r] - dsum) * scale;
+            }
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+            for (int cp = 0; cp < 2; ++cp) {
+                const bf16x8 dsf = pack_frag(s[sb], cp);
+#pragma unroll
+                for (int d = 0; d < C::NDB; ++d) {
+                    const bf16x8 ktf = read_tfrag(sKt, C::TPITCH, d * 32 + lq, sb * 32 + 16 * cp + 4 * hh);
+                    acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf, acc[d], 0, 0, 0);
+                }
+            }
+    }
+    if (q < L) {
+        bf16_t* op = dQ + ((long)b * L + q) * lddq + (long)h * HD;
+#pragma unroll
+        for (int d = 0; d < C::NDB; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int dd = d * 32 + 8 * g4 + 4 * hh;
+                if (dd < HD) {
+                    u32x2 o;
+                    o[0] = pack_bf2(acc[d][4 * g4], acc[d][4 * g4 + 1]);
+                    o[1] = pack_bf2(acc[d][4 * g4 + 2], acc[d][4 * g4 + 3]);
+                    *reinterpret_cast<u32x2*>(op + dd) = o;
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dK, dV
+// grid (ceil(L/128), Hkv, B): 4 waves x 32 keys; loops over the G = H/Hkv query heads of the group and 32-row query tiles.
+//   S[q][key]  = Q . K^T      (lane owns ONE key column, 16 query rows per block)
+//   dV^T[d][key] += dO^T[d][q] . P[q][key]        dK^T[d][key] += Q^T[d][q] . dS[q][key]
+#define QT_PITCH 80  // 32 queries * 2 B + 16
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                           const bf16_t* __restrict__ V, const bf16_t* __restrict__ Qt,
+                                                           const bf16_t* __restrict__ dO, const bf16_t* __restrict__ dOt,
+                                                           const int* __restrict__ kmask, const float* __restrict__ LSE,
+                                                           const float* __restrict__ Dsum, bf16_t* __restrict__ dK,
+                                                           bf16_t* __restrict__ dV, int L, int Lp, int H, int Hkv, long ldq,
+                                                           long ldk, long ldv, long ldo, long lddk, long lddv, float scale) {
+    using C = AttnCfg<HD>;
+    __shared__ __attribute__((aligned(16))) char smem[2 * 32 * C::KPITCH + 2 * C::DP * QT_PITCH + 2 * 32 * 4];
+    char* sQ = smem;
+    char* sdO = smem + 32 * C::KPITCH;
+    char* sQt = smem + 2 * 32 * C::KPITCH;
+    char* sdOt = sQt + C::DP * QT_PITCH;
+    float* sLse = reinterpret_cast<float*>(sdOt + C::DP * QT_PITCH);
+    float* sDs = sLse + 32;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hh = lane >> 5, lk = lane & 31;
+    const int b = blockIdx.z, hk = blockIdx.y, G = H / Hkv;
+    const int kblk0 = blockIdx.x * 128, k0 = kblk0 + wave * 32, key = k0 + lk;
+    const int keyc = key < L ? key : L - 1;
+    const float c = scale * LOG2E;
+    const bool key_ok = key < L && (kmask == nullptr || kmask[(long)b * L + keyc] != 0);
+
+    bf16x8 kf[C::NKS], vf[C::NKS];
+#pragma unroll
+    for (int ks = 0; ks < C::NKS; ++ks) {
+        const int ch = ks * 2 + hh;
+        u32x4 a = {0u, 0u, 0u, 0u}, w = {0u, 0u, 0u, 0u};
+        if (ch * 8 < HD) {
+            a = *reinterpret_cast<const u32x4*>(K + ((long)b * L + keyc) * ldk + (long)hk * HD + ch * 8);
+            w = *reinterpret_cast<const u32x4*>(V + ((long)b * L + keyc) * ldv + (long)hk * HD + ch * 8);
+        }
+        kf[ks] = as_bf16x8(a);
+        vf[ks] = as_bf16x8(w);
+    }
+    f32x16 dkacc[C::NDB], dvacc[C::NDB];
+#pragma unroll
+    for (int d = 0; d < C::NDB; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dkacc[d][e] = 0.f; dvacc[d][e] = 0.f; }
+
+    const int qstart = CAUSAL ? (kblk0 / 32) : 0;  // first 32-row query tile that can see this key block
+    const int nqt = (L + 31) / 32;
+    for (int g = 0; g < G; ++g) {
+        const int h = hk * G + g;
+        const bf16_t* Qb = Q + (long)b * L * ldq + (long)h * HD;
+        const bf16_t* dOb = dO + (long)b * L * ldo + (long)h * HD;
+        const bf16_t* Qtb = Qt + ((long)b * H + h) * HD * Lp;
+        const bf16_t* dOtb = dOt + ((long)b * H + h) * HD * Lp;
+        for (int qt = qstart; qt < nqt; ++qt) {
+            const int q0 = qt * 32;
+            __syncthreads();
+            load_tile<32, C::NCK, C::KPITCH>(Qb + (long)q0 * ldq, ldq, L - q0, HD, sQ);
+            load_tile<32, C::NCK, C::KPITCH>(dOb + (long)q0 * ldo, ldo, L - q0, HD, sdO);
+            load_tile<HD, 4, QT_PITCH>(Qtb + q0, Lp, HD, Lp - q0, sQt);
+            load_tile<HD, 4, QT_PITCH>(dOtb + q0, Lp, HD, Lp - q0, sdOt);
+            if (threadIdx.x < 32) {
+                const int qq = q0 + threadIdx.x;
+                sLse[threadIdx.x] = qq < L ? LSE[((long)b * H + h) * L + qq] * LOG2E : INFINITY;
+                sDs[threadIdx.x] = qq < L ? Dsum[((long)b * H + h) * L + qq] : 0.f;
+            }
+            __syncthreads();
+            if (CAUSAL && q0 + 31 < k0) continue;  // wave-uniform: every query of the tile precedes this wave's keys
+
+            f32x16 s, dp;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < C::NKS; ++ks) {
+                const int off = lk * C::KPITCH + (ks * 2 + hh) * 16;
+                const bf16x8 qa = *reinterpret_cast<const bf16x8*>(sQ + off);
+                const bf16x8 da = *reinterpret_cast<const bf16x8*>(sdO + off);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp, 0, 0, 0);
+            }
+            f32x16 ds;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ql = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                float v = key_ok ? s[r] * c : -INFINITY;
+                if (CAUSAL && key > q0 + ql) v = -INFINITY;
+                const float p = exp2f(v - sLse[ql]);
+                s[r] = p;
+                ds[r] = p * (dp[r] - sDs[ql]) * scale;
+            }
+#pragma unroll
+            for (int cp = 0; cp < 2; ++cp) {
+                const bf16x8 pf = pack_frag(s, cp);
+                const bf16x8 dsf = pack_frag(ds, cp);
+#pragma unroll
+                for (int d = 0; d < C::NDB; ++d) {
+                    const bf16x8 dot = read_tfrag(sdOt, QT_PITCH, d * 32 + lk, 16 * cp + 4 * hh);
+                    const bf16x8 qtf = read_tfrag(sQt, QT_PITCH, d * 32 + lk, 16 * cp + 4 * hh);
+                    dvacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot, pf, dvacc[d], 0, 0, 0);
+                    dkacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsf, dkacc[d], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (key < L) {
+        bf16_t* kp = dK + ((long)b * L + key) * lddk + (long)hk * HD;
+        bf16_t* vp = dV + ((long)b * L + key) * lddv + (long)hk * HD;
+#pragma unroll
+        for (int d = 0; d < C::NDB; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int dd = d * 32 + 8 * g4 + 4 * hh;
+                if (dd < HD) {
+                    u32x2 o, w;
+                    o[0] = pack_bf2(dkacc[d][4 * g4], dkacc[d][4 * g4 + 1]);
+                    o[1] = pack_bf2(dkacc[d][4 * g4 + 2], dkacc[d][4 * g4 + 3]);
+                    w[0] = pack_bf2(dvacc[d][4 * g4], dvacc[d][4 * g4 + 1]);
+                    w[1] = pack_bf2(dvacc[d][4 * g4 + 2], dvacc[d][4 * g4 + 3]);
+                    *reinterpret_cast<u32x2*>(kp + dd) = o;
+                    *reinterpret_cast<u32x2*>(vp + dd) = w;
+                }
+            }
+    }
+}
+
+template <int HD>
+static int launch_fwd(bool causal, dim3 grid, hipStream_t s, const bf16_t* Q, const bf16_t* K, const bf16_t* Vt,
+                      const int* kmask, bf16_t* O, float* LSE, int L, int Lp, int H, int Hkv, long ldq, long ldk, long ldo,
+                      float scale) {
+    if (causal)
+        hipLaunchKernelGGL((attn_fwd_kernel<HD, true>), grid, dim3(256), 0, s, Q, K, Vt, kmask, O, LSE, L, Lp, H, Hkv, ldq,
+                           ldk, ldo, scale);
+    else
+        hipLaunchKernelGGL((attn_fwd_kernel<HD, false>), grid, dim3(256), 0, s, Q, K, Vt, kmask, O, LSE, L, Lp, H, Hkv, ldq,
+                           ldk, ldo, scale);
+    return mantis_check_launch();
+}
+
+template <int HD>
+static int launch_bwd(bool causal, hipStream_t s, const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* Qt,
+                      const bf16_t* Kt, const bf16_t* dO, const bf16_t* dOt, const int* kmask, const float* LSE,
+                      const float* Dsum, bf16_t* dQ, bf16_t* dK, bf16_t* dV, int B, int L, int Lp, int H, int Hkv, long ldq,
+                      long ldk, long ldv, long ldo, long lddq, long lddk, long lddv, float scale) {
+    const dim3 gq(cdiv(L, 128), H, B), gk(cdiv(L, 128), Hkv, B);
+    if (causal) {
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, true>), gq, dim3(256), 0, s, Q, K, V, Kt, dO, kmask, LSE, Dsum, dQ, L, Lp, H,
+                           Hkv, ldq, ldk, ldv, ldo, lddq, scale);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, true>), gk, dim3(256), 0, s, Q, K, V, Qt, dO, dOt, kmask, LSE, Dsum, dK, dV,
+                           L, Lp, H, Hkv, ldq, ldk, ldv, ldo, lddk, lddv, scale);
+    } else {
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, false>), gq, dim3(256), 0, s, Q, K, V, Kt, dO, kmask, LSE, Dsum, dQ, L, Lp,
+                           H, Hkv, ldq, ldk, ldv, ldo, lddq, scale);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, false>), gk, dim3(256), 0, s, Q, K, V, Qt, dO, dOt, kmask, LSE, Dsum, dK,
+                           dV, L, Lp, H, Hkv, ldq, ldk, ldv, ldo, lddk, lddv, scale);
+    }
+    return mantis_check_launch();
+}
+
+extern "C" {
+
+// Q [B,L,H,hd] (row stride ldq), K [B,L,Hkv,hd] (ldk), Vt [B,Hkv,hd,Lp] (keys contiguous, zero beyond L), kmask int32[B,L] or
+// NULL, O [B,L,H,hd] (ldo), LSE fp32 [B,H,L] or NULL.  hd in {16, 64, 72, 128}.
+int mantis_attn_fwd(const void* Q, const void* K, const void* Vt, const int32_t* kmask, void* O, float* LSE, int B, int L,
+                    int Lp, int H, int Hkv, int hd, int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal,
+                    void* stream) {
+    if (B <= 0 || L <= 0 || H <= 0 || Hkv <= 0 || H % Hkv || Lp % 8 || Lp < L) return MANTIS_EINVAL;
+    if (ldq % 8 || ldk % 8 || ldo % 4) return MANTIS_EUNSUPPORTED;
+    const dim3 grid(cdiv(L, 128), H, B);
+    hipStream_t s = (hipStream_t)stream;
+#define FWD(HD) return launch_fwd<HD>(causal != 0, grid, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)Vt, kmask, \
+                                      (bf16_t*)O, LSE, L, Lp, H, Hkv, (long)ldq, (long)ldk, (long)ldo, scale)
+    switch (hd) {
+        case 16: FWD(16);
+        case 64: FWD(64);
+        case 72: FWD(72);
+        case 128: FWD(128);
+        default: return MANTIS_EUNSUPPORTED;
+    }
+#undef FWD
+}
+
+// Dsum [B,H,L] = rowsum(dO * O)
+int mantis_attn_dsum(const void* dO, const void* O, float* Dsum, int B, int L, int H, int hd, int64_t ldo, void* stream) {
+    if (hd % 8 || ldo % 8) return MANTIS_EUNSUPPORTED;
+    const long rows = (long)B * L;
+    hipLaunchKernelGGL(attn_dsum_kernel, dim3(cdiv(rows * H, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dO,
+                       (const bf16_t*)O, Dsum, rows, H, hd, L, (long)ldo);
+    return mantis_check_launch();
+}
+
+// Qt,dOt [B,H,hd,Lp]; Kt [B,Hkv,hd,Lp]; dQ/dK/dV written with row strides lddq/lddk/lddv (head h at column h*hd).
+int mantis_attn_bwd(const void* Q, const void* K, const void* V, const void* Qt, const void* Kt, const void* dO, const void* dOt,
+                    const int32_t* kmask, const float* LSE, const float* Dsum, void* dQ, void* dK, void* dV, int B, int L,
+                    int Lp, int H, int Hkv, int hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddq,
+                    int64_t lddk, int64_t lddv, float scale, int causal, void* stream) {
+    if (B <= 0 || L <= 0 || H <= 0 || Hkv <= 0 || H % Hkv || Lp % 8 || Lp < L) return MANTIS_EINVAL;
+    if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8 || lddq % 4 || lddk % 4 || lddv % 4) return MANTIS_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+#define BWD(HD) return launch_bwd<HD>(causal != 0, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)Qt, \
+                                      (const bf16_t*)Kt, (const bf16_t*)dO, (const bf16_t*)dOt, kmask, LSE, Dsum, (bf16_t*)dQ, \
+                                      (bf16_t*)dK, (bf16_t*)dV, B, L, Lp, H, Hkv, (long)ldq, (long)ldk, (long)ldv, (long)ldo, \
+                                      (long)lddq, (long)lddk, (long)lddv, scale)
+    switch (hd) {
+        case 16: BWD(16);
+        case 64: BWD(64);
+        case 128: BWD(128);
+        default: return MANTIS_EUNSUPPORTED;
+    }
+#undef BWD
+}
+
+}  // extern "C"

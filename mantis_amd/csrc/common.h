@@ -1,0 +1,69 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of libmantis_hip.so.
+// wave = 64 lanes; bf16 is handled as raw 16-bit patterns so loads/stores vectorise to 16 B per lane.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MANTIS_OK 0
+#define MANTIS_EINVAL (-1)
+#define MANTIS_EUNSUPPORTED (-2)
+#define MANTIS_ELAUNCH (-3)
+
+typedef unsigned short bf16_t;  // raw bits
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ float bf2f(bf16_t x) { return __uint_as_float(((unsigned int)x) << 16); }
+__device__ __forceinline__ float bf2f_lo(unsigned int w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf2f_hi(unsigned int w) { return __uint_as_float(w & 0xffff0000u); }
+// round-to-nearest-even, NaN preserved (same rounding torch uses for float->bfloat16)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    unsigned int u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x0040u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ unsigned int pack_bf2(float lo, float hi) {
+    return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// block-wide sum for blockDim.x <= 1024 (<=16 waves); `red` is >=16 floats of LDS; result broadcast to all threads.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float t = (lane < nw) ? red[lane] : 0.f;
+    t = wave_sum(t);
+    return t;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float t = (lane < nw) ? red[lane] : -INFINITY;
+    t = wave_max(t);
+    return t;
+}
+
+static inline int mantis_check_launch() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MANTIS_OK : MANTIS_ELAUNCH;
+}
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

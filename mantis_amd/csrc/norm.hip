@@ -1,0 +1,223 @@
+// RMSNorm fwd/bwd (Llama) and LayerNorm fwd (frozen ViT) for gfx950.
+//
+// Replaces (reference path): HF LlamaRMSNorm.forward (transformers/models/llama/modeling_llama.py:60-65) and its autograd
+// backward, reached from /root/reference/mantis/models/mllava/modeling_llava.py:510; nn.LayerNorm inside the SigLIP/CLIP
+// encoder layers (transformers/models/siglip/modeling_siglip.py:325-358), reached from modeling_llava.py:456.
+//
+// HBM-bound: one 64-lane wave owns a row (16 B per lane per access, wave-shuffle reductions, no LDS, no barriers).
+// Algorithmic bytes: fwd 2*rows*d*2 B; bwd reads dy,x and writes dx (3*rows*d*2 B) + a [partials,d] fp32 dW slab.
+#include "common.h"
+
+#define NORM_WAVES 4
+#define NORM_MAXC 16  // chunks of 8 per lane -> d <= 64*8*16 = 8192
+
+// y = w * bf16(x * rsqrt(mean(x^2) + eps))      (stats fp32, two roundings exactly as the reference does)
+__global__ __launch_bounds__(64 * NORM_WAVES) void rmsnorm_fwd_kernel(const bf16_t* __restrict__ x,
+                                                                      const bf16_t* __restrict__ w,
+                                                                      bf16_t* __restrict__ y, float* __restrict__ rstd_out,
+                                                                      long rows, int d, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * NORM_WAVES + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * NORM_WAVES;
+    const int cpr = d >> 3;
+    for (long r = wave; r < rows; r += nwaves) {
+        const bf16_t* xr = x + r * d;
+        float ss = 0.f;
+        for (int c = lane; c < cpr; c += 64) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(xr + c * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = bf2f_lo(v[e]), b = bf2f_hi(v[e]);
+                ss += a * a + b * b;
+            }
+        }
+        ss = wave_sum(ss);
+        const float rstd = rsqrtf(ss / (float)d + eps);
+        if (lane == 0 && rstd_out) rstd_out[r] = rstd;
+        for (int c = lane; c < cpr; c += 64) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(xr + c * 8);
+            const u32x4 g = *reinterpret_cast<const u32x4*>(w + c * 8);
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = bf2f(f2bf(bf2f_lo(v[e]) * rstd)) * bf2f_lo(g[e]);
+                const float b = bf2f(f2bf(bf2f_hi(v[e]) * rstd)) * bf2f_hi(g[e]);
+                o[e] = pack_bf2(a, b);
+            }
+            *reinterpret_cast<u32x4*>(y + r * d + c * 8) = o;
+        }
+    }
+}
+
+// dx = rstd * (g - xhat * mean(g * xhat)) [+ dres],  g = dy * w, xhat = x * rstd;   dW partial[wave] += dy * xhat
+__global__ __launch_bounds__(64 * NORM_WAVES) void rmsnorm_bwd_kernel(
+    const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+    const float* __restrict__ rstd_in, const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
+    float* __restrict__ dw_partial, long rows, int d) {
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * NORM_WAVES + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * NORM_WAVES;
+    const int cpr = d >> 3;
+    float dwacc[NORM_MAXC][8];
+#pragma unroll
+    for (int k = 0; k < NORM_MAXC; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dwacc[k][e] = 0.f;
+    for (long r = wave; r < rows; r += nwaves) {
+        const float rstd = rstd_in[r];
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < NORM_MAXC; ++k) {
+            const int c = lane + 64 * k;
+            if (c < cpr) {
+                const u32x4 vd = *reinterpret_cast<const u32x4*>(dy + r * d + c * 8);
+                const u32x4 vx = *reinterpret_cast<const u32x4*>(x + r * d + c * 8);
+                const u32x4 vw = *reinterpret_cast<const u32x4*>(w + c * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d0 = bf2f_lo(vd[e]), d1 = bf2f_hi(vd[e]);
+                    const float x0 = bf2f_lo(vx[e]) * rstd, x1 = bf2f_hi(vx[e]) * rstd;
+                    dot += d0 * bf2f_lo(vw[e]) * x0 + d1 * bf2f_hi(vw[e]) * x1;
+                    dwacc[k][2 * e] += d0 * x0;
+                    dwacc[k][2 * e + 1] += d1 * x1;
+                }
+            }
+        }
+        dot = wave_sum(dot) / (float)d;
+#pragma unroll
+        for (int k = 0; k < NORM_MAXC; ++k) {
+            const int c = lane + 64 * k;
+            if (c < cpr) {
+                const u32x4 vd = *reinterpret_cast<const u32x4*>(dy + r * d + c * 8);
+                const u32x4 vx = *reinterpret_cast<const u32x4*>(x + r * d + c * 8);
+                const u32x4 vw = *reinterpret_cast<const u32x4*>(w + c * 8);
+                u32x4 vr = {0u, 0u, 0u, 0u};
+                if (dres) vr = *reinterpret_cast<const u32x4*>(dres + r * d + c * 8);
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x0 = bf2f_lo(vx[e]) * rstd, x1 = bf2f_hi(vx[e]) * rstd;
+                    const float a = rstd * (bf2f_lo(vd[e]) * bf2f_lo(vw[e]) - x0 * dot) + bf2f_lo(vr[e]);
+                    const float b = rstd * (bf2f_hi(vd[e]) * bf2f_hi(vw[e]) - x1 * dot) + bf2f_hi(vr[e]);
+                    o[e] = pack_bf2(a, b);
+                }
+                *reinterpret_cast<u32x4*>(dx + r * d + c * 8) = o;
+            }
+        }
+    }
+    if (dw_partial) {
+        float* out = dw_partial + wave * d;
+#pragma unroll
+        for (int k = 0; k < NORM_MAXC; ++k) {
+            const int c = lane + 64 * k;
+            if (c < cpr) {
+                *reinterpret_cast<f32x4*>(out + c * 8) = f32x4{dwacc[k][0], dwacc[k][1], dwacc[k][2], dwacc[k][3]};
+                *reinterpret_cast<f32x4*>(out + c * 8 + 4) = f32x4{dwacc[k][4], dwacc[k][5], dwacc[k][6], dwacc[k][7]};
+            }
+        }
+    }
+}
+
+// grad[j] (+)= sum_p partial[p][j]   (fixed summation order -> deterministic)
+__global__ void reduce_partials_kernel(const float* __restrict__ partial, int P, int d, bf16_t* __restrict__ grad,
+                                       int accumulate) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= d) return;
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += partial[(long)p * d + j];
+    if (accumulate) s += bf2f(grad[j]);
+    grad[j] = f2bf(s);
+}
+
+// LayerNorm forward: y = bf16((x - mean) * rsqrt(var + eps) * w + b), stats fp32 (matches at::layer_norm on bf16 input)
+__global__ __launch_bounds__(64 * NORM_WAVES) void layernorm_fwd_kernel(const bf16_t* __restrict__ x,
+                                                                        const bf16_t* __restrict__ w,
+                                                                        const bf16_t* __restrict__ bias,
+                                                                        bf16_t* __restrict__ y, long rows, int d,
+                                                                        float eps) {
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * NORM_WAVES + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * NORM_WAVES;
+    const int cpr = d >> 3;
+    for (long r = wave; r < rows; r += nwaves) {
+        const bf16_t* xr = x + r * d;
+        float s = 0.f;
+        for (int c = lane; c < cpr; c += 64) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(xr + c * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s += bf2f_lo(v[e]) + bf2f_hi(v[e]);
+        }
+        const float mean = wave_sum(s) / (float)d;
+        float q = 0.f;
+        for (int c = lane; c < cpr; c += 64) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(xr + c * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = bf2f_lo(v[e]) - mean, b = bf2f_hi(v[e]) - mean;
+                q += a * a + b * b;
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+        for (int c = lane; c < cpr; c += 64) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(xr + c * 8);
+            const u32x4 g = *reinterpret_cast<const u32x4*>(w + c * 8);
+            const u32x4 bb = *reinterpret_cast<const u32x4*>(bias + c * 8);
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = (bf2f_lo(v[e]) - mean) * rstd * bf2f_lo(g[e]) + bf2f_lo(bb[e]);
+                const float b = (bf2f_hi(v[e]) - mean) * rstd * bf2f_hi(g[e]) + bf2f_hi(bb[e]);
+                o[e] = pack_bf2(a, b);
+            }
+            *reinterpret_cast<u32x4*>(y + r * d + c * 8) = o;
+        }
+    }
+}
+
+static inline int norm_grid(long rows) {
+    long g = (rows + NORM_WAVES - 1) / NORM_WAVES;
+    return (int)(g < 1 ? 1 : (g > 1024 ? 1024 : g));
+}
+
+extern "C" {
+
+int mantis_rmsnorm_fwd(const void* x, const void* weight, void* y, float* rstd, int64_t rows, int d, float eps,
+                       void* stream) {
+    if (d % 8 || d <= 0) return MANTIS_EUNSUPPORTED;
+    if (rows == 0) return MANTIS_OK;
+    hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(norm_grid(rows)), dim3(64 * NORM_WAVES), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, (const bf16_t*)weight, (bf16_t*)y, rstd, (long)rows, d, eps);
+    return mantis_check_launch();
+}
+
+// workspace: >= mantis_rmsnorm_bwd_partials(rows) * d floats.  grad_weight (+)= dW (bf16).  dres optional (fused residual-grad add).
+int mantis_rmsnorm_bwd_partials(int64_t rows) {
+    long g = (rows + NORM_WAVES - 1) / NORM_WAVES;
+    g = g < 1 ? 1 : (g > 256 ? 256 : g);
+    return (int)(g * NORM_WAVES);
+}
+
+int mantis_rmsnorm_bwd(const void* dy, const void* x, const void* weight, const float* rstd, const void* dres, void* dx,
+                       void* grad_weight, int accumulate, float* workspace, int64_t rows, int d, void* stream) {
+    if (d % 8 || d <= 0 || d > 64 * 8 * NORM_MAXC) return MANTIS_EUNSUPPORTED;
+    if (rows == 0) return MANTIS_OK;
+    const int P = mantis_rmsnorm_bwd_partials(rows);
+    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(P / NORM_WAVES), dim3(64 * NORM_WAVES), 0, (hipStream_t)stream,
+                       (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)weight, rstd, (const bf16_t*)dres, (bf16_t*)dx,
+                       grad_weight ? workspace : nullptr, (long)rows, d);
+    if (grad_weight)
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(d, 256)), dim3(256), 0, (hipStream_t)stream, workspace, P, d,
+                           (bf16_t*)grad_weight, accumulate);
+    return mantis_check_launch();
+}
+
+int mantis_layernorm_fwd(const void* x, const void* weight, const void* bias, void* y, int64_t rows, int d, float eps,
+                         void* stream) {
+    if (d % 8 || d <= 0) return MANTIS_EUNSUPPORTED;
+    if (rows == 0) return MANTIS_OK;
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(norm_grid(rows)), dim3(64 * NORM_WAVES), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, (const bf16_t*)weight, (const bf16_t*)bias, (bf16_t*)y, (long)rows, d, eps);
+    return mantis_check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,106 @@
+// Fused AdamW over flat buffers + global-norm clipping helpers, gfx950.
+//
+// Replaces (reference path): optimizer.step() / clip_grad_norm_ of the HF training loop
+// (transformers/trainer.py:1785-1796, :2535-2545; lr 1e-5, wd 0, max_grad_norm 1.0 per
+// /root/reference/mantis/train/scripts/train_mllava.sh:162-165) which the reference runs through DeepSpeed's fused Adam
+// with fp32 master weights.  All parameters live in ONE flat bf16 arena (and one flat grad arena), so the whole model is
+// a single HBM-bound launch: per element read g(2)+p32(4)+m(4)+v(4), write p32(4)+m(4)+v(4)+p16(2) = 28 B.
+#include "common.h"
+
+__global__ void adamw_kernel(bf16_t* __restrict__ p16, const bf16_t* __restrict__ g16, float* __restrict__ p32,
+                             float* __restrict__ m, float* __restrict__ v, long n8, float lr, float b1, float b2, float eps,
+                             float wd, float bc1, float bc2, const float* __restrict__ gscale) {
+    const float gs = gscale ? *gscale : 1.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        const u32x4 g = *reinterpret_cast<const u32x4*>(g16 + i * 8);
+        f32x4 pa = *reinterpret_cast<f32x4*>(p32 + i * 8), pb = *reinterpret_cast<f32x4*>(p32 + i * 8 + 4);
+        f32x4 ma = *reinterpret_cast<f32x4*>(m + i * 8), mb = *reinterpret_cast<f32x4*>(m + i * 8 + 4);
+        f32x4 va = *reinterpret_cast<f32x4*>(v + i * 8), vb = *reinterpret_cast<f32x4*>(v + i * 8 + 4);
+        float gf[8], pf[8], mf[8], vf[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            gf[2 * e] = bf2f_lo(g[e]) * gs; gf[2 * e + 1] = bf2f_hi(g[e]) * gs;
+            pf[e] = pa[e]; pf[4 + e] = pb[e]; mf[e] = ma[e]; mf[4 + e] = mb[e]; vf[e] = va[e]; vf[4 + e] = vb[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            pf[e] *= (1.f - lr * wd);                         // decoupled weight decay (torch.optim.AdamW)
+            mf[e] = b1 * mf[e] + (1.f - b1) * gf[e];
+            vf[e] = b2 * vf[e] + (1.f - b2) * gf[e] * gf[e];
+            const float denom = sqrtf(vf[e] / bc2) + eps;
+            pf[e] -= (lr / bc1) * (mf[e] / denom);
+        }
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[e] = pack_bf2(pf[2 * e], pf[2 * e + 1]);
+            pa[e] = pf[e]; pb[e] = pf[4 + e]; ma[e] = mf[e]; mb[e] = mf[4 + e]; va[e] = vf[e]; vb[e] = vf[4 + e];
+        }
+        *reinterpret_cast<f32x4*>(p32 + i * 8) = pa; *reinterpret_cast<f32x4*>(p32 + i * 8 + 4) = pb;
+        *reinterpret_cast<f32x4*>(m + i * 8) = ma;   *reinterpret_cast<f32x4*>(m + i * 8 + 4) = mb;
+        *reinterpret_cast<f32x4*>(v + i * 8) = va;   *reinterpret_cast<f32x4*>(v + i * 8 + 4) = vb;
+        *reinterpret_cast<u32x4*>(p16 + i * 8) = o;
+    }
+}
+
+#define SUMSQ_BLOCKS 1024
+__global__ void sumsq_partial_kernel(const bf16_t* __restrict__ x, long n8, float* __restrict__ partial) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(x + i * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float a = bf2f_lo(v[e]), b = bf2f_hi(v[e]); s += a * a + b * b; }
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__global__ void sumsq_finish_kernel(const float* __restrict__ partial, int P, float* __restrict__ out, int accumulate) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) s += partial[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[0] = accumulate ? out[0] + s : s;
+}
+// scale = min(1, max_norm / (norm + 1e-6))   (torch.nn.utils.clip_grad_norm_)
+__global__ void clip_scale_kernel(const float* __restrict__ sumsq, float max_norm, float* __restrict__ scale, float* __restrict__ norm) {
+    const float nrm = sqrtf(sumsq[0]);
+    if (norm) norm[0] = nrm;
+    const float c = max_norm / (nrm + 1e-6f);
+    scale[0] = c < 1.f ? c : 1.f;
+}
+
+extern "C" {
+
+int mantis_adamw(void* param_bf16, const void* grad_bf16, float* master, float* exp_avg, float* exp_avg_sq, int64_t n,
+                 float lr, float beta1, float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2,
+                 const float* grad_scale_dev, void* stream) {
+    if (n % 8) return MANTIS_EUNSUPPORTED;
+    if (n == 0) return MANTIS_OK;
+    long g = (n / 8 + 255) / 256;
+    g = g > 4096 ? 4096 : g;
+    hipLaunchKernelGGL(adamw_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (bf16_t*)param_bf16,
+                       (const bf16_t*)grad_bf16, master, exp_avg, exp_avg_sq, (long)(n / 8), lr, beta1, beta2, eps,
+                       weight_decay, bias_corr1, bias_corr2, grad_scale_dev);
+    return mantis_check_launch();
+}
+
+int mantis_sumsq_partials(int64_t n) { return SUMSQ_BLOCKS; }
+
+int mantis_sumsq(const void* x_bf16, int64_t n, float* partials_ws, float* out, int accumulate, void* stream) {
+    if (n % 8) return MANTIS_EUNSUPPORTED;
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x_bf16,
+                       (long)(n / 8), partials_ws);
+    hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, partials_ws, SUMSQ_BLOCKS, out,
+                       accumulate);
+    return mantis_check_launch();
+}
+
+int mantis_clip_scale(const float* sumsq, float max_norm, float* scale_out, float* norm_out, void* stream) {
+    hipLaunchKernelGGL(clip_scale_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, max_norm, scale_out, norm_out);
+    return mantis_check_launch();
+}
+
+int mantis_version(void) { return 1; }
+
+}  // extern "C"

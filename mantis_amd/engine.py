@@ -1,0 +1,250 @@
+"""Explicit forward + backward of the Mantis LLaVA training step over the HIP operator API (`hip_ops`).
+
+This is the host side of rows B..J of SURVEY.md section 8a: it sequences the gfx950 kernels, owns which activations are
+kept for backward (and which are recomputed), and writes gradients straight into the flat gradient arena -- there is no
+autograd graph.  Reference control flow being reproduced:
+  LlavaForConditionalGeneration.forward        /root/reference/mantis/models/mllava/modeling_llava.py:364-549
+  HF LlamaModel / LlamaDecoderLayer forward    transformers/models/llama/modeling_llama.py:284-325,367-418
+  HF Siglip/CLIP vision encoder forward        transformers/models/siglip/modeling_siglip.py:250-358
+  accelerator.backward(loss)                   transformers/trainer.py:1961  (autograd of all of the above)
+
+Work the reference does that this engine does not (results identical): the last ViT layer + post_layernorm + pooling head
+(dead), the [B,L,V] logits tensor (only rows that can carry a label reach lm_head), 27 kept ViT hidden states.
+"""
+import numpy as np
+import torch
+
+from . import hip_ops as K   # the ONLY compute backend; tests may monkeypatch `engine.K` with the oracle to test host logic
+
+
+class PackCountError(ValueError):
+    pass
+
+
+def _inv_freq(head_dim, theta):
+    # transformers/models/llama/modeling_llama.py:95-110 (default rope), computed on the host in fp32 like the reference
+    return 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+
+
+class LlavaEngine:
+    def __init__(self, model):
+        self.m = model
+        self.cfg = model.config
+
+    # ------------------------------------------------------------------------------------------------ vision tower (frozen)
+    def vision_forward(self, pixels, record=None):
+        """pixels fp32 [I,3,H,W] on device -> selected image features [I*N', d_v] (N' excludes CLS under "default")."""
+        m, vc = self.m, self.cfg.vision_config
+        vt = m.vt
+        I = pixels.shape[0]
+        P, dv = vc.patch_size, vc.hidden_size
+        N = (pixels.shape[2] // P) * (pixels.shape[3] // P)
+        patches = K.im2col(pixels, P, vt["patch_kp"])
+        pe = K.gemm_nt(patches, vt["patch_w_padded"](), bias=vt["patch_b"])
+        x = K.vit_assemble(pe, vt["pos"], vt["cls"], I, N)
+        NT = N + (1 if vt["cls"] is not None else 0)
+        eps = vc.layer_norm_eps
+        if vt["pre_ln"] is not None:
+            x = K.layernorm_fwd(x, vt["pre_ln"][0], vt["pre_ln"][1], eps)
+        nh = vc.num_attention_heads
+        hd = dv // nh
+        n_layers = vc.num_hidden_layers + self.cfg.vision_feature_layer + 1   # hidden_states[-2] = output of layer N-2
+        for i in range(n_layers):
+            lw = vt["layers"][i]
+            y = K.layernorm_fwd(x, lw["ln1_w"], lw["ln1_b"], eps)
+            qkv = K.gemm_nt(y, lw["qkv_w"], bias=lw["qkv_b"])
+            o, _ = K.attn_fwd(qkv, I, NT, nh, nh, hd, None, hd ** -0.5, False, want_lse=False)
+            x = K.gemm_nt(o, lw["out_w"], bias=lw["out_b"], residual=x)
+            y = K.layernorm_fwd(x, lw["ln2_w"], lw["ln2_b"], eps)
+            hmid = K.gemm_nt(y, lw["fc1_w"], bias=lw["fc1_b"], act=vc.hidden_act)
+            x = K.gemm_nt(hmid, lw["fc2_w"], bias=lw["fc2_b"], residual=x)
+        strat = self.cfg.vision_feature_select_strategy
+        if strat == "default":          # modeling_llava.py:460-461
+            if vt["cls"] is None:
+                x = K.drop_cls(x, I, N - 1)
+                N = N - 1
+            else:
+                x = K.drop_cls(x, I, N)
+        elif strat != "full":
+            raise ValueError(f"Unexpected select feature strategy: {strat}")
+        return x, N
+
+    # ------------------------------------------------------------------------------------------------ full step
+    def step(self, input_ids, attention_mask, labels, pixel_values, grad_scale=1.0, loss_scale=1.0, compute_grads=True,
+             overwrite_grads=True, need_logits=False, record=None, on_bucket_ready=None):
+        """One forward (+ backward).  Returns dict(loss=fp32[1] on device, logits=[B,L,V] or None, plan=...).
+
+        grad_scale multiplies d(loss) (1/GA for Trainer.training_step); loss_scale multiplies the returned loss.
+        overwrite_grads: first micro-batch after zero_grad -> gradient kernels overwrite instead of accumulate."""
+        m, cfg, tc = self.m, self.cfg, self.cfg.text_config
+        dev = m.device
+        ids_cpu = input_ids.detach().to("cpu") if input_ids.device.type != "cpu" else input_ids
+        B, T = ids_cpu.shape
+        ign = cfg.ignore_index
+        pad_id = cfg.pad_token_id if cfg.pad_token_id is not None else -1
+        ids_d = input_ids.to(dev, non_blocking=True)
+        attn_d = attention_mask.to(dev, non_blocking=True).to(torch.int64)
+        lab_d = None if labels is None else labels.to(dev, non_blocking=True).to(torch.int64)
+
+        # ---- rows B..E: pixels -> ViT -> projector
+        img = None
+        saved_proj = None
+        I = 0
+        N = 1
+        if pixel_values is not None and T != 1:
+            if isinstance(pixel_values, (list, tuple)):        # modeling_llava.py:431-432
+                pixel_values = torch.cat([p for p in pixel_values if p is not None], dim=0)
+            pix = pixel_values.to(dev, non_blocking=True).to(torch.float32).contiguous()
+            I = pix.shape[0]
+            feats, N = self.vision_forward(pix, record)
+            if record is not None:
+                record["projector_in"] = feats.view(I, N, -1)
+            pw = m.proj
+            h1 = K.gemm_nt(feats, pw["w1"], bias=pw["b1"])
+            a1 = K.act_fwd(h1, cfg.projector_hidden_act)
+            img = K.gemm_nt(a1, pw["w2"], bias=pw["b2"])
+            saved_proj = (feats, h1, a1)
+            if record is not None:
+                record["projector_out"] = img.view(I, N, -1)
+            # modeling_llava.py:347-351 -- the slot count equals (#<image> tokens)*N by construction, so the reference's
+            # check reduces to #tokens == #images; evaluated on the host copy of input_ids (no device sync in the hot loop)
+            n_tok = int((ids_cpu == cfg.image_token_index).sum())
+            if n_tok != I:
+                raise PackCountError(
+                    f"The input provided to the model are wrong. The number of image tokens is {n_tok} while"
+                    f" the number of image given to the model is {I}. This prevents correct indexing and breaks batch generation.")
+            kmax = int((ids_cpu == cfg.image_token_index).sum(-1).max())
+            L = kmax * (N - 1) + T
+            plan = K.pack_plan(ids_d, attn_d, lab_d, N, I, cfg.image_token_index, pad_id, ign, L)
+        else:
+            # text-only: the reference skips the merge; positions default to arange (HF LlamaModel)
+            L = T
+            plan = K.pack_plan(ids_d, attn_d, lab_d, 1, 0, -(2 ** 62), pad_id, ign, L)
+            plan.position_ids = torch.arange(T, device=dev, dtype=torch.int64)[None].expand(B, T).contiguous()
+        emb_w = m.lm["embed"]
+        x = K.pack_rows_fwd(plan, ids_d, emb_w, img)        # rows F+G fused: [B*L, d]
+        if record is not None:
+            record.update(merged_embeds=x.view(B, L, -1), merged_attention_mask=plan.attention_mask,
+                          merged_labels=plan.labels, merged_position_ids=plan.position_ids)
+
+        # ---- row H: Llama decoder
+        d, H, Hkv, hd = tc.hidden_size, tc.num_attention_heads, tc.num_key_value_heads, tc.head_dim
+        eps = tc.rms_norm_eps
+        scale = hd ** -0.5
+        inv_freq = _inv_freq(hd, tc.rope_theta).to(dev)
+        cos, sin = K.rope_table(plan.position_ids.reshape(-1), inv_freq)
+        kmask = plan.kmask
+        saved = []
+        nl = tc.num_hidden_layers
+        for i in range(nl):
+            lw = m.lm["layers"][i]
+            n1, rstd1 = K.rmsnorm_fwd(x, lw["ln1"], eps)
+            qkv = K.gemm_nt(n1, lw["qkv"])
+            K.rope_apply_(qkv, cos, sin, H + Hkv, hd)
+            o, lse = K.attn_fwd(qkv, B, L, H, Hkv, hd, kmask, scale, True)
+            x_mid = K.gemm_nt(o, lw["o"], residual=x)
+            n2, rstd2 = K.rmsnorm_fwd(x_mid, lw["ln2"], eps)
+            gu = K.gemm_nt(n2, lw["gu"])
+            a = K.swiglu_fwd(gu)
+            x_out = K.gemm_nt(a, lw["down"], residual=x_mid)
+            if compute_grads:
+                saved.append((x, rstd1, qkv, o, lse, x_mid, rstd2, gu))
+            x = x_out
+            if record is not None:
+                record[f"llm_layer{i}_out"] = x.view(B, L, -1)
+        del n1, n2, a
+
+        # ---- row I: final norm, lm_head, masked shifted CE
+        V = tc.vocab_size
+        Vp = K.pad8(V)
+        logits_full = None
+        if need_logits:
+            nf_all, _ = K.rmsnorm_fwd(x, m.lm["norm"], eps, want_rstd=False)
+            if record is not None:
+                record["llm_final_norm"] = nf_all.view(B, L, -1)
+            lg = K.gemm_nt(nf_all, m.lm["head"], ldc=Vp)
+            logits_full = lg.view(B, L, Vp)[:, :, :V]
+        loss = None
+        if labels is not None or compute_grads:
+            h_ce = K.gather_rows(x, plan.ce_row)                       # [B*T, d] rows that can carry a label
+            nf, rstdf = K.rmsnorm_fwd(h_ce, m.lm["norm"], eps)
+            logits = K.gemm_nt(nf, m.lm["head"], ldc=Vp)              # [B*T, Vp]
+            loss, count = K.ce_fwd_bwd(logits, plan.ce_tgt, V, grad_scale, loss_scale, write_grad=compute_grads)
+        out = dict(loss=loss, logits=logits_full, plan=plan)
+        if not compute_grads:
+            return out
+
+        # ================================================================================================ backward (row J)
+        g = m.grads                      # dict name -> grad view (None if frozen)
+        acc = not overwrite_grads
+
+        def gw(key):
+            return g.get(key)
+
+        dlogits = logits                 # overwritten in place by the CE kernel
+        if gw("head") is not None:
+            K.linear_dw(dlogits[:, :V], nf, gw("head"), acc)
+        dnf = K.linear_dx(dlogits, m.lm["head"], k=Vp)
+        dh_ce = K.rmsnorm_bwd(dnf, h_ce, m.lm["norm"], rstdf, None, gw("norm"), acc)
+        dx = K.scatter_rows(dh_ce, plan.ce_row, B * L)
+        del dlogits, logits, dnf, nf, h_ce, dh_ce
+        if on_bucket_ready is not None:
+            on_bucket_ready("head")
+
+        for i in reversed(range(nl)):
+            lw = m.lm["layers"][i]
+            lg_ = m.grads_layers[i]
+            x_in, rstd1, qkv, o, lse, x_mid, rstd2, gu = saved.pop()
+            a = K.swiglu_fwd(gu)
+            if lg_["down"] is not None:
+                K.linear_dw(dx, a, lg_["down"], acc)
+            da = K.linear_dx(dx, lw["down"])
+            del a
+            dgu = K.swiglu_bwd(da, gu)
+            del da, gu
+            n2, _ = K.rmsnorm_fwd(x_mid, lw["ln2"], eps, want_rstd=False)
+            if lg_["gu"] is not None:
+                K.linear_dw(dgu, n2, lg_["gu"], acc)
+            dn2 = K.linear_dx(dgu, lw["gu"])
+            del dgu, n2
+            dx_mid = K.rmsnorm_bwd(dn2, x_mid, lw["ln2"], rstd2, dx, lg_["ln2"], acc)
+            del dn2, dx
+            if lg_["o"] is not None:
+                K.linear_dw(dx_mid, o, lg_["o"], acc)
+            do = K.linear_dx(dx_mid, lw["o"])
+            dqkv = K.attn_bwd(qkv, o, do, lse, B, L, H, Hkv, hd, kmask, scale, True)
+            del do, o
+            K.rope_apply_(dqkv, cos, sin, H + Hkv, hd, backward=True)
+            n1, _ = K.rmsnorm_fwd(x_in, lw["ln1"], eps, want_rstd=False)
+            if lg_["qkv"] is not None:
+                K.linear_dw(dqkv, n1, lg_["qkv"], acc)
+            dn1 = K.linear_dx(dqkv, lw["qkv"])
+            del dqkv, n1, qkv
+            dx = K.rmsnorm_bwd(dn1, x_in, lw["ln1"], rstd1, dx_mid, lg_["ln1"], acc)
+            del dn1, dx_mid, x_in
+            if on_bucket_ready is not None:
+                on_bucket_ready(("layer", i))
+
+        # ---- rows G, F, E backward: merged-row grads -> embedding rows + image-feature rows -> projector
+        if gw("embed") is not None:
+            if overwrite_grads:
+                gw("embed").zero_()
+            K.embed_grad(dx, ids_d, plan, gw("embed"), True)
+        if img is not None and (gw("w1") is not None or gw("w2") is not None):
+            feats, h1, a1 = saved_proj
+            dimg = K.gather_rows(dx, plan.img_slot)
+            if gw("b2") is not None:
+                K.colsum(dimg, gw("b2"), acc)
+                K.linear_dw(dimg, a1, gw("w2"), acc)
+            da1 = K.linear_dx(dimg, m.proj["w2"])
+            dh1 = K.act_bwd(da1, h1, cfg.projector_hidden_act)
+            if gw("b1") is not None:
+                K.colsum(dh1, gw("b1"), acc)
+                K.linear_dw(dh1, feats, gw("w1"), acc)
+        elif overwrite_grads:
+            for k in ("w1", "b1", "w2", "b2"):       # no image in this batch: projector receives exactly zero gradient
+                if gw(k) is not None:
+                    gw(k).zero_()
+        if on_bucket_ready is not None:
+            on_bucket_ready("front")
+        return out

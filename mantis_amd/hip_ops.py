@@ -1,0 +1,335 @@
+"""Tensor-level wrappers over the C-ABI (include/mantis_hip.h): torch is used ONLY for device memory and the stream handle.
+
+Every function launches hand-written gfx950 kernels through libmantis_hip.so; nothing here falls back to torch math.
+Conventions: activations are 2-D bf16 [rows, cols] (possibly strided rows), weights are [out, in] as in nn.Linear."""
+import math
+
+import torch
+
+from . import _lib
+
+_L = _lib.load()
+BF16 = torch.bfloat16
+ACT_KIND = {"gelu": 0, "gelu_pytorch_tanh": 1, "quick_gelu": 2, "silu": 3}
+GEMM_ACT = {None: 0, "gelu": 1, "gelu_pytorch_tanh": 2, "quick_gelu": 3}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _chk2d(t, name):
+    if t.dtype != BF16 or t.dim() != 2 or t.stride(1) != 1 or not t.is_cuda:
+        raise ValueError(f"{name}: expected a 2-D bf16 CUDA tensor with unit column stride, got {t.dtype} {tuple(t.shape)} "
+                         f"{t.stride()} {t.device}")
+
+
+def pad8(n):
+    return (n + 7) // 8 * 8
+
+
+# ----------------------------------------------------------------------------------------------------------- GEMM family
+def gemm_nt(a, b, bias=None, act=None, residual=None, out=None, accumulate=False, n_valid=None, k=None, ldc=None):
+    """out[M,N] = epi(a[M,K] @ b[N,K]^T).  `k` overrides the contraction length (zero-padded operands)."""
+    _chk2d(a, "a"), _chk2d(b, "b")
+    M, K = a.shape
+    N = b.shape[0] if n_valid is None else n_valid
+    K = K if k is None else k
+    if out is None:
+        out = torch.empty((M, N if ldc is None else ldc), dtype=BF16, device=a.device)   # ldc > N: padded row stride
+    else:
+        _chk2d(out, "out")
+    C = out
+    flags = (1 if bias is not None else 0) | (GEMM_ACT[act] << 1) | (16 if residual is not None else 0) | (32 if accumulate else 0)
+    rc = _L.mantis_gemm_bf16_nt(_p(a), a.stride(0), _p(b), b.stride(0), _p(C), C.stride(0), M, N, K, _p(bias), _p(residual),
+                                0 if residual is None else residual.stride(0), flags, _stream())
+    _lib.check(rc, f"gemm_nt M={M} N={N} K={K}")
+    return out
+
+
+def transpose(x, rpad=None):
+    """[R, C] -> [C, Rpad] (Rpad = R rounded up to 8, zero filled)."""
+    _chk2d(x, "x")
+    R, C = x.shape
+    Rp = pad8(R) if rpad is None else rpad
+    out = torch.empty((C, Rp), dtype=BF16, device=x.device)
+    rc = _L.mantis_transpose(_p(x), _p(out), R, C, Rp, x.stride(0), Rp, 1, 1, 0, 0, 0, 0, _stream())
+    _lib.check(rc, f"transpose {R}x{C}")
+    return out
+
+
+def transpose_heads(x, B, Lseq, nheads, hd, col0, Lp):
+    """x: [B*L, ld] activation; heads at columns col0 + h*hd.  Returns [B, nheads, hd, Lp] (sequence contiguous)."""
+    _chk2d(x, "x")
+    out = torch.empty((B, nheads, hd, Lp), dtype=BF16, device=x.device)
+    ld = x.stride(0)
+    base = x.data_ptr() + col0 * 2
+    rc = _L.mantis_transpose(base, _p(out), Lseq, hd, Lp, ld, Lp, B, nheads, Lseq * ld, hd, nheads * hd * Lp, hd * Lp,
+                             _stream())
+    _lib.check(rc, "transpose_heads")
+    return out
+
+
+def linear_fwd(x, w, bias=None, act=None, residual=None):
+    return gemm_nt(x, w, bias=bias, act=act, residual=residual)
+
+
+def linear_dx(dy, w, k=None):
+    """dx[M, in] = dy[M, out] @ w[out, in]   (NT GEMM on w^T)."""
+    wt = transpose(w)                       # [in, pad8(out)]
+    return gemm_nt(dy, wt, k=wt.shape[1] if k is None else k)
+
+
+def linear_dw(dy, x, grad_w, accumulate):
+    """grad_w[out, in] (+)= dy[M, out]^T @ x[M, in]."""
+    dyt = transpose(dy)                     # [out (+pad columns of dy), Mp]
+    xt = transpose(x)                       # [in, Mp]
+    gemm_nt(dyt[: grad_w.shape[0]], xt, out=grad_w, accumulate=accumulate, k=dyt.shape[1])
+
+
+def colsum(x, grad, accumulate):
+    """grad[N] (+)= sum_m x[m, n]  (bias gradient)."""
+    _chk2d(x, "x")
+    M, N = x.shape
+    P = _L.mantis_colsum_partials(M)
+    ws = torch.empty((P, N), dtype=torch.float32, device=x.device)
+    _lib.check(_L.mantis_colsum(_p(x), _p(grad), int(accumulate), _p(ws), M, N, x.stride(0), _stream()), "colsum")
+
+
+# ----------------------------------------------------------------------------------------------------------- norms / acts
+def rmsnorm_fwd(x, w, eps, want_rstd=True):
+    _chk2d(x, "x")
+    rows, d = x.shape
+    y = torch.empty_like(x)
+    rstd = torch.empty((rows,), dtype=torch.float32, device=x.device) if want_rstd else None
+    _lib.check(_L.mantis_rmsnorm_fwd(_p(x), _p(w), _p(y), _p(rstd), rows, d, float(eps), _stream()), "rmsnorm_fwd")
+    return y, rstd
+
+
+def rmsnorm_bwd(dy, x, w, rstd, dres, grad_w, accumulate):
+    rows, d = x.shape
+    dx = torch.empty_like(x)
+    ws = None
+    if grad_w is not None:
+        ws = torch.empty((_L.mantis_rmsnorm_bwd_partials(rows), d), dtype=torch.float32, device=x.device)
+    _lib.check(_L.mantis_rmsnorm_bwd(_p(dy), _p(x), _p(w), _p(rstd), _p(dres), _p(dx), _p(grad_w), int(accumulate), _p(ws),
+                                     rows, d, _stream()), "rmsnorm_bwd")
+    return dx
+
+
+def layernorm_fwd(x, w, b, eps):
+    _chk2d(x, "x")
+    y = torch.empty_like(x)
+    _lib.check(_L.mantis_layernorm_fwd(_p(x), _p(w), _p(b), _p(y), x.shape[0], x.shape[1], float(eps), _stream()), "layernorm")
+    return y
+
+
+def swiglu_fwd(gu):
+    M, I2 = gu.shape
+    out = torch.empty((M, I2 // 2), dtype=BF16, device=gu.device)
+    _lib.check(_L.mantis_swiglu_fwd(_p(gu), _p(out), M, I2 // 2, gu.stride(0), _stream()), "swiglu_fwd")
+    return out
+
+
+def swiglu_bwd(dact, gu):
+    M, I2 = gu.shape
+    dgu = torch.empty_like(gu)
+    _lib.check(_L.mantis_swiglu_bwd(_p(dact), _p(gu), _p(dgu), M, I2 // 2, gu.stride(0), _stream()), "swiglu_bwd")
+    return dgu
+
+
+def act_fwd(x, kind):
+    y = torch.empty_like(x)
+    _lib.check(_L.mantis_act_fwd(_p(x), _p(y), x.numel(), ACT_KIND[kind], _stream()), "act_fwd")
+    return y
+
+
+def act_bwd(dy, x, kind):
+    dx = torch.empty_like(x)
+    _lib.check(_L.mantis_act_bwd(_p(dy), _p(x), _p(dx), x.numel(), ACT_KIND[kind], _stream()), "act_bwd")
+    return dx
+
+
+def add(a, b):
+    y = torch.empty_like(a)
+    _lib.check(_L.mantis_add(_p(a), _p(b), _p(y), a.numel(), _stream()), "add")
+    return y
+
+
+# ----------------------------------------------------------------------------------------------------------- rope / attention
+def rope_table(position_ids, inv_freq):
+    """position_ids int64 [R]; inv_freq fp32 [hd/2] (computed on the host exactly as the reference does)."""
+    R, half = position_ids.numel(), inv_freq.numel()
+    cos = torch.empty((R, half), dtype=BF16, device=position_ids.device)
+    sin = torch.empty_like(cos)
+    _lib.check(_L.mantis_rope_table(_p(position_ids), _p(inv_freq), _p(cos), _p(sin), R, half, _stream()), "rope_table")
+    return cos, sin
+
+
+def rope_apply_(x, cos, sin, nheads, hd, backward=False):
+    _chk2d(x, "x")
+    _lib.check(_L.mantis_rope_apply(_p(x), _p(cos), _p(sin), x.shape[0], nheads, hd, x.stride(0), int(backward), _stream()),
+               "rope_apply")
+    return x
+
+
+def attn_fwd(qkv, B, Lseq, H, Hkv, hd, kmask, scale, causal, want_lse=True):
+    """qkv: [B*L, (H+2Hkv)*hd] fused projection output (q | k | v).  Returns o [B*L, H*hd], lse [B,H,L], vt."""
+    _chk2d(qkv, "qkv")
+    Lp = pad8(Lseq)
+    ld = qkv.stride(0)
+    vt = transpose_heads(qkv, B, Lseq, Hkv, hd, (H + Hkv) * hd, Lp)
+    o = torch.empty((B * Lseq, H * hd), dtype=BF16, device=qkv.device)
+    lse = torch.empty((B, H, Lseq), dtype=torch.float32, device=qkv.device) if want_lse else None
+    q_ptr = qkv.data_ptr()
+    k_ptr = q_ptr + H * hd * 2
+    rc = _L.mantis_attn_fwd(q_ptr, k_ptr, _p(vt), _p(kmask), _p(o), _p(lse), B, Lseq, Lp, H, Hkv, hd, ld, ld, H * hd,
+                            float(scale), int(causal), _stream())
+    _lib.check(rc, f"attn_fwd hd={hd}")
+    return o, lse
+
+
+def attn_bwd(qkv, o, do, lse, B, Lseq, H, Hkv, hd, kmask, scale, causal):
+    """Returns dqkv [B*L, (H+2Hkv)*hd] (gradient w.r.t. the post-RoPE q, k and v)."""
+    Lp = pad8(Lseq)
+    ld = qkv.stride(0)
+    dsum = torch.empty((B, H, Lseq), dtype=torch.float32, device=qkv.device)
+    _lib.check(_L.mantis_attn_dsum(_p(do), _p(o), _p(dsum), B, Lseq, H, hd, do.stride(0), _stream()), "attn_dsum")
+    qt = transpose_heads(qkv, B, Lseq, H, hd, 0, Lp)
+    kt = transpose_heads(qkv, B, Lseq, Hkv, hd, H * hd, Lp)
+    dot = transpose_heads(do, B, Lseq, H, hd, 0, Lp)
+    dqkv = torch.empty_like(qkv)
+    q_ptr = qkv.data_ptr()
+    k_ptr = q_ptr + H * hd * 2
+    v_ptr = q_ptr + (H + Hkv) * hd * 2
+    dq_ptr = dqkv.data_ptr()
+    dk_ptr = dq_ptr + H * hd * 2
+    dv_ptr = dq_ptr + (H + Hkv) * hd * 2
+    ldd = dqkv.stride(0)
+    rc = _L.mantis_attn_bwd(q_ptr, k_ptr, v_ptr, _p(qt), _p(kt), _p(do), _p(dot), _p(kmask), _p(lse), _p(dsum), dq_ptr, dk_ptr,
+                            dv_ptr, B, Lseq, Lp, H, Hkv, hd, ld, ld, ld, do.stride(0), ldd, ldd, ldd, float(scale),
+                            int(causal), _stream())
+    _lib.check(rc, f"attn_bwd hd={hd}")
+    return dqkv
+
+
+# ----------------------------------------------------------------------------------------------------------- packing / loss
+class PackPlan:
+    __slots__ = ("B", "T", "L", "N", "I", "src", "attention_mask", "labels", "position_ids", "kmask", "text_pos", "img_slot",
+                 "ce_row", "ce_tgt", "status")
+
+
+def pack_plan(input_ids, attention_mask, labels, num_patches, num_images, image_token_index, pad_token_id, ignore_index, L):
+    B, T = input_ids.shape
+    dev = input_ids.device
+    pl = PackPlan()
+    pl.B, pl.T, pl.L, pl.N, pl.I = B, T, L, num_patches, num_images
+    pl.src = torch.empty((B, L), dtype=torch.int32, device=dev)
+    pl.attention_mask = torch.empty((B, L), dtype=torch.int64, device=dev)
+    pl.labels = torch.empty((B, L), dtype=torch.int64, device=dev)
+    pl.position_ids = torch.empty((B, L), dtype=torch.int64, device=dev)
+    pl.kmask = torch.empty((B, L), dtype=torch.int32, device=dev)
+    pl.text_pos = torch.empty((B, T), dtype=torch.int32, device=dev)
+    pl.img_slot = torch.full((max(1, num_images * num_patches),), -1, dtype=torch.int32, device=dev)
+    pl.ce_row = torch.empty((B * T,), dtype=torch.int32, device=dev)
+    pl.ce_tgt = torch.empty((B * T,), dtype=torch.int32, device=dev)
+    pl.status = torch.zeros((4,), dtype=torch.int32, device=dev)
+    rc = _L.mantis_pack_plan(_p(input_ids), _p(attention_mask), _p(labels), B, T, num_patches, num_images, image_token_index,
+                             pad_token_id, ignore_index, L, _p(pl.src), _p(pl.attention_mask), _p(pl.labels),
+                             _p(pl.position_ids), _p(pl.kmask), _p(pl.text_pos), _p(pl.img_slot), _p(pl.ce_row), _p(pl.ce_tgt),
+                             _p(pl.status), _stream())
+    _lib.check(rc, "pack_plan")
+    return pl
+
+
+def pack_rows_fwd(plan, input_ids, embed_weight, image_features):
+    d = embed_weight.shape[1]
+    out = torch.empty((plan.B * plan.L, d), dtype=BF16, device=embed_weight.device)
+    rc = _L.mantis_pack_rows_fwd(_p(plan.src), _p(input_ids), _p(embed_weight), _p(image_features), _p(out), plan.B, plan.T,
+                                 plan.L, d, embed_weight.shape[0], _stream())
+    _lib.check(rc, "pack_rows_fwd")
+    return out
+
+
+def gather_rows(x, idx):
+    out = torch.empty((idx.numel(), x.shape[1]), dtype=BF16, device=x.device)
+    _lib.check(_L.mantis_gather_rows(_p(x), _p(idx), _p(out), idx.numel(), x.shape[1], _stream()), "gather_rows")
+    return out
+
+
+def scatter_rows(x, idx, nrows_out):
+    out = torch.zeros((nrows_out, x.shape[1]), dtype=BF16, device=x.device)
+    _lib.check(_L.mantis_scatter_rows(_p(x), _p(idx), _p(out), idx.numel(), x.shape[1], _stream()), "scatter_rows")
+    return out
+
+
+def embed_grad(dmerged, input_ids, plan, grad_weight, accumulate):
+    n = plan.B * plan.T
+    ws = torch.empty((2, n), dtype=torch.int32, device=dmerged.device)
+    rc = _L.mantis_embed_grad(_p(dmerged), _p(input_ids), _p(plan.text_pos), ws[0].data_ptr(), ws[1].data_ptr(), _p(grad_weight),
+                              plan.B, plan.T, plan.L, dmerged.shape[1], grad_weight.shape[0], int(accumulate), _stream())
+    _lib.check(rc, "embed_grad")
+
+
+def ce_fwd_bwd(logits, targets, V, grad_scale, loss_scale, write_grad=True):
+    """logits [R, ld>=pad8(V)] bf16 -> overwritten with dlogits; returns (loss[1] fp32, count[1] int32)."""
+    R = logits.shape[0]
+    ws = torch.empty((R,), dtype=torch.float32, device=logits.device)
+    count = torch.empty((1,), dtype=torch.int32, device=logits.device)
+    loss = torch.empty((1,), dtype=torch.float32, device=logits.device)
+    rc = _L.mantis_ce_fwd_bwd(_p(logits), _p(targets), R, V, logits.stride(0), float(grad_scale), float(loss_scale),
+                              int(write_grad), _p(ws), None, _p(count), _p(loss), _stream())
+    _lib.check(rc, "ce_fwd_bwd")
+    return loss, count
+
+
+# ----------------------------------------------------------------------------------------------------------- ViT front end
+def im2col(pixels, patch, kp):
+    I, C, H, W = pixels.shape
+    n = (H // patch) * (W // patch)
+    out = torch.empty((I * n, kp), dtype=BF16, device=pixels.device)
+    _lib.check(_L.mantis_im2col(_p(pixels), _p(out), I, C, H, W, patch, kp, _stream()), "im2col")
+    return out
+
+
+def vit_assemble(patch_out, pos_emb, cls_emb, I, N):
+    d = patch_out.shape[1]
+    nt = N + (1 if cls_emb is not None else 0)
+    out = torch.empty((I * nt, d), dtype=BF16, device=patch_out.device)
+    _lib.check(_L.mantis_vit_assemble(_p(patch_out), _p(pos_emb), _p(cls_emb), _p(out), I, N, d, _stream()), "vit_assemble")
+    return out
+
+
+def drop_cls(x, I, N):
+    out = torch.empty((I * N, x.shape[1]), dtype=BF16, device=x.device)
+    _lib.check(_L.mantis_drop_cls(_p(x), _p(out), I, N, x.shape[1], _stream()), "drop_cls")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------- optimizer
+def adamw_flat(param, grad, master, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=None):
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    rc = _L.mantis_adamw(_p(param), _p(grad), _p(master), _p(m), _p(v), param.numel(), lr, beta1, beta2, eps, wd, bc1, bc2,
+                         _p(grad_scale), _stream())
+    _lib.check(rc, "adamw")
+
+
+def grad_sumsq(x, out, accumulate=False):
+    ws = torch.empty((_L.mantis_sumsq_partials(x.numel()),), dtype=torch.float32, device=x.device)
+    _lib.check(_L.mantis_sumsq(_p(x), x.numel(), _p(ws), _p(out), int(accumulate), _stream()), "sumsq")
+
+
+def clip_scale(sumsq, max_norm):
+    scale = torch.empty((1,), dtype=torch.float32, device=sumsq.device)
+    norm = torch.empty((1,), dtype=torch.float32, device=sumsq.device)
+    _lib.check(_L.mantis_clip_scale(_p(sumsq), float(max_norm), _p(scale), _p(norm), _stream()), "clip_scale")
+    return scale, norm
+
+
+def synchronize():
+    torch.cuda.synchronize()

@@ -1,0 +1,414 @@
+"""Drop-in module for the reference's `LlavaForConditionalGeneration`
+(/root/reference/mantis/models/mllava/modeling_llava.py:251-262 constructor, :364-549 forward): same forward keyword
+arguments, same output fields, same parameter names (state_dict-compatible with the reference / HF checkpoints), but
+
+  * every parameter is a VIEW into one flat bf16 arena in HBM (and every gradient a view into one flat gradient arena):
+    q|k|v and gate|up are stored adjacently so the fused projections are zero-copy views, data-parallel buckets are
+    contiguous slices, and the optimizer is a single launch over the arena;
+  * forward+backward run through `LlavaEngine` (hand-written gfx950 kernels via the C-ABI), not autograd.
+
+`forward(..., labels=...)` in training mode with grad enabled runs the fused forward+backward and returns a loss whose
+`.backward()` (called by a stock `transformers.Trainer`) publishes the already-computed gradients scaled by the incoming
+gradient; `MantisHipTrainer.training_step` (trainer.py) skips even that and accumulates straight into `.grad`.
+"""
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+from torch import nn
+
+from .configuration_llava import LlavaConfig
+from . import engine as _engine
+
+
+@dataclass
+class LlavaCausalLMOutputWithPast:
+    """modeling_llava.py:63-103"""
+    loss: Optional[torch.Tensor] = None
+    logits: Optional[torch.Tensor] = None
+    past_key_values: Optional[Tuple] = None
+    hidden_states: Optional[Tuple] = None
+    attentions: Optional[Tuple] = None
+    image_hidden_states: Optional[Tuple] = None
+
+    def __getitem__(self, k):
+        if isinstance(k, str):
+            return getattr(self, k)
+        return tuple(v for v in (self.loss, self.logits, self.past_key_values, self.hidden_states, self.attentions,
+                                 self.image_hidden_states) if v is not None)[k]
+
+    def keys(self):
+        return [k for k in ("loss", "logits", "past_key_values", "hidden_states", "attentions", "image_hidden_states")
+                if getattr(self, k) is not None]
+
+
+def _param_specs(cfg: LlavaConfig):
+    """(name, shape) in ARENA ORDER: [vision tower | projector | embed | layer 0..n-1 | final norm | lm_head]."""
+    vc, tc = cfg.vision_config, cfg.text_config
+    dv, iv, P, C = vc.hidden_size, vc.intermediate_size, vc.patch_size, vc.num_channels
+    is_clip = vc.model_type == "clip_vision_model"
+    npos = (vc.image_size // P) ** 2 + (1 if is_clip else 0)
+    s = []
+    vtp = "vision_tower."
+    if is_clip:
+        s.append((vtp + "embeddings.class_embedding", (dv,)))
+    s.append((vtp + "embeddings.patch_embedding.weight", (dv, C, P, P)))
+    if not is_clip:
+        s.append((vtp + "embeddings.patch_embedding.bias", (dv,)))
+    s.append((vtp + "embeddings.position_embedding.weight", (npos, dv)))
+    if is_clip:
+        s += [(vtp + "pre_layrnorm.weight", (dv,)), (vtp + "pre_layrnorm.bias", (dv,))]
+    for i in range(vc.num_hidden_layers):
+        p = f"{vtp}encoder.layers.{i}."
+        s += [(p + "self_attn.q_proj.weight", (dv, dv)), (p + "self_attn.k_proj.weight", (dv, dv)),
+              (p + "self_attn.v_proj.weight", (dv, dv)),
+              (p + "self_attn.q_proj.bias", (dv,)), (p + "self_attn.k_proj.bias", (dv,)), (p + "self_attn.v_proj.bias", (dv,)),
+              (p + "self_attn.out_proj.weight", (dv, dv)), (p + "self_attn.out_proj.bias", (dv,)),
+              (p + "layer_norm1.weight", (dv,)), (p + "layer_norm1.bias", (dv,)),
+              (p + "layer_norm2.weight", (dv,)), (p + "layer_norm2.bias", (dv,)),
+              (p + "mlp.fc1.weight", (iv, dv)), (p + "mlp.fc1.bias", (iv,)),
+              (p + "mlp.fc2.weight", (dv, iv)), (p + "mlp.fc2.bias", (dv,))]
+    s += [(vtp + "post_layernorm.weight", (dv,)), (vtp + "post_layernorm.bias", (dv,))]
+    d, it, V = tc.hidden_size, tc.intermediate_size, tc.vocab_size
+    H, Hkv, hd = tc.num_attention_heads, tc.num_key_value_heads, tc.head_dim
+    s += [("multi_modal_projector.linear_1.weight", (d, dv)), ("multi_modal_projector.linear_1.bias", (d,)),
+          ("multi_modal_projector.linear_2.weight", (d, d)), ("multi_modal_projector.linear_2.bias", (d,))]
+    s.append(("language_model.model.embed_tokens.weight", (V, d)))
+    for i in range(tc.num_hidden_layers):
+        p = f"language_model.model.layers.{i}."
+        s += [(p + "self_attn.q_proj.weight", (H * hd, d)), (p + "self_attn.k_proj.weight", (Hkv * hd, d)),
+              (p + "self_attn.v_proj.weight", (Hkv * hd, d)), (p + "self_attn.o_proj.weight", (d, H * hd)),
+              (p + "mlp.gate_proj.weight", (it, d)), (p + "mlp.up_proj.weight", (it, d)),
+              (p + "mlp.down_proj.weight", (d, it)),
+              (p + "input_layernorm.weight", (d,)), (p + "post_attention_layernorm.weight", (d,))]
+    s += [("language_model.model.norm.weight", (d,)), ("language_model.lm_head.weight", (V, d))]
+    return s
+
+
+def _numel(shape):
+    n = 1
+    for x in shape:
+        n *= x
+    return n
+
+
+class LlavaForConditionalGeneration(nn.Module):
+    config_class = LlavaConfig
+    supports_gradient_checkpointing = False
+
+    def __init__(self, config: LlavaConfig, device=None, dtype=torch.bfloat16, init="normal", seed=0):
+        super().__init__()
+        if dtype != torch.bfloat16:
+            raise NotImplementedError("the gfx950 path computes in bf16 (fp32 accumulate); construct with dtype=torch.bfloat16")
+        self.config = config
+        self.vocab_size = config.vocab_size
+        self.pad_token_id = config.pad_token_id if config.pad_token_id is not None else -1
+        dev = torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        specs = _param_specs(config)
+        offs, off = {}, 0
+        for name, shape in specs:
+            offs[name] = off
+            off += (_numel(shape) + 7) // 8 * 8       # keep every parameter 16-byte aligned
+        self._specs, self._offs, self._arena_numel = specs, offs, off
+        self.arena = torch.zeros(off, dtype=dtype, device=dev)
+        self._trainable_start = offs["multi_modal_projector.linear_1.weight"]
+        for name, shape in specs:
+            view = self.arena[offs[name]: offs[name] + _numel(shape)].view(shape)
+            p = nn.Parameter(view, requires_grad=not name.startswith("vision_tower."))   # train_mllava.py:240-242
+            self._attach(name, p)
+        self.grad_arena = None
+        self._grad_offs = None
+        self.engine = _engine.LlavaEngine(self)
+        self._build_views()
+        if init == "normal":
+            self.reset_parameters(seed)
+        self.train()
+
+    # ------------------------------------------------------------------ module tree with the reference's parameter names
+    def _attach(self, dotted, param):
+        mod = self
+        parts = dotted.split(".")
+        for p in parts[:-1]:
+            if p not in mod._modules:
+                mod.add_module(p, nn.Module())
+            mod = mod._modules[p]
+        mod.register_parameter(parts[-1], param)
+
+    def _param(self, name):
+        mod = self
+        parts = name.split(".")
+        for p in parts[:-1]:
+            mod = mod._modules[p]
+        return mod._parameters[parts[-1]]
+
+    def _flat(self, first, last_incl, rows, cols):
+        a = self._offs[first]
+        b = self._offs[last_incl] + _numel(dict(self._specs)[last_incl])
+        assert b - a == rows * cols, (first, last_incl, b - a, rows, cols)
+        return self.arena[a:b].view(rows, cols)
+
+    @property
+    def device(self):
+        return self.arena.device
+
+    @property
+    def dtype(self):
+        return self.arena.dtype
+
+    def _build_views(self):
+        cfg, vc, tc = self.config, self.config.vision_config, self.config.text_config
+        g = lambda n: self._param(n).data
+        dv, P, C = vc.hidden_size, vc.patch_size, vc.num_channels
+        is_clip = vc.model_type == "clip_vision_model"
+        vtp = "vision_tower."
+        kraw = C * P * P
+        kp = (kraw + 7) // 8 * 8
+
+        def patch_w_padded():
+            w = g(vtp + "embeddings.patch_embedding.weight").view(dv, kraw)
+            if kp == kraw:
+                return w
+            out = torch.zeros((dv, kp), dtype=w.dtype, device=w.device)
+            out[:, :kraw] = w
+            return out
+        layers = []
+        for i in range(vc.num_hidden_layers):
+            p = f"{vtp}encoder.layers.{i}."
+            layers.append(dict(
+                qkv_w=self._flat(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", 3 * dv, dv),
+                qkv_b=self._flat(p + "self_attn.q_proj.bias", p + "self_attn.v_proj.bias", 1, 3 * dv).view(-1),
+                out_w=g(p + "self_attn.out_proj.weight"), out_b=g(p + "self_attn.out_proj.bias"),
+                ln1_w=g(p + "layer_norm1.weight"), ln1_b=g(p + "layer_norm1.bias"),
+                ln2_w=g(p + "layer_norm2.weight"), ln2_b=g(p + "layer_norm2.bias"),
+                fc1_w=g(p + "mlp.fc1.weight"), fc1_b=g(p + "mlp.fc1.bias"),
+                fc2_w=g(p + "mlp.fc2.weight"), fc2_b=g(p + "mlp.fc2.bias")))
+        self.vt = dict(patch_kp=kp, patch_w_padded=patch_w_padded,
+                       patch_b=None if is_clip else g(vtp + "embeddings.patch_embedding.bias"),
+                       pos=g(vtp + "embeddings.position_embedding.weight"),
+                       cls=g(vtp + "embeddings.class_embedding") if is_clip else None,
+                       pre_ln=(g(vtp + "pre_layrnorm.weight"), g(vtp + "pre_layrnorm.bias")) if is_clip else None,
+                       layers=layers)
+        self.proj = dict(w1=g("multi_modal_projector.linear_1.weight"), b1=g("multi_modal_projector.linear_1.bias"),
+                         w2=g("multi_modal_projector.linear_2.weight"), b2=g("multi_modal_projector.linear_2.bias"))
+        d, it = tc.hidden_size, tc.intermediate_size
+        H, Hkv, hd = tc.num_attention_heads, tc.num_key_value_heads, tc.head_dim
+        ll = []
+        for i in range(tc.num_hidden_layers):
+            p = f"language_model.model.layers.{i}."
+            ll.append(dict(qkv=self._flat(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", (H + 2 * Hkv) * hd, d),
+                           o=g(p + "self_attn.o_proj.weight"),
+                           gu=self._flat(p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight", 2 * it, d),
+                           down=g(p + "mlp.down_proj.weight"),
+                           ln1=g(p + "input_layernorm.weight"), ln2=g(p + "post_attention_layernorm.weight")))
+        self.lm = dict(embed=g("language_model.model.embed_tokens.weight"), layers=ll,
+                       norm=g("language_model.model.norm.weight"), head=g("language_model.lm_head.weight"))
+
+    @torch.no_grad()
+    def reset_parameters(self, seed=0):
+        """normal(0, initializer_range), norm weights 1, biases 0 (modeling_llava.py:150-170 / HF _init_weights)."""
+        std = self.config.text_config.get("initializer_range", 0.02)
+        gen = torch.Generator(device=self.device).manual_seed(seed)
+        for name, p in self.named_parameters():
+            if p.dim() == 1 and "class_embedding" not in name:
+                p.fill_(1.0 if ("norm" in name and name.endswith("weight")) else 0.0)
+            else:
+                # chunked to bound the fp32 temporary (lm_head is 0.5 G elements)
+                flat = p.view(-1)
+                step = 1 << 26
+                for a in range(0, flat.numel(), step):
+                    b = min(flat.numel(), a + step)
+                    flat[a:b] = torch.randn(b - a, generator=gen, device=self.device, dtype=torch.float32).mul_(std)
+
+    # ------------------------------------------------------------------ reference-compatible accessors
+    def get_input_embeddings(self):
+        return self.language_model.model.embed_tokens
+
+    def get_output_embeddings(self):
+        return self.language_model.lm_head
+
+    def tie_weights(self, *a, **k):
+        return None
+
+    def load_reference_state_dict(self, sd, strict=True):
+        """Accepts the reference's state_dict names (HF-5 flat `vision_tower.*` or 4.x `vision_tower.vision_model.*`);
+        pooling-head tensors of SigLIP (dead on this path) are ignored."""
+        own = dict(self.named_parameters())
+        seen = set()
+        with torch.no_grad():
+            for k, v in sd.items():
+                k2 = k.replace("vision_tower.vision_model.", "vision_tower.")
+                if k2 not in own:
+                    if ".head." in k2 or k2.endswith("position_ids"):
+                        continue
+                    if strict:
+                        raise KeyError(f"unexpected key {k}")
+                    continue
+                t = torch.as_tensor(v)
+                own[k2].copy_(t.to(own[k2].dtype).reshape(own[k2].shape))
+                seen.add(k2)
+        missing = [k for k in own if k not in seen]
+        if strict and missing:
+            raise KeyError(f"missing keys: {missing[:5]}...")
+        return missing
+
+    def _apply(self, fn, recurse=True):
+        # parameters are views of one arena; moving / casting them individually would break the fused layouts
+        probe = fn(torch.zeros(1, dtype=self.arena.dtype, device=self.arena.device))
+        if probe.dtype != self.arena.dtype or probe.device != self.arena.device:
+            raise RuntimeError("LlavaForConditionalGeneration lives in a flat bf16 arena: construct it with device=... instead "
+                               "of calling .to()/.half()/.float()")
+        return self
+
+    # ------------------------------------------------------------------ gradients
+    def _ensure_grad_arena(self):
+        """(Re)attach `.grad` views.  Returns True if the gradients are known to be zero-initialised garbage that the
+        next backward may OVERWRITE (i.e. every trainable .grad was None, the state after Trainer's model.zero_grad())."""
+        trainable = [(n, p) for n, p in self.named_parameters() if p.requires_grad]
+        key = tuple(n for n, _ in trainable)
+        if self.grad_arena is None or self._grad_key != key:
+            offs, off = {}, 0
+            for n, p in trainable:
+                offs[n] = off
+                off += (p.numel() + 7) // 8 * 8
+            self.grad_arena = torch.zeros(off, dtype=self.arena.dtype, device=self.device)
+            self._grad_offs, self._grad_key = offs, key
+            self._grad_views = {n: self.grad_arena[offs[n]: offs[n] + p.numel()].view(p.shape) for n, p in trainable}
+            self._build_grad_views()
+            for n, p in trainable:
+                p.grad = None
+        all_none = all(p.grad is None for _, p in trainable)
+        for n, p in trainable:
+            if p.grad is None:
+                if not all_none:
+                    self._grad_views[n].zero_()
+                p.grad = self._grad_views[n]
+            elif p.grad.data_ptr() != self._grad_views[n].data_ptr():
+                # a foreign gradient tensor was installed: fold it into the arena view
+                self._grad_views[n].copy_(p.grad)
+                p.grad = self._grad_views[n]
+        return all_none
+
+    def _gflat(self, first, last_incl, rows, cols):
+        if first not in self._grad_offs:
+            return None
+        if last_incl not in self._grad_offs:
+            raise NotImplementedError(f"{first}..{last_incl} must be trainable together (fused projection)")
+        a = self._grad_offs[first]
+        b = self._grad_offs[last_incl] + self._param(last_incl).numel()
+        assert b - a == rows * cols
+        return self.grad_arena[a:b].view(rows, cols)
+
+    def _build_grad_views(self):
+        tc = self.config.text_config
+        gv = self._grad_views.get
+        d, it = tc.hidden_size, tc.intermediate_size
+        H, Hkv, hd = tc.num_attention_heads, tc.num_key_value_heads, tc.head_dim
+        self.grads = dict(head=gv("language_model.lm_head.weight"), norm=gv("language_model.model.norm.weight"),
+                          embed=gv("language_model.model.embed_tokens.weight"),
+                          w1=gv("multi_modal_projector.linear_1.weight"), b1=gv("multi_modal_projector.linear_1.bias"),
+                          w2=gv("multi_modal_projector.linear_2.weight"), b2=gv("multi_modal_projector.linear_2.bias"))
+        self.grads_layers = []
+        for i in range(tc.num_hidden_layers):
+            p = f"language_model.model.layers.{i}."
+            self.grads_layers.append(dict(
+                qkv=self._gflat(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", (H + 2 * Hkv) * hd, d),
+                o=gv(p + "self_attn.o_proj.weight"),
+                gu=self._gflat(p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight", 2 * it, d),
+                down=gv(p + "mlp.down_proj.weight"), ln1=gv(p + "input_layernorm.weight"),
+                ln2=gv(p + "post_attention_layernorm.weight")))
+
+    def grad_buckets(self):
+        """Contiguous slices of the gradient arena in the order backward completes them (for the DP reducer):
+        'head' (final norm + lm_head), ('layer', n-1) .. ('layer', 0), 'front' (projector + embedding)."""
+        self._ensure_grad_arena()
+        offs = self._grad_offs
+        names = list(self._grad_key)
+
+        def span(pred):
+            sel = [n for n in names if pred(n)]
+            if not sel:
+                return None
+            a = min(offs[n] for n in sel)
+            b = max(offs[n] + (self._param(n).numel() + 7) // 8 * 8 for n in sel)
+            return self.grad_arena[a:b]
+        out = {"head": span(lambda n: n.startswith("language_model.model.norm") or n.startswith("language_model.lm_head"))}
+        for i in range(self.config.text_config.num_hidden_layers):
+            out[("layer", i)] = span(lambda n, i=i: n.startswith(f"language_model.model.layers.{i}."))
+        out["front"] = span(lambda n: n.startswith("multi_modal_projector.") or n.startswith("language_model.model.embed_tokens"))
+        return {k: v for k, v in out.items() if v is not None}
+
+    # ------------------------------------------------------------------ forward (contract 2 of SURVEY.md section 8b)
+    def forward(self, input_ids=None, pixel_values=None, attention_mask=None, position_ids=None, past_key_values=None,
+                inputs_embeds=None, vision_feature_layer=None, vision_feature_select_strategy=None, labels=None,
+                use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None, return_logits=None,
+                _record=None):
+        if inputs_embeds is not None or past_key_values is not None or use_cache:
+            raise NotImplementedError("generation / KV-cache paths are out of scope (SURVEY.md section 2); training forward only")
+        if output_attentions or output_hidden_states:
+            raise NotImplementedError("output_attentions / output_hidden_states are not produced by the fused kernels")
+        if vision_feature_layer is not None and vision_feature_layer != self.config.vision_feature_layer:
+            raise NotImplementedError("per-call vision_feature_layer override")
+        if vision_feature_select_strategy is not None and vision_feature_select_strategy != self.config.vision_feature_select_strategy:
+            if vision_feature_select_strategy not in ("default", "full"):
+                raise ValueError(f"Unexpected select feature strategy: {vision_feature_select_strategy}")
+            raise NotImplementedError("per-call vision_feature_select_strategy override")
+        return_dict = return_dict if return_dict is not None else self.config.use_return_dict
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)
+        want_grads = self.training and labels is not None and torch.is_grad_enabled() and \
+            any(p.requires_grad for p in self.parameters())
+        if return_logits is None:
+            return_logits = not want_grads        # training: the [B,L,V] logits are never materialised unless asked for
+        if want_grads:
+            loss = _FusedStep.apply(self, input_ids, attention_mask, labels, pixel_values, return_logits, _record,
+                                    self._loss_anchor())
+            logits = self._last_logits
+        else:
+            out = self.engine.step(input_ids, attention_mask, labels, pixel_values, compute_grads=False,
+                                   need_logits=return_logits, record=_record)
+            loss = None if labels is None else out["loss"].reshape(())
+            logits = out["logits"]
+        if not return_dict:
+            return ((loss,) if loss is not None else ()) + ((logits,) if logits is not None else ())
+        return LlavaCausalLMOutputWithPast(loss=loss, logits=logits)
+
+    def _loss_anchor(self):
+        # a tiny differentiable input so autograd calls _FusedStep.backward (parameters themselves bypass autograd)
+        if not hasattr(self, "_anchor") or self._anchor.device != self.device:
+            self._anchor = torch.zeros((), device=self.device, dtype=torch.float32, requires_grad=True)
+        return self._anchor
+
+
+class _FusedStep(torch.autograd.Function):
+    """Bridge for callers that drive the model through autograd (stock `Trainer.training_step`: `loss.backward()`).
+    forward runs the fused forward+backward into a scratch gradient arena; backward adds `grad_output * scratch` to
+    `.grad`.  (MantisHipTrainer bypasses this and accumulates in place with the right scale.)"""
+
+    @staticmethod
+    def forward(ctx, model, input_ids, attention_mask, labels, pixel_values, need_logits, record, anchor):
+        model._ensure_grad_arena()
+        live = model.grad_arena
+        scratch = torch.zeros_like(live)
+        # run the step with gradients redirected into `scratch`
+        model.grad_arena = scratch
+        model._grad_views_live = model._grad_views
+        model._grad_views = {n: scratch[o: o + model._param(n).numel()].view(model._param(n).shape)
+                             for n, o in model._grad_offs.items()}
+        model._build_grad_views()
+        try:
+            out = model.engine.step(input_ids, attention_mask, labels, pixel_values, grad_scale=1.0, loss_scale=1.0,
+                                    compute_grads=True, overwrite_grads=True, need_logits=need_logits, record=record)
+        finally:
+            model.grad_arena = live
+            model._grad_views = model._grad_views_live
+            model._build_grad_views()
+        model._last_logits = out["logits"]
+        ctx.model, ctx.scratch = model, scratch
+        return out["loss"].reshape(()).clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        model, scratch = ctx.model, ctx.scratch
+        model._ensure_grad_arena()
+        model.grad_arena.add_(scratch, alpha=float(grad_out))   # compatibility path only (one host sync)
+        return (None,) * 8

@@ -1,0 +1,64 @@
+"""Drop-in for `transformers.Trainer.training_step` (contract 1 of SURVEY.md section 8b).
+
+Reference: transformers/trainer.py:1892-1963, driven by /root/reference/mantis/train/train_mllava.py:312-329:
+    model.train(); inputs = _prepare_inputs(inputs); loss = compute_loss(model, inputs); loss /= GA;
+    accelerator.backward(loss)  (DDP bucket all-reduce fires here);  return loss.detach()
+Here the forward, the backward and the gradient accumulation into `.grad` are one pass over hand-written gfx950 kernels
+(`LlavaEngine.step`), with 1/GA folded into the loss-gradient seed, and the data-parallel bucket all-reduces (RCCL) are
+launched from inside the backward as each bucket's gradients complete.
+
+`MantisHipTrainer` is transformers-free; `as_hf_trainer()` returns a `transformers.Trainer` subclass whose
+`training_step` is this one, for users who keep the stock HF training loop (the reference already subclasses Trainer the
+same way in train_intern_vl_25.py:104-122)."""
+import torch
+
+
+class MantisHipTrainer:
+    def __init__(self, model=None, gradient_accumulation_steps=1, reducer=None):
+        self.model = model
+        self.current_gradient_accumulation_steps = gradient_accumulation_steps
+        self.reducer = reducer
+        self._micro = 0
+
+    def _prepare_inputs(self, inputs):
+        # HF:trainer.py:2203-2235 moves tensors to the device; here the engine does the H2D itself (non_blocking) because
+        # it needs the host copy of input_ids for the packing-shape bookkeeping.
+        if not isinstance(inputs, dict) or "input_ids" not in inputs:
+            raise ValueError("training_step expects the batch dict produced by the Mantis collator "
+                             "(input_ids, attention_mask, labels, pixel_values)")
+        return inputs
+
+    def training_step(self, model, inputs, num_items_in_batch=None):
+        """-> 0-dim detached loss tensor on the model's device, already divided by the accumulation steps."""
+        model.train()
+        inputs = self._prepare_inputs(inputs)
+        ga = max(1, int(self.current_gradient_accumulation_steps))
+        overwrite = model._ensure_grad_arena()
+        self._micro += 1
+        sync = self.reducer is not None and (self._micro % ga == 0)
+        hook = self.reducer.bucket_ready if sync else None
+        if sync:
+            self.reducer.begin()
+        out = model.engine.step(inputs["input_ids"], inputs["attention_mask"], inputs.get("labels"),
+                                inputs.get("pixel_values"), grad_scale=1.0 / ga, loss_scale=1.0 / ga, compute_grads=True,
+                                overwrite_grads=overwrite, on_bucket_ready=hook)
+        if sync:
+            self.reducer.finish()
+        return out["loss"].reshape(()).detach()
+
+
+def as_hf_trainer():
+    """transformers.Trainer subclass using the fused step (imported lazily: transformers is optional)."""
+    from transformers import Trainer
+
+    class MantisHipHFTrainer(Trainer):
+        def training_step(self, model, inputs, num_items_in_batch=None):
+            ga = getattr(self, "current_gradient_accumulation_steps", None) or self.args.gradient_accumulation_steps
+            impl = getattr(self, "_mantis_impl", None)
+            if impl is None:
+                impl = self._mantis_impl = MantisHipTrainer(model, ga, getattr(self, "mantis_reducer", None))
+            impl.current_gradient_accumulation_steps = ga
+            inner = model.module if hasattr(model, "module") else model
+            return impl.training_step(inner, inputs, num_items_in_batch)
+
+    return MantisHipHFTrainer

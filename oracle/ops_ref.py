@@ -1,0 +1,364 @@
+"""ORACLE (test infrastructure, never imported by the product path).
+
+torch-CPU restatement of every operator in `mantis_amd/hip_ops.py`, with the SAME function signatures, so that
+  * `tests/test_hip_ops_gpu.py` (-m gpu) can compare each gfx950 kernel with its reference on identical inputs, and
+  * `tests/test_engine_host_logic.py` (CPU) can drive the product's host logic (mantis_amd/engine.py: kernel sequencing,
+    what is saved / recomputed, gradient plumbing) with this module monkeypatched in place of the HIP backend and
+    check it against the golden vectors recorded from the reference.
+Math is done in fp32 on the (bf16 or fp32) inputs and rounded once to the input dtype, except where the reference's own
+bf16 graph rounds more often (RMSNorm, SwiGLU, RoPE: noted inline).  Per-op formulas follow oracle/llava_ref.py, which
+is pinned against the reference by tests/test_oracle_vs_golden.py.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import llava_ref as R
+from . import pack_ref
+
+
+def pad8(n):
+    return (n + 7) // 8 * 8
+
+
+def _f(x):
+    return x.float()
+
+
+def gemm_nt(a, b, bias=None, act=None, residual=None, out=None, accumulate=False, n_valid=None, k=None, ldc=None):
+    K = a.shape[1] if k is None else k
+    N = b.shape[0] if n_valid is None else n_valid
+    av, bv = _f(a)[:, :K], _f(b)[:N, :K]
+    if av.shape[1] < K:      # caller relies on zero padding of the shorter operand
+        av = F.pad(av, (0, K - av.shape[1]))
+    if bv.shape[1] < K:
+        bv = F.pad(bv, (0, K - bv.shape[1]))
+    y = av @ bv.t()
+    dt = a.dtype
+    if bias is not None:
+        y = y + _f(bias)[:N]
+    if act is not None:
+        y = R.ACT[act](y.to(dt).float())
+    if residual is not None:
+        y = y.to(dt).float() + _f(residual)[:, :N]
+    if out is None:
+        out = torch.zeros((a.shape[0], N if ldc is None else ldc), dtype=dt)
+        out[:, :N] = y.to(dt)
+        return out
+    if accumulate:
+        y = y + _f(out)[:, :N]
+    out[:, :N] = y.to(out.dtype)
+    return out
+
+
+def transpose(x, rpad=None):
+    Rr, C = x.shape
+    Rp = pad8(Rr) if rpad is None else rpad
+    out = torch.zeros((C, Rp), dtype=x.dtype)
+    out[:, :Rr] = x.t()
+    return out
+
+
+def linear_fwd(x, w, bias=None, act=None, residual=None):
+    return gemm_nt(x, w, bias=bias, act=act, residual=residual)
+
+
+def linear_dx(dy, w, k=None):
+    n = w.shape[0]
+    return (_f(dy)[:, :n] @ _f(w)).to(dy.dtype)
+
+
+def linear_dw(dy, x, grad_w, accumulate):
+    n = grad_w.shape[0]
+    g = _f(dy)[:, :n].t() @ _f(x)
+    if accumulate:
+        g = g + _f(grad_w)
+    grad_w.copy_(g.to(grad_w.dtype))
+
+
+def colsum(x, grad, accumulate):
+    g = _f(x).sum(0)
+    if accumulate:
+        g = g + _f(grad)
+    grad.copy_(g.to(grad.dtype))
+
+
+def rmsnorm_fwd(x, w, eps, want_rstd=True):
+    xf = _f(x)
+    rstd = torch.rsqrt(xf.pow(2).mean(-1) + eps)
+    y = (_f((xf * rstd[:, None]).to(x.dtype)) * _f(w)).to(x.dtype)      # two roundings, as LlamaRMSNorm does in bf16
+    return y, (rstd if want_rstd else None)
+
+
+def rmsnorm_bwd(dy, x, w, rstd, dres, grad_w, accumulate):
+    xf, g = _f(x), _f(dy) * _f(w)
+    xhat = xf * rstd[:, None]
+    dx = rstd[:, None] * (g - xhat * (g * xhat).mean(-1, keepdim=True))
+    if dres is not None:
+        dx = dx + _f(dres)
+    if grad_w is not None:
+        gw = (_f(dy) * xhat).sum(0)
+        if accumulate:
+            gw = gw + _f(grad_w)
+        grad_w.copy_(gw.to(grad_w.dtype))
+    return dx.to(x.dtype)
+
+
+def layernorm_fwd(x, w, b, eps):
+    return F.layer_norm(_f(x), (x.shape[-1],), _f(w), _f(b), eps).to(x.dtype)
+
+
+def swiglu_fwd(gu):
+    I = gu.shape[1] // 2
+    g, u = _f(gu[:, :I]), _f(gu[:, I:])
+    return (_f(F.silu(g).to(gu.dtype)) * u).to(gu.dtype)
+
+
+def swiglu_bwd(dact, gu):
+    I = gu.shape[1] // 2
+    g, u, d = _f(gu[:, :I]), _f(gu[:, I:]), _f(dact)
+    s = torch.sigmoid(g)
+    silu = g * s
+    return torch.cat([d * u * (s + silu * (1 - s)), d * silu], dim=1).to(gu.dtype)
+
+
+def act_fwd(x, kind):
+    return R.ACT[kind](_f(x)).to(x.dtype)
+
+
+def act_bwd(dy, x, kind):
+    xf = _f(x).detach().requires_grad_(True)
+    with torch.enable_grad():
+        y = R.ACT[kind](xf)
+    (g,) = torch.autograd.grad(y, xf, _f(dy))
+    return g.to(x.dtype)
+
+
+def add(a, b):
+    return (_f(a) + _f(b)).to(a.dtype)
+
+
+def rope_table(position_ids, inv_freq):
+    f = position_ids.reshape(-1, 1).float() * inv_freq.float()[None]
+    return f.cos().to(torch.bfloat16), f.sin().to(torch.bfloat16)
+
+
+def rope_apply_(x, cos, sin, nheads, hd, backward=False):
+    Rr = x.shape[0]
+    half = hd // 2
+    v = x[:, : nheads * hd].reshape(Rr, nheads, hd)
+    x1, x2 = _f(v[..., :half]), _f(v[..., half:])
+    c, s = _f(cos)[:, None, :], _f(sin)[:, None, :]
+    dt = x.dtype
+    if not backward:
+        r = lambda t: t.to(dt).float()      # the reference's bf16 graph rounds each product and the sum
+        o1 = r(x1 * c) - r(x2 * s)
+        o2 = r(x2 * c) + r(x1 * s)
+    else:
+        o1 = x1 * c + x2 * s
+        o2 = x2 * c - x1 * s
+    x[:, : nheads * hd] = torch.cat([o1, o2], dim=-1).reshape(Rr, nheads * hd).to(dt)
+    return x
+
+
+def _split_qkv(qkv, B, L, H, Hkv, hd):
+    q = qkv[:, : H * hd].reshape(B, L, H, hd).transpose(1, 2)
+    k = qkv[:, H * hd: (H + Hkv) * hd].reshape(B, L, Hkv, hd).transpose(1, 2)
+    v = qkv[:, (H + Hkv) * hd: (H + 2 * Hkv) * hd].reshape(B, L, Hkv, hd).transpose(1, 2)
+    return q, k, v
+
+
+def _scores(q, k, scale, causal, kmask, H, Hkv):
+    rep = H // Hkv
+    kk = k.repeat_interleave(rep, dim=1) if rep > 1 else k
+    s = torch.matmul(_f(q), _f(kk).transpose(-1, -2)) * scale
+    L, Lk = s.shape[-2:]
+    if causal:
+        s = s.masked_fill(~torch.ones(L, Lk, dtype=torch.bool).tril(), float("-inf"))
+    if kmask is not None:
+        s = s.masked_fill(kmask[:, None, None, :] == 0, float("-inf"))
+    return s
+
+
+def attn_fwd(qkv, B, Lseq, H, Hkv, hd, kmask, scale, causal, want_lse=True):
+    q, k, v = _split_qkv(qkv, B, Lseq, H, Hkv, hd)
+    s = _scores(q, k, scale, causal, kmask, H, Hkv)
+    lse = torch.logsumexp(s, dim=-1)
+    p = torch.exp(s - lse[..., None]).nan_to_num(0.0)
+    rep = H // Hkv
+    vv = v.repeat_interleave(rep, dim=1) if rep > 1 else v
+    o = torch.matmul(p, _f(vv)).transpose(1, 2).reshape(B * Lseq, H * hd).to(qkv.dtype)
+    lse = torch.where(torch.isinf(lse) & (lse < 0), torch.full_like(lse, float("inf")), lse)
+    return o, (lse if want_lse else None)
+
+
+def attn_bwd(qkv, o, do, lse, B, Lseq, H, Hkv, hd, kmask, scale, causal):
+    q, k, v = _split_qkv(qkv, B, Lseq, H, Hkv, hd)
+    rep = H // Hkv
+    s = _scores(q, k, scale, causal, kmask, H, Hkv)
+    p = torch.exp(s - lse[..., None]).nan_to_num(0.0)
+    dO = _f(do).reshape(B, Lseq, H, hd).transpose(1, 2)
+    O = _f(o).reshape(B, Lseq, H, hd).transpose(1, 2)
+    vv = _f(v).repeat_interleave(rep, dim=1) if rep > 1 else _f(v)
+    kk = _f(k).repeat_interleave(rep, dim=1) if rep > 1 else _f(k)
+    dsum = (dO * O).sum(-1, keepdim=True)
+    dP = torch.matmul(dO, vv.transpose(-1, -2))
+    dS = p * (dP - dsum) * scale
+    dq = torch.matmul(dS, kk)
+    dk = torch.matmul(dS.transpose(-1, -2), _f(q))
+    dv = torch.matmul(p.transpose(-1, -2), dO)
+    if rep > 1:
+        dk = dk.reshape(B, Hkv, rep, Lseq, hd).sum(2)
+        dv = dv.reshape(B, Hkv, rep, Lseq, hd).sum(2)
+    out = torch.zeros_like(qkv)
+    out[:, : H * hd] = dq.transpose(1, 2).reshape(B * Lseq, H * hd).to(qkv.dtype)
+    out[:, H * hd: (H + Hkv) * hd] = dk.transpose(1, 2).reshape(B * Lseq, Hkv * hd).to(qkv.dtype)
+    out[:, (H + Hkv) * hd: (H + 2 * Hkv) * hd] = dv.transpose(1, 2).reshape(B * Lseq, Hkv * hd).to(qkv.dtype)
+    return out
+
+
+class PackPlan:
+    pass
+
+
+def pack_plan(input_ids, attention_mask, labels, num_patches, num_images, image_token_index, pad_token_id, ignore_index, L):
+    ids = input_ids.numpy()
+    pl = pack_ref.pack_plan(ids, attention_mask.numpy(), None if labels is None else labels.numpy(), num_images,
+                            num_patches, image_token_index, pad_token_id, ignore_index)
+    assert pl["L"] == L
+    B, T = ids.shape
+    out = PackPlan()
+    out.B, out.T, out.L, out.N, out.I = B, T, L, num_patches, num_images
+    kind, sidx = pl["src_kind"], pl["src_idx"]
+    src = np.where(kind == pack_ref.TEXT, sidx, np.where(kind == pack_ref.IMAGE, sidx | (1 << 30), -1)).astype(np.int32)
+    out.src = torch.from_numpy(src)
+    out.attention_mask = torch.from_numpy(pl["attention_mask"])
+    out.labels = torch.from_numpy(pl["labels"] if pl["labels"] is not None else np.full((B, L), ignore_index, np.int64))
+    out.position_ids = torch.from_numpy(pl["position_ids"])
+    out.kmask = (out.attention_mask != 0).to(torch.int32)
+    m = ids == image_token_index
+    tp = np.where(m, -1, pl["text_pos"]).astype(np.int32)
+    out.text_pos = torch.from_numpy(tp)
+    slot = np.full((max(1, num_images * num_patches),), -1, np.int32)
+    bb, pp = np.nonzero(kind == pack_ref.IMAGE)
+    slot[sidx[bb, pp]] = (bb * L + pp).astype(np.int32)
+    out.img_slot = torch.from_numpy(slot)
+    ce_row = np.full((B * T,), -1, np.int32)
+    ce_tgt = np.full((B * T,), -100, np.int32)
+    am = attention_mask.numpy()
+    lab = None if labels is None else labels.numpy()
+    for b in range(B):
+        for t in range(T):
+            if tp[b, t] >= 1:
+                ce_row[b * T + t] = b * L + tp[b, t] - 1
+                if lab is not None and am[b, t] != 0 and lab[b, t] != ignore_index:
+                    ce_tgt[b * T + t] = lab[b, t]
+    out.ce_row, out.ce_tgt = torch.from_numpy(ce_row), torch.from_numpy(ce_tgt)
+    out.status = torch.zeros(4, dtype=torch.int32)
+    return out
+
+
+def pack_rows_fwd(plan, input_ids, embed_weight, image_features):
+    d = embed_weight.shape[1]
+    out = torch.zeros((plan.B * plan.L, d), dtype=embed_weight.dtype)
+    src = plan.src.reshape(-1)
+    rows = torch.arange(plan.B * plan.L)
+    b = rows // plan.L
+    txt = (src >= 0) & (src < (1 << 30))
+    out[txt] = embed_weight[input_ids[b[txt], src[txt].long()]]
+    im = src >= (1 << 30)
+    if im.any():
+        out[im] = image_features[(src[im] & ((1 << 30) - 1)).long()]
+    return out
+
+
+def gather_rows(x, idx):
+    out = torch.zeros((idx.numel(), x.shape[1]), dtype=x.dtype)
+    ok = idx >= 0
+    out[ok] = x[idx[ok].long()]
+    return out
+
+
+def scatter_rows(x, idx, nrows_out):
+    out = torch.zeros((nrows_out, x.shape[1]), dtype=x.dtype)
+    ok = idx >= 0
+    out[idx[ok].long()] = x[ok]
+    return out
+
+
+def embed_grad(dmerged, input_ids, plan, grad_weight, accumulate):
+    g = _f(grad_weight)
+    tp = plan.text_pos.reshape(-1)
+    ids = input_ids.reshape(-1)
+    ok = tp >= 0
+    if not accumulate:          # overwrite mode only touches the rows that occur
+        g[ids[ok]] = 0
+    b = torch.arange(ids.numel()) // plan.T
+    rows = (b * plan.L + tp.long())[ok]
+    g.index_add_(0, ids[ok], _f(dmerged)[rows])
+    grad_weight.copy_(g.to(grad_weight.dtype))
+
+
+def ce_fwd_bwd(logits, targets, V, grad_scale, loss_scale, write_grad=True):
+    x = _f(logits)[:, :V]
+    t = targets.long()
+    valid = t >= 0
+    cnt = int(valid.sum())
+    lse = torch.logsumexp(x, dim=-1)
+    picked = x.gather(1, t.clamp(min=0)[:, None])[:, 0]
+    row_loss = torch.where(valid, lse - picked, torch.zeros_like(lse))
+    loss = loss_scale * row_loss.sum() / cnt if cnt else torch.tensor(float("nan"))
+    if write_grad:
+        g = torch.softmax(x, -1)
+        g[torch.arange(x.shape[0])[valid], t[valid]] -= 1.0
+        g = g * (grad_scale / cnt if cnt else float("inf"))
+        g[~valid] = 0
+        logits.zero_()
+        logits[:, :V] = g.to(logits.dtype)
+    return loss.reshape(1).float(), torch.tensor([cnt], dtype=torch.int32)
+
+
+def im2col(pixels, patch, kp):
+    I, C, H, W = pixels.shape
+    cols = F.unfold(pixels.float(), kernel_size=patch, stride=patch)       # [I, C*P*P, N]
+    out = torch.zeros((I * cols.shape[2], kp), dtype=torch.bfloat16)
+    out[:, : cols.shape[1]] = cols.transpose(1, 2).reshape(-1, cols.shape[1]).to(torch.bfloat16)
+    return out
+
+
+def vit_assemble(patch_out, pos_emb, cls_emb, I, N):
+    d = patch_out.shape[1]
+    x = _f(patch_out).reshape(I, N, d)
+    if cls_emb is not None:
+        x = torch.cat([_f(cls_emb).expand(I, 1, d), x], dim=1)
+    x = x + _f(pos_emb)[None]
+    return x.reshape(-1, d).to(patch_out.dtype)
+
+
+def drop_cls(x, I, N):
+    d = x.shape[1]
+    return x.reshape(I, N + 1, d)[:, 1:].reshape(I * N, d).contiguous()
+
+
+def adamw_flat(param, grad, master, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=None):
+    g = _f(grad) * (float(grad_scale) if grad_scale is not None else 1.0)
+    master.mul_(1 - lr * wd)
+    m.mul_(beta1).add_(g, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
+    master.addcdiv_(m, (v / bc2).sqrt() + eps, value=-lr / bc1)
+    param.copy_(master.to(param.dtype))
+
+
+def grad_sumsq(x, out, accumulate=False):
+    s = _f(x).pow(2).sum()
+    out[0] = out[0] + s if accumulate else s
+
+
+def clip_scale(sumsq, max_norm):
+    norm = sumsq.sqrt()
+    return torch.clamp(max_norm / (norm + 1e-6), max=1.0).reshape(1), norm.reshape(1)
+
+
+def synchronize():
+    pass

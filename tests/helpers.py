@@ -1,0 +1,92 @@
+"""Shared test helpers (test infrastructure)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_case(name):
+    return np.load(os.path.join(G, name + ".npz"))
+
+
+def golden_cfg_and_weights(flavour):
+    z = np.load(os.path.join(G, f"weights_{flavour}.npz"))
+    meta = json.loads(str(z["__config__"]))
+    return meta, {k: z[k] for k in z.files if k != "__config__"}
+
+
+def build_product_model(flavour, device):
+    """The product module (flat bf16 arena) loaded with the golden weights rounded to bf16."""
+    from mantis_amd.configuration_llava import LlavaConfig
+    from mantis_amd.modeling_llava import LlavaForConditionalGeneration
+    meta, sd = golden_cfg_and_weights(flavour)
+    model = LlavaForConditionalGeneration(LlavaConfig.from_oracle_meta(meta), device=device, init=None)
+    model.load_reference_state_dict(sd)
+    return model, meta, sd
+
+
+def build_oracle_bf16_weights(flavour):
+    """Oracle model (fp32 math) on the SAME bf16-rounded weights the product model holds."""
+    from oracle.llava_ref import LlavaRef
+    meta, sd = golden_cfg_and_weights(flavour)
+    sd = {k: torch.from_numpy(v).to(torch.bfloat16).float() for k, v in sd.items()}
+    return LlavaRef(sd, meta)
+
+
+def pixels_list(z, prefix=""):
+    if prefix + "pixel_values" not in z.files:
+        return None
+    pv = torch.from_numpy(z[prefix + "pixel_values"])
+    return list(torch.split(pv, z[prefix + "pixel_counts"].tolist()))
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def cosine(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+
+
+def check_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-3, grad_cos=0.995, grad_rel=6e-2):
+    """bf16 product path vs fp32 oracle on identical (bf16-rounded) weights.  Tolerances: SURVEY.md section 8c."""
+    orec = {}
+    oracle.zero_grad()
+    oloss, ologits = oracle.forward(z["input_ids"], pixels_list(z), z["attention_mask"], z["labels"], record=orec)
+    oloss.backward()
+    # integers bit-exact
+    for k in ("merged_attention_mask", "merged_labels", "merged_position_ids"):
+        if k in orec:
+            assert np.array_equal(rec[k].cpu().numpy(), orec[k].numpy()), k
+    loss = float(out["loss"].float().cpu().reshape(-1)[0])
+    assert abs(loss - float(oloss)) <= loss_rtol * abs(float(oloss)), (loss, float(oloss))
+    am = (orec["merged_attention_mask"] if "merged_attention_mask" in orec else torch.from_numpy(z["attention_mask"])).bool().numpy()
+    for k in orec:
+        if k.startswith("llm_layer") or k in ("projector_out", "merged_embeds"):
+            a = rec[k].float().cpu().numpy()
+            b = orec[k].detach().numpy()
+            if k.startswith("llm_layer") or k == "merged_embeds":
+                a, b = a[am], b[am]
+            assert rel_l2(a, b) < 3e-2, (k, rel_l2(a, b))
+    report = {}
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        og = oracle.w[name].grad
+        assert p.grad is not None, name
+        g = p.grad.float().cpu().numpy()
+        if og is None:          # parameter unused by this batch (projector on a text-only batch): exact zeros expected
+            assert not g.any(), name
+            continue
+        c, r = cosine(g, og.numpy()), rel_l2(g, og.numpy())
+        report[name] = (c, r)
+        if np.linalg.norm(og.numpy()) < 1e-12:
+            assert np.linalg.norm(g) < 1e-6, name
+            continue
+        assert c >= grad_cos and r <= grad_rel, (name, c, r)
+    return report
