@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Headline benchmark: train samples/s of the Mantis-8B-SigLIP-Llama-3 step on N MI355X (BASELINE.json configs[1]/[2]).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \
+        bench.py --gpus 8 --steps 5 --warmup 2
+
+One step = one `MantisHipTrainer.training_step` (ViT forward, projector, packing, 32-layer Llama-3 forward + backward,
+gradient all-reduce over RCCL when N > 1) followed by the fused clip + AdamW update (`--no-optimizer` times the bare
+training_step boundary of the reference, transformers/trainer.py:1892-1963).  Weak scaling: 2 samples per GPU
+(4 images 336x336 + 512 text tokens each -> merged length 2812), synthetic inputs and random-init weights.
+
+Prints ONE JSON line (rank 0) with the driver's fields plus
+  roofline      dominant kernel (the bf16 MFMA GEMM): algorithmic FLOPs / HIP-event time per launch, live in the timed steps
+  cpu_baseline  the oracle's CPU restatement of the same training_step ("port"), timed on this host's cores on a bounded
+                sample (1 sample, 1 ViT + {1,2} LLM layers + lm_head) and extrapolated linearly in depth
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_SAMPLE = 1.351e14      # SURVEY.md section 8d (ViT fwd x1, projector + LLM fwd+bwd x3, causal attention at 1/2)
+PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def synthetic_batch(cfg, B, T, n_img, img_hw, rank, step=0):
+    import torch
+    g = torch.Generator().manual_seed(1234 + rank + 1000 * step)
+    ids = torch.randint(0, 128000 if cfg.vocab_size > 128000 else cfg.vocab_size - 2, (B, T), generator=g)
+    for b in range(B):
+        pos = torch.randperm(T - 1, generator=g)[:n_img].sort().values
+        ids[b, pos] = cfg.image_token_index
+    labels = ids.clone()
+    labels[:, : T // 2] = -100
+    labels[ids == cfg.image_token_index] = -100
+    pix = [torch.randn(n_img, 3, img_hw, img_hw, generator=g) for _ in range(B)]
+    return dict(input_ids=ids, attention_mask=torch.ones_like(ids), labels=labels, pixel_values=pix)
+
+
+def cpu_baseline(cfg_name):
+    """Oracle ("port") timing on the host cores; bounded sample, depth extrapolated.  Returns the cpu_baseline object."""
+    import torch
+    from oracle.llava_ref import LlavaRef, random_weights
+    from mantis_amd import configuration_llava as C
+    cfg = getattr(C, cfg_name)()
+    full_v, full_l = cfg.vision_config.num_hidden_layers + cfg.vision_feature_layer + 1, cfg.text_config.num_hidden_layers
+    meta = dict(vision=cfg.vision_config.to_dict(), text=cfg.text_config.to_dict(), image_token_index=cfg.image_token_index,
+                pad_token_id=cfg.pad_token_id, vision_feature_select_strategy=cfg.vision_feature_select_strategy,
+                vision_feature_layer=cfg.vision_feature_layer, projector_hidden_act=cfg.projector_hidden_act)
+    meta["vision"]["num_hidden_layers"] = 2
+    meta["text"]["num_hidden_layers"] = 2
+    w = random_weights(meta, seed=0)
+    model = LlavaRef(w, meta)
+    del w
+    tiny = cfg_name == "mantis_tiny"
+    batch = synthetic_batch(cfg, 1, 128 if tiny else 512, 1 if tiny else 4, cfg.vision_config.image_size, 0)
+
+    def run(nv, nl):
+        model.zero_grad()
+        t0 = time.perf_counter()
+        model.training_step(batch, n_vit_layers=nv, n_llm_layers=nl)
+        return time.perf_counter() - t0
+    with torch.no_grad():
+        pv = torch.cat(batch["pixel_values"], 0)
+        t0 = time.perf_counter(); model.vision_tower(pv, 1); tv1 = time.perf_counter() - t0
+        t0 = time.perf_counter(); model.vision_tower(pv, 2); tv2 = time.perf_counter() - t0
+    t11 = run(1, 1)
+    t12 = run(1, 2)
+    per_llm, per_vit = max(t12 - t11, 1e-9), max(tv2 - tv1, 1e-9)
+    total = t11 + (full_l - 1) * per_llm + (full_v - 1) * per_vit
+    return dict(value=1.0 / total, unit="samples/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"oracle/llava_ref.py training_step, fp32, 1 sample ({'1 img 224^2 + 128' if tiny else '4 img 336^2 + 512'} "
+                       f"tok), measured 1 ViT + 1 and 2 LLM layers + lm_head ({t11:.1f}s, {t12:.1f}s; ViT layer {per_vit:.2f}s), "
+                       f"extrapolated linearly to {full_v} ViT / {full_l} LLM layers = {total:.0f}s per sample")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="mantis_8b_siglip_llama3", choices=["mantis_8b_siglip_llama3", "mantis_tiny"])
+    ap.add_argument("--batch-per-gpu", type=int, default=2)
+    ap.add_argument("--no-optimizer", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if local_rank == 0:
+        __graft_entry__.build()
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.barrier()
+    from mantis_amd import configuration_llava as C
+    from mantis_amd import hip_ops as K
+    from mantis_amd.modeling_llava import LlavaForConditionalGeneration
+    from mantis_amd.trainer import MantisHipTrainer
+    from mantis_amd.dp import GradReducer
+    from mantis_amd.optim import FusedAdamW
+
+    cfg = getattr(C, args.config)()
+    tiny = args.config == "mantis_tiny"
+    B = args.batch_per_gpu
+    T, n_img = (128, 1) if tiny else (512, 4)
+    model = LlavaForConditionalGeneration(cfg, device=f"cuda:{local_rank}", seed=0)      # same seed -> identical replicas
+    reducer = GradReducer(model) if world > 1 else None
+    trainer = MantisHipTrainer(model, gradient_accumulation_steps=1, reducer=reducer)
+    opt = None if args.no_optimizer else FusedAdamW(model, lr=1e-5, weight_decay=0.0, max_grad_norm=1.0)
+    batches = [synthetic_batch(cfg, B, T, n_img, cfg.vision_config.image_size, rank, s) for s in range(2)]
+    for bt in batches:      # pinned host buffers, as dataloader_pin_memory does in the reference loop
+        bt["pixel_values"] = [p.pin_memory() for p in bt["pixel_values"]]
+
+    def one_step(i):
+        loss = trainer.training_step(model, batches[i % len(batches)])
+        if opt is not None:
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+        else:
+            for p in model.parameters():
+                p.grad = None
+        return loss
+
+    for i in range(args.warmup):
+        loss = one_step(i)
+    timer = None if args.no_kernel_timer else []
+    K.KERNEL_TIMER = timer
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = one_step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    K.KERNEL_TIMER = None
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    loss_val = float(loss)
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        value = world * B * args.steps / elapsed
+        roof = None
+        if timer:
+            tot_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in timer)
+            tot_fl = sum(f for _, f, _, _ in timer)
+            ach = tot_fl / (tot_ms * 1e-3) / 1e12
+            roof = dict(bound="mfma", kernel="gemm_nt_kernel", achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                        frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=None, launches_per_step=len(timer) // args.steps,
+                        avg_launch_us=round(1e3 * tot_ms / len(timer), 1), gemm_ms_per_step=round(tot_ms / args.steps, 1),
+                        step_model_tflops=round(FLOP_PER_SAMPLE * B / (ms * 1e-3) / 1e12, 1) if not tiny else None,
+                        step_frac_of_peak=round(FLOP_PER_SAMPLE * B / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if not tiny else None)
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args.config)
+        out = dict(metric="train samples/sec (4 img x 336^2 + 512 tok) Mantis-8B-SigLIP-Llama-3" if not tiny
+                   else "train samples/sec Mantis-tiny (1 img 224^2 + 128 tok)",
+                   value=round(value, 4), unit="samples/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   ms_per_step=round(ms, 2), higher_is_better=True, scaling="weak", vs_baseline=None, dtype="bf16",
+                   data="synthetic", loss=round(loss_val, 4),
+                   config=dict(workload=f"{args.config}: ViT fwd + projector + packing + Llama fwd/bwd"
+                                        f"{'' if args.no_optimizer else ' + clip + fused AdamW'}; {B} samples/GPU, "
+                                        f"{n_img} img + {T} tok per sample; random-init weights",
+                               global_batch=world * B, seq_len=T, merged_seq_len=T - n_img + n_img * (cfg.vision_config.image_size // cfg.vision_config.patch_size) ** 2,
+                               parallelism=f"dp{world}", optimizer=not args.no_optimizer),
+                   roofline=roof, cpu_baseline=cpu)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -12,6 +12,8 @@ _L = _lib.load()
 BF16 = torch.bfloat16
 ACT_KIND = {"gelu": 0, "gelu_pytorch_tanh": 1, "quick_gelu": 2, "silu": 3}
 GEMM_ACT = {None: 0, "gelu": 1, "gelu_pytorch_tanh": 2, "quick_gelu": 3}
+# bench.py sets this to a list to collect (kernel, algorithmic flops, start event, end event) per GEMM launch
+KERNEL_TIMER = None
 
 
 def _stream():
@@ -45,9 +47,17 @@ def gemm_nt(a, b, bias=None, act=None, residual=None, out=None, accumulate=False
         _chk2d(out, "out")
     C = out
     flags = (1 if bias is not None else 0) | (GEMM_ACT[act] << 1) | (16 if residual is not None else 0) | (32 if accumulate else 0)
+    prof = KERNEL_TIMER
+    if prof is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()          # torch's current stream == the stream handed to the kernel below
     rc = _L.mantis_gemm_bf16_nt(_p(a), a.stride(0), _p(b), b.stride(0), _p(C), C.stride(0), M, N, K, _p(bias), _p(residual),
                                 0 if residual is None else residual.stride(0), flags, _stream())
     _lib.check(rc, f"gemm_nt M={M} N={N} K={K}")
+    if prof is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        prof.append(("gemm_nt_kernel", 2.0 * M * N * K, e0, e1))
     return out
 
 

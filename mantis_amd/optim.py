@@ -1,0 +1,63 @@
+"""Fused AdamW + global-norm clipping over the flat parameter / gradient arenas.
+
+Reference behaviour being replaced: `clip_grad_norm_(max_grad_norm=1.0)` + `optimizer.step()` + `model.zero_grad()` of the
+HF loop (transformers/trainer.py:1785-1796, :2535-2545) with the hyper-parameters of
+/root/reference/mantis/train/scripts/train_mllava.sh:162-165 (AdamW, lr 1e-5, wd 0), which the reference executes through
+DeepSpeed's fused Adam with fp32 master weights.  Here: one sum-of-squares launch, one scalar kernel, one AdamW launch
+over the whole trainable arena; the clip coefficient stays on the device (no host sync)."""
+import torch
+
+from . import hip_ops as K
+
+
+class FusedAdamW:
+    def __init__(self, model, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0):
+        self.model = model
+        self.lr, self.betas, self.eps, self.wd, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
+        self.step_count = 0
+        model._ensure_grad_arena()
+        names = list(model._grad_key)
+        self._segments = self._plan(names)
+        n = model.grad_arena.numel()
+        dev = model.device
+        self.master = torch.empty(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        for p_off, g_off, cnt in self._segments:
+            self.master[g_off:g_off + cnt].copy_(model.arena[p_off:p_off + cnt])
+        self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.last_grad_norm = None
+
+    def _plan(self, names):
+        """Maximal runs where the parameter arena and the gradient arena advance together -> (param_off, grad_off, numel)."""
+        m = self.model
+        segs = []
+        for n in names:
+            cnt = (m._param(n).numel() + 7) // 8 * 8
+            po, go = m._offs[n], m._grad_offs[n]
+            if segs and segs[-1][0] + segs[-1][2] == po and segs[-1][1] + segs[-1][2] == go:
+                segs[-1] = (segs[-1][0], segs[-1][1], segs[-1][2] + cnt)
+            else:
+                segs.append((po, go, cnt))
+        return segs
+
+    def step(self):
+        m = self.model
+        self.step_count += 1
+        scale = None
+        if self.max_grad_norm is not None and self.max_grad_norm > 0:
+            K.grad_sumsq(m.grad_arena, self._sumsq, accumulate=False)
+            scale, self.last_grad_norm = K.clip_scale(self._sumsq, self.max_grad_norm)
+        for p_off, g_off, cnt in self._segments:
+            K.adamw_flat(m.arena[p_off:p_off + cnt], m.grad_arena[g_off:g_off + cnt], self.master[g_off:g_off + cnt],
+                         self.exp_avg[g_off:g_off + cnt], self.exp_avg_sq[g_off:g_off + cnt], self.lr, self.betas[0],
+                         self.betas[1], self.eps, self.wd, self.step_count, grad_scale=scale)
+
+    def zero_grad(self, set_to_none=True):
+        """model.zero_grad() of the HF loop: dropping the .grad views lets the next backward overwrite instead of accumulate."""
+        for p in self.model.parameters():
+            if p.requires_grad:
+                if set_to_none:
+                    p.grad = None
+                elif p.grad is not None:
+                    p.grad.zero_()

@@ -1,0 +1,422 @@
+"""Parity checks of every gfx950 kernel (through the C-ABI, via mantis_amd.hip_ops) against the oracle's operator
+restatement (oracle/ops_ref.py) on identical seeded inputs.  Used by tests/test_hip_ops_gpu.py (-m gpu) and by
+tools/gpu_selftest.py (which runs ALL of them and writes a JSON report instead of stopping at the first failure).
+
+Tolerances: integer / index / copy work bit-exact; bf16 kernels vs the fp32 oracle on the same bf16 inputs:
+relative L2 error <= 1e-2 (bf16 has 8 mantissa bits: ~4e-3 per element), attention 2e-2, gradients 3e-2."""
+import numpy as np
+import torch
+
+from oracle import ops_ref as R
+from oracle import pack_ref
+from tests import helpers as Hh
+
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def K():
+    import mantis_amd.hip_ops as k
+    return k
+
+
+def rnd(*shape, seed=0, scale=1.0, dtype=BF):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def close(a, b, tol, what):
+    r = rel(a, b)
+    assert np.isfinite(r) and r <= tol, f"{what}: rel_l2={r:.3e} > {tol}"
+    return r
+
+
+# ------------------------------------------------------------------------------------------------------------- GEMM
+GEMM_SHAPES = [(128, 128, 64), (32, 32, 16), (54, 64, 64), (300, 200, 72), (257, 388, 1152), (1000, 4304, 1152),
+               (520, 1152, 4304), (1024, 302, 256), (77, 40, 8)]
+
+
+def check_gemm(M, N, K_, flags="plain"):
+    k = K()
+    a, b = rnd(M, K_, seed=1), rnd(N, K_, seed=2, scale=0.1)
+    bias = rnd(N, seed=3) if "bias" in flags else None
+    res = rnd(M, N, seed=4) if "res" in flags else None
+    act = {"gelu": "gelu", "tanh": "gelu_pytorch_tanh", "quick": "quick_gelu"}.get(flags.split("+")[-1]) if "+" in flags else None
+    ref = R.gemm_nt(a, b, bias=bias, act=act, residual=res)
+    out = k.gemm_nt(a.to(DEV), b.to(DEV), bias=None if bias is None else bias.to(DEV), act=act,
+                    residual=None if res is None else res.to(DEV))
+    return close(out, ref, 1e-2, f"gemm {M}x{N}x{K_} {flags}")
+
+
+def check_gemm_accumulate_padded():
+    k = K()
+    M, N, K_ = 200, 302, 128
+    a, b = rnd(M, K_, seed=5), rnd(N, K_, seed=6, scale=0.1)
+    c0 = rnd(M, 304, seed=7)
+    ref = c0.clone()
+    R.gemm_nt(a, b, out=ref[:, :N], accumulate=True)
+    c = c0.to(DEV)
+    k.gemm_nt(a.to(DEV), b.to(DEV), out=c[:, :N], accumulate=True)
+    assert torch.equal(c[:, N:].cpu(), c0[:, N:]), "gemm wrote outside its N columns"
+    return close(c[:, :N], ref[:, :N], 1e-2, "gemm accumulate, ldc > N, N % 4 != 0")
+
+
+def check_transpose():
+    k = K()
+    worst = 0
+    for (r, c) in [(54, 64), (1000, 4304), (5, 8), (577, 72), (64, 64), (130, 200)]:
+        x = rnd(r, c, seed=r + c)
+        out = k.transpose(x.to(DEV)).cpu()
+        ref = R.transpose(x)
+        assert torch.equal(out, ref), f"transpose {r}x{c} not bit-exact"
+    x = rnd(2 * 37, 6 * 16, seed=9)                      # heads inside a fused activation
+    out = k.transpose_heads(x.to(DEV), 2, 37, 3, 16, 32, 40).cpu()
+    ref = torch.zeros(2, 3, 16, 40, dtype=BF)
+    ref[..., :37] = x[:, 32:80].reshape(2, 37, 3, 16).permute(0, 2, 3, 1)
+    assert torch.equal(out, ref), "transpose_heads not bit-exact"
+    return worst
+
+
+def check_linear_dx_dw():
+    k = K()
+    M, O, I = 333, 176, 64
+    dy, w, x = rnd(M, O, seed=1), rnd(O, I, seed=2, scale=0.1), rnd(M, I, seed=3)
+    r1 = close(k.linear_dx(dy.to(DEV), w.to(DEV)), R.linear_dx(dy, w), 1e-2, "linear_dx")
+    g0 = rnd(O, I, seed=4)
+    gref = g0.clone()
+    R.linear_dw(dy, x, gref, True)
+    g = g0.to(DEV)
+    k.linear_dw(dy.to(DEV), x.to(DEV), g, True)
+    r2 = close(g, gref, 1e-2, "linear_dw accumulate")
+    return max(r1, r2)
+
+
+# ------------------------------------------------------------------------------------------------------------- norms / acts
+def check_rmsnorm(rows=323, d=768):
+    k = K()
+    x, w = rnd(rows, d, seed=1), (1 + 0.1 * rnd(d, seed=2).float()).to(BF)
+    yr, rr = R.rmsnorm_fwd(x, w, 1e-5)
+    y, rs = k.rmsnorm_fwd(x.to(DEV), w.to(DEV), 1e-5)
+    r1 = close(y, yr, 4e-3, "rmsnorm_fwd")
+    close(rs, rr, 1e-5, "rmsnorm rstd")
+    dy, dres = rnd(rows, d, seed=3), rnd(rows, d, seed=4)
+    g0 = rnd(d, seed=5)
+    gref = g0.clone()
+    dxr = R.rmsnorm_bwd(dy, x, w, rr, dres, gref, True)
+    g = g0.to(DEV)
+    dx = k.rmsnorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), rs, dres.to(DEV), g, True)
+    r2 = close(dx, dxr, 5e-3, "rmsnorm_bwd dx")
+    r3 = close(g, gref, 1e-2, "rmsnorm_bwd dw")
+    return max(r1, r2, r3)
+
+
+def check_layernorm():
+    k = K()
+    x, w, b = rnd(577, 1152, seed=1), rnd(1152, seed=2), rnd(1152, seed=3)
+    return close(k.layernorm_fwd(x.to(DEV), w.to(DEV), b.to(DEV), 1e-6), R.layernorm_fwd(x, w, b, 1e-6), 4e-3, "layernorm")
+
+
+def check_acts():
+    k = K()
+    worst = 0
+    gu = rnd(200, 2 * 176, seed=1, scale=2.0)
+    worst = max(worst, close(k.swiglu_fwd(gu.to(DEV)), R.swiglu_fwd(gu), 5e-3, "swiglu_fwd"))
+    da = rnd(200, 176, seed=2)
+    worst = max(worst, close(k.swiglu_bwd(da.to(DEV), gu.to(DEV)), R.swiglu_bwd(da, gu), 5e-3, "swiglu_bwd"))
+    x, dy = rnd(64, 200, seed=3, scale=2.0), rnd(64, 200, seed=4)
+    for kind in ("gelu", "gelu_pytorch_tanh", "quick_gelu", "silu"):
+        worst = max(worst, close(k.act_fwd(x.to(DEV), kind), R.act_fwd(x, kind), 5e-3, f"act_fwd {kind}"))
+        worst = max(worst, close(k.act_bwd(dy.to(DEV), x.to(DEV), kind), R.act_bwd(dy, x, kind), 6e-3, f"act_bwd {kind}"))
+    a, b = rnd(10, 64, seed=5), rnd(10, 64, seed=6)
+    assert torch.equal(k.add(a.to(DEV), b.to(DEV)).cpu(), R.add(a, b)), "add"
+    xs = rnd(777, 300, seed=7)
+    g0 = rnd(300, seed=8)
+    gref = g0.clone()
+    R.colsum(xs, gref, True)
+    g = g0.to(DEV)
+    k.colsum(xs.to(DEV), g, True)
+    worst = max(worst, close(g, gref, 1e-2, "colsum"))
+    return worst
+
+
+def check_rope():
+    k = K()
+    B, L, H, Hkv, hd = 2, 77, 4, 2, 16
+    pos = torch.randint(0, 3000, (B * L,), generator=torch.Generator().manual_seed(1))
+    inv = 1.0 / (500000.0 ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+    cr, sr = R.rope_table(pos, inv)
+    c, s = k.rope_table(pos.to(DEV), inv.to(DEV))
+    # device cosf/sinf vs torch: allow 1 bf16 ulp on a few entries
+    assert (c.float().cpu() - cr.float()).abs().max() <= 2 ** -7 and (s.float().cpu() - sr.float()).abs().max() <= 2 ** -7
+    worst = 0
+    for hd_ in (16, 64, 128):
+        qkv = rnd(B * L, (H + 2 * Hkv) * hd_, seed=2)
+        inv = 1.0 / (500000.0 ** (torch.arange(0, hd_, 2, dtype=torch.float32) / hd_))
+        cr, sr = R.rope_table(pos, inv)
+        for bwd in (False, True):
+            ref = R.rope_apply_(qkv.clone(), cr, sr, H + Hkv, hd_, bwd)
+            out = k.rope_apply_(qkv.clone().to(DEV), cr.to(DEV), sr.to(DEV), H + Hkv, hd_, bwd)
+            worst = max(worst, close(out, ref, 2e-3 if not bwd else 4e-3, f"rope hd={hd_} bwd={bwd}"))
+            assert torch.equal(out[:, (H + Hkv) * hd_:].cpu(), qkv[:, (H + Hkv) * hd_:]), "rope touched v"
+    return worst
+
+
+# ------------------------------------------------------------------------------------------------------------- attention
+def _kmask(B, L, mode, seed=0):
+    if mode is None:
+        return None
+    m = torch.ones(B, L, dtype=torch.int32)
+    g = torch.Generator().manual_seed(seed)
+    for b in range(B):
+        n = int(torch.randint(1, max(2, L // 3), (1,), generator=g))
+        if mode == "right":
+            m[b, L - n:] = 0
+        else:
+            m[b, :n] = 0
+    return m
+
+
+def check_attn_fwd(B, L, H, Hkv, hd, causal, mask):
+    k = K()
+    qkv = rnd(B * L, (H + 2 * Hkv) * hd, seed=L + hd)
+    km = _kmask(B, L, mask, seed=L)
+    oref, lref = R.attn_fwd(qkv, B, L, H, Hkv, hd, km, hd ** -0.5, causal)
+    o, lse = k.attn_fwd(qkv.to(DEV), B, L, H, Hkv, hd, None if km is None else km.to(DEV), hd ** -0.5, causal)
+    valid = torch.isfinite(lref)                      # fully-masked query rows are don't-care
+    vo = valid.transpose(1, 2).reshape(B * L, H, 1).expand(B * L, H, hd).reshape(B * L, H * hd)
+    r = close(o.cpu().float() * vo, oref.float() * vo, 2e-2, f"attn_fwd o B{B} L{L} H{H}/{Hkv} hd{hd} causal={causal} mask={mask}")
+    close(torch.where(valid, lse.cpu(), torch.zeros_like(lref)), torch.where(valid, lref, torch.zeros_like(lref)), 2e-3, "attn lse")
+    return r
+
+
+def check_attn_bwd(B, L, H, Hkv, hd, causal, mask):
+    k = K()
+    qkv = rnd(B * L, (H + 2 * Hkv) * hd, seed=L + hd + 1)
+    do = rnd(B * L, H * hd, seed=L + 7)
+    km = _kmask(B, L, mask, seed=L)
+    if km is not None:                                # gradients never reach masked (pad) query rows on the real path
+        do = do * km.reshape(B * L, 1).to(BF)
+    oref, lref = R.attn_fwd(qkv, B, L, H, Hkv, hd, km, hd ** -0.5, causal)
+    dref = R.attn_bwd(qkv, oref, do, lref, B, L, H, Hkv, hd, km, hd ** -0.5, causal)
+    qd, kd = qkv.to(DEV), None if km is None else km.to(DEV)
+    o, lse = k.attn_fwd(qd, B, L, H, Hkv, hd, kd, hd ** -0.5, causal)
+    d = k.attn_bwd(qd, o, do.to(DEV), lse, B, L, H, Hkv, hd, kd, hd ** -0.5, causal)
+    names = ["dq", "dk", "dv"]
+    cuts = [0, H * hd, (H + Hkv) * hd, (H + 2 * Hkv) * hd]
+    worst = 0
+    for i, n in enumerate(names):
+        worst = max(worst, close(d[:, cuts[i]:cuts[i + 1]], dref[:, cuts[i]:cuts[i + 1]], 3e-2,
+                                 f"attn_bwd {n} B{B} L{L} H{H}/{Hkv} hd{hd} causal={causal} mask={mask}"))
+    return worst
+
+
+ATTN_FWD_CASES = [(2, 54, 4, 2, 16, True, "right"), (2, 54, 4, 2, 16, True, "left"), (3, 17, 4, 4, 16, False, None),
+                  (2, 197, 12, 12, 64, False, None), (2, 577, 16, 16, 72, False, None), (1, 323, 12, 12, 64, True, None),
+                  (1, 700, 8, 2, 128, True, "right"), (1, 128, 4, 1, 128, True, None), (1, 129, 2, 2, 64, True, "left")]
+ATTN_BWD_CASES = [(2, 54, 4, 2, 16, True, "right"), (2, 54, 4, 2, 16, True, "left"), (1, 323, 12, 12, 64, True, None),
+                  (1, 300, 8, 2, 128, True, "right"), (1, 129, 2, 2, 64, True, None), (2, 40, 2, 2, 16, False, None)]
+
+
+# ------------------------------------------------------------------------------------------------------------- packing / CE
+def _plan_inputs(case):
+    z = Hh.load_case(case)
+    return z, torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"]), torch.from_numpy(z["labels"])
+
+
+def check_pack_golden(case):
+    """Integer plan bit-exact vs the reference's recorded merged mask / labels / position ids, rows bit-exact copies."""
+    k = K()
+    z, ids, am, lab = _plan_inputs(case)
+    N, I = z["projector_out"].shape[1], z["projector_out"].shape[0]
+    kmax = int((ids == 298).sum(-1).max())
+    L = kmax * (N - 1) + ids.shape[1]
+    pl = k.pack_plan(ids.to(DEV), am.to(DEV), lab.to(DEV), N, I, 298, 299, -100, L)
+    st = pl.status.cpu().tolist()
+    assert st[0] == 0 and st[1] == I * N, st
+    assert np.array_equal(pl.attention_mask.cpu().numpy(), z["merged_attention_mask"]), "merged attention mask"
+    assert np.array_equal(pl.labels.cpu().numpy(), z["merged_labels"]), "merged labels"
+    assert np.array_equal(pl.position_ids.cpu().numpy(), z["merged_position_ids"]), "merged position ids"
+    rp = R.pack_plan(ids, am, lab, N, I, 298, 299, -100, L)
+    for f in ("src", "kmask", "text_pos", "img_slot", "ce_row", "ce_tgt"):
+        assert torch.equal(getattr(pl, f).cpu(), getattr(rp, f)), f
+    _, sd = Hh.golden_cfg_and_weights(case.split("_")[0])
+    emb = torch.from_numpy(sd["language_model.model.embed_tokens.weight"]).to(BF)
+    feats = torch.from_numpy(z["projector_out"]).to(BF).reshape(I * N, -1)
+    out = k.pack_rows_fwd(pl, ids.to(DEV), emb.to(DEV), feats.to(DEV)).cpu()
+    ref = R.pack_rows_fwd(rp, ids, emb, feats)
+    assert torch.equal(out, ref), "packed rows not bit-exact"
+    # the reference's merged embeddings, rounded to bf16, must be reproduced exactly too
+    assert torch.equal(out.reshape(ids.shape[0], L, -1), torch.from_numpy(z["merged_embeds"]).to(BF)), "vs golden merged_embeds"
+    return 0.0
+
+
+def check_pack_random():
+    k = K()
+    g = np.random.default_rng(5)
+    for trial in range(6):
+        B, T, N = int(g.integers(1, 5)), int(g.integers(8, 700)), int(g.integers(2, 40))
+        kimg = int(g.integers(0, 5))
+        ids = g.integers(0, 1000, size=(B, T))
+        am = np.ones((B, T), np.int64)
+        for b in range(B):
+            pos = g.choice(T - 1, size=min(kimg, T - 1), replace=False)
+            ids[b, pos] = 5000
+            if trial % 2 and b > 0:
+                npad = int(g.integers(1, 4))
+                ids[b, T - npad:] = 5001
+                am[b, T - npad:] = 0
+        lab = np.where(g.random((B, T)) < 0.5, ids, -100)
+        I = int((ids == 5000).sum())
+        L = int((ids == 5000).sum(-1).max()) * (N - 1) + T
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(torch.int64)
+        pl = k.pack_plan(t(ids).to(DEV), t(am).to(DEV), t(lab).to(DEV), N, I, 5000, 5001, -100, L)
+        rp = R.pack_plan(t(ids), t(am), t(lab), N, I, 5000, 5001, -100, L)
+        assert pl.status.cpu().tolist()[0] == 0
+        for f in ("src", "attention_mask", "labels", "position_ids", "kmask", "text_pos", "img_slot", "ce_row", "ce_tgt"):
+            assert torch.equal(getattr(pl, f).cpu(), getattr(rp, f)), (trial, f)
+    # count mismatch is reported (reference raises ValueError)
+    ids = torch.tensor([[1, 5000, 2, 5000, 3]])
+    pl = k.pack_plan(ids.to(DEV), torch.ones_like(ids).to(DEV), ids.to(DEV), 4, 1, 5000, 5001, -100, 2 * 3 + 5)
+    assert pl.status.cpu().tolist()[0] == 1
+    return 0.0
+
+
+def check_gather_scatter_embed():
+    k = K()
+    x = rnd(50, 64, seed=1)
+    idx = torch.tensor([3, -1, 49, 0, 7, -1], dtype=torch.int32)
+    assert torch.equal(k.gather_rows(x.to(DEV), idx.to(DEV)).cpu(), R.gather_rows(x, idx))
+    y = rnd(6, 64, seed=2)
+    assert torch.equal(k.scatter_rows(y.to(DEV), idx.to(DEV), 50).cpu(), R.scatter_rows(y, idx, 50))
+    # embedding gradient with repeated ids, two samples, image tokens excluded; deterministic -> compare to fp32 ref
+    B, T, N, V, d = 2, 40, 5, 97, 64
+    g = np.random.default_rng(3)
+    ids = g.integers(0, 20, size=(B, T))
+    ids[:, 7] = 90
+    ids_t = torch.from_numpy(ids)
+    am = torch.ones_like(ids_t)
+    L = (N - 1) + T
+    pl = k.pack_plan(ids_t.to(DEV), am.to(DEV), ids_t.to(DEV), N, B, 90, 91, -100, L)
+    rp = R.pack_plan(ids_t, am, ids_t, N, B, 90, 91, -100, L)
+    dm = rnd(B * L, d, seed=4)
+    g0 = rnd(V, d, seed=5)
+    gref = g0.clone()
+    R.embed_grad(dm, ids_t, rp, gref, True)
+    gd = g0.to(DEV)
+    k.embed_grad(dm.to(DEV), ids_t.to(DEV), pl, gd, True)
+    r = close(gd, gref, 4e-3, "embed_grad")
+    gd2 = g0.to(DEV)
+    k.embed_grad(dm.to(DEV), ids_t.to(DEV), pl, gd2, True)
+    assert torch.equal(gd, gd2), "embed_grad is not deterministic"
+    return r
+
+
+def check_ce(R_=64, V=300, frac_ignored=0.3):
+    k = K()
+    Vp = R.pad8(V)
+    lg = torch.zeros(R_, Vp, dtype=BF)
+    lg[:, :V] = rnd(R_, V, seed=V, scale=3.0)
+    g = torch.Generator().manual_seed(V)
+    tgt = torch.randint(0, V, (R_,), generator=g, dtype=torch.int32)
+    tgt[torch.rand(R_, generator=g) < frac_ignored] = -100
+    ref = lg.clone()
+    lref, cref = R.ce_fwd_bwd(ref, tgt, V, 0.25, 0.25)
+    x = lg.to(DEV)
+    loss, cnt = k.ce_fwd_bwd(x, tgt.to(DEV), V, 0.25, 0.25)
+    assert int(cnt.cpu()) == int(cref)
+    assert abs(float(loss.cpu()) - float(lref)) <= 2e-4 * abs(float(lref)) + 1e-6, (float(loss.cpu()), float(lref))
+    return close(x, ref, 1e-2, f"ce dlogits V={V}")
+
+
+def check_vit_front():
+    k = K()
+    pix = torch.randn(3, 3, 56, 56, generator=torch.Generator().manual_seed(1))
+    out = k.im2col(pix.to(DEV), 14, 592).cpu()
+    assert torch.equal(out, R.im2col(pix, 14, 592)), "im2col"
+    po, pos, cls = rnd(3 * 16, 64, seed=2), rnd(17, 64, seed=3), rnd(64, seed=4)
+    assert torch.equal(k.vit_assemble(po.to(DEV), pos[:16].contiguous().to(DEV), None, 3, 16).cpu(), R.vit_assemble(po, pos[:16], None, 3, 16))
+    a = k.vit_assemble(po.to(DEV), pos.to(DEV), cls.to(DEV), 3, 16)
+    assert torch.equal(a.cpu(), R.vit_assemble(po, pos, cls, 3, 16))
+    assert torch.equal(k.drop_cls(a, 3, 16).cpu(), R.drop_cls(a.cpu(), 3, 16))
+    return 0.0
+
+
+def check_optim():
+    k = K()
+    n = 8 * 1000
+    p32 = torch.randn(n, generator=torch.Generator().manual_seed(1))
+    g = rnd(n, seed=2, scale=0.01)
+    m, v = torch.zeros(n), torch.zeros(n)
+    p = p32.to(BF)
+    pr, mr, vr, p32r = p.clone(), m.clone(), v.clone(), p32.clone()
+    pd, gd, p32d, md, vd = p.to(DEV), g.to(DEV), p32.to(DEV), m.to(DEV), v.to(DEV)
+    for step in (1, 2, 3):
+        R.adamw_flat(pr, g, p32r, mr, vr, 1e-3, 0.9, 0.999, 1e-8, 0.01, step)
+        k.adamw_flat(pd, gd, p32d, md, vd, 1e-3, 0.9, 0.999, 1e-8, 0.01, step)
+    r = close(p32d, p32r, 1e-5, "adamw master")
+    close(pd, pr, 1e-3, "adamw bf16 param")
+    ss = torch.zeros(1, device=DEV)
+    k.grad_sumsq(gd, ss)
+    assert abs(float(ss.cpu()) - float(g.float().pow(2).sum())) < 1e-4 * float(g.float().pow(2).sum())
+    sc, nm = k.clip_scale(ss, 0.5)
+    assert abs(float(nm.cpu()) - float(g.float().norm())) < 1e-3 * float(g.float().norm())
+    return r
+
+
+# ------------------------------------------------------------------------------------------------------------- whole step
+MODEL_CASES = ["siglip_b1_img1", "siglip_b1_img4", "siglip_b2_equal_rightpad", "siglip_b2_unequal_quirk", "siglip_b1_text_only",
+               "clip_b2_equal_rightpad"]
+
+
+def check_model_step(case):
+    """The product path end to end (HIP kernels) vs the oracle model on the golden inputs: loss, activations, every gradient."""
+    flavour = case.split("_")[0]
+    z = Hh.load_case(case)
+    model, _, _ = Hh.build_product_model(flavour, DEV)
+    oracle = Hh.build_oracle_bf16_weights(flavour)
+    assert model._ensure_grad_arena()
+    rec = {}
+    out = model.engine.step(torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"]), torch.from_numpy(z["labels"]),
+                            Hh.pixels_list(z), compute_grads=True, overwrite_grads=True, need_logits=True, record=rec)
+    torch.cuda.synchronize()
+    rep = Hh.check_step_against_oracle(model, oracle, z, out, rec)
+    assert abs(float(out["loss"].cpu()) - float(z["loss"])) < 0.03 * float(z["loss"])      # vs the reference's own loss
+    return 1.0 - min(c for c, _ in rep.values())
+
+
+def all_checks():
+    """name -> thunk, in dependency order (cheap and fundamental first)."""
+    c = {}
+    c["transpose"] = check_transpose
+    for s in GEMM_SHAPES:
+        c[f"gemm_{s[0]}x{s[1]}x{s[2]}"] = (lambda s=s: check_gemm(*s))
+    for f in ("bias", "bias+gelu", "bias+tanh", "bias+quick", "res", "bias+res"):
+        c[f"gemm_epi_{f}"] = (lambda f=f: check_gemm(300, 200, 72, f))
+    c["gemm_accumulate_padded"] = check_gemm_accumulate_padded
+    c["linear_dx_dw"] = check_linear_dx_dw
+    c["rmsnorm"] = check_rmsnorm
+    c["rmsnorm_4096"] = lambda: check_rmsnorm(100, 4096)
+    c["layernorm"] = check_layernorm
+    c["acts"] = check_acts
+    c["rope"] = check_rope
+    for a in ATTN_FWD_CASES:
+        c["attn_fwd_" + "_".join(map(str, a))] = (lambda a=a: check_attn_fwd(*a))
+    for a in ATTN_BWD_CASES:
+        c["attn_bwd_" + "_".join(map(str, a))] = (lambda a=a: check_attn_bwd(*a))
+    for case in ("siglip_b1_img1", "siglip_b1_img2_adjacent", "siglip_b1_img4", "siglip_b1_img_first_last",
+                 "siglip_b2_equal_rightpad", "siglip_b2_equal_nopad", "siglip_b2_unequal_quirk", "clip_b2_equal_rightpad"):
+        c["pack_golden_" + case] = (lambda case=case: check_pack_golden(case))
+    c["pack_random"] = check_pack_random
+    c["gather_scatter_embed"] = check_gather_scatter_embed
+    c["ce_300"] = check_ce
+    c["ce_32002"] = lambda: check_ce(40, 32002, 0.5)
+    c["vit_front"] = check_vit_front
+    c["optim"] = check_optim
+    for case in MODEL_CASES:
+        c["model_step_" + case] = (lambda case=case: check_model_step(case))
+    return c
