@@ -183,7 +183,7 @@ class LlavaEngine:
 
         dlogits = logits                 # overwritten in place by the CE kernel
         if gw("head") is not None:
-            K.linear_dw(dlogits[:, :V], nf, gw("head"), acc)
+            K.linear_dw(dlogits, nf, gw("head"), acc)      # pad columns [V, Vp) are zero
         dnf = K.linear_dx(dlogits, m.lm["head"], k=Vp)
         dh_ce = K.rmsnorm_bwd(dnf, h_ce, m.lm["norm"], rstdf, None, gw("norm"), acc)
         dx = K.scatter_rows(dh_ce, plan.ce_row, B * L)
