@@ -7,28 +7,32 @@
 // Backward GEMMs (dX = dY.W, dW = dY^T.X) use the same kernel on transposed operands (rope.hip: mantis_transpose).
 //
 // Structure (MFMA-bound, fp32 accumulate):
-//   * 128x128 output tile per 256-thread workgroup (4 waves, 2x2), each wave 64x64 = 2x2 v_mfma_f32_32x32x16_bf16 blocks
+//   * BM x BN output tile per workgroup (256x256 with 8 waves of 128x64, or 128x128 with 4 waves of 64x64 for small / badly
+//     quantised shapes); every wave tile is built from v_mfma_f32_32x32x16_bf16 blocks
 //   * K step 64; A/B tiles go HBM -> LDS with global_load_lds (16 B per lane, no VGPR round trip), double buffered,
-//     one barrier per K step; the LDS image is XOR-swizzled through the *source* address so the ds_read_b128
-//     fragment reads are <= 2-way bank conflicted (cdna guide T2 / rule 21)
+//     one barrier per K step
+//   * LDS image [rows][64 k]: 16-B chunk c of row r sits at slot c ^ ((r >> 1) & 7): two rows share a 256-B bank row, so the
+//     16 rows of a ds_read_b128 lane group hit 16 distinct slots (conflict free).  global_load_lds writes lane-linearly,
+//     so the swizzle is applied on the SOURCE address and again on the fragment read (cdna guide rule 21)
+//   * PIPE > 0: fragment reads are issued one k-step ahead of the MFMAs that consume them (hand-placed ds_read_b128 +
+//     counted lgkmcnt), MFMA clusters run at raised wave priority, and the next tile's global_load_lds are spread
+//     between the MFMA clusters instead of being issued as one burst
 //   * operands are fed swapped (mfma(a = B rows, b = A rows)) so each lane owns ONE output row m and 4 consecutive n:
 //     the epilogue (bias, GELU variants, residual add, grad accumulation) is 8-byte vector loads/stores
 //   * edges: rows beyond M/N are clamped on load and predicated on store; K tails read a zero page (K % 8 == 0)
-//   * workgroup -> tile map is XCD-aware (contiguous tile range per XCD, 8-row groups) so the 64 tiles resident on
-//     one XCD share A/B panels in that XCD's private 4 MiB L2
+//   * workgroup -> tile map is XCD-aware (contiguous tile range per XCD, 8-row groups) so the tiles resident on one XCD
+//     share A/B panels in that XCD's private 4 MiB L2
 // Algorithmic FLOPs per launch: 2*M*N*K.
 #include "common.h"
 
-#define BM 128
-#define BN 128
 #define BK 64
-#define TILE_BYTES (128 * BK * 2)  // one operand tile: 16 KiB
-
 #define EPI_BIAS 1
 #define EPI_ACT_SHIFT 1
 #define EPI_ACT_MASK (7 << EPI_ACT_SHIFT)  // 0 none, 1 gelu(erf), 2 gelu(tanh), 3 quick_gelu
 #define EPI_RESIDUAL 16
 #define EPI_ACCUM 32
+#define EPI_VARIANT_SHIFT 8                 // bits 8-11: tile variant (0 = auto)
+#define EPI_VARIANT_MASK (15 << EPI_VARIANT_SHIFT)
 
 typedef __attribute__((address_space(3))) void lds_void;
 
@@ -46,100 +50,56 @@ __device__ __forceinline__ float gemm_act(float x, int kind) {
     }
 }
 
-// Stage one 128 x 64 operand tile.  Each wave issues 4 global_load_lds, each moving 8 rows x 128 B; lane l lands at
-// LDS byte (rowblock*1024 + l*16) = (row = l>>3, slot = l&7) and fetches logical 16-B chunk (slot ^ (row&7)).
+// One global_load_lds: 8 rows x 128 B of an operand tile (row block rb) -> LDS.
+__device__ __forceinline__ void stage_piece(const bf16_t* __restrict__ G, long ld, int row0, int rows_total, int k0, int K,
+                                            char* lds_tile, int rb, int lane) {
+    const int rl = lane >> 3;
+    const int chunk = (lane & 7) ^ ((rb * 4 + (rl >> 1)) & 7);
+    const int k = k0 + chunk * 8;
+    int grow = row0 + rb * 8 + rl;
+    grow = grow < rows_total ? grow : rows_total - 1;
+    const bf16_t* src = (k < K) ? (G + (long)grow * ld + k) : reinterpret_cast<const bf16_t*>(g_zero_page);
+    __builtin_amdgcn_global_load_lds(src, (lds_void*)(lds_tile + rb * 1024), 16, 0, 0);
+}
+
+template <int ROWS, int NW>
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, long ld, int row0, int rows_total, int k0, int K,
                                            char* lds_tile, int wave, int lane) {
-    const int rl = lane >> 3;
-    const int chunk = (lane & 7) ^ rl;
-    const int k = k0 + chunk * 8;
+    constexpr int PER = ROWS / 8 / NW;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int rb = wave * 4 + j;
-        int grow = row0 + rb * 8 + rl;
-        grow = grow < rows_total ? grow : rows_total - 1;
-        const bf16_t* src = (k < K) ? (G + (long)grow * ld + k) : reinterpret_cast<const bf16_t*>(g_zero_page);
-        __builtin_amdgcn_global_load_lds(src, (lds_void*)(lds_tile + rb * 1024), 16, 0, 0);
-    }
+    for (int j = 0; j < PER; ++j) stage_piece(G, ld, row0, rows_total, k0, K, lds_tile, wave * PER + j, lane);
 }
 
 __device__ __forceinline__ bf16x8 read_frag(const char* tile, int row, int chunk) {
-    return *reinterpret_cast<const bf16x8*>(tile + row * 128 + ((chunk ^ (row & 7)) << 4));
+    return *reinterpret_cast<const bf16x8*>(tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
-                                                         bf16_t* __restrict__ C, int M, int N, int K, long lda, long ldb,
-                                                         long ldc, const bf16_t* __restrict__ bias,
-                                                         const bf16_t* __restrict__ res, long ldr, int flags, int tiles_m,
-                                                         int tiles_n) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+// hand-placed LDS fragment read: the compiler neither counts it nor moves it (cdna guide 5.7 form iii)
+template <int OFF>
+__device__ __forceinline__ void lds_read_b128(bf16x8& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
 
-    // XCD-aware tile assignment: workgroup b runs on XCD b % 8; give every XCD a contiguous range of tile ids.
-    const int nwg = tiles_m * tiles_n;
-    const int bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    const int tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int GROUP = 8;
-    const int per_group = GROUP * tiles_n;
-    const int g = tile_id / per_group;
-    const int first_m = g * GROUP;
-    const int gsz = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
-    const int in_g = tile_id - g * per_group;
-    const int tm_idx = first_m + in_g % gsz;
-    const int tn_idx = in_g / gsz;
-    const int m0 = tm_idx * BM, n0 = tn_idx * BN;
+template <int N_>
+__device__ __forceinline__ void read_frags(bf16x8 (&dst)[N_], unsigned addr) {
+    lds_read_b128<0>(dst[0], addr);
+    if constexpr (N_ > 1) lds_read_b128<4096>(dst[1], addr);
+    if constexpr (N_ > 2) lds_read_b128<8192>(dst[2], addr);
+    if constexpr (N_ > 3) lds_read_b128<12288>(dst[3], addr);
+}
 
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const int nk = (K + BK - 1) / BK;
-    stage_tile(A, lda, m0, M, 0, K, smem, wave, lane);
-    stage_tile(B, ldb, n0, N, 0, K, smem + TILE_BYTES, wave, lane);
-
-    for (int t = 0; t < nk; ++t) {
-        char* cur = smem + (t & 1) * 2 * TILE_BYTES;
-        char* nxt = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t + 1 < nk) {
-            stage_tile(A, lda, m0, M, (t + 1) * BK, K, nxt, wave, lane);
-            stage_tile(B, ldb, n0, N, (t + 1) * BK, K, nxt + TILE_BYTES, wave, lane);
-        }
-        const char* At = cur;
-        const char* Bt = cur + TILE_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int chunk = ks * 2 + (lane >> 5);
-            bf16x8 fa[2], fb[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                fb[i] = read_frag(Bt, wn * 64 + i * 32 + (lane & 31), chunk);
-                fa[i] = read_frag(At, wm * 64 + i * 32 + (lane & 31), chunk);
-            }
-#pragma unroll
-            for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-                for (int tm = 0; tm < 2; ++tm)
-                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[tn], fa[tm], acc[tn][tm], 0, 0, 0);
-        }
-    }
-
-    // epilogue: lane owns row m, columns n = nb + 8*g4 + {0..3}
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TN][TM], bf16_t* __restrict__ C, int M, int N, long ldc,
+                                              const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res, long ldr,
+                                              int flags, int mw0, int nw0, int lane) {
     const int act = (flags & EPI_ACT_MASK) >> EPI_ACT_SHIFT;
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
-        const int m = m0 + wm * 64 + tm * 32 + (lane & 31);
+    for (int tm = 0; tm < TM; ++tm) {
+        const int m = mw0 + tm * 32 + (lane & 31);
         if (m >= M) continue;
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            const int nb = n0 + wn * 64 + tn * 32 + 4 * (lane >> 5);
+        for (int tn = 0; tn < TN; ++tn) {
+            const int nb = nw0 + tn * 32 + 4 * (lane >> 5);
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const int n = nb + 8 * g4;
@@ -193,11 +153,405 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const bf16_t* __restric
     }
 }
 
+// PIPE: 0 = compiler-scheduled inner loop; 1 = hand-placed fragment prefetch; 2 = 1 + s_setprio around the MFMA clusters;
+//       3 = 2 + next tile's global_load_lds spread between the k-steps
+template <int BM, int BN, int WM, int WN, int PIPE>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_nt_kernel(
+    const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C, int M, int N, int K, long lda, long ldb,
+    long ldc, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res, long ldr, int flags, int tiles_m, int tiles_n) {
+    constexpr int NWN = BN / WN, NW = (BM / WM) * NWN, TM = WM / 32, TN = WN / 32;
+    constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+    constexpr int PER_A = BM / 8 / NW, PER_B = BN / 8 / NW;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / NWN, wn = wave % NWN;
+
+    // XCD-aware tile assignment: workgroup b runs on XCD b % 8; give every XCD a contiguous range of tile ids.
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int GROUP = 8;
+    const int per_group = GROUP * tiles_n;
+    const int g = tile_id / per_group;
+    const int first_m = g * GROUP;
+    const int gsz = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+    const int in_g = tile_id - g * per_group;
+    const int m0 = (first_m + in_g % gsz) * BM, n0 = (in_g / gsz) * BN;
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = (K + BK - 1) / BK;
+    stage_tile<BM, NW>(A, lda, m0, M, 0, K, smem, wave, lane);
+    stage_tile<BN, NW>(B, ldb, n0, N, 0, K, smem + A_BYTES, wave, lane);
+
+    if constexpr (PIPE == 0) {
+        for (int t = 0; t < nk; ++t) {
+            char* cur = smem + (t & 1) * STAGE;
+            char* nxt = smem + ((t + 1) & 1) * STAGE;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t + 1 < nk) {
+                stage_tile<BM, NW>(A, lda, m0, M, (t + 1) * BK, K, nxt, wave, lane);
+                stage_tile<BN, NW>(B, ldb, n0, N, (t + 1) * BK, K, nxt + A_BYTES, wave, lane);
+            }
+            const char* At = cur;
+            const char* Bt = cur + A_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int chunk = ks * 2 + (lane >> 5);
+                bf16x8 fa[TM], fb[TN];
+#pragma unroll
+                for (int i = 0; i < TN; ++i) fb[i] = read_frag(Bt, wn * WN + i * 32 + (lane & 31), chunk);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = read_frag(At, wm * WM + i * 32 + (lane & 31), chunk);
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+                        acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[tn], fa[tm], acc[tn][tm], 0, 0, 0);
+            }
+        }
+    } else {
+        // per-lane LDS byte offsets of the 4 k-step chunks inside a row (identical for every 32-row block: 32 rows = 16 bank rows)
+        const unsigned rowoff = (unsigned)(lane & 31) * 128u;
+        const unsigned f = ((unsigned)(lane & 31) >> 1) & 7u;
+        unsigned xo[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) xo[ks] = rowoff + ((((unsigned)(ks * 2 + (lane >> 5))) ^ f) << 4);
+        const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;   // LDS byte address
+        const unsigned a_base = lds0 + (unsigned)(wm * WM) * 128u;
+        const unsigned b_base = lds0 + (unsigned)A_BYTES + (unsigned)(wn * WN) * 128u;
+        bf16x8 fa[2][TM], fb[2][TN];
+
+        for (int t = 0; t < nk; ++t) {
+            const unsigned so = (unsigned)(t & 1) * (unsigned)STAGE;
+            char* nxt = smem + ((t + 1) & 1) * STAGE;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const bool more = (PIPE != 8) && (t + 1 < nk);
+            if ((PIPE < 3 || PIPE >= 8) && more) {   // (PIPE 8: experiment without loads, 9: without MFMAs)
+                stage_tile<BM, NW>(A, lda, m0, M, (t + 1) * BK, K, nxt, wave, lane);
+                stage_tile<BN, NW>(B, ldb, n0, N, (t + 1) * BK, K, nxt + A_BYTES, wave, lane);
+            }
+            read_frags<TN>(fb[0], b_base + so + xo[0]);
+            read_frags<TM>(fa[0], a_base + so + xo[0]);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int cb = ks & 1, nb = cb ^ 1;
+                if (ks < 3) {
+                    read_frags<TN>(fb[nb], b_base + so + xo[ks + 1]);
+                    read_frags<TM>(fa[nb], a_base + so + xo[ks + 1]);
+                    if constexpr (TM + TN == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+                    else if constexpr (TM + TN == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (PIPE >= 2) __builtin_amdgcn_s_setprio(1);
+                if constexpr (PIPE == 9) {
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) asm volatile("" ::"v"(fb[cb][tn]));
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm) asm volatile("" ::"v"(fa[cb][tm]));
+                } else {
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+                        acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cb][tn], fa[cb][tm], acc[tn][tm], 0, 0, 0);
+                }
+                if (PIPE >= 2) __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (PIPE >= 3 && PIPE < 8 && more) {
+                    // a quarter of this wave's share of the next tile per k-step
+                    constexpr int QA = PER_A / 4 > 0 ? PER_A / 4 : 1, QB = PER_B / 4 > 0 ? PER_B / 4 : 1;
+#pragma unroll
+                    for (int j = 0; j < QA; ++j)
+                        if (ks * QA + j < PER_A)
+                            stage_piece(A, lda, m0, M, (t + 1) * BK, K, nxt, wave * PER_A + ks * QA + j, lane);
+#pragma unroll
+                    for (int j = 0; j < QB; ++j)
+                        if (ks * QB + j < PER_B)
+                            stage_piece(B, ldb, n0, N, (t + 1) * BK, K, nxt + A_BYTES, wave * PER_B + ks * QB + j, lane);
+                }
+            }
+        }
+    }
+
+    gemm_epilogue<TM, TN>(acc, C, M, N, ldc, bias, res, ldr, flags, m0 + wm * WM, n0 + wn * WN, lane);
+}
+
+template <int BM, int BN, int WM, int WN, int PIPE>
+static int launch_gemm(hipStream_t s, const bf16_t* A, const bf16_t* B, bf16_t* C, int M, int N, int K, long lda, long ldb,
+                       long ldc, const bf16_t* bias, const bf16_t* res, long ldr, int flags) {
+    const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, PIPE>), dim3(tiles_m * tiles_n), dim3((BM / WM) * (BN / WN) * 64), 0, s, A,
+                       B, C, M, N, K, lda, ldb, ldc, bias, res, ldr, flags, tiles_m, tiles_n);
+    return mantis_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 256x256 "ring" kernel: the whole 160 KiB LDS is a ring of ten 16-KiB slabs (one slab = 128 rows x 64 k of A or B), i.e.
+// 2.5 K-steps.  Slab (t, p) -- K-step t, part p in {A rows 0-127, B rows 0-127, A rows 128-255, B rows 128-255} -- lives
+// in slot (4t + p) % 10.  At the start of K-step t (after ONE raw s_barrier, which also retires K-step t-1's readers) the
+// four freed slots are refilled with parts 2,3 of step t+1 and parts 0,1 of step t+2, so 64-96 KiB of global_load_lds are
+// always in flight per CU and the loads get 1-2 K-steps of lead; the only vector-memory wait is a COUNTED
+// s_waitcnt vmcnt(4) (this wave's newest two slabs may still be in flight) -- the queue is never drained in the loop.
+template <int PIPE>
+__global__ __launch_bounds__(512) void gemm_nt_ring_kernel(
+    const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C, int M, int N, int K, long lda, long ldb,
+    long ldc, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res, long ldr, int flags, int tiles_m, int tiles_n) {
+    constexpr int TM = 4, TN = 2, SLAB = 16384;
+    __shared__ __attribute__((aligned(16))) char smem[10 * SLAB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int GROUP = 8;
+    const int per_group = GROUP * tiles_n;
+    const int g = tile_id / per_group;
+    const int first_m = g * GROUP;
+    const int gsz = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+    const int in_g = tile_id - g * per_group;
+    const int m0 = (first_m + in_g % gsz) * 256, n0 = (in_g / gsz) * 256;
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // slab (t, p): two global_load_lds per wave (pieces 2w, 2w+1 of the 16 eight-row pieces); K-steps past the end read zeros
+    auto issue = [&](int t, int p) {
+        char* dst = smem + ((4 * t + p) % 10) * SLAB;
+        const int half = p >> 1;
+        if (p & 1) {
+            stage_piece(B, ldb, n0 + half * 128, N, t * BK, K, dst, 2 * wave, lane);
+            stage_piece(B, ldb, n0 + half * 128, N, t * BK, K, dst, 2 * wave + 1, lane);
+        } else {
+            stage_piece(A, lda, m0 + half * 128, M, t * BK, K, dst, 2 * wave, lane);
+            stage_piece(A, lda, m0 + half * 128, M, t * BK, K, dst, 2 * wave + 1, lane);
+        }
+    };
+
+    const int nk = (K + BK - 1) / BK;
+    issue(0, 0); issue(0, 1); issue(0, 2); issue(0, 3);
+    issue(1, 0); issue(1, 1);
+
+    const unsigned rowoff = (unsigned)(lane & 31) * 128u;
+    const unsigned f = ((unsigned)(lane & 31) >> 1) & 7u;
+    unsigned xo[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) xo[ks] = rowoff + ((((unsigned)(ks * 2 + (lane >> 5))) ^ f) << 4);
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    bf16x8 fa[2][TM], fb[2][TN];
+
+    for (int t = 0; t < nk; ++t) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // everything except step t+1's parts 0,1 (this wave's 4 newest) landed
+        __builtin_amdgcn_s_barrier();
+        if (PIPE < 2) {
+            issue(t + 1, 2); issue(t + 1, 3);
+            issue(t + 2, 0); issue(t + 2, 1);
+        }
+        const unsigned a_base = lds0 + (unsigned)((4 * t + 2 * wm) % 10) * SLAB;                                  // A half wm
+        const unsigned b_base = lds0 + (unsigned)((4 * t + 1 + 2 * (wn >> 1)) % 10) * SLAB + (unsigned)(wn & 1) * 8192u;  // B half
+        read_frags<TN>(fb[0], b_base + xo[0]);
+        read_frags<TM>(fa[0], a_base + xo[0]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int cb = ks & 1, nb = cb ^ 1;
+            if (ks < 3) {
+                read_frags<TN>(fb[nb], b_base + xo[ks + 1]);
+                read_frags<TM>(fa[nb], a_base + xo[ks + 1]);
+                asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (PIPE >= 1) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cb][tn], fa[cb][tm], acc[tn][tm], 0, 0, 0);
+            if (PIPE >= 1) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (PIPE >= 2) {   // refill one freed slab per k-step: the DMA issue slots hide under the partner wave's MFMA cluster
+                if (ks == 0) issue(t + 1, 2);
+                if (ks == 1) issue(t + 1, 3);
+                if (ks == 2) issue(t + 2, 0);
+                if (ks == 3) issue(t + 2, 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the trailing zero-page loads before the LDS is released
+    gemm_epilogue<TM, TN>(acc, C, M, N, ldc, bias, res, ldr, flags, m0 + wm * 128, n0 + wn * 64, lane);
+}
+
+static int launch_gemm_ring(int pipe, hipStream_t s, const bf16_t* A, const bf16_t* B, bf16_t* C, int M, int N, int K, long lda,
+                            long ldb, long ldc, const bf16_t* bias, const bf16_t* res, long ldr, int flags) {
+    const int tiles_m = cdiv(M, 256), tiles_n = cdiv(N, 256);
+    if (pipe == 2)
+        hipLaunchKernelGGL((gemm_nt_ring_kernel<2>), dim3(tiles_m * tiles_n), dim3(512), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias,
+                           res, ldr, flags, tiles_m, tiles_n);
+    else if (pipe)
+        hipLaunchKernelGGL((gemm_nt_ring_kernel<1>), dim3(tiles_m * tiles_n), dim3(512), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias,
+                           res, ldr, flags, tiles_m, tiles_n);
+    else
+        hipLaunchKernelGGL((gemm_nt_ring_kernel<0>), dim3(tiles_m * tiles_n), dim3(512), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias,
+                           res, ldr, flags, tiles_m, tiles_n);
+    return mantis_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 256x256 "ping-pong" kernel.  Same 10-slab LDS ring as above, but the two wave groups of a workgroup (waves 0-3 own A rows
+// 0-127, waves 4-7 own A rows 128-255; every SIMD hosts one wave of each group) run HALF A K-STEP out of phase: when one
+// group stands at a K-step boundary (waiting for its slabs, restarting its fragment pipeline) the other group is in the
+// middle of its K-step with fragments already in registers, so the SIMD's matrix pipe always has MFMAs to issue.
+// Time advances in half-steps h; one raw s_barrier per half-step.  Slabs are ordered by first use:
+//   idx 4t+0 = A[0:128) of K-step t, 4t+1 = B[0:128), 4t+2 = B[128:256), 4t+3 = A[128:256);  slot = idx % 10.
+// Boundary h = 2t   frees idx 4t-4 (group 0 left K-step t-1)        -> refill with idx 4t+6
+// Boundary h = 2t+1 frees idx 4t-3..4t-1 (group 1 left K-step t-1)  -> refill with idx 4t+7, 4t+8, 4t+9
+// and at every boundary `s_waitcnt vmcnt(6)` (this wave's three newest slabs may be in flight) guarantees what the group
+// that starts a K-step there needs.
+template <int DUMMY>
+__global__ __launch_bounds__(512) void gemm_nt_pp_kernel(
+    const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C, int M, int N, int K, long lda, long ldb,
+    long ldc, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res, long ldr, int flags, int tiles_m, int tiles_n) {
+    constexpr int TM = 4, TN = 2, SLAB = 16384;
+    __shared__ __attribute__((aligned(16))) char smem[10 * SLAB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wn = wave & 3;
+
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int GROUP = 8;
+    const int per_group = GROUP * tiles_n;
+    const int g = tile_id / per_group;
+    const int first_m = g * GROUP;
+    const int gsz = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+    const int in_g = tile_id - g * per_group;
+    const int m0 = (first_m + in_g % gsz) * 256, n0 = (in_g / gsz) * 256;
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    auto issue = [&](int idx) {   // slab idx: two global_load_lds per wave
+        const int t = idx >> 2, p = idx & 3;
+        char* dst = smem + (idx % 10) * SLAB;
+        if (p == 1 || p == 2) {
+            stage_piece(B, ldb, n0 + (p - 1) * 128, N, t * BK, K, dst, 2 * wave, lane);
+            stage_piece(B, ldb, n0 + (p - 1) * 128, N, t * BK, K, dst, 2 * wave + 1, lane);
+        } else {
+            stage_piece(A, lda, m0 + (p == 3 ? 128 : 0), M, t * BK, K, dst, 2 * wave, lane);
+            stage_piece(A, lda, m0 + (p == 3 ? 128 : 0), M, t * BK, K, dst, 2 * wave + 1, lane);
+        }
+    };
+    const int nk = (K + BK - 1) / BK;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) issue(i);
+
+    const unsigned rowoff = (unsigned)(lane & 31) * 128u;
+    const unsigned f = ((unsigned)(lane & 31) >> 1) & 7u;
+    unsigned xo[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) xo[ks] = rowoff + ((((unsigned)(ks * 2 + (lane >> 5))) ^ f) << 4);
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    bf16x8 fa[2][TM], fb[2][TN];
+    unsigned a_base = 0, b_base = 0;
+
+    auto mfma_block = [&](int cb) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+                acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cb][tn], fa[cb][tm], acc[tn][tm], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // first half of K-step t: k-steps 0,1 (and the fragment reads of k-step 2 are left in flight across the boundary)
+    auto first_half = [&](int t) {
+        a_base = lds0 + (unsigned)((4 * t + (grp ? 3 : 0)) % 10) * SLAB;
+        b_base = lds0 + (unsigned)((4 * t + 1 + (wn >> 1)) % 10) * SLAB + (unsigned)(wn & 1) * 8192u;
+        read_frags<TN>(fb[0], b_base + xo[0]);
+        read_frags<TM>(fa[0], a_base + xo[0]);
+        read_frags<TN>(fb[1], b_base + xo[1]);
+        read_frags<TM>(fa[1], a_base + xo[1]);
+        asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        mfma_block(0);
+        read_frags<TN>(fb[0], b_base + xo[2]);
+        read_frags<TM>(fa[0], a_base + xo[2]);
+        asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        mfma_block(1);
+    };
+    auto second_half = [&]() {
+        read_frags<TN>(fb[1], b_base + xo[3]);
+        read_frags<TM>(fa[1], a_base + xo[3]);
+        asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        mfma_block(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mfma_block(1);
+    };
+
+    // one copy of each half in the instruction stream; which one a wave runs at boundary h depends only on (h - grp) parity
+    for (int h = 0; h <= 2 * nk; ++h) {
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (h & 1) {
+            issue(2 * h + 5); issue(2 * h + 6); issue(2 * h + 7);
+        } else {
+            issue(2 * h + 6);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int lh = h - grp;
+        if (lh >= 0 && lh < 2 * nk) {
+            if (lh & 1) second_half();
+            else first_half(lh >> 1);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    gemm_epilogue<TM, TN>(acc, C, M, N, ldc, bias, res, ldr, flags, m0 + grp * 128, n0 + wn * 64, lane);
+}
+
+static int launch_gemm_pp(hipStream_t s, const bf16_t* A, const bf16_t* B, bf16_t* C, int M, int N, int K, long lda, long ldb,
+                          long ldc, const bf16_t* bias, const bf16_t* res, long ldr, int flags) {
+    const int tiles_m = cdiv(M, 256), tiles_n = cdiv(N, 256);
+    hipLaunchKernelGGL((gemm_nt_pp_kernel<0>), dim3(tiles_m * tiles_n), dim3(512), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias, res,
+                       ldr, flags, tiles_m, tiles_n);
+    return mantis_check_launch();
+}
+
 extern "C" {
 
 // C[M,N] (bf16, row stride ldc) = epilogue(A[M,K] . B[N,K]^T); A,B,C 16-B aligned, lda/ldb % 8 == 0, K % 8 == 0.
 // flags: bit0 bias[n] add | bits1-3 activation (1 gelu-erf, 2 gelu-tanh, 3 quick-gelu) | bit4 + residual[m,n] (stride ldr)
-//        | bit5 accumulate into C (C += result, used for gradient accumulation)
+//        | bit5 accumulate into C (C += result, used for gradient accumulation) | bits8-11 tile variant (0 = auto)
 int mantis_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
                         const void* bias, const void* residual, int64_t ldr, int flags, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0) return MANTIS_EINVAL;
@@ -205,11 +559,34 @@ int mantis_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, 
     if (((uintptr_t)A | (uintptr_t)B) & 15) return MANTIS_EUNSUPPORTED;
     if ((flags & EPI_BIAS) && !bias) return MANTIS_EINVAL;
     if ((flags & EPI_RESIDUAL) && !residual) return MANTIS_EINVAL;
-    const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
-    hipLaunchKernelGGL(gemm_nt_kernel, dim3(tiles_m * tiles_n), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)A,
-                       (const bf16_t*)B, (bf16_t*)C, M, N, K, (long)lda, (long)ldb, (long)ldc, (const bf16_t*)bias,
-                       (const bf16_t*)residual, (long)ldr, flags, tiles_m, tiles_n);
-    return mantis_check_launch();
+    hipStream_t s = (hipStream_t)stream;
+    int variant = (flags & EPI_VARIANT_MASK) >> EPI_VARIANT_SHIFT;
+    if (variant == 0) {
+        // tile choice by wave quantisation: 256x256 tiles run 1 workgroup per CU (256 slots), 128x128 tiles 2 per CU (512 slots);
+        // the 256x256 ring kernel is ~15 % faster per tile-flop (measured, profiles/), so it wins unless its last round is empty-ish
+        const double r256 = (double)cdiv(M, 256) * cdiv(N, 256) / 256.0, r128 = (double)cdiv(M, 128) * cdiv(N, 128) / 512.0;
+        const double e256 = r256 / (double)(long)(r256 + 0.999999) * 1.15, e128 = r128 / (double)(long)(r128 + 0.999999);
+        variant = (M >= 512 && N >= 512 && e256 >= e128) ? 12 : 1;
+    }
+#define GEMM_ARGS s, (const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C, M, N, K, (long)lda, (long)ldb, (long)ldc, \
+                  (const bf16_t*)bias, (const bf16_t*)residual, (long)ldr, flags
+    switch (variant) {
+        case 1: return launch_gemm<128, 128, 64, 64, 0>(GEMM_ARGS);
+        case 2: return launch_gemm<256, 256, 128, 64, 0>(GEMM_ARGS);
+        case 3: return launch_gemm<256, 256, 128, 64, 1>(GEMM_ARGS);
+        case 4: return launch_gemm<256, 256, 128, 64, 2>(GEMM_ARGS);
+        case 5: return launch_gemm<256, 256, 128, 64, 3>(GEMM_ARGS);
+        case 6: return launch_gemm<128, 128, 64, 64, 2>(GEMM_ARGS);
+        case 7: return launch_gemm<128, 128, 64, 64, 3>(GEMM_ARGS);
+        case 8: return launch_gemm<256, 256, 128, 64, 8>(GEMM_ARGS);
+        case 9: return launch_gemm<256, 256, 128, 64, 9>(GEMM_ARGS);
+        case 10: return launch_gemm_ring(1, GEMM_ARGS);
+        case 11: return launch_gemm_ring(0, GEMM_ARGS);
+        case 12: return launch_gemm_ring(2, GEMM_ARGS);
+        case 13: return launch_gemm_pp(GEMM_ARGS);
+        default: return MANTIS_EINVAL;
+    }
+#undef GEMM_ARGS
 }
 
 }  // extern "C"

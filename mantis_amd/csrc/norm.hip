@@ -118,15 +118,24 @@ __global__ __launch_bounds__(64 * NORM_WAVES) void rmsnorm_bwd_kernel(
     }
 }
 
-// grad[j] (+)= sum_p partial[p][j]   (fixed summation order -> deterministic)
-__global__ void reduce_partials_kernel(const float* __restrict__ partial, int P, int d, bf16_t* __restrict__ grad,
-                                       int accumulate) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= d) return;
+// grad[j] (+)= sum_p partial[p][j]   (fixed summation order -> deterministic).  64 columns x 16 row groups per workgroup.
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ partial, int P, int d,
+                                                               bf16_t* __restrict__ grad, int accumulate) {
+    __shared__ float red[16][64];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + c;
     float s = 0.f;
-    for (int p = 0; p < P; ++p) s += partial[(long)p * d + j];
-    if (accumulate) s += bf2f(grad[j]);
-    grad[j] = f2bf(s);
+    if (j < d)
+        for (int p = g; p < P; p += 16) s += partial[(long)p * d + j];
+    red[g][c] = s;
+    __syncthreads();
+    if (g == 0 && j < d) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][c];
+        if (accumulate) t += bf2f(grad[j]);
+        grad[j] = f2bf(t);
+    }
 }
 
 // LayerNorm forward: y = bf16((x - mean) * rsqrt(var + eps) * w + b), stats fp32 (matches at::layer_norm on bf16 input)
@@ -206,7 +215,7 @@ int mantis_rmsnorm_bwd(const void* dy, const void* x, const void* weight, const 
                        (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)weight, rstd, (const bf16_t*)dres, (bf16_t*)dx,
                        grad_weight ? workspace : nullptr, (long)rows, d);
     if (grad_weight)
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(d, 256)), dim3(256), 0, (hipStream_t)stream, workspace, P, d,
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(d, 64)), dim3(1024), 0, (hipStream_t)stream, workspace, P, d,
                            (bf16_t*)grad_weight, accumulate);
     return mantis_check_launch();
 }

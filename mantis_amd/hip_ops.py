@@ -35,7 +35,7 @@ def pad8(n):
 
 
 # ----------------------------------------------------------------------------------------------------------- GEMM family
-def gemm_nt(a, b, bias=None, act=None, residual=None, out=None, accumulate=False, n_valid=None, k=None, ldc=None):
+def gemm_nt(a, b, bias=None, act=None, residual=None, out=None, accumulate=False, n_valid=None, k=None, ldc=None, variant=0):
     """out[M,N] = epi(a[M,K] @ b[N,K]^T).  `k` overrides the contraction length (zero-padded operands)."""
     _chk2d(a, "a"), _chk2d(b, "b")
     M, K = a.shape
@@ -46,7 +46,7 @@ def gemm_nt(a, b, bias=None, act=None, residual=None, out=None, accumulate=False
     else:
         _chk2d(out, "out")
     C = out
-    flags = (1 if bias is not None else 0) | (GEMM_ACT[act] << 1) | (16 if residual is not None else 0) | (32 if accumulate else 0)
+    flags = (1 if bias is not None else 0) | (GEMM_ACT[act] << 1) | (16 if residual is not None else 0) | (32 if accumulate else 0) | (variant << 8)
     prof = KERNEL_TIMER
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
