@@ -35,9 +35,9 @@ SIGNATURES = {
     "mantis_rope_apply": [P, P, P, L, I, I, L, I, P],
     "mantis_transpose": [P, P, I, I, I, L, L, I, I, L, L, L, L, P],
     "mantis_gemm_bf16_nt": [P, L, P, L, P, L, I, I, I, P, P, L, I, P],
-    "mantis_attn_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, L, L, L, F, I, P],
+    "mantis_attn_fwd": [P, P, P, P, P, P, I, I, I, I, I, L, L, L, L, F, I, P],
     "mantis_attn_dsum": [P, P, P, I, I, I, I, L, P],
-    "mantis_attn_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, L, L, L, L, L, L, L, F, I, P],
+    "mantis_attn_bwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, L, L, L, L, L, L, L, F, I, P],
     "mantis_ce_fwd_bwd": [P, P, I, I, L, F, F, I, P, P, P, P, P],
     "mantis_im2col": [P, P, I, I, I, I, I, I, P],
     "mantis_vit_assemble": [P, P, P, P, I, I, I, P],

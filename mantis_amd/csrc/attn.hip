@@ -12,48 +12,27 @@
 //    query column (lane & 31) and 16 keys per 32-key block: the row max / row sum are in-lane reductions plus a single
 //    lane <-> lane+32 exchange, and the rescale factor is lane-uniform.
 //  * the P (or dS) accumulator registers feed the next MFMA's B operand DIRECTLY: the contraction order over keys is
-//    permuted to match the accumulator layout (keys {4h+e+8c}), and the A operand (V^T / K^T / dO^T / Q^T, read from a
-//    key-contiguous LDS image) follows the same permutation -- no cross-lane shuffles, no LDS round trip for P.
-//  * operands whose contraction index is not their contiguous axis (V for P.V, K for dS.K, Q and dO for the dK/dV products)
-//    are consumed from pre-transposed global copies [B, heads, hd, Lp] (rope.hip: mantis_transpose), staged in LDS with a
-//    144-byte pitch (2-way worst case on ds_read_b64).
+//    permuted to match the accumulator layout (keys {4h+e+8c}), and the A operand follows the same permutation.
+//  * operands whose contraction index is not their contiguous axis (V for P.V, K for dS.K, Q and dO for dK/dV) are read from
+//    the SAME row-major LDS tile with ds_read_b64_tr_b16 (hardware transposing read: a 16-lane group fetches a 4x16 block and
+//    lane t receives column t) -- no transposed copies in HBM or LDS.
+//  * K/V (or Q/dO) tiles are double buffered in LDS: the next tile's global loads are issued into registers before the MFMA
+//    work of the current tile and written to the other buffer afterwards (one barrier per tile).
+//  * causal work is dispatched heaviest-first; the dK/dV kernel runs one workgroup per (key block, QUERY head) and a small
+//    reduction sums the GQA group, so the grid is H/Hkv times larger than a per-kv-head walk.
 // Algorithmic FLOPs: forward 4*L*Lk*hd per head (half for causal); backward 2.5x forward (+1x recompute of S and dP here).
 #include "common.h"
 
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
 
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
 __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) {
     union { u32x4 u; bf16x8 b; } c;
     c.u = v;
     return c.b;
-}
-
-// Cooperative global -> LDS tile load through registers (16 B per lane).  Tile = ROWS x NCH chunks(8 bf16); element (r, c*8)
-// comes from g[r*gstride + c*8]; rows >= rows_valid or chunk start >= cols_valid are zero-filled.
-template <int ROWS, int NCH, int PITCH>
-__device__ __forceinline__ void load_tile(const bf16_t* __restrict__ g, long gstride, int rows_valid, int cols_valid,
-                                          char* lds) {
-    for (int idx = threadIdx.x; idx < ROWS * NCH; idx += 256) {
-        const int r = idx / NCH, c = idx - r * NCH;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (r < rows_valid && c * 8 < cols_valid) v = *reinterpret_cast<const u32x4*>(g + (long)r * gstride + c * 8);
-        *reinterpret_cast<u32x4*>(lds + r * PITCH + c * 16) = v;
-    }
-}
-
-// A-operand fragment from a key-contiguous (transposed) LDS image: row = d, 8 "slots" = keys {o, o+1, o+2, o+3, o+8, .., o+11}
-__device__ __forceinline__ bf16x8 read_tfrag(const char* lds, int pitch, int row, int col0) {
-    const u32x2 a = *reinterpret_cast<const u32x2*>(lds + row * pitch + col0 * 2);
-    const u32x2 b = *reinterpret_cast<const u32x2*>(lds + row * pitch + col0 * 2 + 16);
-    return as_bf16x8(u32x4{a[0], a[1], b[0], b[1]});
-}
-
-__device__ __forceinline__ bf16x8 pack_frag(const f32x16& s, int cp) {
-    u32x4 u;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) u[e] = pack_bf2(s[8 * cp + 2 * e], s[8 * cp + 2 * e + 1]);
-    return as_bf16x8(u);
 }
 
 template <int HD>
@@ -63,26 +42,72 @@ struct AttnCfg {
     static constexpr int NKS = KP / 16;
     static constexpr int NDB = DP / 32;
     static constexpr int NCK = KP / 8;
-    static constexpr int KPITCH = KP * 2 + 16;
-    static constexpr int TPITCH = 144;                // 64 keys * 2 B + 16
+    static constexpr int PITCH = DP * 2 + 16;        // row pitch in bytes (rows hold DP columns so tr reads of pad cols stay in-row)
+    static constexpr int NCH = DP / 8;               // 16-B chunks staged per row
 };
 
+// global -> registers (issue early) and registers -> LDS (write late): a ROWS x NCH-chunk row-major tile, 256 threads.
+// rows >= rows_valid and chunks starting at column >= cols_valid are zero.
+template <int ROWS, int NCH>
+struct TileRegs {
+    static constexpr int N = (ROWS * NCH + 255) / 256;
+    u32x4 v[N];
+    __device__ __forceinline__ void load(const bf16_t* __restrict__ g, long gstride, int rows_valid, int cols_valid) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const int idx = threadIdx.x + j * 256;
+            const int r = idx / NCH, c = idx - r * NCH;
+            v[j] = u32x4{0u, 0u, 0u, 0u};
+            if (idx < ROWS * NCH && r < rows_valid && c * 8 < cols_valid)
+                v[j] = *reinterpret_cast<const u32x4*>(g + (long)r * gstride + c * 8);
+        }
+    }
+    __device__ __forceinline__ void store(char* lds, int pitch) const {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const int idx = threadIdx.x + j * 256;
+            const int r = idx / NCH, c = idx - r * NCH;
+            if (idx < ROWS * NCH) *reinterpret_cast<u32x4*>(lds + r * pitch + c * 16) = v[j];
+        }
+    }
+};
+
+// A-operand fragment with the contraction index running over ROWS of a row-major LDS tile: lane (i = col0 + (lane & 31), h)
+// receives rows {row0 + 4h + 0..3, row0 + 8 + 4h + 0..3} of column i -- two hardware-transposing reads.
+__device__ __forceinline__ bf16x8 read_tr_frag(const char* tile, int pitch, int row0, int col0, int lane) {
+    const int s = lane & 15, g16 = (lane >> 4) & 1, h = lane >> 5;
+    const char* p = tile + (row0 + 4 * h + (s >> 2)) * pitch + (col0 + 16 * g16 + (s & 3) * 4) * 2;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 8 * pitch));
+    union { s16x4 s2[2]; bf16x8 f; } u;
+    u.s2[0] = a;
+    u.s2[1] = b;
+    return u.f;
+}
+
+__device__ __forceinline__ bf16x8 pack_frag(const f32x16& s, int cp) {
+    u32x4 u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) u[e] = pack_bf2(s[8 * cp + 2 * e], s[8 * cp + 2 * e + 1]);
+    return as_bf16x8(u);
+}
+
 // ------------------------------------------------------------------------------------------------ forward
-// grid (ceil(L/128), H, B); 4 waves x 32 query rows; KV tiles of 64 keys.
+// grid (ceil(L/128), H, B); 4 waves x 32 query rows; KV tiles of 64 keys, double buffered.
 template <int HD, bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                       const bf16_t* __restrict__ Vt, const int* __restrict__ kmask,
-                                                       bf16_t* __restrict__ O, float* __restrict__ LSE, int L, int Lp, int H,
-                                                       int Hkv, long ldq, long ldk, long ldo, float scale) {
+                                                       const bf16_t* __restrict__ V, const int* __restrict__ kmask,
+                                                       bf16_t* __restrict__ O, float* __restrict__ LSE, int L, int H, int Hkv,
+                                                       long ldq, long ldk, long ldv, long ldo, float scale) {
     using C = AttnCfg<HD>;
-    __shared__ __attribute__((aligned(16))) char smem[64 * C::KPITCH + C::DP * C::TPITCH + 64 * 4];
-    char* sK = smem;
-    char* sV = smem + 64 * C::KPITCH;
-    float* sBias = reinterpret_cast<float*>(smem + 64 * C::KPITCH + C::DP * C::TPITCH);
+    constexpr int TILE = 64 * C::PITCH;
+    constexpr int BUF = 2 * TILE + 64 * 4;
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hh = lane >> 5, lq = lane & 31;
     const int b = blockIdx.z, h = blockIdx.y, hk = h / (H / Hkv);
-    const int qblk0 = blockIdx.x * 128, q0 = qblk0 + wave * 32, q = q0 + lq;
+    const int qb = CAUSAL ? (gridDim.x - 1 - blockIdx.x) : blockIdx.x;   // causal: longest rows first
+    const int qblk0 = qb * 128, q0 = qblk0 + wave * 32, q = q0 + lq;
     const int qc = q < L ? q : L - 1;
     const float c = scale * LOG2E;
 
@@ -104,73 +129,92 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     const int kend = CAUSAL ? (qblk0 + 128 < L ? qblk0 + 128 : L) : L;
     const int ntiles = (kend + 63) / 64;
     const bf16_t* Kb = K + (long)b * L * ldk + (long)hk * HD;
-    const bf16_t* Vb = Vt + ((long)b * Hkv + hk) * HD * Lp;
+    const bf16_t* Vb = V + (long)b * L * ldv + (long)hk * HD;
+
+    TileRegs<64, C::NCH> rk, rv;
+    float rbias = 0.f;
+    auto gload = [&](int t) {
+        const int key0 = t * 64;
+        rk.load(Kb + (long)key0 * ldk, ldk, L - key0, HD);
+        rv.load(Vb + (long)key0 * ldv, ldv, L - key0, HD);
+        if (threadIdx.x < 64) {
+            const int key = key0 + threadIdx.x;
+            rbias = (key < L && (kmask == nullptr || kmask[(long)b * L + key] != 0)) ? 0.f : -INFINITY;
+        }
+    };
+    auto lstore = [&](int buf) {
+        char* base = smem + buf * BUF;
+        rk.store(base, C::PITCH);
+        rv.store(base + TILE, C::PITCH);
+        if (threadIdx.x < 64) reinterpret_cast<float*>(base + 2 * TILE)[threadIdx.x] = rbias;
+    };
+    gload(0);
+    lstore(0);
+    __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
         const int key0 = t * 64;
-        __syncthreads();
-        load_tile<64, C::NCK, C::KPITCH>(Kb + (long)key0 * ldk, ldk, L - key0, HD, sK);
-        load_tile<HD, 8, C::TPITCH>(Vb + key0, Lp, HD, Lp - key0, sV);
-        if (threadIdx.x < 64) {
-            const int key = key0 + threadIdx.x;
-            const bool ok = key < L && (kmask == nullptr || kmask[(long)b * L + key] != 0);
-            sBias[threadIdx.x] = ok ? 0.f : -INFINITY;
-        }
-        __syncthreads();
-        if (CAUSAL && key0 > q0 + 31) continue;  // wave-uniform: whole tile is in this wave's future
-
-        f32x16 s[2];
+        const char* sK = smem + (t & 1) * BUF;
+        const char* sV = sK + TILE;
+        const float* sBias = reinterpret_cast<const float*>(sK + 2 * TILE);
+        const bool more = t + 1 < ntiles;
+        if (more) gload(t + 1);
+        if (!(CAUSAL && key0 > q0 + 31)) {   // wave-uniform: skip tiles entirely in this wave's future
+            f32x16 s[2];
 #pragma unroll
-        for (int sb = 0; sb < 2; ++sb) {
+            for (int sb = 0; sb < 2; ++sb) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) s[sb][e] = 0.f;
+                for (int e = 0; e < 16; ++e) s[sb][e] = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < C::NKS; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (sb * 32 + lq) * C::KPITCH + (ks * 2 + hh) * 16);
-                s[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[sb], 0, 0, 0);
-            }
-        }
-        float mx = -INFINITY;
-#pragma unroll
-        for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kl = sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                float v = s[sb][r] * c + sBias[kl];
-                if (CAUSAL && key0 + kl > q) v = -INFINITY;
-                s[sb][r] = v;
-                mx = fmaxf(mx, v);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float msafe = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = (m_new == -INFINITY) ? 1.f : exp2f(m_run - m_new);
-        float psum = 0.f;
-#pragma unroll
-        for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = exp2f(s[sb][r] - msafe);
-                s[sb][r] = p;
-                psum += p;
-            }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int d = 0; d < C::NDB; ++d)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
-#pragma unroll
-        for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-            for (int cp = 0; cp < 2; ++cp) {
-                const bf16x8 pf = pack_frag(s[sb], cp);
-#pragma unroll
-                for (int d = 0; d < C::NDB; ++d) {
-                    const bf16x8 vf = read_tfrag(sV, C::TPITCH, d * 32 + lq, sb * 32 + 16 * cp + 4 * hh);
-                    oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[d], 0, 0, 0);
+                for (int ks = 0; ks < C::NKS; ++ks) {
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (sb * 32 + lq) * C::PITCH + (ks * 2 + hh) * 16);
+                    s[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[sb], 0, 0, 0);
                 }
             }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kl = sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    float v = s[sb][r] * c + sBias[kl];
+                    if (CAUSAL && key0 + kl > q) v = -INFINITY;
+                    s[sb][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float msafe = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = (m_new == -INFINITY) ? 1.f : exp2f(m_run - m_new);
+            float psum = 0.f;
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = exp2f(s[sb][r] - msafe);
+                    s[sb][r] = p;
+                    psum += p;
+                }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int d = 0; d < C::NDB; ++d)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                for (int cp = 0; cp < 2; ++cp) {
+                    const bf16x8 pf = pack_frag(s[sb], cp);
+#pragma unroll
+                    for (int d = 0; d < C::NDB; ++d) {
+                        const bf16x8 vf = read_tr_frag(sV, C::PITCH, sb * 32 + 16 * cp, d * 32, lane);
+                        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[d], 0, 0, 0);
+                    }
+                }
+        }
+        if (more) lstore((t + 1) & 1);
+        __syncthreads();
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
@@ -216,24 +260,22 @@ __global__ void attn_dsum_kernel(const bf16_t* __restrict__ dO, const bf16_t* __
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ
-// Same walk as the forward: grid (ceil(L/128), H, B), KV tiles of 64 keys.  dQ^T[d][q] += K^T[d][key] . dS^T[key][q].
+// Same walk as the forward.  dQ^T[d][q] += K^T[d][key] . dS^T[key][q]  (K^T fragments: transposing reads of the K tile).
 template <int HD, bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                          const bf16_t* __restrict__ V, const bf16_t* __restrict__ Kt,
-                                                          const bf16_t* __restrict__ dO, const int* __restrict__ kmask,
-                                                          const float* __restrict__ LSE, const float* __restrict__ Dsum,
-                                                          bf16_t* __restrict__ dQ, int L, int Lp, int H, int Hkv, long ldq,
-                                                          long ldk, long ldv, long ldo, long lddq, float scale) {
+                                                          const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
+                                                          const int* __restrict__ kmask, const float* __restrict__ LSE,
+                                                          const float* __restrict__ Dsum, bf16_t* __restrict__ dQ, int L, int H,
+                                                          int Hkv, long ldq, long ldk, long ldv, long ldo, long lddq, float scale) {
     using C = AttnCfg<HD>;
-    __shared__ __attribute__((aligned(16))) char smem[2 * 64 * C::KPITCH + C::DP * C::TPITCH + 64 * 4];
-    char* sK = smem;
-    char* sV = smem + 64 * C::KPITCH;
-    char* sKt = smem + 2 * 64 * C::KPITCH;
-    float* sBias = reinterpret_cast<float*>(smem + 2 * 64 * C::KPITCH + C::DP * C::TPITCH);
+    constexpr int TILE = 64 * C::PITCH;
+    constexpr int BUF = 2 * TILE + 64 * 4;
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hh = lane >> 5, lq = lane & 31;
     const int b = blockIdx.z, h = blockIdx.y, hk = h / (H / Hkv);
-    const int qblk0 = blockIdx.x * 128, q0 = qblk0 + wave * 32, q = q0 + lq;
+    const int qb = CAUSAL ? (gridDim.x - 1 - blockIdx.x) : blockIdx.x;
+    const int qblk0 = qb * 128, q0 = qblk0 + wave * 32, q = q0 + lq;
     const int qc = q < L ? q : L - 1;
     const float c = scale * LOG2E;
 
@@ -261,57 +303,74 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     const int ntiles = (kend + 63) / 64;
     const bf16_t* Kb = K + (long)b * L * ldk + (long)hk * HD;
     const bf16_t* Vb = V + (long)b * L * ldv + (long)hk * HD;
-    const bf16_t* Ktb = Kt + ((long)b * Hkv + hk) * HD * Lp;
+
+    TileRegs<64, C::NCH> rk, rv;
+    float rbias = 0.f;
+    auto gload = [&](int t) {
+        const int key0 = t * 64;
+        rk.load(Kb + (long)key0 * ldk, ldk, L - key0, HD);
+        rv.load(Vb + (long)key0 * ldv, ldv, L - key0, HD);
+        if (threadIdx.x < 64) {
+            const int key = key0 + threadIdx.x;
+            rbias = (key < L && (kmask == nullptr || kmask[(long)b * L + key] != 0)) ? 0.f : -INFINITY;
+        }
+    };
+    auto lstore = [&](int buf) {
+        char* base = smem + buf * BUF;
+        rk.store(base, C::PITCH);
+        rv.store(base + TILE, C::PITCH);
+        if (threadIdx.x < 64) reinterpret_cast<float*>(base + 2 * TILE)[threadIdx.x] = rbias;
+    };
+    gload(0);
+    lstore(0);
+    __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
         const int key0 = t * 64;
-        __syncthreads();
-        load_tile<64, C::NCK, C::KPITCH>(Kb + (long)key0 * ldk, ldk, L - key0, HD, sK);
-        load_tile<64, C::NCK, C::KPITCH>(Vb + (long)key0 * ldv, ldv, L - key0, HD, sV);
-        load_tile<HD, 8, C::TPITCH>(Ktb + key0, Lp, HD, Lp - key0, sKt);
-        if (threadIdx.x < 64) {
-            const int key = key0 + threadIdx.x;
-            const bool ok = key < L && (kmask == nullptr || kmask[(long)b * L + key] != 0);
-            sBias[threadIdx.x] = ok ? 0.f : -INFINITY;
-        }
-        __syncthreads();
-        if (CAUSAL && key0 > q0 + 31) continue;
-
-        f32x16 s[2], dp[2];
+        const char* sK = smem + (t & 1) * BUF;
+        const char* sV = sK + TILE;
+        const float* sBias = reinterpret_cast<const float*>(sK + 2 * TILE);
+        const bool more = t + 1 < ntiles;
+        if (more) gload(t + 1);
+        if (!(CAUSAL && key0 > q0 + 31)) {
+            f32x16 s[2], dp[2];
 #pragma unroll
-        for (int sb = 0; sb < 2; ++sb) {
+            for (int sb = 0; sb < 2; ++sb) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { s[sb][e] = 0.f; dp[sb][e] = 0.f; }
+                for (int e = 0; e < 16; ++e) { s[sb][e] = 0.f; dp[sb][e] = 0.f; }
 #pragma unroll
-            for (int ks = 0; ks < C::NKS; ++ks) {
-                const int off = (sb * 32 + lq) * C::KPITCH + (ks * 2 + hh) * 16;
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + off);
-                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sV + off);
-                s[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[sb], 0, 0, 0);
-                dp[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp[sb], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kl = sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                float v = s[sb][r] * c + sBias[kl];
-                if (CAUSAL && key0 + kl > q) v = -INFINITY;
-                const float p = exp2f(v - lse2);  // lse = +inf for fully masked rows -> p = 0
-                s[sb][r] = p * (dp[sb][r] - dsum) * scale;
-            }
-#pragma unroll
-        for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-            for (int cp = 0; cp < 2; ++cp) {
-                const bf16x8 dsf = pack_frag(s[sb], cp);
-#pragma unroll
-                for (int d = 0; d < C::NDB; ++d) {
-                    const bf16x8 ktf = read_tfrag(sKt, C::TPITCH, d * 32 + lq, sb * 32 + 16 * cp + 4 * hh);
-                    acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf, acc[d], 0, 0, 0);
+                for (int ks = 0; ks < C::NKS; ++ks) {
+                    const int off = (sb * 32 + lq) * C::PITCH + (ks * 2 + hh) * 16;
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + off);
+                    const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sV + off);
+                    s[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[sb], 0, 0, 0);
+                    dp[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp[sb], 0, 0, 0);
                 }
             }
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kl = sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    float v = s[sb][r] * c + sBias[kl];
+                    if (CAUSAL && key0 + kl > q) v = -INFINITY;
+                    const float p = exp2f(v - lse2);  // lse = +inf for fully masked rows -> p = 0
+                    s[sb][r] = p * (dp[sb][r] - dsum) * scale;
+                }
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                for (int cp = 0; cp < 2; ++cp) {
+                    const bf16x8 dsf = pack_frag(s[sb], cp);
+#pragma unroll
+                    for (int d = 0; d < C::NDB; ++d) {
+                        const bf16x8 ktf = read_tr_frag(sK, C::PITCH, sb * 32 + 16 * cp, d * 32, lane);
+                        acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf, acc[d], 0, 0, 0);
+                    }
+                }
+        }
+        if (more) lstore((t + 1) & 1);
+        __syncthreads();
     }
     if (q < L) {
         bf16_t* op = dQ + ((long)b * L + q) * lddq + (long)h * HD;
@@ -331,30 +390,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
-// grid (ceil(L/128), Hkv, B): 4 waves x 32 keys; loops over the G = H/Hkv query heads of the group and 32-row query tiles.
+// grid (ceil(L/128), H, B): 4 waves x 32 keys for ONE query head (GQA group summed afterwards); walks 32-row query tiles.
 //   S[q][key]  = Q . K^T      (lane owns ONE key column, 16 query rows per block)
 //   dV^T[d][key] += dO^T[d][q] . P[q][key]        dK^T[d][key] += Q^T[d][q] . dS[q][key]
-#define QT_PITCH 80  // 32 queries * 2 B + 16
+// dKp/dVp: per-QUERY-head outputs [B*L, H*hd] (row stride ldp), or the final dK/dV when H == Hkv.
 template <int HD, bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                           const bf16_t* __restrict__ V, const bf16_t* __restrict__ Qt,
-                                                           const bf16_t* __restrict__ dO, const bf16_t* __restrict__ dOt,
+                                                           const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
                                                            const int* __restrict__ kmask, const float* __restrict__ LSE,
-                                                           const float* __restrict__ Dsum, bf16_t* __restrict__ dK,
-                                                           bf16_t* __restrict__ dV, int L, int Lp, int H, int Hkv, long ldq,
-                                                           long ldk, long ldv, long ldo, long lddk, long lddv, float scale) {
+                                                           const float* __restrict__ Dsum, bf16_t* __restrict__ dKp,
+                                                           bf16_t* __restrict__ dVp, int L, int H, int Hkv, long ldq, long ldk,
+                                                           long ldv, long ldo, long ldpk, long ldpv, float scale) {
     using C = AttnCfg<HD>;
-    __shared__ __attribute__((aligned(16))) char smem[2 * 32 * C::KPITCH + 2 * C::DP * QT_PITCH + 2 * 32 * 4];
-    char* sQ = smem;
-    char* sdO = smem + 32 * C::KPITCH;
-    char* sQt = smem + 2 * 32 * C::KPITCH;
-    char* sdOt = sQt + C::DP * QT_PITCH;
-    float* sLse = reinterpret_cast<float*>(sdOt + C::DP * QT_PITCH);
-    float* sDs = sLse + 32;
+    constexpr int TILE = 32 * C::PITCH;
+    constexpr int BUF = 2 * TILE + 2 * 32 * 4;
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hh = lane >> 5, lk = lane & 31;
-    const int b = blockIdx.z, hk = blockIdx.y, G = H / Hkv;
-    const int kblk0 = blockIdx.x * 128, k0 = kblk0 + wave * 32, key = k0 + lk;
+    const int b = blockIdx.z, h = blockIdx.y, hk = h / (H / Hkv);
+    const int kblk0 = blockIdx.x * 128, k0 = kblk0 + wave * 32, key = k0 + lk;   // causal: key block 0 is the heaviest, first
     const int keyc = key < L ? key : L - 1;
     const float c = scale * LOG2E;
     const bool key_ok = key < L && (kmask == nullptr || kmask[(long)b * L + keyc] != 0);
@@ -379,33 +433,52 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
 
     const int qstart = CAUSAL ? (kblk0 / 32) : 0;  // first 32-row query tile that can see this key block
     const int nqt = (L + 31) / 32;
-    for (int g = 0; g < G; ++g) {
-        const int h = hk * G + g;
-        const bf16_t* Qb = Q + (long)b * L * ldq + (long)h * HD;
-        const bf16_t* dOb = dO + (long)b * L * ldo + (long)h * HD;
-        const bf16_t* Qtb = Qt + ((long)b * H + h) * HD * Lp;
-        const bf16_t* dOtb = dOt + ((long)b * H + h) * HD * Lp;
-        for (int qt = qstart; qt < nqt; ++qt) {
-            const int q0 = qt * 32;
-            __syncthreads();
-            load_tile<32, C::NCK, C::KPITCH>(Qb + (long)q0 * ldq, ldq, L - q0, HD, sQ);
-            load_tile<32, C::NCK, C::KPITCH>(dOb + (long)q0 * ldo, ldo, L - q0, HD, sdO);
-            load_tile<HD, 4, QT_PITCH>(Qtb + q0, Lp, HD, Lp - q0, sQt);
-            load_tile<HD, 4, QT_PITCH>(dOtb + q0, Lp, HD, Lp - q0, sdOt);
-            if (threadIdx.x < 32) {
-                const int qq = q0 + threadIdx.x;
-                sLse[threadIdx.x] = qq < L ? LSE[((long)b * H + h) * L + qq] * LOG2E : INFINITY;
-                sDs[threadIdx.x] = qq < L ? Dsum[((long)b * H + h) * L + qq] : 0.f;
-            }
-            __syncthreads();
-            if (CAUSAL && q0 + 31 < k0) continue;  // wave-uniform: every query of the tile precedes this wave's keys
+    const bf16_t* Qb = Q + (long)b * L * ldq + (long)h * HD;
+    const bf16_t* dOb = dO + (long)b * L * ldo + (long)h * HD;
 
+    TileRegs<32, C::NCH> rq, rdo;
+    float rl = 0.f, rd = 0.f;
+    auto gload = [&](int qt) {
+        const int q0 = qt * 32;
+        rq.load(Qb + (long)q0 * ldq, ldq, L - q0, HD);
+        rdo.load(dOb + (long)q0 * ldo, ldo, L - q0, HD);
+        if (threadIdx.x < 32) {
+            const int qq = q0 + threadIdx.x;
+            rl = qq < L ? LSE[((long)b * H + h) * L + qq] * LOG2E : INFINITY;
+            rd = qq < L ? Dsum[((long)b * H + h) * L + qq] : 0.f;
+        }
+    };
+    auto lstore = [&](int buf) {
+        char* base = smem + buf * BUF;
+        rq.store(base, C::PITCH);
+        rdo.store(base + TILE, C::PITCH);
+        if (threadIdx.x < 32) {
+            reinterpret_cast<float*>(base + 2 * TILE)[threadIdx.x] = rl;
+            reinterpret_cast<float*>(base + 2 * TILE)[32 + threadIdx.x] = rd;
+        }
+    };
+    if (qstart < nqt) {
+        gload(qstart);
+        lstore(0);
+    }
+    __syncthreads();
+
+    for (int qt = qstart; qt < nqt; ++qt) {
+        const int q0 = qt * 32;
+        const int cur = (qt - qstart) & 1;
+        const char* sQ = smem + cur * BUF;
+        const char* sdO = sQ + TILE;
+        const float* sLse = reinterpret_cast<const float*>(sQ + 2 * TILE);
+        const float* sDs = sLse + 32;
+        const bool more = qt + 1 < nqt;
+        if (more) gload(qt + 1);
+        if (!(CAUSAL && q0 + 31 < k0)) {  // wave-uniform: skip tiles whose every query precedes this wave's keys
             f32x16 s, dp;
 #pragma unroll
             for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < C::NKS; ++ks) {
-                const int off = lk * C::KPITCH + (ks * 2 + hh) * 16;
+                const int off = lk * C::PITCH + (ks * 2 + hh) * 16;
                 const bf16x8 qa = *reinterpret_cast<const bf16x8*>(sQ + off);
                 const bf16x8 da = *reinterpret_cast<const bf16x8*>(sdO + off);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);
@@ -427,17 +500,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
                 const bf16x8 dsf = pack_frag(ds, cp);
 #pragma unroll
                 for (int d = 0; d < C::NDB; ++d) {
-                    const bf16x8 dot = read_tfrag(sdOt, QT_PITCH, d * 32 + lk, 16 * cp + 4 * hh);
-                    const bf16x8 qtf = read_tfrag(sQt, QT_PITCH, d * 32 + lk, 16 * cp + 4 * hh);
+                    const bf16x8 dot = read_tr_frag(sdO, C::PITCH, 16 * cp, d * 32, lane);
+                    const bf16x8 qtf = read_tr_frag(sQ, C::PITCH, 16 * cp, d * 32, lane);
                     dvacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot, pf, dvacc[d], 0, 0, 0);
                     dkacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsf, dkacc[d], 0, 0, 0);
                 }
             }
         }
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
     }
     if (key < L) {
-        bf16_t* kp = dK + ((long)b * L + key) * lddk + (long)hk * HD;
-        bf16_t* vp = dV + ((long)b * L + key) * lddv + (long)hk * HD;
+        bf16_t* kp = dKp + ((long)b * L + key) * ldpk + (long)(H == Hkv ? hk : h) * HD;
+        bf16_t* vp = dVp + ((long)b * L + key) * ldpv + (long)(H == Hkv ? hk : h) * HD;
 #pragma unroll
         for (int d = 0; d < C::NDB; ++d)
 #pragma unroll
@@ -456,52 +531,92 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
     }
 }
 
+// dK[m, hk*hd + d] = sum_g dKp[m, (hk*G + g)*hd + d]  (and dV): fp32 sum of the G per-query-head partials, 16 B per lane
+__global__ void attn_group_reduce_kernel(const bf16_t* __restrict__ pk, const bf16_t* __restrict__ pv, bf16_t* __restrict__ dK,
+                                         bf16_t* __restrict__ dV, long rows, int Hkv, int G, int HD, long ldp, long lddk, long lddv) {
+    const int cph = HD >> 3;
+    const long total = rows * Hkv * cph;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % cph);
+        const long t = i / cph;
+        const int hk = (int)(t % Hkv);
+        const long r = t / Hkv;
+        float ak[8], av[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ak[e] = 0.f; av[e] = 0.f; }
+        for (int g = 0; g < G; ++g) {
+            const long off = r * ldp + (long)(hk * G + g) * HD + cc * 8;
+            const u32x4 a = *reinterpret_cast<const u32x4*>(pk + off);
+            const u32x4 w = *reinterpret_cast<const u32x4*>(pv + off);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ak[2 * e] += bf2f_lo(a[e]); ak[2 * e + 1] += bf2f_hi(a[e]);
+                av[2 * e] += bf2f_lo(w[e]); av[2 * e + 1] += bf2f_hi(w[e]);
+            }
+        }
+        u32x4 ok, ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ok[e] = pack_bf2(ak[2 * e], ak[2 * e + 1]); ov[e] = pack_bf2(av[2 * e], av[2 * e + 1]); }
+        *reinterpret_cast<u32x4*>(dK + r * lddk + (long)hk * HD + cc * 8) = ok;
+        *reinterpret_cast<u32x4*>(dV + r * lddv + (long)hk * HD + cc * 8) = ov;
+    }
+}
+
 template <int HD>
-static int launch_fwd(bool causal, dim3 grid, hipStream_t s, const bf16_t* Q, const bf16_t* K, const bf16_t* Vt,
-                      const int* kmask, bf16_t* O, float* LSE, int L, int Lp, int H, int Hkv, long ldq, long ldk, long ldo,
-                      float scale) {
+static int launch_fwd(bool causal, dim3 grid, hipStream_t s, const bf16_t* Q, const bf16_t* K, const bf16_t* V, const int* kmask,
+                      bf16_t* O, float* LSE, int L, int H, int Hkv, long ldq, long ldk, long ldv, long ldo, float scale) {
     if (causal)
-        hipLaunchKernelGGL((attn_fwd_kernel<HD, true>), grid, dim3(256), 0, s, Q, K, Vt, kmask, O, LSE, L, Lp, H, Hkv, ldq,
-                           ldk, ldo, scale);
+        hipLaunchKernelGGL((attn_fwd_kernel<HD, true>), grid, dim3(256), 0, s, Q, K, V, kmask, O, LSE, L, H, Hkv, ldq, ldk, ldv,
+                           ldo, scale);
     else
-        hipLaunchKernelGGL((attn_fwd_kernel<HD, false>), grid, dim3(256), 0, s, Q, K, Vt, kmask, O, LSE, L, Lp, H, Hkv, ldq,
-                           ldk, ldo, scale);
+        hipLaunchKernelGGL((attn_fwd_kernel<HD, false>), grid, dim3(256), 0, s, Q, K, V, kmask, O, LSE, L, H, Hkv, ldq, ldk, ldv,
+                           ldo, scale);
     return mantis_check_launch();
 }
 
 template <int HD>
-static int launch_bwd(bool causal, hipStream_t s, const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* Qt,
-                      const bf16_t* Kt, const bf16_t* dO, const bf16_t* dOt, const int* kmask, const float* LSE,
-                      const float* Dsum, bf16_t* dQ, bf16_t* dK, bf16_t* dV, int B, int L, int Lp, int H, int Hkv, long ldq,
-                      long ldk, long ldv, long ldo, long lddq, long lddk, long lddv, float scale) {
-    const dim3 gq(cdiv(L, 128), H, B), gk(cdiv(L, 128), Hkv, B);
+static int launch_bwd(bool causal, hipStream_t s, const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* dO,
+                      const int* kmask, const float* LSE, const float* Dsum, bf16_t* dQ, bf16_t* dK, bf16_t* dV, bf16_t* ws, int B,
+                      int L, int H, int Hkv, long ldq, long ldk, long ldv, long ldo, long lddq, long lddk, long lddv, float scale) {
+    const dim3 gq(cdiv(L, 128), H, B);
+    const int G = H / Hkv;
+    const long rows = (long)B * L;
+    bf16_t* pk = G == 1 ? dK : ws;
+    bf16_t* pv = G == 1 ? dV : ws + rows * H * HD;
+    const long ldpk = G == 1 ? lddk : (long)H * HD, ldpv = G == 1 ? lddv : (long)H * HD;
     if (causal) {
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, true>), gq, dim3(256), 0, s, Q, K, V, Kt, dO, kmask, LSE, Dsum, dQ, L, Lp, H,
-                           Hkv, ldq, ldk, ldv, ldo, lddq, scale);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, true>), gk, dim3(256), 0, s, Q, K, V, Qt, dO, dOt, kmask, LSE, Dsum, dK, dV,
-                           L, Lp, H, Hkv, ldq, ldk, ldv, ldo, lddk, lddv, scale);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, true>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, L, H, Hkv, ldq,
+                           ldk, ldv, ldo, lddq, scale);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, true>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, pk, pv, L, H, Hkv,
+                           ldq, ldk, ldv, ldo, ldpk, ldpv, scale);
     } else {
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, false>), gq, dim3(256), 0, s, Q, K, V, Kt, dO, kmask, LSE, Dsum, dQ, L, Lp,
-                           H, Hkv, ldq, ldk, ldv, ldo, lddq, scale);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, false>), gk, dim3(256), 0, s, Q, K, V, Qt, dO, dOt, kmask, LSE, Dsum, dK,
-                           dV, L, Lp, H, Hkv, ldq, ldk, ldv, ldo, lddk, lddv, scale);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, false>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, L, H, Hkv, ldq,
+                           ldk, ldv, ldo, lddq, scale);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, false>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, pk, pv, L, H, Hkv,
+                           ldq, ldk, ldv, ldo, ldpk, ldpv, scale);
+    }
+    if (G > 1) {
+        const long total = rows * Hkv * (HD / 8);
+        long g = (total + 255) / 256;
+        g = g > 2048 ? 2048 : g;
+        hipLaunchKernelGGL(attn_group_reduce_kernel, dim3((int)g), dim3(256), 0, s, pk, pv, dK, dV, rows, Hkv, G, HD, (long)H * HD,
+                           lddk, lddv);
     }
     return mantis_check_launch();
 }
 
 extern "C" {
 
-// Q [B,L,H,hd] (row stride ldq), K [B,L,Hkv,hd] (ldk), Vt [B,Hkv,hd,Lp] (keys contiguous, zero beyond L), kmask int32[B,L] or
-// NULL, O [B,L,H,hd] (ldo), LSE fp32 [B,H,L] or NULL.  hd in {16, 64, 72, 128}.
-int mantis_attn_fwd(const void* Q, const void* K, const void* Vt, const int32_t* kmask, void* O, float* LSE, int B, int L,
-                    int Lp, int H, int Hkv, int hd, int64_t ldq, int64_t ldk, int64_t ldo, float scale, int causal,
-                    void* stream) {
-    if (B <= 0 || L <= 0 || H <= 0 || Hkv <= 0 || H % Hkv || Lp % 8 || Lp < L) return MANTIS_EINVAL;
-    if (ldq % 8 || ldk % 8 || ldo % 4) return MANTIS_EUNSUPPORTED;
+// Q [B,L,H,hd] (row stride ldq), K,V [B,L,Hkv,hd] (ldk, ldv), kmask int32[B,L] or NULL, O [B,L,H,hd] (ldo),
+// LSE fp32 [B,H,L] or NULL.  hd in {16, 64, 72, 128}.
+int mantis_attn_fwd(const void* Q, const void* K, const void* V, const int32_t* kmask, void* O, float* LSE, int B, int L, int H,
+                    int Hkv, int hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale, int causal, void* stream) {
+    if (B <= 0 || L <= 0 || H <= 0 || Hkv <= 0 || H % Hkv) return MANTIS_EINVAL;
+    if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4) return MANTIS_EUNSUPPORTED;
     const dim3 grid(cdiv(L, 128), H, B);
     hipStream_t s = (hipStream_t)stream;
-#define FWD(HD) return launch_fwd<HD>(causal != 0, grid, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)Vt, kmask, \
-                                      (bf16_t*)O, LSE, L, Lp, H, Hkv, (long)ldq, (long)ldk, (long)ldo, scale)
+#define FWD(HD) return launch_fwd<HD>(causal != 0, grid, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, kmask, \
+                                      (bf16_t*)O, LSE, L, H, Hkv, (long)ldq, (long)ldk, (long)ldv, (long)ldo, scale)
     switch (hd) {
         case 16: FWD(16);
         case 64: FWD(64);
@@ -521,18 +636,19 @@ int mantis_attn_dsum(const void* dO, const void* O, float* Dsum, int B, int L, i
     return mantis_check_launch();
 }
 
-// Qt,dOt [B,H,hd,Lp]; Kt [B,Hkv,hd,Lp]; dQ/dK/dV written with row strides lddq/lddk/lddv (head h at column h*hd).
-int mantis_attn_bwd(const void* Q, const void* K, const void* V, const void* Qt, const void* Kt, const void* dO, const void* dOt,
-                    const int32_t* kmask, const float* LSE, const float* Dsum, void* dQ, void* dK, void* dV, int B, int L,
-                    int Lp, int H, int Hkv, int hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddq,
-                    int64_t lddk, int64_t lddv, float scale, int causal, void* stream) {
-    if (B <= 0 || L <= 0 || H <= 0 || Hkv <= 0 || H % Hkv || Lp % 8 || Lp < L) return MANTIS_EINVAL;
-    if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8 || lddq % 4 || lddk % 4 || lddv % 4) return MANTIS_EUNSUPPORTED;
+// dQ/dK/dV written with row strides lddq/lddk/lddv (head h at column h*hd).  workspace: 2 * B*L*H*hd bf16 when H > Hkv
+// (per-query-head dK/dV partials, summed over the GQA group afterwards), unused otherwise.
+int mantis_attn_bwd(const void* Q, const void* K, const void* V, const void* dO, const int32_t* kmask, const float* LSE,
+                    const float* Dsum, void* dQ, void* dK, void* dV, void* workspace, int B, int L, int H, int Hkv, int hd,
+                    int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, float scale,
+                    int causal, void* stream) {
+    if (B <= 0 || L <= 0 || H <= 0 || Hkv <= 0 || H % Hkv) return MANTIS_EINVAL;
+    if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8 || lddq % 4 || lddk % 8 || lddv % 8) return MANTIS_EUNSUPPORTED;
+    if (H != Hkv && !workspace) return MANTIS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-#define BWD(HD) return launch_bwd<HD>(causal != 0, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)Qt, \
-                                      (const bf16_t*)Kt, (const bf16_t*)dO, (const bf16_t*)dOt, kmask, LSE, Dsum, (bf16_t*)dQ, \
-                                      (bf16_t*)dK, (bf16_t*)dV, B, L, Lp, H, Hkv, (long)ldq, (long)ldk, (long)ldv, (long)ldo, \
-                                      (long)lddq, (long)lddk, (long)lddv, scale)
+#define BWD(HD) return launch_bwd<HD>(causal != 0, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dO, \
+                                      kmask, LSE, Dsum, (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV, (bf16_t*)workspace, B, L, H, Hkv, \
+                                      (long)ldq, (long)ldk, (long)ldv, (long)ldo, (long)lddq, (long)lddk, (long)lddv, scale)
     switch (hd) {
         case 16: BWD(16);
         case 64: BWD(64);

@@ -188,16 +188,15 @@ def rope_apply_(x, cos, sin, nheads, hd, backward=False):
 
 
 def attn_fwd(qkv, B, Lseq, H, Hkv, hd, kmask, scale, causal, want_lse=True):
-    """qkv: [B*L, (H+2Hkv)*hd] fused projection output (q | k | v).  Returns o [B*L, H*hd], lse [B,H,L], vt."""
+    """qkv: [B*L, (H+2Hkv)*hd] fused projection output (q | k | v).  Returns o [B*L, H*hd], lse [B,H,L]."""
     _chk2d(qkv, "qkv")
-    Lp = pad8(Lseq)
     ld = qkv.stride(0)
-    vt = transpose_heads(qkv, B, Lseq, Hkv, hd, (H + Hkv) * hd, Lp)
     o = torch.empty((B * Lseq, H * hd), dtype=BF16, device=qkv.device)
     lse = torch.empty((B, H, Lseq), dtype=torch.float32, device=qkv.device) if want_lse else None
     q_ptr = qkv.data_ptr()
     k_ptr = q_ptr + H * hd * 2
-    rc = _L.mantis_attn_fwd(q_ptr, k_ptr, _p(vt), _p(kmask), _p(o), _p(lse), B, Lseq, Lp, H, Hkv, hd, ld, ld, H * hd,
+    v_ptr = q_ptr + (H + Hkv) * hd * 2
+    rc = _L.mantis_attn_fwd(q_ptr, k_ptr, v_ptr, _p(kmask), _p(o), _p(lse), B, Lseq, H, Hkv, hd, ld, ld, ld, H * hd,
                             float(scale), int(causal), _stream())
     _lib.check(rc, f"attn_fwd hd={hd}")
     return o, lse
@@ -205,14 +204,11 @@ def attn_fwd(qkv, B, Lseq, H, Hkv, hd, kmask, scale, causal, want_lse=True):
 
 def attn_bwd(qkv, o, do, lse, B, Lseq, H, Hkv, hd, kmask, scale, causal):
     """Returns dqkv [B*L, (H+2Hkv)*hd] (gradient w.r.t. the post-RoPE q, k and v)."""
-    Lp = pad8(Lseq)
     ld = qkv.stride(0)
     dsum = torch.empty((B, H, Lseq), dtype=torch.float32, device=qkv.device)
     _lib.check(_L.mantis_attn_dsum(_p(do), _p(o), _p(dsum), B, Lseq, H, hd, do.stride(0), _stream()), "attn_dsum")
-    qt = transpose_heads(qkv, B, Lseq, H, hd, 0, Lp)
-    kt = transpose_heads(qkv, B, Lseq, Hkv, hd, H * hd, Lp)
-    dot = transpose_heads(do, B, Lseq, H, hd, 0, Lp)
     dqkv = torch.empty_like(qkv)
+    ws = torch.empty((2, B * Lseq, H * hd), dtype=BF16, device=qkv.device) if H != Hkv else None
     q_ptr = qkv.data_ptr()
     k_ptr = q_ptr + H * hd * 2
     v_ptr = q_ptr + (H + Hkv) * hd * 2
@@ -220,9 +216,8 @@ def attn_bwd(qkv, o, do, lse, B, Lseq, H, Hkv, hd, kmask, scale, causal):
     dk_ptr = dq_ptr + H * hd * 2
     dv_ptr = dq_ptr + (H + Hkv) * hd * 2
     ldd = dqkv.stride(0)
-    rc = _L.mantis_attn_bwd(q_ptr, k_ptr, v_ptr, _p(qt), _p(kt), _p(do), _p(dot), _p(kmask), _p(lse), _p(dsum), dq_ptr, dk_ptr,
-                            dv_ptr, B, Lseq, Lp, H, Hkv, hd, ld, ld, ld, do.stride(0), ldd, ldd, ldd, float(scale),
-                            int(causal), _stream())
+    rc = _L.mantis_attn_bwd(q_ptr, k_ptr, v_ptr, _p(do), _p(kmask), _p(lse), _p(dsum), dq_ptr, dk_ptr, dv_ptr, _p(ws), B, Lseq, H,
+                            Hkv, hd, ld, ld, ld, do.stride(0), ldd, ldd, ldd, float(scale), int(causal), _stream())
     _lib.check(rc, f"attn_bwd hd={hd}")
     return dqkv
 
