@@ -306,15 +306,15 @@ static int launch_gemm(hipStream_t s, const bf16_t* A, const bf16_t* B, bf16_t* 
 // four freed slots are refilled with parts 2,3 of step t+1 and parts 0,1 of step t+2, so 64-96 KiB of global_load_lds are
 // always in flight per CU and the loads get 1-2 K-steps of lead; the only vector-memory wait is a COUNTED
 // s_waitcnt vmcnt(4) (this wave's newest two slabs may still be in flight) -- the queue is never drained in the loop.
-template <int PIPE>
-__global__ __launch_bounds__(512) void gemm_nt_ring_kernel(
+template <int PIPE, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_nt_ring_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C, int M, int N, int K, long lda, long ldb,
     long ldc, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res, long ldr, int flags, int tiles_m, int tiles_n) {
-    constexpr int TM = 4, TN = 2, SLAB = 16384;
+    constexpr int TM = 4, TN = NW == 8 ? 2 : 4, SLAB = 16384, PPW = 16 / NW;   // NW == 4: one 128x128 wave tile per SIMD
     __shared__ __attribute__((aligned(16))) char smem[10 * SLAB];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = NW == 8 ? wave >> 2 : wave >> 1, wn = NW == 8 ? (wave & 3) : (wave & 1);
 
     const int nwg = tiles_m * tiles_n;
     const int bid = blockIdx.x;
@@ -340,12 +340,10 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(
     auto issue = [&](int t, int p) {
         char* dst = smem + ((4 * t + p) % 10) * SLAB;
         const int half = p >> 1;
-        if (p & 1) {
-            stage_piece(B, ldb, n0 + half * 128, N, t * BK, K, dst, 2 * wave, lane);
-            stage_piece(B, ldb, n0 + half * 128, N, t * BK, K, dst, 2 * wave + 1, lane);
-        } else {
-            stage_piece(A, lda, m0 + half * 128, M, t * BK, K, dst, 2 * wave, lane);
-            stage_piece(A, lda, m0 + half * 128, M, t * BK, K, dst, 2 * wave + 1, lane);
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            if (p & 1) stage_piece(B, ldb, n0 + half * 128, N, t * BK, K, dst, PPW * wave + j, lane);
+            else stage_piece(A, lda, m0 + half * 128, M, t * BK, K, dst, PPW * wave + j, lane);
         }
     };
 
@@ -362,14 +360,16 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(
     bf16x8 fa[2][TM], fb[2][TN];
 
     for (int t = 0; t < nk; ++t) {
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // everything except step t+1's parts 0,1 (this wave's 4 newest) landed
+        if (NW == 8) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but step t+1's parts 0,1 (this wave's newest) landed
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (PIPE < 2) {
             issue(t + 1, 2); issue(t + 1, 3);
             issue(t + 2, 0); issue(t + 2, 1);
         }
         const unsigned a_base = lds0 + (unsigned)((4 * t + 2 * wm) % 10) * SLAB;                                  // A half wm
-        const unsigned b_base = lds0 + (unsigned)((4 * t + 1 + 2 * (wn >> 1)) % 10) * SLAB + (unsigned)(wn & 1) * 8192u;  // B half
+        const unsigned b_base = NW == 8 ? lds0 + (unsigned)((4 * t + 1 + 2 * (wn >> 1)) % 10) * SLAB + (unsigned)(wn & 1) * 8192u
+                                        : lds0 + (unsigned)((4 * t + 1 + 2 * wn) % 10) * SLAB;                     // B half
         read_frags<TN>(fb[0], b_base + xo[0]);
         read_frags<TM>(fa[0], a_base + xo[0]);
 #pragma unroll
@@ -378,7 +378,8 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(
             if (ks < 3) {
                 read_frags<TN>(fb[nb], b_base + xo[ks + 1]);
                 read_frags<TM>(fa[nb], a_base + xo[ks + 1]);
-                asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+                if (NW == 8) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
@@ -401,41 +402,65 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the trailing zero-page loads before the LDS is released
-    gemm_epilogue<TM, TN>(acc, C, M, N, ldc, bias, res, ldr, flags, m0 + wm * 128, n0 + wn * 64, lane);
+    gemm_epilogue<TM, TN>(acc, C, M, N, ldc, bias, res, ldr, flags, m0 + wm * 128, n0 + wn * (NW == 8 ? 64 : 128), lane);
 }
 
 static int launch_gemm_ring(int pipe, hipStream_t s, const bf16_t* A, const bf16_t* B, bf16_t* C, int M, int N, int K, long lda,
                             long ldb, long ldc, const bf16_t* bias, const bf16_t* res, long ldr, int flags) {
     const int tiles_m = cdiv(M, 256), tiles_n = cdiv(N, 256);
-    if (pipe == 2)
-        hipLaunchKernelGGL((gemm_nt_ring_kernel<2>), dim3(tiles_m * tiles_n), dim3(512), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias,
+    if (pipe == 4)
+        hipLaunchKernelGGL((gemm_nt_ring_kernel<2, 4>), dim3(tiles_m * tiles_n), dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias,
+                           res, ldr, flags, tiles_m, tiles_n);
+    else if (pipe == 2)
+        hipLaunchKernelGGL((gemm_nt_ring_kernel<2, 8>), dim3(tiles_m * tiles_n), dim3(512), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias,
                            res, ldr, flags, tiles_m, tiles_n);
     else if (pipe)
-        hipLaunchKernelGGL((gemm_nt_ring_kernel<1>), dim3(tiles_m * tiles_n), dim3(512), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias,
+        hipLaunchKernelGGL((gemm_nt_ring_kernel<1, 8>), dim3(tiles_m * tiles_n), dim3(512), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias,
                            res, ldr, flags, tiles_m, tiles_n);
     else
-        hipLaunchKernelGGL((gemm_nt_ring_kernel<0>), dim3(tiles_m * tiles_n), dim3(512), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias,
+        hipLaunchKernelGGL((gemm_nt_ring_kernel<0, 8>), dim3(tiles_m * tiles_n), dim3(512), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias,
                            res, ldr, flags, tiles_m, tiles_n);
     return mantis_check_launch();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// 256x256 "ping-pong" kernel.  Same 10-slab LDS ring as above, but the two wave groups of a workgroup (waves 0-3 own A rows
-// 0-127, waves 4-7 own A rows 128-255; every SIMD hosts one wave of each group) run HALF A K-STEP out of phase: when one
-// group stands at a K-step boundary (waiting for its slabs, restarting its fragment pipeline) the other group is in the
-// middle of its K-step with fragments already in registers, so the SIMD's matrix pipe always has MFMAs to issue.
-// Time advances in half-steps h; one raw s_barrier per half-step.  Slabs are ordered by first use:
-//   idx 4t+0 = A[0:128) of K-step t, 4t+1 = B[0:128), 4t+2 = B[128:256), 4t+3 = A[128:256);  slot = idx % 10.
-// Boundary h = 2t   frees idx 4t-4 (group 0 left K-step t-1)        -> refill with idx 4t+6
-// Boundary h = 2t+1 frees idx 4t-3..4t-1 (group 1 left K-step t-1)  -> refill with idx 4t+7, 4t+8, 4t+9
-// and at every boundary `s_waitcnt vmcnt(6)` (this wave's three newest slabs may be in flight) guarantees what the group
-// that starts a K-step there needs.
+// 256x256 "ping-pong" kernel (K step 32).  The two wave groups of a workgroup (waves 0-3 own A rows 0-127, waves 4-7 own A
+// rows 128-255; every SIMD hosts one wave of each group) run the SAME instruction stream, but group 1 enters the loop one
+// barrier later, i.e. half a K-step out of phase.  A K-step is two phases of 8 MFMAs per wave:
+//   phase 0 (after a barrier): read the k-step-0 fragments (exposed LDS latency), prefetch the k-step-1 fragments, MFMA 0
+//   phase 1 (after a barrier): MFMA 1 on the prefetched fragments -- no exposed latency
+// so whenever one group sits in its exposed-latency phase the other group's MFMAs keep the SIMD's matrix pipe busy.
+// LDS is a ring of twenty 8-KiB slabs (one slab = 128 rows x 32 k of A or B; slab idx = 4*kstep + part, slot = idx % 20),
+// i.e. five K-steps: with the half-step lag a K-step's slabs must be resident from half a step before the leading group
+// starts it until the trailing group leaves it.  Per K-step each wave issues 4 global_load_lds (one 1-KiB piece of each
+// slab) four K-steps ahead and waits with a COUNTED s_waitcnt vmcnt(8); the queue is never drained inside the loop.
+// LDS image per slab: [128 rows][32 k] = 64 B rows, four rows per 256-B bank row; chunk c of row r at slot c ^ ((r >> 2) & 3).
+__device__ __forceinline__ void stage_piece32(const bf16_t* __restrict__ G, long ld, int row0, int rows_total, int k0, int K,
+                                              char* lds_slab, int piece, int lane) {
+    const int rl = lane >> 2;                      // 16 rows x 64 B per global_load_lds
+    const int row = piece * 16 + rl;
+    const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+    const int k = k0 + chunk * 8;
+    int grow = row0 + row;
+    grow = grow < rows_total ? grow : rows_total - 1;
+    const bf16_t* src = (k < K) ? (G + (long)grow * ld + k) : reinterpret_cast<const bf16_t*>(g_zero_page);
+    __builtin_amdgcn_global_load_lds(src, (lds_void*)(lds_slab + piece * 1024), 16, 0, 0);
+}
+
+template <int N_>
+__device__ __forceinline__ void read_frags32(bf16x8 (&dst)[N_], unsigned addr) {   // 32-row blocks are 2048 B apart
+    lds_read_b128<0>(dst[0], addr);
+    if constexpr (N_ > 1) lds_read_b128<2048>(dst[1], addr);
+    if constexpr (N_ > 2) lds_read_b128<4096>(dst[2], addr);
+    if constexpr (N_ > 3) lds_read_b128<6144>(dst[3], addr);
+}
+
 template <int DUMMY>
 __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C, int M, int N, int K, long lda, long ldb,
     long ldc, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res, long ldr, int flags, int tiles_m, int tiles_n) {
-    constexpr int TM = 4, TN = 2, SLAB = 16384;
-    __shared__ __attribute__((aligned(16))) char smem[10 * SLAB];
+    constexpr int TM = 4, TN = 2, SLAB = 8192, RING = 20, KS = 32;
+    __shared__ __attribute__((aligned(16))) char smem[RING * SLAB];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2, wn = wave & 3;
@@ -460,81 +485,64 @@ __global__ __launch_bounds__(512) void gemm_nt_pp_kernel(
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    auto issue = [&](int idx) {   // slab idx: two global_load_lds per wave
-        const int t = idx >> 2, p = idx & 3;
-        char* dst = smem + (idx % 10) * SLAB;
-        if (p == 1 || p == 2) {
-            stage_piece(B, ldb, n0 + (p - 1) * 128, N, t * BK, K, dst, 2 * wave, lane);
-            stage_piece(B, ldb, n0 + (p - 1) * 128, N, t * BK, K, dst, 2 * wave + 1, lane);
-        } else {
-            stage_piece(A, lda, m0 + (p == 3 ? 128 : 0), M, t * BK, K, dst, 2 * wave, lane);
-            stage_piece(A, lda, m0 + (p == 3 ? 128 : 0), M, t * BK, K, dst, 2 * wave + 1, lane);
-        }
+    // K-step t: four slabs (A lo, B lo, B hi, A hi); this wave moves piece `wave` (16 rows) of each
+    auto issue_kstep = [&](int t) {
+        const int base = (4 * t) % RING;
+        stage_piece32(A, lda, m0, M, t * KS, K, smem + (base + 0) * SLAB, wave, lane);
+        stage_piece32(B, ldb, n0, N, t * KS, K, smem + (base + 1) * SLAB, wave, lane);
+        stage_piece32(B, ldb, n0 + 128, N, t * KS, K, smem + (base + 2) * SLAB, wave, lane);
+        stage_piece32(A, lda, m0 + 128, M, t * KS, K, smem + (base + 3) * SLAB, wave, lane);
     };
-    const int nk = (K + BK - 1) / BK;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) issue(i);
+    const int nk = (K + KS - 1) / KS;
+    issue_kstep(0); issue_kstep(1); issue_kstep(2); issue_kstep(3);
 
-    const unsigned rowoff = (unsigned)(lane & 31) * 128u;
-    const unsigned f = ((unsigned)(lane & 31) >> 1) & 7u;
-    unsigned xo[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) xo[ks] = rowoff + ((((unsigned)(ks * 2 + (lane >> 5))) ^ f) << 4);
+    const unsigned f = ((unsigned)(lane & 31) >> 2) & 3u;
+    const unsigned rowoff = (unsigned)(lane & 31) * 64u;
+    const unsigned xo0 = rowoff + (((unsigned)(0 + (lane >> 5)) ^ f) << 4);
+    const unsigned xo1 = rowoff + (((unsigned)(2 + (lane >> 5)) ^ f) << 4);
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned a_part = grp ? 3u : 0u, b_part = 1u + (unsigned)(wn >> 1), b_off = (unsigned)(wn & 1) * 4096u;
     bf16x8 fa[2][TM], fb[2][TN];
-    unsigned a_base = 0, b_base = 0;
 
-    auto mfma_block = [&](int cb) {
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // K-step 0 landed (this wave's pieces)
+    if (grp == 1) __builtin_amdgcn_s_barrier();             // group 1 runs one barrier (half a K-step) behind group 0
+
+    for (int t = 0; t < nk; ++t) {
+        // ---- phase 0
+        __builtin_amdgcn_s_barrier();
+        const unsigned base = (unsigned)((4 * t) % RING);
+        const unsigned a_base = lds0 + ((base + a_part) % RING) * SLAB;
+        const unsigned b_base = lds0 + ((base + b_part) % RING) * SLAB + b_off;
+        read_frags32<TN>(fb[0], b_base + xo0);
+        read_frags32<TM>(fa[0], a_base + xo0);
+        read_frags32<TN>(fb[1], b_base + xo1);
+        read_frags32<TM>(fa[1], a_base + xo1);
+        asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
-                acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cb][tn], fa[cb][tm], acc[tn][tm], 0, 0, 0);
+                acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0][tn], fa[0][tm], acc[tn][tm], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-    };
-    // first half of K-step t: k-steps 0,1 (and the fragment reads of k-step 2 are left in flight across the boundary)
-    auto first_half = [&](int t) {
-        a_base = lds0 + (unsigned)((4 * t + (grp ? 3 : 0)) % 10) * SLAB;
-        b_base = lds0 + (unsigned)((4 * t + 1 + (wn >> 1)) % 10) * SLAB + (unsigned)(wn & 1) * 8192u;
-        read_frags<TN>(fb[0], b_base + xo[0]);
-        read_frags<TM>(fa[0], a_base + xo[0]);
-        read_frags<TN>(fb[1], b_base + xo[1]);
-        read_frags<TM>(fa[1], a_base + xo[1]);
-        asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-        mfma_block(0);
-        read_frags<TN>(fb[0], b_base + xo[2]);
-        read_frags<TM>(fa[0], a_base + xo[2]);
-        asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-        mfma_block(1);
-    };
-    auto second_half = [&]() {
-        read_frags<TN>(fb[1], b_base + xo[3]);
-        read_frags<TM>(fa[1], a_base + xo[3]);
-        asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-        mfma_block(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        mfma_block(1);
-    };
-
-    // one copy of each half in the instruction stream; which one a wave runs at boundary h depends only on (h - grp) parity
-    for (int h = 0; h <= 2 * nk; ++h) {
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        // ---- phase 1: K-step t+1 must be resident for whoever starts it at this barrier; K-step t-1 is retired by it
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (h & 1) {
-            issue(2 * h + 5); issue(2 * h + 6); issue(2 * h + 7);
-        } else {
-            issue(2 * h + 6);
-        }
+        issue_kstep(t + 4);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        const int lh = h - grp;
-        if (lh >= 0 && lh < 2 * nk) {
-            if (lh & 1) second_half();
-            else first_half(lh >> 1);
-        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+                acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[1][tn], fa[1][tm], acc[tn][tm], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
     }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     gemm_epilogue<TM, TN>(acc, C, M, N, ldc, bias, res, ldr, flags, m0 + grp * 128, n0 + wn * 64, lane);
 }
@@ -584,6 +592,7 @@ int mantis_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, 
         case 11: return launch_gemm_ring(0, GEMM_ARGS);
         case 12: return launch_gemm_ring(2, GEMM_ARGS);
         case 13: return launch_gemm_pp(GEMM_ARGS);
+        case 14: return launch_gemm_ring(4, GEMM_ARGS);
         default: return MANTIS_EINVAL;
     }
 #undef GEMM_ARGS
