@@ -264,6 +264,8 @@ class LlavaForConditionalGeneration(nn.Module):
         """(Re)attach `.grad` views.  Returns True if the gradients are known to be zero-initialised garbage that the
         next backward may OVERWRITE (i.e. every trainable .grad was None, the state after Trainer's model.zero_grad())."""
         trainable = [(n, p) for n, p in self.named_parameters() if p.requires_grad]
+        if any(n.startswith("vision_tower.") for n, _ in trainable):
+            raise NotImplementedError("the vision tower is frozen on this path (train_mllava.py:240-242): no backward kernels for it")
         key = tuple(n for n, _ in trainable)
         if self.grad_arena is None or self._grad_key != key:
             offs, off = {}, 0
