@@ -95,7 +95,7 @@ __device__ __forceinline__ bf16x8 pack_frag(const f32x16& s, int cp) {
 // ------------------------------------------------------------------------------------------------ forward
 // grid (ceil(L/128), H, B); 4 waves x 32 query rows; KV tiles of 64 keys, double buffered.
 template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                        const bf16_t* __restrict__ V, const int* __restrict__ kmask,
                                                        bf16_t* __restrict__ O, float* __restrict__ LSE, int L, int H, int Hkv,
                                                        long ldq, long ldk, long ldv, long ldo, float scale) {
@@ -131,25 +131,28 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     const bf16_t* Kb = K + (long)b * L * ldk + (long)hk * HD;
     const bf16_t* Vb = V + (long)b * L * ldv + (long)hk * HD;
 
-    TileRegs<64, C::NCH> rk, rv;
-    float rbias = 0.f;
-    auto gload = [&](int t) {
+    // tile t -> LDS buffer (t & 1): global -> registers -> LDS in one go (registers are only live across the copy, so the kernel
+    // fits 2 waves per SIMD; the copy of tile t+1 overlaps the MFMA work of the co-resident workgroup / partner waves)
+    auto stage = [&](int t) {
         const int key0 = t * 64;
-        rk.load(Kb + (long)key0 * ldk, ldk, L - key0, HD);
-        rv.load(Vb + (long)key0 * ldv, ldv, L - key0, HD);
+        char* base = smem + (t & 1) * BUF;
+        {
+            TileRegs<64, C::NCH> rk;
+            rk.load(Kb + (long)key0 * ldk, ldk, L - key0, HD);
+            rk.store(base, C::PITCH);
+        }
+        {
+            TileRegs<64, C::NCH> rv;
+            rv.load(Vb + (long)key0 * ldv, ldv, L - key0, HD);
+            rv.store(base + TILE, C::PITCH);
+        }
         if (threadIdx.x < 64) {
             const int key = key0 + threadIdx.x;
-            rbias = (key < L && (kmask == nullptr || kmask[(long)b * L + key] != 0)) ? 0.f : -INFINITY;
+            reinterpret_cast<float*>(base + 2 * TILE)[threadIdx.x] =
+                (key < L && (kmask == nullptr || kmask[(long)b * L + key] != 0)) ? 0.f : -INFINITY;
         }
     };
-    auto lstore = [&](int buf) {
-        char* base = smem + buf * BUF;
-        rk.store(base, C::PITCH);
-        rv.store(base + TILE, C::PITCH);
-        if (threadIdx.x < 64) reinterpret_cast<float*>(base + 2 * TILE)[threadIdx.x] = rbias;
-    };
-    gload(0);
-    lstore(0);
+    stage(0);
     __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
         const char* sV = sK + TILE;
         const float* sBias = reinterpret_cast<const float*>(sK + 2 * TILE);
         const bool more = t + 1 < ntiles;
-        if (more) gload(t + 1);
+        if (more) stage(t + 1);
         if (!(CAUSAL && key0 > q0 + 31)) {   // wave-uniform: skip tiles entirely in this wave's future
             f32x16 s[2];
 #pragma unroll
@@ -213,7 +216,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
                     }
                 }
         }
-        if (more) lstore((t + 1) & 1);
         __syncthreads();
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -262,7 +264,7 @@ __global__ void attn_dsum_kernel(const bf16_t* __restrict__ dO, const bf16_t* __
 // ------------------------------------------------------------------------------------------------ backward: dQ
 // Same walk as the forward.  dQ^T[d][q] += K^T[d][key] . dS^T[key][q]  (K^T fragments: transposing reads of the K tile).
 template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                           const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
                                                           const int* __restrict__ kmask, const float* __restrict__ LSE,
                                                           const float* __restrict__ Dsum, bf16_t* __restrict__ dQ, int L, int H,
@@ -304,25 +306,28 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     const bf16_t* Kb = K + (long)b * L * ldk + (long)hk * HD;
     const bf16_t* Vb = V + (long)b * L * ldv + (long)hk * HD;
 
-    TileRegs<64, C::NCH> rk, rv;
-    float rbias = 0.f;
-    auto gload = [&](int t) {
+    // tile t -> LDS buffer (t & 1): global -> registers -> LDS in one go (registers are only live across the copy, so the kernel
+    // fits 2 waves per SIMD; the copy of tile t+1 overlaps the MFMA work of the co-resident workgroup / partner waves)
+    auto stage = [&](int t) {
         const int key0 = t * 64;
-        rk.load(Kb + (long)key0 * ldk, ldk, L - key0, HD);
-        rv.load(Vb + (long)key0 * ldv, ldv, L - key0, HD);
+        char* base = smem + (t & 1) * BUF;
+        {
+            TileRegs<64, C::NCH> rk;
+            rk.load(Kb + (long)key0 * ldk, ldk, L - key0, HD);
+            rk.store(base, C::PITCH);
+        }
+        {
+            TileRegs<64, C::NCH> rv;
+            rv.load(Vb + (long)key0 * ldv, ldv, L - key0, HD);
+            rv.store(base + TILE, C::PITCH);
+        }
         if (threadIdx.x < 64) {
             const int key = key0 + threadIdx.x;
-            rbias = (key < L && (kmask == nullptr || kmask[(long)b * L + key] != 0)) ? 0.f : -INFINITY;
+            reinterpret_cast<float*>(base + 2 * TILE)[threadIdx.x] =
+                (key < L && (kmask == nullptr || kmask[(long)b * L + key] != 0)) ? 0.f : -INFINITY;
         }
     };
-    auto lstore = [&](int buf) {
-        char* base = smem + buf * BUF;
-        rk.store(base, C::PITCH);
-        rv.store(base + TILE, C::PITCH);
-        if (threadIdx.x < 64) reinterpret_cast<float*>(base + 2 * TILE)[threadIdx.x] = rbias;
-    };
-    gload(0);
-    lstore(0);
+    stage(0);
     __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
@@ -331,7 +336,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
         const char* sV = sK + TILE;
         const float* sBias = reinterpret_cast<const float*>(sK + 2 * TILE);
         const bool more = t + 1 < ntiles;
-        if (more) gload(t + 1);
+        if (more) stage(t + 1);
         if (!(CAUSAL && key0 > q0 + 31)) {
             f32x16 s[2], dp[2];
 #pragma unroll
@@ -369,7 +374,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
                     }
                 }
         }
-        if (more) lstore((t + 1) & 1);
         __syncthreads();
     }
     if (q < L) {
@@ -390,25 +394,38 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
-// grid (ceil(L/128), H, B): 4 waves x 32 keys for ONE query head (GQA group summed afterwards); walks 32-row query tiles.
+// One workgroup per (key block, QUERY head, batch); GQA groups are summed afterwards.  A wave owns 32 keys and -- to keep the
+// accumulators at 64 registers so that two waves fit per SIMD -- HALF of the head dimension when hd >= 64: waves (kg, dh)
+// with the same key group kg recompute S and dP (cheap next to the exposed latency of 1 wave/SIMD) and each accumulates its
+// own d-half of dK and dV.  Walks 32-row query tiles, double buffered.
 //   S[q][key]  = Q . K^T      (lane owns ONE key column, 16 query rows per block)
 //   dV^T[d][key] += dO^T[d][q] . P[q][key]        dK^T[d][key] += Q^T[d][q] . dS[q][key]
 // dKp/dVp: per-QUERY-head outputs [B*L, H*hd] (row stride ldp), or the final dK/dV when H == Hkv.
+template <int HD>
+struct DkvCfg {
+    static constexpr int DS = AttnCfg<HD>::NDB >= 2 ? 2 : 1;   // waves sharing a key group (d-split)
+    static constexpr int NDW = AttnCfg<HD>::NDB / DS;          // 32-wide d-blocks per wave
+    static constexpr int KEYS = (4 / DS) * 32;                 // keys per workgroup
+};
+
 template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
-                                                           const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
-                                                           const int* __restrict__ kmask, const float* __restrict__ LSE,
-                                                           const float* __restrict__ Dsum, bf16_t* __restrict__ dKp,
-                                                           bf16_t* __restrict__ dVp, int L, int H, int Hkv, long ldq, long ldk,
-                                                           long ldv, long ldo, long ldpk, long ldpv, float scale) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                              const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
+                                                              const int* __restrict__ kmask, const float* __restrict__ LSE,
+                                                              const float* __restrict__ Dsum, bf16_t* __restrict__ dKp,
+                                                              bf16_t* __restrict__ dVp, int L, int H, int Hkv, long ldq, long ldk,
+                                                              long ldv, long ldo, long ldpk, long ldpv, float scale) {
     using C = AttnCfg<HD>;
-    constexpr int TILE = 32 * C::PITCH;
-    constexpr int BUF = 2 * TILE + 2 * 32 * 4;
+    using D = DkvCfg<HD>;
+    constexpr int QT = 64;                          // query rows staged per barrier (processed as two 32-row passes)
+    constexpr int TILE = QT * C::PITCH;
+    constexpr int BUF = 2 * TILE + 2 * QT * 4;
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hh = lane >> 5, lk = lane & 31;
+    const int kg = wave / D::DS, dh = wave % D::DS;
     const int b = blockIdx.z, h = blockIdx.y, hk = h / (H / Hkv);
-    const int kblk0 = blockIdx.x * 128, k0 = kblk0 + wave * 32, key = k0 + lk;   // causal: key block 0 is the heaviest, first
+    const int kblk0 = blockIdx.x * D::KEYS, k0 = kblk0 + kg * 32, key = k0 + lk;   // causal: key block 0 is the heaviest, first
     const int keyc = key < L ? key : L - 1;
     const float c = scale * LOG2E;
     const bool key_ok = key < L && (kmask == nullptr || kmask[(long)b * L + keyc] != 0);
@@ -425,54 +442,50 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
         kf[ks] = as_bf16x8(a);
         vf[ks] = as_bf16x8(w);
     }
-    f32x16 dkacc[C::NDB], dvacc[C::NDB];
+    f32x16 dkacc[D::NDW], dvacc[D::NDW];
 #pragma unroll
-    for (int d = 0; d < C::NDB; ++d)
+    for (int d = 0; d < D::NDW; ++d)
 #pragma unroll
         for (int e = 0; e < 16; ++e) { dkacc[d][e] = 0.f; dvacc[d][e] = 0.f; }
 
-    const int qstart = CAUSAL ? (kblk0 / 32) : 0;  // first 32-row query tile that can see this key block
-    const int nqt = (L + 31) / 32;
+    const int qstart = CAUSAL ? (kblk0 / QT) : 0;  // first query tile that can see this key block
+    const int nqt = (L + QT - 1) / QT;
     const bf16_t* Qb = Q + (long)b * L * ldq + (long)h * HD;
     const bf16_t* dOb = dO + (long)b * L * ldo + (long)h * HD;
 
-    TileRegs<32, C::NCH> rq, rdo;
-    float rl = 0.f, rd = 0.f;
-    auto gload = [&](int qt) {
-        const int q0 = qt * 32;
-        rq.load(Qb + (long)q0 * ldq, ldq, L - q0, HD);
-        rdo.load(dOb + (long)q0 * ldo, ldo, L - q0, HD);
-        if (threadIdx.x < 32) {
+    auto stage = [&](int qt) {
+        const int q0 = qt * QT;
+        char* base = smem + ((qt - qstart) & 1) * BUF;
+        {
+            TileRegs<QT, C::NCH> rq;
+            rq.load(Qb + (long)q0 * ldq, ldq, L - q0, HD);
+            rq.store(base, C::PITCH);
+        }
+        {
+            TileRegs<QT, C::NCH> rdo;
+            rdo.load(dOb + (long)q0 * ldo, ldo, L - q0, HD);
+            rdo.store(base + TILE, C::PITCH);
+        }
+        if (threadIdx.x < QT) {
             const int qq = q0 + threadIdx.x;
-            rl = qq < L ? LSE[((long)b * H + h) * L + qq] * LOG2E : INFINITY;
-            rd = qq < L ? Dsum[((long)b * H + h) * L + qq] : 0.f;
+            reinterpret_cast<float*>(base + 2 * TILE)[threadIdx.x] = qq < L ? LSE[((long)b * H + h) * L + qq] * LOG2E : INFINITY;
+            reinterpret_cast<float*>(base + 2 * TILE)[QT + threadIdx.x] = qq < L ? Dsum[((long)b * H + h) * L + qq] : 0.f;
         }
     };
-    auto lstore = [&](int buf) {
-        char* base = smem + buf * BUF;
-        rq.store(base, C::PITCH);
-        rdo.store(base + TILE, C::PITCH);
-        if (threadIdx.x < 32) {
-            reinterpret_cast<float*>(base + 2 * TILE)[threadIdx.x] = rl;
-            reinterpret_cast<float*>(base + 2 * TILE)[32 + threadIdx.x] = rd;
-        }
-    };
-    if (qstart < nqt) {
-        gload(qstart);
-        lstore(0);
-    }
+    if (qstart < nqt) stage(qstart);
     __syncthreads();
 
     for (int qt = qstart; qt < nqt; ++qt) {
-        const int q0 = qt * 32;
-        const int cur = (qt - qstart) & 1;
-        const char* sQ = smem + cur * BUF;
+        const char* tQ = smem + ((qt - qstart) & 1) * BUF;
+        if (qt + 1 < nqt) stage(qt + 1);
+#pragma unroll 1
+        for (int pass = 0; pass < QT / 32; ++pass) {
+        const int q0 = qt * QT + pass * 32;
+        const char* sQ = tQ + pass * 32 * C::PITCH;
         const char* sdO = sQ + TILE;
-        const float* sLse = reinterpret_cast<const float*>(sQ + 2 * TILE);
-        const float* sDs = sLse + 32;
-        const bool more = qt + 1 < nqt;
-        if (more) gload(qt + 1);
-        if (!(CAUSAL && q0 + 31 < k0)) {  // wave-uniform: skip tiles whose every query precedes this wave's keys
+        const float* sLse = reinterpret_cast<const float*>(tQ + 2 * TILE) + pass * 32;
+        const float* sDs = sLse + QT;
+        if (!(CAUSAL && q0 + 31 < k0)) {  // wave-uniform: skip passes whose every query precedes this wave's keys
             f32x16 s, dp;
 #pragma unroll
             for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
@@ -499,25 +512,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
                 const bf16x8 pf = pack_frag(s, cp);
                 const bf16x8 dsf = pack_frag(ds, cp);
 #pragma unroll
-                for (int d = 0; d < C::NDB; ++d) {
-                    const bf16x8 dot = read_tr_frag(sdO, C::PITCH, 16 * cp, d * 32, lane);
-                    const bf16x8 qtf = read_tr_frag(sQ, C::PITCH, 16 * cp, d * 32, lane);
+                for (int d = 0; d < D::NDW; ++d) {
+                    const int dcol = (dh * D::NDW + d) * 32;
+                    const bf16x8 dot = read_tr_frag(sdO, C::PITCH, 16 * cp, dcol, lane);
+                    const bf16x8 qtf = read_tr_frag(sQ, C::PITCH, 16 * cp, dcol, lane);
                     dvacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot, pf, dvacc[d], 0, 0, 0);
                     dkacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsf, dkacc[d], 0, 0, 0);
                 }
             }
         }
-        if (more) lstore(cur ^ 1);
+        }
         __syncthreads();
     }
     if (key < L) {
         bf16_t* kp = dKp + ((long)b * L + key) * ldpk + (long)(H == Hkv ? hk : h) * HD;
         bf16_t* vp = dVp + ((long)b * L + key) * ldpv + (long)(H == Hkv ? hk : h) * HD;
 #pragma unroll
-        for (int d = 0; d < C::NDB; ++d)
+        for (int d = 0; d < D::NDW; ++d)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
-                const int dd = d * 32 + 8 * g4 + 4 * hh;
+                const int dd = (dh * D::NDW + d) * 32 + 8 * g4 + 4 * hh;
                 if (dd < HD) {
                     u32x2 o, w;
                     o[0] = pack_bf2(dkacc[d][4 * g4], dkacc[d][4 * g4 + 1]);
@@ -578,7 +592,7 @@ template <int HD>
 static int launch_bwd(bool causal, hipStream_t s, const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* dO,
                       const int* kmask, const float* LSE, const float* Dsum, bf16_t* dQ, bf16_t* dK, bf16_t* dV, bf16_t* ws, int B,
                       int L, int H, int Hkv, long ldq, long ldk, long ldv, long ldo, long lddq, long lddk, long lddv, float scale) {
-    const dim3 gq(cdiv(L, 128), H, B);
+    const dim3 gq(cdiv(L, 128), H, B), gk(cdiv(L, DkvCfg<HD>::KEYS), H, B);
     const int G = H / Hkv;
     const long rows = (long)B * L;
     bf16_t* pk = G == 1 ? dK : ws;
@@ -587,12 +601,12 @@ static int launch_bwd(bool causal, hipStream_t s, const bf16_t* Q, const bf16_t*
     if (causal) {
         hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, true>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, L, H, Hkv, ldq,
                            ldk, ldv, ldo, lddq, scale);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, true>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, pk, pv, L, H, Hkv,
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, true>), gk, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, pk, pv, L, H, Hkv,
                            ldq, ldk, ldv, ldo, ldpk, ldpv, scale);
     } else {
         hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, false>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, L, H, Hkv, ldq,
                            ldk, ldv, ldo, lddq, scale);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, false>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, pk, pv, L, H, Hkv,
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, false>), gk, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, pk, pv, L, H, Hkv,
                            ldq, ldk, ldv, ldo, ldpk, ldpv, scale);
     }
     if (G > 1) {

@@ -360,9 +360,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring_kernel(
     bf16x8 fa[2][TM], fb[2][TN];
 
     for (int t = 0; t < nk; ++t) {
-        if (NW == 8) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but step t+1's parts 0,1 (this wave's newest) landed
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if (PIPE != 6) {
+            if (NW == 8) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but step t+1's parts 0,1 (this wave's newest) landed
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        }
+        if (PIPE != 5) __builtin_amdgcn_s_barrier();
         if (PIPE < 2) {
             issue(t + 1, 2); issue(t + 1, 3);
             issue(t + 2, 0); issue(t + 2, 1);
@@ -408,7 +410,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring_kernel(
 static int launch_gemm_ring(int pipe, hipStream_t s, const bf16_t* A, const bf16_t* B, bf16_t* C, int M, int N, int K, long lda,
                             long ldb, long ldc, const bf16_t* bias, const bf16_t* res, long ldr, int flags) {
     const int tiles_m = cdiv(M, 256), tiles_n = cdiv(N, 256);
-    if (pipe == 4)
+    if (pipe == 5 || pipe == 6) {
+        if (pipe == 5)
+            hipLaunchKernelGGL((gemm_nt_ring_kernel<5, 8>), dim3(tiles_m * tiles_n), dim3(512), 0, s, A, B, C, M, N, K, lda, ldb, ldc,
+                               bias, res, ldr, flags, tiles_m, tiles_n);
+        else
+            hipLaunchKernelGGL((gemm_nt_ring_kernel<6, 8>), dim3(tiles_m * tiles_n), dim3(512), 0, s, A, B, C, M, N, K, lda, ldb, ldc,
+                               bias, res, ldr, flags, tiles_m, tiles_n);
+    } else if (pipe == 4)
         hipLaunchKernelGGL((gemm_nt_ring_kernel<2, 4>), dim3(tiles_m * tiles_n), dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias,
                            res, ldr, flags, tiles_m, tiles_n);
     else if (pipe == 2)
@@ -586,13 +595,13 @@ int mantis_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, 
         case 5: return launch_gemm<256, 256, 128, 64, 3>(GEMM_ARGS);
         case 6: return launch_gemm<128, 128, 64, 64, 2>(GEMM_ARGS);
         case 7: return launch_gemm<128, 128, 64, 64, 3>(GEMM_ARGS);
-        case 8: return launch_gemm<256, 256, 128, 64, 8>(GEMM_ARGS);
-        case 9: return launch_gemm<256, 256, 128, 64, 9>(GEMM_ARGS);
         case 10: return launch_gemm_ring(1, GEMM_ARGS);
         case 11: return launch_gemm_ring(0, GEMM_ARGS);
         case 12: return launch_gemm_ring(2, GEMM_ARGS);
         case 13: return launch_gemm_pp(GEMM_ARGS);
         case 14: return launch_gemm_ring(4, GEMM_ARGS);
+        case 8: return launch_gemm_ring(5, GEMM_ARGS);   // timing experiments (wrong results)
+        case 9: return launch_gemm_ring(6, GEMM_ARGS);
         default: return MANTIS_EINVAL;
     }
 #undef GEMM_ARGS

@@ -148,11 +148,13 @@ class LlavaEngine:
             a = K.swiglu_fwd(gu)
             x_out = K.gemm_nt(a, lw["down"], residual=x_mid)
             if compute_grads:
-                saved.append((x, rstd1, qkv, o, lse, x_mid, rstd2, gu))
+                # 288 GB of HBM: keep the cheap-to-recompute tensors too (n1, n2, a: +370 MB per layer) instead of re-running
+                # RMSNorm / SwiGLU in the backward
+                saved.append((x, rstd1, qkv, o, lse, x_mid, rstd2, gu, n1, n2, a))
             x = x_out
             if record is not None:
                 record[f"llm_layer{i}_out"] = x.view(B, L, -1)
-        del n1, n2, a
+        n1 = n2 = a = None
 
         # ---- row I: final norm, lm_head, masked shifted CE
         V = tc.vocab_size
@@ -194,15 +196,13 @@ class LlavaEngine:
         for i in reversed(range(nl)):
             lw = m.lm["layers"][i]
             lg_ = m.grads_layers[i]
-            x_in, rstd1, qkv, o, lse, x_mid, rstd2, gu = saved.pop()
-            a = K.swiglu_fwd(gu)
+            x_in, rstd1, qkv, o, lse, x_mid, rstd2, gu, n1, n2, a = saved.pop()
             if lg_["down"] is not None:
                 K.linear_dw(dx, a, lg_["down"], acc)
             da = K.linear_dx(dx, lw["down"])
             del a
             dgu = K.swiglu_bwd(da, gu)
             del da, gu
-            n2, _ = K.rmsnorm_fwd(x_mid, lw["ln2"], eps, want_rstd=False)
             if lg_["gu"] is not None:
                 K.linear_dw(dgu, n2, lg_["gu"], acc)
             dn2 = K.linear_dx(dgu, lw["gu"])
@@ -215,7 +215,6 @@ class LlavaEngine:
             dqkv = K.attn_bwd(qkv, o, do, lse, B, L, H, Hkv, hd, kmask, scale, True)
             del do, o
             K.rope_apply_(dqkv, cos, sin, H + Hkv, hd, backward=True)
-            n1, _ = K.rmsnorm_fwd(x_in, lw["ln1"], eps, want_rstd=False)
             if lg_["qkv"] is not None:
                 K.linear_dw(dqkv, n1, lg_["qkv"], acc)
             dn1 = K.linear_dx(dqkv, lw["qkv"])
