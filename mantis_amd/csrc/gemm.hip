@@ -33,6 +33,8 @@
 #define EPI_ACCUM 32
 #define EPI_VARIANT_SHIFT 8                 // bits 8-11: tile variant (0 = auto)
 #define EPI_VARIANT_MASK (15 << EPI_VARIANT_SHIFT)
+#define EPI_A_KMAJOR 4096                   // A given as [K, M] (element (m,k) at A[k*lda + m])
+#define EPI_B_KMAJOR 8192                   // B given as [K, N]
 
 typedef __attribute__((address_space(3))) void lds_void;
 
@@ -86,6 +88,48 @@ __device__ __forceinline__ void read_frags(bf16x8 (&dst)[N_], unsigned addr) {
     if constexpr (N_ > 1) lds_read_b128<4096>(dst[1], addr);
     if constexpr (N_ > 2) lds_read_b128<8192>(dst[2], addr);
     if constexpr (N_ > 3) lds_read_b128<12288>(dst[3], addr);
+}
+
+
+// ---- K-major operands (element (row, k) at G[k*ld + row]): what dX = dY.W (B = W) and dW = dY^T.X (A = dY, B = X) need.
+// LDS image of a ROWS x 64 tile: [64 k][ROWS] bf16; a 64-B segment (one 32-row MFMA block of one k-row) sits at block index
+// blk ^ (k & 3), so the four k-rows a ds_read_b64_tr_b16 lane group touches land on the four 64-B quarters of a bank row.
+template <int ROWS>
+__device__ __forceinline__ void stage_piece_km(const bf16_t* __restrict__ G, long ld, int row0, int k0, int K, char* lds_tile,
+                                               int piece, int lane) {
+    constexpr int CPR = ROWS / 8;        // 16-B chunks per k-row
+    constexpr int RPP = 64 / CPR;        // k-rows per 1-KiB global_load_lds
+    const int kk = piece * RPP + lane / CPR;
+    const int slot = lane % CPR;
+    const int c = slot ^ ((kk & 3) << 2);
+    const int k = k0 + kk;
+    const long col = (long)row0 + c * 8;
+    const bf16_t* src = (k < K && col + 8 <= ld) ? (G + (long)k * ld + col) : reinterpret_cast<const bf16_t*>(g_zero_page);
+    __builtin_amdgcn_global_load_lds(src, (lds_void*)(lds_tile + piece * 1024), 16, 0, 0);
+}
+
+template <int ROWS, int NW>
+__device__ __forceinline__ void stage_tile_km(const bf16_t* __restrict__ G, long ld, int row0, int k0, int K, char* lds_tile,
+                                              int wave, int lane) {
+    constexpr int PER = ROWS / 8 / NW;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) stage_piece_km<ROWS>(G, ld, row0, k0, K, lds_tile, wave * PER + j, lane);
+}
+
+typedef __attribute__((ext_vector_type(4))) short gs16x4;
+typedef __attribute__((address_space(3))) gs16x4 lds_gs16x4;
+
+// fragment for MFMA block `blk` (32 rows) and k-step ks from a K-major tile: lane (i = lane & 31, kg = lane >> 5) receives
+// k = ks*16 + kg*8 + 0..7 of row blk*32 + i  (two hardware-transposing reads of 4 k-rows x 16 rows each)
+template <int ROWS>
+__device__ __forceinline__ bf16x8 read_frag_km(const char* tile, int blk, int ks, int lane) {
+    const int s = lane & 15, g16 = (lane >> 4) & 1, kg = lane >> 5;
+    const int kk = ks * 16 + kg * 8 + (s >> 2);      // (kk & 3) == (s >> 2) & 3 for both halves
+    const char* p = tile + kk * (ROWS * 2) + ((blk ^ ((s >> 2) & 3)) << 6) + g16 * 32 + (s & 3) * 8;
+    union { gs16x4 h[2]; bf16x8 f; } u;
+    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_gs16x4*)p);
+    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_gs16x4*)(p + 4 * ROWS * 2));
+    return u.f;
 }
 
 template <int TM, int TN>
@@ -155,7 +199,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TN][TM], bf16_t* __r
 
 // PIPE: 0 = compiler-scheduled inner loop; 1 = hand-placed fragment prefetch; 2 = 1 + s_setprio around the MFMA clusters;
 //       3 = 2 + next tile's global_load_lds spread between the k-steps
-template <int BM, int BN, int WM, int WN, int PIPE>
+template <int BM, int BN, int WM, int WN, int PIPE, bool AKM = false, bool BKM = false>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_nt_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C, int M, int N, int K, long lda, long ldb,
     long ldc, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res, long ldr, int flags, int tiles_m, int tiles_n) {
@@ -189,8 +233,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_nt_kernel(
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int nk = (K + BK - 1) / BK;
-    stage_tile<BM, NW>(A, lda, m0, M, 0, K, smem, wave, lane);
-    stage_tile<BN, NW>(B, ldb, n0, N, 0, K, smem + A_BYTES, wave, lane);
+    if constexpr (AKM) stage_tile_km<BM, NW>(A, lda, m0, 0, K, smem, wave, lane);
+    else stage_tile<BM, NW>(A, lda, m0, M, 0, K, smem, wave, lane);
+    if constexpr (BKM) stage_tile_km<BN, NW>(B, ldb, n0, 0, K, smem + A_BYTES, wave, lane);
+    else stage_tile<BN, NW>(B, ldb, n0, N, 0, K, smem + A_BYTES, wave, lane);
 
     if constexpr (PIPE == 0) {
         for (int t = 0; t < nk; ++t) {
@@ -199,8 +245,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_nt_kernel(
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (t + 1 < nk) {
-                stage_tile<BM, NW>(A, lda, m0, M, (t + 1) * BK, K, nxt, wave, lane);
-                stage_tile<BN, NW>(B, ldb, n0, N, (t + 1) * BK, K, nxt + A_BYTES, wave, lane);
+                if constexpr (AKM) stage_tile_km<BM, NW>(A, lda, m0, (t + 1) * BK, K, nxt, wave, lane);
+                else stage_tile<BM, NW>(A, lda, m0, M, (t + 1) * BK, K, nxt, wave, lane);
+                if constexpr (BKM) stage_tile_km<BN, NW>(B, ldb, n0, (t + 1) * BK, K, nxt + A_BYTES, wave, lane);
+                else stage_tile<BN, NW>(B, ldb, n0, N, (t + 1) * BK, K, nxt + A_BYTES, wave, lane);
             }
             const char* At = cur;
             const char* Bt = cur + A_BYTES;
@@ -209,9 +257,15 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_nt_kernel(
                 const int chunk = ks * 2 + (lane >> 5);
                 bf16x8 fa[TM], fb[TN];
 #pragma unroll
-                for (int i = 0; i < TN; ++i) fb[i] = read_frag(Bt, wn * WN + i * 32 + (lane & 31), chunk);
+                for (int i = 0; i < TN; ++i) {
+                    if constexpr (BKM) fb[i] = read_frag_km<BN>(Bt, wn * (WN / 32) + i, ks, lane);
+                    else fb[i] = read_frag(Bt, wn * WN + i * 32 + (lane & 31), chunk);
+                }
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[i] = read_frag(At, wm * WM + i * 32 + (lane & 31), chunk);
+                for (int i = 0; i < TM; ++i) {
+                    if constexpr (AKM) fa[i] = read_frag_km<BM>(At, wm * (WM / 32) + i, ks, lane);
+                    else fa[i] = read_frag(At, wm * WM + i * 32 + (lane & 31), chunk);
+                }
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
@@ -290,13 +344,37 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_nt_kernel(
     gemm_epilogue<TM, TN>(acc, C, M, N, ldc, bias, res, ldr, flags, m0 + wm * WM, n0 + wn * WN, lane);
 }
 
-template <int BM, int BN, int WM, int WN, int PIPE>
+template <int BM, int BN, int WM, int WN, int PIPE, bool AKM = false, bool BKM = false>
 static int launch_gemm(hipStream_t s, const bf16_t* A, const bf16_t* B, bf16_t* C, int M, int N, int K, long lda, long ldb,
                        long ldc, const bf16_t* bias, const bf16_t* res, long ldr, int flags) {
     const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, PIPE>), dim3(tiles_m * tiles_n), dim3((BM / WM) * (BN / WN) * 64), 0, s, A,
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, PIPE, AKM, BKM>), dim3(tiles_m * tiles_n), dim3((BM / WM) * (BN / WN) * 64), 0, s, A,
                        B, C, M, N, K, lda, ldb, ldc, bias, res, ldr, flags, tiles_m, tiles_n);
     return mantis_check_launch();
+}
+
+
+// hand-placed transposing fragment reads for K-major operands in the ring kernel: two ds_read_b64_tr_b16 per fragment
+template <int OFF>
+__device__ __forceinline__ void lds_read_tr64(gs16x4& dst, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+template <int KS>
+__device__ __forceinline__ void read_frag_km_asm(bf16x8& dst, unsigned addr) {
+    union { gs16x4 h[2]; bf16x8 f; } u;
+    lds_read_tr64<KS * 4096>(u.h[0], addr);
+    lds_read_tr64<KS * 4096 + 1024>(u.h[1], addr);
+    dst = u.f;
+}
+template <int N_>
+__device__ __forceinline__ void read_frags_km(bf16x8 (&dst)[N_], unsigned slab, const unsigned (&xb)[N_], int ks) {
+#pragma unroll
+    for (int i = 0; i < N_; ++i) {
+        if (ks == 0) read_frag_km_asm<0>(dst[i], slab + xb[i]);
+        else if (ks == 1) read_frag_km_asm<1>(dst[i], slab + xb[i]);
+        else if (ks == 2) read_frag_km_asm<2>(dst[i], slab + xb[i]);
+        else read_frag_km_asm<3>(dst[i], slab + xb[i]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -306,7 +384,7 @@ static int launch_gemm(hipStream_t s, const bf16_t* A, const bf16_t* B, bf16_t* 
 // four freed slots are refilled with parts 2,3 of step t+1 and parts 0,1 of step t+2, so 64-96 KiB of global_load_lds are
 // always in flight per CU and the loads get 1-2 K-steps of lead; the only vector-memory wait is a COUNTED
 // s_waitcnt vmcnt(4) (this wave's newest two slabs may still be in flight) -- the queue is never drained in the loop.
-template <int PIPE, int NW>
+template <int PIPE, int NW, bool AKM = false, bool BKM = false>
 __global__ __launch_bounds__(NW * 64) void gemm_nt_ring_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C, int M, int N, int K, long lda, long ldb,
     long ldc, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res, long ldr, int flags, int tiles_m, int tiles_n) {
@@ -342,8 +420,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring_kernel(
         const int half = p >> 1;
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
-            if (p & 1) stage_piece(B, ldb, n0 + half * 128, N, t * BK, K, dst, PPW * wave + j, lane);
-            else stage_piece(A, lda, m0 + half * 128, M, t * BK, K, dst, PPW * wave + j, lane);
+            if (p & 1) {
+                if constexpr (BKM) stage_piece_km<128>(B, ldb, n0 + half * 128, t * BK, K, dst, PPW * wave + j, lane);
+                else stage_piece(B, ldb, n0 + half * 128, N, t * BK, K, dst, PPW * wave + j, lane);
+            } else {
+                if constexpr (AKM) stage_piece_km<128>(A, lda, m0 + half * 128, t * BK, K, dst, PPW * wave + j, lane);
+                else stage_piece(A, lda, m0 + half * 128, M, t * BK, K, dst, PPW * wave + j, lane);
+            }
         }
     };
 
@@ -358,6 +441,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring_kernel(
     for (int ks = 0; ks < 4; ++ks) xo[ks] = rowoff + ((((unsigned)(ks * 2 + (lane >> 5))) ^ f) << 4);
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     bf16x8 fa[2][TM], fb[2][TN];
+    // K-major operands: transposing reads, address = slab + lane part + (blk ^ j) * 64 [+ immediates ks*4096, half*1024]
+    const unsigned kj = (unsigned)(lane & 15) >> 2;
+    const unsigned klane = kj * 256u + (((unsigned)lane >> 4) & 1u) * 32u + ((unsigned)lane & 3u) * 8u + ((unsigned)lane >> 5) * 2048u;
+    unsigned kxa[TM], kxb[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) kxa[i] = klane + ((((unsigned)i) ^ kj) << 6);
+#pragma unroll
+    for (int i = 0; i < TN; ++i) kxb[i] = klane + ((((unsigned)((NW == 8 ? (wn & 1) * 2 : 0) + i)) ^ kj) << 6);
 
     for (int t = 0; t < nk; ++t) {
         if (PIPE != 6) {
@@ -372,16 +463,29 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring_kernel(
         const unsigned a_base = lds0 + (unsigned)((4 * t + 2 * wm) % 10) * SLAB;                                  // A half wm
         const unsigned b_base = NW == 8 ? lds0 + (unsigned)((4 * t + 1 + 2 * (wn >> 1)) % 10) * SLAB + (unsigned)(wn & 1) * 8192u
                                         : lds0 + (unsigned)((4 * t + 1 + 2 * wn) % 10) * SLAB;                     // B half
-        read_frags<TN>(fb[0], b_base + xo[0]);
-        read_frags<TM>(fa[0], a_base + xo[0]);
+        const unsigned b_slab = b_base - (NW == 8 ? (unsigned)(wn & 1) * 8192u : 0u);
+        auto rdB = [&](bf16x8 (&dst)[TN], int ks) {
+            if constexpr (BKM) read_frags_km<TN>(dst, b_slab, kxb, ks);
+            else read_frags<TN>(dst, b_base + xo[ks]);
+        };
+        auto rdA = [&](bf16x8 (&dst)[TM], int ks) {
+            if constexpr (AKM) read_frags_km<TM>(dst, a_base, kxa, ks);
+            else read_frags<TM>(dst, a_base + xo[ks]);
+        };
+        constexpr int NRD = (AKM ? 2 * TM : TM) + (BKM ? 2 * TN : TN);   // DS instructions per k-step
+        rdB(fb[0], 0);
+        rdA(fa[0], 0);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int cb = ks & 1, nb = cb ^ 1;
             if (ks < 3) {
-                read_frags<TN>(fb[nb], b_base + xo[ks + 1]);
-                read_frags<TM>(fa[nb], a_base + xo[ks + 1]);
-                if (NW == 8) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-                else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                rdB(fb[nb], ks + 1);
+                rdA(fa[nb], ks + 1);
+                if constexpr (NRD == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+                else if constexpr (NRD == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                else if constexpr (NRD == 10) asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory");
+                else if constexpr (NRD == 12) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
@@ -405,6 +509,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring_kernel(
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the trailing zero-page loads before the LDS is released
     gemm_epilogue<TM, TN>(acc, C, M, N, ldc, bias, res, ldr, flags, m0 + wm * 128, n0 + wn * (NW == 8 ? 64 : 128), lane);
+}
+
+template <bool AKM, bool BKM>
+static int launch_gemm_ring_km(hipStream_t s, const bf16_t* A, const bf16_t* B, bf16_t* C, int M, int N, int K, long lda, long ldb,
+                               long ldc, const bf16_t* bias, const bf16_t* res, long ldr, int flags) {
+    const int tiles_m = cdiv(M, 256), tiles_n = cdiv(N, 256);
+    hipLaunchKernelGGL((gemm_nt_ring_kernel<2, 8, AKM, BKM>), dim3(tiles_m * tiles_n), dim3(512), 0, s, A, B, C, M, N, K, lda, ldb, ldc,
+                       bias, res, ldr, flags, tiles_m, tiles_n);
+    return mantis_check_launch();
 }
 
 static int launch_gemm_ring(int pipe, hipStream_t s, const bf16_t* A, const bf16_t* B, bf16_t* C, int M, int N, int K, long lda,
@@ -572,7 +685,13 @@ extern "C" {
 int mantis_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
                         const void* bias, const void* residual, int64_t ldr, int flags, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0) return MANTIS_EINVAL;
-    if (K % 8 || lda % 8 || ldb % 8 || lda < K || ldb < K || ldc < N) return MANTIS_EUNSUPPORTED;
+    const bool akm = flags & EPI_A_KMAJOR, bkm = flags & EPI_B_KMAJOR;
+    if (lda % 8 || ldb % 8 || ldc < N) return MANTIS_EUNSUPPORTED;
+    const int K8 = (K + 7) / 8 * 8;
+    if ((!akm && lda < K8) || (!bkm && ldb < K8) || (akm && lda < M) || (bkm && ldb < N)) return MANTIS_EUNSUPPORTED;
+    // row-major operands are fetched in whole 16-B chunks along K: with K % 8 != 0 the tail chunk must meet zeros on the other
+    // side, which only a K-major operand (rows k >= K come from the zero page) guarantees; the row-major pad must be finite
+    if (!akm && !bkm && (K % 8)) return MANTIS_EUNSUPPORTED;
     if (((uintptr_t)A | (uintptr_t)B) & 15) return MANTIS_EUNSUPPORTED;
     if ((flags & EPI_BIAS) && !bias) return MANTIS_EINVAL;
     if ((flags & EPI_RESIDUAL) && !residual) return MANTIS_EINVAL;
@@ -587,6 +706,13 @@ int mantis_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, 
     }
 #define GEMM_ARGS s, (const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C, M, N, K, (long)lda, (long)ldb, (long)ldc, \
                   (const bf16_t*)bias, (const bf16_t*)residual, (long)ldr, flags
+    if (akm || bkm) {   // K-major operand(s): compiler-scheduled kernels with transposing fragment reads
+        const bool big = variant != 1;
+        const bool ring = variant == 12 || variant == 15;
+        if (akm && bkm) return ring ? launch_gemm_ring_km<true, true>(GEMM_ARGS) : big ? launch_gemm<256, 256, 128, 64, 0, true, true>(GEMM_ARGS) : launch_gemm<128, 128, 64, 64, 0, true, true>(GEMM_ARGS);
+        if (bkm) return ring ? launch_gemm_ring_km<false, true>(GEMM_ARGS) : big ? launch_gemm<256, 256, 128, 64, 0, false, true>(GEMM_ARGS) : launch_gemm<128, 128, 64, 64, 0, false, true>(GEMM_ARGS);
+        return ring ? launch_gemm_ring_km<true, false>(GEMM_ARGS) : big ? launch_gemm<256, 256, 128, 64, 0, true, false>(GEMM_ARGS) : launch_gemm<128, 128, 64, 64, 0, true, false>(GEMM_ARGS);
+    }
     switch (variant) {
         case 1: return launch_gemm<128, 128, 64, 64, 0>(GEMM_ARGS);
         case 2: return launch_gemm<256, 256, 128, 64, 0>(GEMM_ARGS);

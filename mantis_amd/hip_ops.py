@@ -35,25 +35,35 @@ def pad8(n):
 
 
 # ----------------------------------------------------------------------------------------------------------- GEMM family
-def gemm_nt(a, b, bias=None, act=None, residual=None, out=None, accumulate=False, n_valid=None, k=None, ldc=None, variant=0):
-    """out[M,N] = epi(a[M,K] @ b[N,K]^T).  `k` overrides the contraction length (zero-padded operands)."""
+def gemm_nt(a, b, bias=None, act=None, residual=None, out=None, accumulate=False, n_valid=None, k=None, ldc=None, variant=0,
+            a_kmajor=False, b_kmajor=False):
+    """out[M,N] = epi(A . B^T) with A = a[M,K] (or a[K,M] if a_kmajor), B = b[N,K] (or b[K,N] if b_kmajor).
+    `k` overrides the contraction length (zero-padded operands)."""
     _chk2d(a, "a"), _chk2d(b, "b")
-    M, K = a.shape
-    N = b.shape[0] if n_valid is None else n_valid
+    if a_kmajor:
+        K, M = a.shape
+    else:
+        M, K = a.shape
+    if b_kmajor:
+        N = b.shape[1]
+    else:
+        N = b.shape[0]
+    N = N if n_valid is None else n_valid
     K = K if k is None else k
     if out is None:
         out = torch.empty((M, N if ldc is None else ldc), dtype=BF16, device=a.device)   # ldc > N: padded row stride
     else:
         _chk2d(out, "out")
     C = out
-    flags = (1 if bias is not None else 0) | (GEMM_ACT[act] << 1) | (16 if residual is not None else 0) | (32 if accumulate else 0) | (variant << 8)
+    flags = (1 if bias is not None else 0) | (GEMM_ACT[act] << 1) | (16 if residual is not None else 0) | (32 if accumulate else 0) \
+        | (variant << 8) | (4096 if a_kmajor else 0) | (8192 if b_kmajor else 0)
     prof = KERNEL_TIMER
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()          # torch's current stream == the stream handed to the kernel below
     rc = _L.mantis_gemm_bf16_nt(_p(a), a.stride(0), _p(b), b.stride(0), _p(C), C.stride(0), M, N, K, _p(bias), _p(residual),
                                 0 if residual is None else residual.stride(0), flags, _stream())
-    _lib.check(rc, f"gemm_nt M={M} N={N} K={K}")
+    _lib.check(rc, f"gemm M={M} N={N} K={K} akm={a_kmajor} bkm={b_kmajor}")
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
@@ -88,17 +98,26 @@ def linear_fwd(x, w, bias=None, act=None, residual=None):
     return gemm_nt(x, w, bias=bias, act=act, residual=residual)
 
 
+def _prefers_256(M, N):
+    """Mirror of the tile heuristic in csrc/gemm.hip (wave quantisation of 256x256 vs 128x128 tiles)."""
+    cd = lambda a, b: (a + b - 1) // b
+    r256, r128 = cd(M, 256) * cd(N, 256) / 256.0, cd(M, 128) * cd(N, 128) / 512.0
+    e256, e128 = r256 / math.ceil(r256) * 1.15, r128 / math.ceil(r128)
+    return M >= 512 and N >= 512 and e256 >= e128
+
+
 def linear_dx(dy, w, k=None):
-    """dx[M, in] = dy[M, out] @ w[out, in]   (NT GEMM on w^T)."""
+    """dx[M, in] = dy[M, out] @ w[out, in].  Shapes that tile well at 256x256 consume the weight K-major as stored (ring kernel
+    with transposing fragment reads); badly quantised ones run the faster 128x128 NT kernel on a transposed weight copy."""
+    if _prefers_256(dy.shape[0], w.shape[1]):
+        return gemm_nt(dy, w, b_kmajor=True, k=w.shape[0])
     wt = transpose(w)                       # [in, pad8(out)]
     return gemm_nt(dy, wt, k=wt.shape[1] if k is None else k)
 
 
 def linear_dw(dy, x, grad_w, accumulate):
-    """grad_w[out, in] (+)= dy[M, out]^T @ x[M, in]."""
-    dyt = transpose(dy)                     # [out (+pad columns of dy), Mp]
-    xt = transpose(x)                       # [in, Mp]
-    gemm_nt(dyt[: grad_w.shape[0]], xt, out=grad_w, accumulate=accumulate, k=dyt.shape[1])
+    """grad_w[out, in] (+)= dy[M, out]^T @ x[M, in]: both activations are consumed K-major as stored."""
+    gemm_nt(dy[:, : grad_w.shape[0]], x, out=grad_w, accumulate=accumulate, a_kmajor=True, b_kmajor=True)
 
 
 def colsum(x, grad, accumulate):
