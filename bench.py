@@ -102,7 +102,8 @@ def main():
     if local_rank == 0:
         __graft_entry__.build()
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_dp = os.environ.get("MANTIS_DP_FORCE") == "1" and "RANK" in os.environ
+    if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         dist.barrier()
@@ -118,7 +119,7 @@ def main():
     B = args.batch_per_gpu
     T, n_img = (128, 1) if tiny else (512, 4)
     model = LlavaForConditionalGeneration(cfg, device=f"cuda:{local_rank}", seed=0)      # same seed -> identical replicas
-    reducer = GradReducer(model) if world > 1 else None
+    reducer = GradReducer(model) if (world > 1 or force_dp) else None
     trainer = MantisHipTrainer(model, gradient_accumulation_steps=1, reducer=reducer)
     opt = None if args.no_optimizer else FusedAdamW(model, lr=1e-5, weight_decay=0.0, max_grad_norm=1.0)
     batches = [synthetic_batch(cfg, B, T, n_img, cfg.vision_config.image_size, rank, s) for s in range(2)]
@@ -185,7 +186,7 @@ def main():
                                parallelism=f"dp{world}", optimizer=not args.no_optimizer),
                    roofline=roof, cpu_baseline=cpu)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dp:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -4,7 +4,6 @@
 // (transformers/models/siglip/modeling_siglip.py:124-130,267-322), the projector
 // (/root/reference/mantis/models/mllava/modeling_llava.py:106-118), Llama q/k/v/o/gate/up/down and lm_head
 // (transformers/models/llama/modeling_llama.py:163-176,229-280,438-492) -- which today run in cuBLAS/hipBLASLt.
-// Backward GEMMs (dX = dY.W, dW = dY^T.X) use the same kernel on transposed operands (rope.hip: mantis_transpose).
 //
 // Structure (MFMA-bound, fp32 accumulate):
 //   * BM x BN output tile per workgroup (256x256 with 8 waves of 128x64, or 128x128 with 4 waves of 64x64 for small / badly
@@ -14,9 +13,13 @@
 //   * LDS image [rows][64 k]: 16-B chunk c of row r sits at slot c ^ ((r >> 1) & 7): two rows share a 256-B bank row, so the
 //     16 rows of a ds_read_b128 lane group hit 16 distinct slots (conflict free).  global_load_lds writes lane-linearly,
 //     so the swizzle is applied on the SOURCE address and again on the fragment read (cdna guide rule 21)
-//   * PIPE > 0: fragment reads are issued one k-step ahead of the MFMAs that consume them (hand-placed ds_read_b128 +
-//     counted lgkmcnt), MFMA clusters run at raised wave priority, and the next tile's global_load_lds are spread
-//     between the MFMA clusters instead of being issued as one burst
+//   * ring kernel (256x256): fragment reads are issued one k-step ahead of the MFMAs that consume them (hand-placed
+//     ds_read_b128 / ds_read_b64_tr_b16 + counted lgkmcnt), MFMA clusters run at raised wave priority, the next tiles'
+//     global_load_lds are spread between the MFMA clusters, and the only vector-memory wait is a counted vmcnt(4)
+//   * operands may be K-major ([K, rows]): dX = dY.W reads the weight as stored, dW = dY^T.X reads both activations as
+//     stored; fragments then come from a [k][rows] LDS image through the hardware-transposing ds_read_b64_tr_b16
+//   * measured dead ends (profiles/r01_gemm_experiments.md): BK=32 ping-pong / strictly alternating wave groups with a
+//     20-slab ring, one 128x128 wave tile per SIMD, 256x128 and 128x256 tiles -- all slower than the ring kernel
 //   * operands are fed swapped (mfma(a = B rows, b = A rows)) so each lane owns ONE output row m and 4 consecutive n:
 //     the epilogue (bias, GELU variants, residual add, grad accumulation) is 8-byte vector loads/stores
 //   * edges: rows beyond M/N are clamped on load and predicated on store; K tails read a zero page (K % 8 == 0)
@@ -197,15 +200,13 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TN][TM], bf16_t* __r
     }
 }
 
-// PIPE: 0 = compiler-scheduled inner loop; 1 = hand-placed fragment prefetch; 2 = 1 + s_setprio around the MFMA clusters;
-//       3 = 2 + next tile's global_load_lds spread between the k-steps
-template <int BM, int BN, int WM, int WN, int PIPE, bool AKM = false, bool BKM = false>
+// Generic kernel (compiler-scheduled inner loop): 128x128 tiles for small / badly quantised shapes, any operand layout.
+template <int BM, int BN, int WM, int WN, bool AKM = false, bool BKM = false>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_nt_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C, int M, int N, int K, long lda, long ldb,
     long ldc, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res, long ldr, int flags, int tiles_m, int tiles_n) {
     constexpr int NWN = BN / WN, NW = (BM / WM) * NWN, TM = WM / 32, TN = WN / 32;
     constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
-    constexpr int PER_A = BM / 8 / NW, PER_B = BN / 8 / NW;
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -238,7 +239,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_nt_kernel(
     if constexpr (BKM) stage_tile_km<BN, NW>(B, ldb, n0, 0, K, smem + A_BYTES, wave, lane);
     else stage_tile<BN, NW>(B, ldb, n0, N, 0, K, smem + A_BYTES, wave, lane);
 
-    if constexpr (PIPE == 0) {
+    {
         for (int t = 0; t < nk; ++t) {
             char* cur = smem + (t & 1) * STAGE;
             char* nxt = smem + ((t + 1) & 1) * STAGE;
@@ -273,82 +274,16 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_nt_kernel(
                         acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[tn], fa[tm], acc[tn][tm], 0, 0, 0);
             }
         }
-    } else {
-        // per-lane LDS byte offsets of the 4 k-step chunks inside a row (identical for every 32-row block: 32 rows = 16 bank rows)
-        const unsigned rowoff = (unsigned)(lane & 31) * 128u;
-        const unsigned f = ((unsigned)(lane & 31) >> 1) & 7u;
-        unsigned xo[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) xo[ks] = rowoff + ((((unsigned)(ks * 2 + (lane >> 5))) ^ f) << 4);
-        const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;   // LDS byte address
-        const unsigned a_base = lds0 + (unsigned)(wm * WM) * 128u;
-        const unsigned b_base = lds0 + (unsigned)A_BYTES + (unsigned)(wn * WN) * 128u;
-        bf16x8 fa[2][TM], fb[2][TN];
-
-        for (int t = 0; t < nk; ++t) {
-            const unsigned so = (unsigned)(t & 1) * (unsigned)STAGE;
-            char* nxt = smem + ((t + 1) & 1) * STAGE;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            const bool more = (PIPE != 8) && (t + 1 < nk);
-            if ((PIPE < 3 || PIPE >= 8) && more) {   // (PIPE 8: experiment without loads, 9: without MFMAs)
-                stage_tile<BM, NW>(A, lda, m0, M, (t + 1) * BK, K, nxt, wave, lane);
-                stage_tile<BN, NW>(B, ldb, n0, N, (t + 1) * BK, K, nxt + A_BYTES, wave, lane);
-            }
-            read_frags<TN>(fb[0], b_base + so + xo[0]);
-            read_frags<TM>(fa[0], a_base + so + xo[0]);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int cb = ks & 1, nb = cb ^ 1;
-                if (ks < 3) {
-                    read_frags<TN>(fb[nb], b_base + so + xo[ks + 1]);
-                    read_frags<TM>(fa[nb], a_base + so + xo[ks + 1]);
-                    if constexpr (TM + TN == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-                    else if constexpr (TM + TN == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (PIPE >= 2) __builtin_amdgcn_s_setprio(1);
-                if constexpr (PIPE == 9) {
-#pragma unroll
-                    for (int tn = 0; tn < TN; ++tn) asm volatile("" ::"v"(fb[cb][tn]));
-#pragma unroll
-                    for (int tm = 0; tm < TM; ++tm) asm volatile("" ::"v"(fa[cb][tm]));
-                } else {
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                    for (int tm = 0; tm < TM; ++tm)
-                        acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cb][tn], fa[cb][tm], acc[tn][tm], 0, 0, 0);
-                }
-                if (PIPE >= 2) __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (PIPE >= 3 && PIPE < 8 && more) {
-                    // a quarter of this wave's share of the next tile per k-step
-                    constexpr int QA = PER_A / 4 > 0 ? PER_A / 4 : 1, QB = PER_B / 4 > 0 ? PER_B / 4 : 1;
-#pragma unroll
-                    for (int j = 0; j < QA; ++j)
-                        if (ks * QA + j < PER_A)
-                            stage_piece(A, lda, m0, M, (t + 1) * BK, K, nxt, wave * PER_A + ks * QA + j, lane);
-#pragma unroll
-                    for (int j = 0; j < QB; ++j)
-                        if (ks * QB + j < PER_B)
-                            stage_piece(B, ldb, n0, N, (t + 1) * BK, K, nxt + A_BYTES, wave * PER_B + ks * QB + j, lane);
-                }
-            }
-        }
     }
 
     gemm_epilogue<TM, TN>(acc, C, M, N, ldc, bias, res, ldr, flags, m0 + wm * WM, n0 + wn * WN, lane);
 }
 
-template <int BM, int BN, int WM, int WN, int PIPE, bool AKM = false, bool BKM = false>
+template <int BM, int BN, int WM, int WN, bool AKM = false, bool BKM = false>
 static int launch_gemm(hipStream_t s, const bf16_t* A, const bf16_t* B, bf16_t* C, int M, int N, int K, long lda, long ldb,
                        long ldc, const bf16_t* bias, const bf16_t* res, long ldr, int flags) {
     const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, PIPE, AKM, BKM>), dim3(tiles_m * tiles_n), dim3((BM / WM) * (BN / WN) * 64), 0, s, A,
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, AKM, BKM>), dim3(tiles_m * tiles_n), dim3((BM / WM) * (BN / WN) * 64), 0, s, A,
                        B, C, M, N, K, lda, ldb, ldc, bias, res, ldr, flags, tiles_m, tiles_n);
     return mantis_check_launch();
 }
@@ -384,15 +319,15 @@ __device__ __forceinline__ void read_frags_km(bf16x8 (&dst)[N_], unsigned slab, 
 // four freed slots are refilled with parts 2,3 of step t+1 and parts 0,1 of step t+2, so 64-96 KiB of global_load_lds are
 // always in flight per CU and the loads get 1-2 K-steps of lead; the only vector-memory wait is a COUNTED
 // s_waitcnt vmcnt(4) (this wave's newest two slabs may still be in flight) -- the queue is never drained in the loop.
-template <int PIPE, int NW, bool AKM = false, bool BKM = false>
-__global__ __launch_bounds__(NW * 64) void gemm_nt_ring_kernel(
+template <bool AKM, bool BKM>
+__global__ __launch_bounds__(512) void gemm_nt_ring_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C, int M, int N, int K, long lda, long ldb,
     long ldc, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res, long ldr, int flags, int tiles_m, int tiles_n) {
-    constexpr int TM = 4, TN = NW == 8 ? 2 : 4, SLAB = 16384, PPW = 16 / NW;   // NW == 4: one 128x128 wave tile per SIMD
+    constexpr int TM = 4, TN = 2, SLAB = 16384, PPW = 2;   // 8 waves: 2 (M) x 4 (N), each 128 x 64
     __shared__ __attribute__((aligned(16))) char smem[10 * SLAB];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = NW == 8 ? wave >> 2 : wave >> 1, wn = NW == 8 ? (wave & 3) : (wave & 1);
+    const int wm = wave >> 2, wn = wave & 3;
 
     const int nwg = tiles_m * tiles_n;
     const int bid = blockIdx.x;
@@ -448,22 +383,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring_kernel(
 #pragma unroll
     for (int i = 0; i < TM; ++i) kxa[i] = klane + ((((unsigned)i) ^ kj) << 6);
 #pragma unroll
-    for (int i = 0; i < TN; ++i) kxb[i] = klane + ((((unsigned)((NW == 8 ? (wn & 1) * 2 : 0) + i)) ^ kj) << 6);
+    for (int i = 0; i < TN; ++i) kxb[i] = klane + ((((unsigned)((wn & 1) * 2 + i)) ^ kj) << 6);
 
     for (int t = 0; t < nk; ++t) {
-        if (PIPE != 6) {
-            if (NW == 8) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but step t+1's parts 0,1 (this wave's newest) landed
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        }
-        if (PIPE != 5) __builtin_amdgcn_s_barrier();
-        if (PIPE < 2) {
-            issue(t + 1, 2); issue(t + 1, 3);
-            issue(t + 2, 0); issue(t + 2, 1);
-        }
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but step t+1's parts 0,1 (this wave's 4 newest loads) landed
+        __builtin_amdgcn_s_barrier();
         const unsigned a_base = lds0 + (unsigned)((4 * t + 2 * wm) % 10) * SLAB;                                  // A half wm
-        const unsigned b_base = NW == 8 ? lds0 + (unsigned)((4 * t + 1 + 2 * (wn >> 1)) % 10) * SLAB + (unsigned)(wn & 1) * 8192u
-                                        : lds0 + (unsigned)((4 * t + 1 + 2 * wn) % 10) * SLAB;                     // B half
-        const unsigned b_slab = b_base - (NW == 8 ? (unsigned)(wn & 1) * 8192u : 0u);
+        const unsigned b_slab = lds0 + (unsigned)((4 * t + 1 + 2 * (wn >> 1)) % 10) * SLAB;                     // B half wn >> 1
+        const unsigned b_base = b_slab + (unsigned)(wn & 1) * 8192u;
         auto rdB = [&](bf16x8 (&dst)[TN], int ks) {
             if constexpr (BKM) read_frags_km<TN>(dst, b_slab, kxb, ks);
             else read_frags<TN>(dst, b_base + xo[ks]);
@@ -490,190 +417,32 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring_kernel(
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (PIPE >= 1) __builtin_amdgcn_s_setprio(1);
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
                     acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cb][tn], fa[cb][tm], acc[tn][tm], 0, 0, 0);
-            if (PIPE >= 1) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-            if (PIPE >= 2) {   // refill one freed slab per k-step: the DMA issue slots hide under the partner wave's MFMA cluster
-                if (ks == 0) issue(t + 1, 2);
-                if (ks == 1) issue(t + 1, 3);
-                if (ks == 2) issue(t + 2, 0);
-                if (ks == 3) issue(t + 2, 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            // refill one freed slab per k-step: the DMA issue slots hide under the partner wave's MFMA cluster
+            if (ks == 0) issue(t + 1, 2);
+            if (ks == 1) issue(t + 1, 3);
+            if (ks == 2) issue(t + 2, 0);
+            if (ks == 3) issue(t + 2, 1);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the trailing zero-page loads before the LDS is released
-    gemm_epilogue<TM, TN>(acc, C, M, N, ldc, bias, res, ldr, flags, m0 + wm * 128, n0 + wn * (NW == 8 ? 64 : 128), lane);
+    gemm_epilogue<TM, TN>(acc, C, M, N, ldc, bias, res, ldr, flags, m0 + wm * 128, n0 + wn * 64, lane);
 }
 
 template <bool AKM, bool BKM>
-static int launch_gemm_ring_km(hipStream_t s, const bf16_t* A, const bf16_t* B, bf16_t* C, int M, int N, int K, long lda, long ldb,
-                               long ldc, const bf16_t* bias, const bf16_t* res, long ldr, int flags) {
+static int launch_gemm_ring(hipStream_t s, const bf16_t* A, const bf16_t* B, bf16_t* C, int M, int N, int K, long lda, long ldb,
+                            long ldc, const bf16_t* bias, const bf16_t* res, long ldr, int flags) {
     const int tiles_m = cdiv(M, 256), tiles_n = cdiv(N, 256);
-    hipLaunchKernelGGL((gemm_nt_ring_kernel<2, 8, AKM, BKM>), dim3(tiles_m * tiles_n), dim3(512), 0, s, A, B, C, M, N, K, lda, ldb, ldc,
-                       bias, res, ldr, flags, tiles_m, tiles_n);
-    return mantis_check_launch();
-}
-
-static int launch_gemm_ring(int pipe, hipStream_t s, const bf16_t* A, const bf16_t* B, bf16_t* C, int M, int N, int K, long lda,
-                            long ldb, long ldc, const bf16_t* bias, const bf16_t* res, long ldr, int flags) {
-    const int tiles_m = cdiv(M, 256), tiles_n = cdiv(N, 256);
-    if (pipe == 5 || pipe == 6) {
-        if (pipe == 5)
-            hipLaunchKernelGGL((gemm_nt_ring_kernel<5, 8>), dim3(tiles_m * tiles_n), dim3(512), 0, s, A, B, C, M, N, K, lda, ldb, ldc,
-                               bias, res, ldr, flags, tiles_m, tiles_n);
-        else
-            hipLaunchKernelGGL((gemm_nt_ring_kernel<6, 8>), dim3(tiles_m * tiles_n), dim3(512), 0, s, A, B, C, M, N, K, lda, ldb, ldc,
-                               bias, res, ldr, flags, tiles_m, tiles_n);
-    } else if (pipe == 4)
-        hipLaunchKernelGGL((gemm_nt_ring_kernel<2, 4>), dim3(tiles_m * tiles_n), dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias,
-                           res, ldr, flags, tiles_m, tiles_n);
-    else if (pipe == 2)
-        hipLaunchKernelGGL((gemm_nt_ring_kernel<2, 8>), dim3(tiles_m * tiles_n), dim3(512), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias,
-                           res, ldr, flags, tiles_m, tiles_n);
-    else if (pipe)
-        hipLaunchKernelGGL((gemm_nt_ring_kernel<1, 8>), dim3(tiles_m * tiles_n), dim3(512), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias,
-                           res, ldr, flags, tiles_m, tiles_n);
-    else
-        hipLaunchKernelGGL((gemm_nt_ring_kernel<0, 8>), dim3(tiles_m * tiles_n), dim3(512), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias,
-                           res, ldr, flags, tiles_m, tiles_n);
-    return mantis_check_launch();
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// 256x256 "ping-pong" kernel (K step 32).  The two wave groups of a workgroup (waves 0-3 own A rows 0-127, waves 4-7 own A
-// rows 128-255; every SIMD hosts one wave of each group) run the SAME instruction stream, but group 1 enters the loop one
-// barrier later, i.e. half a K-step out of phase.  A K-step is two phases of 8 MFMAs per wave:
-//   phase 0 (after a barrier): read the k-step-0 fragments (exposed LDS latency), prefetch the k-step-1 fragments, MFMA 0
-//   phase 1 (after a barrier): MFMA 1 on the prefetched fragments -- no exposed latency
-// so whenever one group sits in its exposed-latency phase the other group's MFMAs keep the SIMD's matrix pipe busy.
-// LDS is a ring of twenty 8-KiB slabs (one slab = 128 rows x 32 k of A or B; slab idx = 4*kstep + part, slot = idx % 20),
-// i.e. five K-steps: with the half-step lag a K-step's slabs must be resident from half a step before the leading group
-// starts it until the trailing group leaves it.  Per K-step each wave issues 4 global_load_lds (one 1-KiB piece of each
-// slab) four K-steps ahead and waits with a COUNTED s_waitcnt vmcnt(8); the queue is never drained inside the loop.
-// LDS image per slab: [128 rows][32 k] = 64 B rows, four rows per 256-B bank row; chunk c of row r at slot c ^ ((r >> 2) & 3).
-__device__ __forceinline__ void stage_piece32(const bf16_t* __restrict__ G, long ld, int row0, int rows_total, int k0, int K,
-                                              char* lds_slab, int piece, int lane) {
-    const int rl = lane >> 2;                      // 16 rows x 64 B per global_load_lds
-    const int row = piece * 16 + rl;
-    const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-    const int k = k0 + chunk * 8;
-    int grow = row0 + row;
-    grow = grow < rows_total ? grow : rows_total - 1;
-    const bf16_t* src = (k < K) ? (G + (long)grow * ld + k) : reinterpret_cast<const bf16_t*>(g_zero_page);
-    __builtin_amdgcn_global_load_lds(src, (lds_void*)(lds_slab + piece * 1024), 16, 0, 0);
-}
-
-template <int N_>
-__device__ __forceinline__ void read_frags32(bf16x8 (&dst)[N_], unsigned addr) {   // 32-row blocks are 2048 B apart
-    lds_read_b128<0>(dst[0], addr);
-    if constexpr (N_ > 1) lds_read_b128<2048>(dst[1], addr);
-    if constexpr (N_ > 2) lds_read_b128<4096>(dst[2], addr);
-    if constexpr (N_ > 3) lds_read_b128<6144>(dst[3], addr);
-}
-
-template <int DUMMY>
-__global__ __launch_bounds__(512) void gemm_nt_pp_kernel(
-    const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C, int M, int N, int K, long lda, long ldb,
-    long ldc, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res, long ldr, int flags, int tiles_m, int tiles_n) {
-    constexpr int TM = 4, TN = 2, SLAB = 8192, RING = 20, KS = 32;
-    __shared__ __attribute__((aligned(16))) char smem[RING * SLAB];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2, wn = wave & 3;
-
-    const int nwg = tiles_m * tiles_n;
-    const int bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    const int tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int GROUP = 8;
-    const int per_group = GROUP * tiles_n;
-    const int g = tile_id / per_group;
-    const int first_m = g * GROUP;
-    const int gsz = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
-    const int in_g = tile_id - g * per_group;
-    const int m0 = (first_m + in_g % gsz) * 256, n0 = (in_g / gsz) * 256;
-
-    f32x16 acc[TN][TM];
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    // K-step t: four slabs (A lo, B lo, B hi, A hi); this wave moves piece `wave` (16 rows) of each
-    auto issue_kstep = [&](int t) {
-        const int base = (4 * t) % RING;
-        stage_piece32(A, lda, m0, M, t * KS, K, smem + (base + 0) * SLAB, wave, lane);
-        stage_piece32(B, ldb, n0, N, t * KS, K, smem + (base + 1) * SLAB, wave, lane);
-        stage_piece32(B, ldb, n0 + 128, N, t * KS, K, smem + (base + 2) * SLAB, wave, lane);
-        stage_piece32(A, lda, m0 + 128, M, t * KS, K, smem + (base + 3) * SLAB, wave, lane);
-    };
-    const int nk = (K + KS - 1) / KS;
-    issue_kstep(0); issue_kstep(1); issue_kstep(2); issue_kstep(3);
-
-    const unsigned f = ((unsigned)(lane & 31) >> 2) & 3u;
-    const unsigned rowoff = (unsigned)(lane & 31) * 64u;
-    const unsigned xo0 = rowoff + (((unsigned)(0 + (lane >> 5)) ^ f) << 4);
-    const unsigned xo1 = rowoff + (((unsigned)(2 + (lane >> 5)) ^ f) << 4);
-    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    const unsigned a_part = grp ? 3u : 0u, b_part = 1u + (unsigned)(wn >> 1), b_off = (unsigned)(wn & 1) * 4096u;
-    bf16x8 fa[2][TM], fb[2][TN];
-
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // K-step 0 landed (this wave's pieces)
-    if (grp == 1) __builtin_amdgcn_s_barrier();             // group 1 runs one barrier (half a K-step) behind group 0
-
-    for (int t = 0; t < nk; ++t) {
-        // ---- phase 0
-        __builtin_amdgcn_s_barrier();
-        const unsigned base = (unsigned)((4 * t) % RING);
-        const unsigned a_base = lds0 + ((base + a_part) % RING) * SLAB;
-        const unsigned b_base = lds0 + ((base + b_part) % RING) * SLAB + b_off;
-        read_frags32<TN>(fb[0], b_base + xo0);
-        read_frags32<TM>(fa[0], a_base + xo0);
-        read_frags32<TN>(fb[1], b_base + xo1);
-        read_frags32<TM>(fa[1], a_base + xo1);
-        asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-                acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[0][tn], fa[0][tm], acc[tn][tm], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- phase 1: K-step t+1 must be resident for whoever starts it at this barrier; K-step t-1 is retired by it
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        issue_kstep(t + 4);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-                acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[1][tn], fa[1][tm], acc[tn][tm], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (grp == 0) __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    gemm_epilogue<TM, TN>(acc, C, M, N, ldc, bias, res, ldr, flags, m0 + grp * 128, n0 + wn * 64, lane);
-}
-
-static int launch_gemm_pp(hipStream_t s, const bf16_t* A, const bf16_t* B, bf16_t* C, int M, int N, int K, long lda, long ldb,
-                          long ldc, const bf16_t* bias, const bf16_t* res, long ldr, int flags) {
-    const int tiles_m = cdiv(M, 256), tiles_n = cdiv(N, 256);
-    hipLaunchKernelGGL((gemm_nt_pp_kernel<0>), dim3(tiles_m * tiles_n), dim3(512), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias, res,
-                       ldr, flags, tiles_m, tiles_n);
+    hipLaunchKernelGGL((gemm_nt_ring_kernel<AKM, BKM>), dim3(tiles_m * tiles_n), dim3(512), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias,
+                       res, ldr, flags, tiles_m, tiles_n);
     return mantis_check_launch();
 }
 
@@ -706,30 +475,20 @@ int mantis_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, 
     }
 #define GEMM_ARGS s, (const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C, M, N, K, (long)lda, (long)ldb, (long)ldc, \
                   (const bf16_t*)bias, (const bf16_t*)residual, (long)ldr, flags
-    if (akm || bkm) {   // K-major operand(s): compiler-scheduled kernels with transposing fragment reads
-        const bool big = variant != 1;
-        const bool ring = variant == 12 || variant == 15;
-        if (akm && bkm) return ring ? launch_gemm_ring_km<true, true>(GEMM_ARGS) : big ? launch_gemm<256, 256, 128, 64, 0, true, true>(GEMM_ARGS) : launch_gemm<128, 128, 64, 64, 0, true, true>(GEMM_ARGS);
-        if (bkm) return ring ? launch_gemm_ring_km<false, true>(GEMM_ARGS) : big ? launch_gemm<256, 256, 128, 64, 0, false, true>(GEMM_ARGS) : launch_gemm<128, 128, 64, 64, 0, false, true>(GEMM_ARGS);
-        return ring ? launch_gemm_ring_km<true, false>(GEMM_ARGS) : big ? launch_gemm<256, 256, 128, 64, 0, true, false>(GEMM_ARGS) : launch_gemm<128, 128, 64, 64, 0, true, false>(GEMM_ARGS);
-    }
-    switch (variant) {
-        case 1: return launch_gemm<128, 128, 64, 64, 0>(GEMM_ARGS);
-        case 2: return launch_gemm<256, 256, 128, 64, 0>(GEMM_ARGS);
-        case 3: return launch_gemm<256, 256, 128, 64, 1>(GEMM_ARGS);
-        case 4: return launch_gemm<256, 256, 128, 64, 2>(GEMM_ARGS);
-        case 5: return launch_gemm<256, 256, 128, 64, 3>(GEMM_ARGS);
-        case 6: return launch_gemm<128, 128, 64, 64, 2>(GEMM_ARGS);
-        case 7: return launch_gemm<128, 128, 64, 64, 3>(GEMM_ARGS);
-        case 10: return launch_gemm_ring(1, GEMM_ARGS);
-        case 11: return launch_gemm_ring(0, GEMM_ARGS);
-        case 12: return launch_gemm_ring(2, GEMM_ARGS);
-        case 13: return launch_gemm_pp(GEMM_ARGS);
-        case 14: return launch_gemm_ring(4, GEMM_ARGS);
-        case 8: return launch_gemm_ring(5, GEMM_ARGS);   // timing experiments (wrong results)
-        case 9: return launch_gemm_ring(6, GEMM_ARGS);
-        default: return MANTIS_EINVAL;
-    }
+    // variant 1 = 128x128 generic kernel, 2 = 256x256 generic kernel, 12 = 256x256 ring kernel (default for well-quantised shapes)
+    const bool ring = variant == 12, big = variant == 2;
+    if (!ring && !big && variant != 1) return MANTIS_EINVAL;
+    if (akm && bkm)
+        return ring ? launch_gemm_ring<true, true>(GEMM_ARGS)
+                    : big ? launch_gemm<256, 256, 128, 64, true, true>(GEMM_ARGS) : launch_gemm<128, 128, 64, 64, true, true>(GEMM_ARGS);
+    if (bkm)
+        return ring ? launch_gemm_ring<false, true>(GEMM_ARGS)
+                    : big ? launch_gemm<256, 256, 128, 64, false, true>(GEMM_ARGS) : launch_gemm<128, 128, 64, 64, false, true>(GEMM_ARGS);
+    if (akm)
+        return ring ? launch_gemm_ring<true, false>(GEMM_ARGS)
+                    : big ? launch_gemm<256, 256, 128, 64, true, false>(GEMM_ARGS) : launch_gemm<128, 128, 64, 64, true, false>(GEMM_ARGS);
+    return ring ? launch_gemm_ring<false, false>(GEMM_ARGS)
+                : big ? launch_gemm<256, 256, 128, 64, false, false>(GEMM_ARGS) : launch_gemm<128, 128, 64, 64, false, false>(GEMM_ARGS);
 #undef GEMM_ARGS
 }
 

@@ -10,6 +10,8 @@ right after the last kernel that writes a bucket (lm_head block, then decoder la
 each call enqueues an async mean all-reduce on RCCL's stream, which runs while the next layer's backward kernels execute.
 Buckets are per decoder layer (436 MB for Llama-3-8B): large messages keep all 7 xGMI links busy, and RCCL picks the
 direct/ring algorithm per size."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -21,6 +23,8 @@ class GradReducer:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self._handles = []
         self._avg = None
+        # MANTIS_DP_FORCE=1 exercises the collective path even on one rank (used to validate the RCCL calls on a 1-GPU box)
+        self._force = os.environ.get("MANTIS_DP_FORCE") == "1" and dist.is_initialized()
 
     def begin(self):
         self._buckets = self.model.grad_buckets()
@@ -37,7 +41,7 @@ class GradReducer:
         return [h], (stage, t)
 
     def bucket_ready(self, key):
-        if self.world == 1:
+        if self.world == 1 and not self._force:
             return
         b = self._buckets.get(key)
         if b is None:

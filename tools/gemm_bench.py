@@ -18,7 +18,7 @@ SHAPES = {  # name: (M, N, K)
 
 
 def main():
-    variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1, 2, 3, 4, 5]
+    variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1, 2, 12]
     names = sys.argv[2].split(",") if len(sys.argv) > 2 else list(SHAPES)
     res = {}
     for name in names:
