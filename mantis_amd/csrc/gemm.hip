@@ -41,6 +41,10 @@
 
 typedef __attribute__((address_space(3))) void lds_void;
 
+// cache policy of the operand-tile DMA: sc0 sc1 (bypass the per-CU vector L1, serve from L2).  A tile is consumed once per CU,
+// so L1 allocation only adds TCP pending-miss stalls (rocprofv3: TCP_PENDING_STALL_CYCLES 44 % of the kernel with default policy)
+#define DMA_AUX 0
+
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page[16];
 
 __device__ __forceinline__ float gemm_act(float x, int kind) {
@@ -56,15 +60,19 @@ __device__ __forceinline__ float gemm_act(float x, int kind) {
 }
 
 // One global_load_lds: 8 rows x 128 B of an operand tile (row block rb) -> LDS.
+// ROT: slot = (chunk + f(row)) mod 8 (a rotation keeps the 8 lanes of a row ascending apart from one wrap, which coalesces better
+// in the vector memory path: +3 % on the 128x128 kernel, measured); otherwise slot = chunk ^ f(row) (1-2 % better in the ring kernel).
+template <bool ROT = false>
 __device__ __forceinline__ void stage_piece(const bf16_t* __restrict__ G, long ld, int row0, int rows_total, int k0, int K,
                                             char* lds_tile, int rb, int lane) {
     const int rl = lane >> 3;
-    const int chunk = (lane & 7) ^ ((rb * 4 + (rl >> 1)) & 7);
+    const int f = (rb * 4 + (rl >> 1)) & 7;
+    const int chunk = ROT ? (((lane & 7) - f) & 7) : ((lane & 7) ^ f);
     const int k = k0 + chunk * 8;
     int grow = row0 + rb * 8 + rl;
     grow = grow < rows_total ? grow : rows_total - 1;
     const bf16_t* src = (k < K) ? (G + (long)grow * ld + k) : reinterpret_cast<const bf16_t*>(g_zero_page);
-    __builtin_amdgcn_global_load_lds(src, (lds_void*)(lds_tile + rb * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(src, (lds_void*)(lds_tile + rb * 1024), 16, 0, DMA_AUX);
 }
 
 template <int ROWS, int NW>
@@ -72,11 +80,11 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ G, long ld
                                            char* lds_tile, int wave, int lane) {
     constexpr int PER = ROWS / 8 / NW;
 #pragma unroll
-    for (int j = 0; j < PER; ++j) stage_piece(G, ld, row0, rows_total, k0, K, lds_tile, wave * PER + j, lane);
+    for (int j = 0; j < PER; ++j) stage_piece<true>(G, ld, row0, rows_total, k0, K, lds_tile, wave * PER + j, lane);
 }
 
-__device__ __forceinline__ bf16x8 read_frag(const char* tile, int row, int chunk) {
-    return *reinterpret_cast<const bf16x8*>(tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+__device__ __forceinline__ bf16x8 read_frag(const char* tile, int row, int chunk) {   // generic kernel: rotation swizzle
+    return *reinterpret_cast<const bf16x8*>(tile + row * 128 + (((chunk + ((row >> 1) & 7)) & 7) << 4));
 }
 
 // hand-placed LDS fragment read: the compiler neither counts it nor moves it (cdna guide 5.7 form iii)
@@ -108,7 +116,7 @@ __device__ __forceinline__ void stage_piece_km(const bf16_t* __restrict__ G, lon
     const int k = k0 + kk;
     const long col = (long)row0 + c * 8;
     const bf16_t* src = (k < K && col + 8 <= ld) ? (G + (long)k * ld + col) : reinterpret_cast<const bf16_t*>(g_zero_page);
-    __builtin_amdgcn_global_load_lds(src, (lds_void*)(lds_tile + piece * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(src, (lds_void*)(lds_tile + piece * 1024), 16, 0, DMA_AUX);
 }
 
 template <int ROWS, int NW>
