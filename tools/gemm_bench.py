@@ -48,8 +48,19 @@ def main():
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / it
             row[v] = round(2.0 * M * N * Kd / ms / 1e9, 1)
+        if os.environ.get("GEMM_BENCH_VENDOR") == "1":     # context only: the vendor library (hipBLASLt via torch) on the same operands
+            bt = b.t()
+            for _ in range(2):
+                torch.mm(a, bt)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(8):
+                torch.mm(a, bt)
+            e1.record()
+            torch.cuda.synchronize()
+            row["vendor"] = round(2.0 * M * N * Kd / (e0.elapsed_time(e1) / 8) / 1e9, 1)
         res[name] = row
-        print(f"{name:10s} {M}x{N}x{Kd}: " + "  ".join(f"v{v}={t:7.1f}TF" for v, t in row.items()), flush=True)
+        print(f"{name:10s} {M}x{N}x{Kd}: " + "  ".join(f"{('v' + str(v)) if not isinstance(v, str) else v}={t:7.1f}TF" for v, t in row.items()), flush=True)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(res, open(os.path.join(ROOT, "gpurun_out", "gemm_bench.json"), "w"), indent=1)
 
