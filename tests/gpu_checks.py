@@ -82,6 +82,17 @@ def check_transpose():
     return worst
 
 
+def check_gemm_kmajor(M, N, K_, a_km, b_km, variant=0):
+    """Native operand layouts: A given as [K, M] and/or B as [K, N] (what dW = dY^T X and dX = dY W consume as stored)."""
+    k = K()
+    a, b = rnd(M, K_, seed=11), rnd(N, K_, seed=12, scale=0.1)
+    ref = R.gemm_nt(a, b)
+    ad = a.t().contiguous().to(DEV) if a_km else a.to(DEV)
+    bd = b.t().contiguous().to(DEV) if b_km else b.to(DEV)
+    out = k.gemm_nt(ad, bd, a_kmajor=a_km, b_kmajor=b_km, variant=variant)
+    return close(out, ref, 1e-2, f"gemm k-major {M}x{N}x{K_} a_km={a_km} b_km={b_km} v={variant}")
+
+
 def check_linear_dx_dw():
     k = K()
     M, O, I = 333, 176, 64
@@ -398,6 +409,10 @@ def all_checks():
     for f in ("bias", "bias+gelu", "bias+tanh", "bias+quick", "res", "bias+res"):
         c[f"gemm_epi_{f}"] = (lambda f=f: check_gemm(300, 200, 72, f))
     c["gemm_accumulate_padded"] = check_gemm_accumulate_padded
+    for (M, N, K_, akm, bkm, v) in [(304, 200, 72, True, True, 1), (300, 200, 72, False, True, 1), (304, 200, 72, True, False, 1),
+                                    (1000, 520, 333 * 8, True, True, 12), (1000, 1152, 4304, False, True, 12),
+                                    (600, 520, 1000, True, False, 12), (520, 600, 54, True, True, 2), (640, 768, 512, False, True, 2)]:
+        c[f"gemm_kmajor_{M}x{N}x{K_}_{int(akm)}{int(bkm)}_v{v}"] = (lambda M=M, N=N, K_=K_, akm=akm, bkm=bkm, v=v: check_gemm_kmajor(M, N, K_, akm, bkm, v))
     c["linear_dx_dw"] = check_linear_dx_dw
     c["rmsnorm"] = check_rmsnorm
     c["rmsnorm_4096"] = lambda: check_rmsnorm(100, 4096)
