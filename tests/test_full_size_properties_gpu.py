@@ -1,0 +1,139 @@
+"""-m gpu: size-independent properties of the hot-path kernels at BASELINE.json's FULL sizes (cfg2: B=2, 4 images x 576
+patches, T=512 -> L=2812, d=4096, 32/8 heads x 128, V=128258), where the CPU oracle is too slow to run as a checker:
+
+  * packing: integer plan bit-exact vs the numpy oracle (fast enough at any size); round trip rows -> gather back
+  * GEMM: multiplying by the identity returns the operand bit-exactly (all layouts / tile kernels); linearity
+  * attention: V = const -> O = const; causality (perturbing future keys leaves earlier rows bit-identical)
+  * cross-entropy: uniform logits -> loss = ln V; every gradient row sums to ~0
+  * whole step (full width, 2 ViT + 2 LLM layers): bitwise reproducible; gradient accumulation doubles gradients
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def _k():
+    import mantis_amd.hip_ops as k
+    return k
+
+
+def _rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    return (torch.randn(*shape, generator=g, device=DEV) * scale).to(BF)
+
+
+def test_pack_full_size_plan_and_round_trip():
+    from oracle import ops_ref as R
+    k = _k()
+    B, T, N, d, V, IMG, PAD = 2, 512, 576, 4096, 128258, 128256, 128257
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(0, 128000, (B, T), generator=g)
+    for b in range(B):
+        ids[b, torch.randperm(T - 1, generator=g)[:4]] = IMG
+    ids[1, -3:] = PAD                                    # right padding on one row
+    am = (ids != PAD).long()
+    lab = torch.where(torch.rand(B, T, generator=g) < 0.5, ids, torch.full_like(ids, -100))
+    I = int((ids == IMG).sum())
+    L = int((ids == IMG).sum(-1).max()) * (N - 1) + T
+    assert L == 2812
+    pl = k.pack_plan(ids.to(DEV), am.to(DEV), lab.to(DEV), N, I, IMG, PAD, -100, L)
+    rp = R.pack_plan(ids, am, lab, N, I, IMG, PAD, -100, L)
+    assert pl.status.cpu().tolist()[0] == 0
+    for f in ("src", "attention_mask", "labels", "position_ids", "kmask", "text_pos", "img_slot", "ce_row", "ce_tgt"):
+        assert torch.equal(getattr(pl, f).cpu(), getattr(rp, f)), f
+    emb, feats = _rnd(V, d, seed=1), _rnd(I * N, d, seed=2)
+    merged = k.pack_rows_fwd(pl, ids.to(DEV), emb, feats)
+    # encode -> decode: every image-feature row and every text row comes back bit-exactly
+    assert torch.equal(k.gather_rows(merged, pl.img_slot), feats)
+    tp = pl.text_pos.reshape(-1)
+    flat = (torch.arange(B * T, device=DEV) // T) * L + tp.long()
+    ok = tp >= 0
+    assert torch.equal(merged[flat[ok]], emb[ids.to(DEV).reshape(-1)[ok]])
+    pad_rows = (pl.src.reshape(-1) == -1)
+    assert not merged[pad_rows].any()
+
+
+@pytest.mark.parametrize("M,N", [(5624, 4096), (5624, 6144), (1024, 4096)])
+def test_gemm_identity_is_exact_in_every_layout(M, N):
+    k = _k()
+    a = _rnd(M, N, seed=M)                               # K = N, B = identity
+    eye = torch.eye(N, device=DEV, dtype=BF)
+    for variant in (1, 2, 12):
+        assert torch.equal(k.gemm_nt(a, eye, variant=variant), a), f"NT variant {variant}"
+        assert torch.equal(k.gemm_nt(a, eye, b_kmajor=True, variant=variant), a), f"NN variant {variant}"
+    at = a.t().contiguous()                              # [K=N, M]: K-major A
+    for variant in (1, 12):
+        assert torch.equal(k.gemm_nt(at, eye, a_kmajor=True, b_kmajor=True, variant=variant), a), f"TN variant {variant}"
+
+
+def test_gemm_linearity_full_shape():
+    k = _k()
+    M, N, K = 5624, 4096, 4096
+    a, b1, b2 = _rnd(M, K, seed=1, scale=0.5), _rnd(N, K, seed=2, scale=0.05), _rnd(N, K, seed=3, scale=0.05)
+    lhs = k.gemm_nt(a, (b1.float() + b2.float()).to(BF)).float()
+    rhs = k.gemm_nt(a, b1).float() + k.gemm_nt(a, b2).float()
+    assert float((lhs - rhs).norm() / rhs.norm()) < 1e-2
+
+
+def test_attention_full_size_constant_values_and_causality():
+    k = _k()
+    B, L, H, Hkv, hd = 2, 2812, 32, 8, 128
+    qkv = _rnd(B * L, (H + 2 * Hkv) * hd, seed=5)
+    qkv[:, (H + Hkv) * hd:] = 0.75                       # V = const -> softmax-weighted mean of a constant is the constant
+    o, lse = k.attn_fwd(qkv, B, L, H, Hkv, hd, None, hd ** -0.5, True)
+    assert torch.isfinite(lse).all()
+    assert float((o.float() - 0.75).abs().max()) <= 2 ** -7
+    # causality: changing K/V of the last 1000 positions must not change any earlier output row, bit for bit
+    qkv2 = qkv.clone()
+    rows = torch.arange(B * L, device=DEV).reshape(B, L)[:, L - 1000:].reshape(-1)
+    qkv2[rows, H * hd:] = _rnd(rows.numel(), 2 * Hkv * hd, seed=6)
+    o2, _ = k.attn_fwd(qkv2, B, L, H, Hkv, hd, None, hd ** -0.5, True)
+    keep = torch.ones(B * L, dtype=torch.bool, device=DEV)
+    keep[rows] = False
+    assert torch.equal(o[keep], o2[keep])
+
+
+def test_cross_entropy_full_vocab_properties():
+    k = _k()
+    R_, V = 64, 128258
+    Vp = k.pad8(V)
+    logits = torch.zeros(R_, Vp, device=DEV, dtype=BF)   # uniform logits
+    tgt = torch.randint(0, V, (R_,), device=DEV, dtype=torch.int32)
+    tgt[::7] = -100
+    loss, cnt = k.ce_fwd_bwd(logits, tgt, V, 1.0, 1.0)
+    assert int(cnt) == int((tgt >= 0).sum())
+    assert abs(float(loss) - math.log(V)) < 1e-3
+    g = logits.float()[:, :V]
+    assert float(g.sum(-1).abs().max()) < 2e-2 / int(cnt)              # rows of (softmax - onehot) sum to zero (bf16 rounding)
+    assert not logits[:, V:].any() and not logits[tgt < 0].any()
+
+
+def test_step_full_width_is_reproducible_and_accumulates():
+    """Full-width Mantis-8B layers (d=4096, 32/8 heads, MLP 14336, V=128258, SigLIP-so400m width) at reduced depth."""
+    from mantis_amd import configuration_llava as C
+    from mantis_amd.modeling_llava import LlavaForConditionalGeneration
+    from mantis_amd.trainer import MantisHipTrainer
+    import bench
+    cfg = C.mantis_8b_siglip_llama3()
+    cfg.vision_config.num_hidden_layers = 3
+    cfg.text_config.num_hidden_layers = 2
+    model = LlavaForConditionalGeneration(cfg, device=DEV, seed=0)
+    batch = bench.synthetic_batch(cfg, 2, 512, 4, 336, 0)
+    tr = MantisHipTrainer(model, gradient_accumulation_steps=1)
+    l1 = tr.training_step(model, batch)
+    g1 = model.grad_arena.clone()
+    for p in model.parameters():
+        p.grad = None
+    l2 = tr.training_step(model, batch)
+    assert torch.equal(l1, l2) and torch.equal(g1, model.grad_arena), "the step is not bitwise reproducible"
+    assert math.isfinite(float(l1)) and 10.0 < float(l1) < 13.5        # ~ln(128258) = 11.76 at random init
+    l3 = tr.training_step(model, batch)                                 # accumulate a second identical micro-batch
+    assert torch.equal(l3, l1)
+    num = (model.grad_arena.float() - 2 * g1.float()).norm()
+    assert float(num / (2 * g1.float()).norm()) < 5e-3
