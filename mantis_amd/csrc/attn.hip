@@ -72,13 +72,46 @@ struct TileRegs {
     }
 };
 
+// LDS tile layouts.  hd == 128: rows are exactly one 256-B bank row, tiles are filled by global_load_lds (fully asynchronous, no
+// staging registers) and 16-B chunk c of row r sits at slot c ^ ((r & 7) << 1): the four consecutive rows of a transposing read
+// hit four different 32-B bank segments and the 16 rows of a ds_read_b128 group are at most 2-way conflicted.
+// Other head sizes: padded rows (pitch = row bytes + 16), staged through registers.
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+template <int HD>
+struct Lay {
+    static constexpr bool DMA = (HD == 128);
+    static constexpr int PITCH = DMA ? 256 : AttnCfg<HD>::PITCH;
+    __device__ static __forceinline__ int chunk_off(int row, int chunk) {
+        return row * PITCH + (DMA ? ((chunk ^ ((row & 7) << 1)) << 4) : (chunk << 4));
+    }
+};
+
+// ROWS x 128 bf16 tile, 256 threads: each wave issues ROWS/16 global_load_lds of 1 KiB (4 rows); rows >= rows_valid are clamped
+// (their scores are masked / their outputs never stored).
+template <int ROWS>
+__device__ __forceinline__ void stage_tile_dma(const bf16_t* __restrict__ g, long gstride, int rows_valid, char* lds) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int PER = ROWS / 16;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int piece = wave * PER + j;
+        int row = piece * 4 + (lane >> 4);
+        const int c = (lane & 15) ^ ((row & 7) << 1);
+        row = row < rows_valid ? row : rows_valid - 1;
+        __builtin_amdgcn_global_load_lds(g + (long)row * gstride + c * 8, (lds_void_t*)(lds + piece * 1024), 16, 0, 0);
+    }
+}
+
 // A-operand fragment with the contraction index running over ROWS of a row-major LDS tile: lane (i = col0 + (lane & 31), h)
 // receives rows {row0 + 4h + 0..3, row0 + 8 + 4h + 0..3} of column i -- two hardware-transposing reads.
-__device__ __forceinline__ bf16x8 read_tr_frag(const char* tile, int pitch, int row0, int col0, int lane) {
+template <int HD>
+__device__ __forceinline__ bf16x8 read_tr_frag(const char* tile, int row0, int col0, int lane) {
     const int s = lane & 15, g16 = (lane >> 4) & 1, h = lane >> 5;
-    const char* p = tile + (row0 + 4 * h + (s >> 2)) * pitch + (col0 + 16 * g16 + (s & 3) * 4) * 2;
+    const int row = row0 + 4 * h + (s >> 2), col = col0 + 16 * g16 + (s & 3) * 4;
+    const char* p = tile + Lay<HD>::chunk_off(row, col >> 3) + (col & 7) * 2;
     const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
-    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 8 * pitch));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 8 * Lay<HD>::PITCH));   // (row + 8) & 7 == row & 7
     union { s16x4 s2[2]; bf16x8 f; } u;
     u.s2[0] = a;
     u.s2[1] = b;
@@ -100,7 +133,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
                                                        bf16_t* __restrict__ O, float* __restrict__ LSE, int L, int H, int Hkv,
                                                        long ldq, long ldk, long ldv, long ldo, float scale) {
     using C = AttnCfg<HD>;
-    constexpr int TILE = 64 * C::PITCH;
+    using Y = Lay<HD>;
+    constexpr int TILE = 64 * Y::PITCH;
     constexpr int BUF = 2 * TILE + 64 * 4;
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
 
@@ -136,15 +170,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     auto stage = [&](int t) {
         const int key0 = t * 64;
         char* base = smem + (t & 1) * BUF;
-        {
-            TileRegs<64, C::NCH> rk;
-            rk.load(Kb + (long)key0 * ldk, ldk, L - key0, HD);
-            rk.store(base, C::PITCH);
-        }
-        {
-            TileRegs<64, C::NCH> rv;
-            rv.load(Vb + (long)key0 * ldv, ldv, L - key0, HD);
-            rv.store(base + TILE, C::PITCH);
+        if constexpr (Y::DMA) {
+            stage_tile_dma<64>(Kb + (long)key0 * ldk, ldk, L - key0, base);
+            stage_tile_dma<64>(Vb + (long)key0 * ldv, ldv, L - key0, base + TILE);
+        } else {
+            {
+                TileRegs<64, C::NCH> rk;
+                rk.load(Kb + (long)key0 * ldk, ldk, L - key0, HD);
+                rk.store(base, C::PITCH);
+            }
+            {
+                TileRegs<64, C::NCH> rv;
+                rv.load(Vb + (long)key0 * ldv, ldv, L - key0, HD);
+                rv.store(base + TILE, C::PITCH);
+            }
         }
         if (threadIdx.x < 64) {
             const int key = key0 + threadIdx.x;
@@ -153,6 +192,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
         }
     };
     stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
@@ -170,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
                 for (int e = 0; e < 16; ++e) s[sb][e] = 0.f;
 #pragma unroll
                 for (int ks = 0; ks < C::NKS; ++ks) {
-                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (sb * 32 + lq) * C::PITCH + (ks * 2 + hh) * 16);
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + Y::chunk_off(sb * 32 + lq, ks * 2 + hh));
                     s[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[sb], 0, 0, 0);
                 }
             }
@@ -188,13 +228,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run, mx);
             const float msafe = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = (m_new == -INFINITY) ? 1.f : exp2f(m_run - m_new);
+            const float alpha = (m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m_run - m_new);
             float psum = 0.f;
 #pragma unroll
             for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float p = exp2f(s[sb][r] - msafe);
+                    const float p = __builtin_amdgcn_exp2f(s[sb][r] - msafe);
                     s[sb][r] = p;
                     psum += p;
                 }
@@ -211,11 +251,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
                     const bf16x8 pf = pack_frag(s[sb], cp);
 #pragma unroll
                     for (int d = 0; d < C::NDB; ++d) {
-                        const bf16x8 vf = read_tr_frag(sV, C::PITCH, sb * 32 + 16 * cp, d * 32, lane);
+                        const bf16x8 vf = read_tr_frag<HD>(sV, sb * 32 + 16 * cp, d * 32, lane);
                         oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[d], 0, 0, 0);
                     }
                 }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile's DMA landed (this wave's pieces)
         __syncthreads();
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -270,7 +311,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
                                                           const float* __restrict__ Dsum, bf16_t* __restrict__ dQ, int L, int H,
                                                           int Hkv, long ldq, long ldk, long ldv, long ldo, long lddq, float scale) {
     using C = AttnCfg<HD>;
-    constexpr int TILE = 64 * C::PITCH;
+    using Y = Lay<HD>;
+    constexpr int TILE = 64 * Y::PITCH;
     constexpr int BUF = 2 * TILE + 64 * 4;
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
 
@@ -311,15 +353,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     auto stage = [&](int t) {
         const int key0 = t * 64;
         char* base = smem + (t & 1) * BUF;
-        {
-            TileRegs<64, C::NCH> rk;
-            rk.load(Kb + (long)key0 * ldk, ldk, L - key0, HD);
-            rk.store(base, C::PITCH);
-        }
-        {
-            TileRegs<64, C::NCH> rv;
-            rv.load(Vb + (long)key0 * ldv, ldv, L - key0, HD);
-            rv.store(base + TILE, C::PITCH);
+        if constexpr (Y::DMA) {
+            stage_tile_dma<64>(Kb + (long)key0 * ldk, ldk, L - key0, base);
+            stage_tile_dma<64>(Vb + (long)key0 * ldv, ldv, L - key0, base + TILE);
+        } else {
+            {
+                TileRegs<64, C::NCH> rk;
+                rk.load(Kb + (long)key0 * ldk, ldk, L - key0, HD);
+                rk.store(base, C::PITCH);
+            }
+            {
+                TileRegs<64, C::NCH> rv;
+                rv.load(Vb + (long)key0 * ldv, ldv, L - key0, HD);
+                rv.store(base + TILE, C::PITCH);
+            }
         }
         if (threadIdx.x < 64) {
             const int key = key0 + threadIdx.x;
@@ -328,6 +375,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
         }
     };
     stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
@@ -345,7 +393,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
                 for (int e = 0; e < 16; ++e) { s[sb][e] = 0.f; dp[sb][e] = 0.f; }
 #pragma unroll
                 for (int ks = 0; ks < C::NKS; ++ks) {
-                    const int off = (sb * 32 + lq) * C::PITCH + (ks * 2 + hh) * 16;
+                    const int off = Y::chunk_off(sb * 32 + lq, ks * 2 + hh);
                     const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + off);
                     const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sV + off);
                     s[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[sb], 0, 0, 0);
@@ -359,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
                     const int kl = sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
                     float v = s[sb][r] * c + sBias[kl];
                     if (CAUSAL && key0 + kl > q) v = -INFINITY;
-                    const float p = exp2f(v - lse2);  // lse = +inf for fully masked rows -> p = 0
+                    const float p = __builtin_amdgcn_exp2f(v - lse2);  // lse = +inf for fully masked rows -> p = 0
                     s[sb][r] = p * (dp[sb][r] - dsum) * scale;
                 }
 #pragma unroll
@@ -369,11 +417,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
                     const bf16x8 dsf = pack_frag(s[sb], cp);
 #pragma unroll
                     for (int d = 0; d < C::NDB; ++d) {
-                        const bf16x8 ktf = read_tr_frag(sK, C::PITCH, sb * 32 + 16 * cp, d * 32, lane);
+                        const bf16x8 ktf = read_tr_frag<HD>(sK, sb * 32 + 16 * cp, d * 32, lane);
                         acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf, acc[d], 0, 0, 0);
                     }
                 }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
     if (q < L) {
@@ -418,7 +467,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     using C = AttnCfg<HD>;
     using D = DkvCfg<HD>;
     constexpr int QT = 64;                          // query rows staged per barrier (processed as two 32-row passes)
-    constexpr int TILE = QT * C::PITCH;
+    using Y = Lay<HD>;
+    constexpr int TILE = QT * Y::PITCH;
     constexpr int BUF = 2 * TILE + 2 * QT * 4;
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
 
@@ -456,15 +506,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     auto stage = [&](int qt) {
         const int q0 = qt * QT;
         char* base = smem + ((qt - qstart) & 1) * BUF;
-        {
-            TileRegs<QT, C::NCH> rq;
-            rq.load(Qb + (long)q0 * ldq, ldq, L - q0, HD);
-            rq.store(base, C::PITCH);
-        }
-        {
-            TileRegs<QT, C::NCH> rdo;
-            rdo.load(dOb + (long)q0 * ldo, ldo, L - q0, HD);
-            rdo.store(base + TILE, C::PITCH);
+        if constexpr (Y::DMA) {
+            stage_tile_dma<QT>(Qb + (long)q0 * ldq, ldq, L - q0, base);
+            stage_tile_dma<QT>(dOb + (long)q0 * ldo, ldo, L - q0, base + TILE);
+        } else {
+            {
+                TileRegs<QT, C::NCH> rq;
+                rq.load(Qb + (long)q0 * ldq, ldq, L - q0, HD);
+                rq.store(base, C::PITCH);
+            }
+            {
+                TileRegs<QT, C::NCH> rdo;
+                rdo.load(dOb + (long)q0 * ldo, ldo, L - q0, HD);
+                rdo.store(base + TILE, C::PITCH);
+            }
         }
         if (threadIdx.x < QT) {
             const int qq = q0 + threadIdx.x;
@@ -473,6 +528,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
         }
     };
     if (qstart < nqt) stage(qstart);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     for (int qt = qstart; qt < nqt; ++qt) {
@@ -481,7 +537,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
 #pragma unroll 1
         for (int pass = 0; pass < QT / 32; ++pass) {
         const int q0 = qt * QT + pass * 32;
-        const char* sQ = tQ + pass * 32 * C::PITCH;
+        const char* sQ = tQ + pass * 32 * Y::PITCH;
         const char* sdO = sQ + TILE;
         const float* sLse = reinterpret_cast<const float*>(tQ + 2 * TILE) + pass * 32;
         const float* sDs = sLse + QT;
@@ -491,7 +547,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
             for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < C::NKS; ++ks) {
-                const int off = lk * C::PITCH + (ks * 2 + hh) * 16;
+                const int off = Y::chunk_off(lk, ks * 2 + hh);
                 const bf16x8 qa = *reinterpret_cast<const bf16x8*>(sQ + off);
                 const bf16x8 da = *reinterpret_cast<const bf16x8*>(sdO + off);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);
@@ -503,7 +559,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
                 const int ql = (r & 3) + 8 * (r >> 2) + 4 * hh;
                 float v = key_ok ? s[r] * c : -INFINITY;
                 if (CAUSAL && key > q0 + ql) v = -INFINITY;
-                const float p = exp2f(v - sLse[ql]);
+                const float p = __builtin_amdgcn_exp2f(v - sLse[ql]);
                 s[r] = p;
                 ds[r] = p * (dp[r] - sDs[ql]) * scale;
             }
@@ -514,14 +570,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
 #pragma unroll
                 for (int d = 0; d < D::NDW; ++d) {
                     const int dcol = (dh * D::NDW + d) * 32;
-                    const bf16x8 dot = read_tr_frag(sdO, C::PITCH, 16 * cp, dcol, lane);
-                    const bf16x8 qtf = read_tr_frag(sQ, C::PITCH, 16 * cp, dcol, lane);
+                    const bf16x8 dot = read_tr_frag<HD>(sdO, 16 * cp, dcol, lane);
+                    const bf16x8 qtf = read_tr_frag<HD>(sQ, 16 * cp, dcol, lane);
                     dvacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot, pf, dvacc[d], 0, 0, 0);
                     dkacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsf, dkacc[d], 0, 0, 0);
                 }
             }
         }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
     if (key < L) {

@@ -19,15 +19,19 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 __device__ __forceinline__ float bf2f(bf16_t x) { return __uint_as_float(((unsigned int)x) << 16); }
 __device__ __forceinline__ float bf2f_lo(unsigned int w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf2f_hi(unsigned int w) { return __uint_as_float(w & 0xffff0000u); }
-// round-to-nearest-even, NaN preserved (same rounding torch uses for float->bfloat16)
+// fp32 -> bf16, round-to-nearest-even (same rounding torch uses): the native __bf16 conversions lower to the hardware
+// v_cvt_pk_bf16_f32 on gfx950 (one instruction per PAIR, no branches) instead of ~6 integer VALU ops + a NaN branch per element.
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ bf16_t f2bf(float f) {
-    unsigned int u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x0040u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+    union { __bf16 b; bf16_t u; } c;
+    c.b = (__bf16)f;
+    return c.u;
 }
 __device__ __forceinline__ unsigned int pack_bf2(float lo, float hi) {
-    return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
+    union { bf16x2_t b; unsigned int u; } c;
+    c.b = __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t);
+    return c.u;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
