@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     using C = AttnCfg<HD>;
     using Y = Lay<HD>;
     constexpr int TILE = 64 * Y::PITCH;
-    constexpr int BUF = 2 * TILE + 64 * 4;
+    constexpr int BUF = 2 * TILE + 64 * 4 + 16;
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hh = lane >> 5, lq = lane & 31;
@@ -185,10 +185,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
                 rv.store(base + TILE, C::PITCH);
             }
         }
-        if (threadIdx.x < 64) {
+        if (threadIdx.x < 64) {     // wave 0: additive key bias (0 / -inf) + one flag "this tile has a masked key"
             const int key = key0 + threadIdx.x;
-            reinterpret_cast<float*>(base + 2 * TILE)[threadIdx.x] =
-                (key < L && (kmask == nullptr || kmask[(long)b * L + key] != 0)) ? 0.f : -INFINITY;
+            const bool ok = key < L && (kmask == nullptr || kmask[(long)b * L + key] != 0);
+            float* bp = reinterpret_cast<float*>(base + 2 * TILE);
+            bp[threadIdx.x] = ok ? 0.f : -INFINITY;
+            const unsigned long long okm = __ballot(ok);
+            if (threadIdx.x == 0) bp[64] = (okm == ~0ull) ? 0.f : 1.f;
         }
     };
     stage(0);
@@ -215,16 +218,29 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
                 }
             }
             float mx = -INFINITY;
+            // wave-uniform: only tiles that touch the diagonal or contain masked keys pay for per-element masking
+            const bool need_mask = (CAUSAL && key0 + 63 > q0) || sBias[64] != 0.f;
+            if (need_mask) {
 #pragma unroll
-            for (int sb = 0; sb < 2; ++sb)
+                for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int kl = sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    float v = s[sb][r] * c + sBias[kl];
-                    if (CAUSAL && key0 + kl > q) v = -INFINITY;
-                    s[sb][r] = v;
-                    mx = fmaxf(mx, v);
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        const int kl = sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                        float v = s[sb][r] * c + sBias[kl];
+                        if (CAUSAL && key0 + kl > q) v = -INFINITY;
+                        s[sb][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+            } else {
+#pragma unroll
+                for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = s[sb][r] * c;
+                        s[sb][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+            }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run, mx);
             const float msafe = (m_new == -INFINITY) ? 0.f : m_new;
@@ -240,10 +256,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
                 }
             l_run = l_run * alpha + psum;
             m_run = m_new;
+            if (__any(alpha != 1.f)) {     // wave-uniform: once the running maxima have settled nothing needs rescaling
 #pragma unroll
-            for (int d = 0; d < C::NDB; ++d)
+                for (int d = 0; d < C::NDB; ++d)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+                    for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
+            }
 #pragma unroll
             for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
@@ -313,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     using C = AttnCfg<HD>;
     using Y = Lay<HD>;
     constexpr int TILE = 64 * Y::PITCH;
-    constexpr int BUF = 2 * TILE + 64 * 4;
+    constexpr int BUF = 2 * TILE + 64 * 4 + 16;
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hh = lane >> 5, lq = lane & 31;
@@ -368,10 +386,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
                 rv.store(base + TILE, C::PITCH);
             }
         }
-        if (threadIdx.x < 64) {
+        if (threadIdx.x < 64) {     // wave 0: additive key bias (0 / -inf) + one flag "this tile has a masked key"
             const int key = key0 + threadIdx.x;
-            reinterpret_cast<float*>(base + 2 * TILE)[threadIdx.x] =
-                (key < L && (kmask == nullptr || kmask[(long)b * L + key] != 0)) ? 0.f : -INFINITY;
+            const bool ok = key < L && (kmask == nullptr || kmask[(long)b * L + key] != 0);
+            float* bp = reinterpret_cast<float*>(base + 2 * TILE);
+            bp[threadIdx.x] = ok ? 0.f : -INFINITY;
+            const unsigned long long okm = __ballot(ok);
+            if (threadIdx.x == 0) bp[64] = (okm == ~0ull) ? 0.f : 1.f;
         }
     };
     stage(0);
@@ -386,41 +407,47 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
         const bool more = t + 1 < ntiles;
         if (more) stage(t + 1);
         if (!(CAUSAL && key0 > q0 + 31)) {
-            f32x16 s[2], dp[2];
+            const bool need_mask = (CAUSAL && key0 + 63 > q0) || sBias[64] != 0.f;   // wave-uniform
+            // one 32-key half at a time: S, dP -> dS -> dQ contribution, so only 32 score registers are live (2 waves per SIMD)
 #pragma unroll
             for (int sb = 0; sb < 2; ++sb) {
+                f32x16 s, dp;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) { s[sb][e] = 0.f; dp[sb][e] = 0.f; }
+                for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
 #pragma unroll
                 for (int ks = 0; ks < C::NKS; ++ks) {
                     const int off = Y::chunk_off(sb * 32 + lq, ks * 2 + hh);
                     const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + off);
                     const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sV + off);
-                    s[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[sb], 0, 0, 0);
-                    dp[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp[sb], 0, 0, 0);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dp, 0, 0, 0);
                 }
-            }
+                if (need_mask) {
 #pragma unroll
-            for (int sb = 0; sb < 2; ++sb)
+                    for (int r = 0; r < 16; ++r) {
+                        const int kl = sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                        float v = s[r] * c + sBias[kl];
+                        if (CAUSAL && key0 + kl > q) v = -INFINITY;
+                        const float p = __builtin_amdgcn_exp2f(v - lse2);  // lse = +inf for fully masked rows -> p = 0
+                        s[r] = p * (dp[r] - dsum) * scale;
+                    }
+                } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int kl = sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    float v = s[sb][r] * c + sBias[kl];
-                    if (CAUSAL && key0 + kl > q) v = -INFINITY;
-                    const float p = __builtin_amdgcn_exp2f(v - lse2);  // lse = +inf for fully masked rows -> p = 0
-                    s[sb][r] = p * (dp[sb][r] - dsum) * scale;
+                    for (int r = 0; r < 16; ++r) {
+                        const float p = __builtin_amdgcn_exp2f(s[r] * c - lse2);
+                        s[r] = p * (dp[r] - dsum) * scale;
+                    }
                 }
-#pragma unroll
-            for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
                 for (int cp = 0; cp < 2; ++cp) {
-                    const bf16x8 dsf = pack_frag(s[sb], cp);
+                    const bf16x8 dsf = pack_frag(s, cp);
 #pragma unroll
                     for (int d = 0; d < C::NDB; ++d) {
                         const bf16x8 ktf = read_tr_frag<HD>(sK, sb * 32 + 16 * cp, d * 32, lane);
                         acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf, acc[d], 0, 0, 0);
                     }
                 }
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -554,14 +581,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp, 0, 0, 0);
             }
             f32x16 ds;
+            const bool need_mask = (CAUSAL && k0 + 31 > q0) || !__all(key_ok);   // wave-uniform
+            if (need_mask) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ql = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                float v = key_ok ? s[r] * c : -INFINITY;
-                if (CAUSAL && key > q0 + ql) v = -INFINITY;
-                const float p = __builtin_amdgcn_exp2f(v - sLse[ql]);
-                s[r] = p;
-                ds[r] = p * (dp[r] - sDs[ql]) * scale;
+                for (int r = 0; r < 16; ++r) {
+                    const int ql = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    float v = key_ok ? s[r] * c : -INFINITY;
+                    if (CAUSAL && key > q0 + ql) v = -INFINITY;
+                    const float p = __builtin_amdgcn_exp2f(v - sLse[ql]);
+                    s[r] = p;
+                    ds[r] = p * (dp[r] - sDs[ql]) * scale;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ql = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    const float p = __builtin_amdgcn_exp2f(s[r] * c - sLse[ql]);
+                    s[r] = p;
+                    ds[r] = p * (dp[r] - sDs[ql]) * scale;
+                }
             }
 #pragma unroll
             for (int cp = 0; cp < 2; ++cp) {
