@@ -82,6 +82,8 @@ int mantis_transpose(const void* in, void* out, int R, int C, int Rpad, int64_t 
  *        dX = dY.W uses B K-major (the weight as stored), dW = dY^T.X uses both K-major -- no transposed copies. */
 int mantis_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
                         const void* bias, const void* residual, int64_t ldr, int flags, void* stream);
+/* tile variant the auto heuristic (flags bits 8-11 == 0) picks: 12 = 256x256 ring kernel, 1 = 128x128 generic kernel */
+int mantis_gemm_pick_variant(int M, int N, int K);
 
 /* ---- attention: HF:models/llama/modeling_llama.py:191-214,262-276; HF:models/siglip/modeling_siglip.py:227-247 */
 int mantis_attn_fwd(const void* Q, const void* K, const void* V, const int32_t* kmask, void* O, float* LSE, int B, int L, int H,

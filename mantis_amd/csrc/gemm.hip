@@ -208,6 +208,89 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TN][TM], bf16_t* __r
     }
 }
 
+// Epilogue of the 256x256 kernel: the MFMA layout gives every lane ONE output row, so storing from registers touches 32 rows x
+// 16 B per instruction (measured: 17 us of a 146 us K = 4096 tile, 34 us with a residual).  Instead every wave transposes its
+// 128 x 64 tile through a wave-private LDS strip, 64 rows x 64 fp32 per pass (row pitch 272 B: conflict-free ds_write_b128),
+// and reads it back as 8 lanes per row x 8 columns per lane: bias / activation / residual / accumulate run on 16-B vectors and
+// every global instruction covers 8 whole 128-B lines.  Arithmetic and rounding order are those of gemm_epilogue (bit-identical).
+#define EPI_PITCH 272
+#define EPI_STRIP (64 * EPI_PITCH)
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_lds(f32x16 (&acc)[TN][TM], char* __restrict__ strip, bf16_t* __restrict__ C, int M,
+                                                  int N, long ldc, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
+                                                  long ldr, int flags, int mw0, int nw0, int lane) {
+    static_assert(TN == 2 && (TM % 2) == 0, "strip is 64 columns wide, two 32-row blocks per pass");
+    const int act = (flags & EPI_ACT_MASK) >> EPI_ACT_SHIFT;
+    const bool vec_ok = !(ldc & 7) && !((uintptr_t)C & 15) && (!(flags & EPI_RESIDUAL) || (!(ldr & 7) && !((uintptr_t)res & 15)));
+    const int rr = lane >> 3, cc = lane & 7;
+    const int n = nw0 + cc * 8;
+#pragma unroll
+    for (int pass = 0; pass < TM / 2; ++pass) {
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 v = {acc[tn][pass * 2 + t2][4 * g4], acc[tn][pass * 2 + t2][4 * g4 + 1], acc[tn][pass * 2 + t2][4 * g4 + 2],
+                                     acc[tn][pass * 2 + t2][4 * g4 + 3]};
+                    *reinterpret_cast<f32x4*>(strip + (t2 * 32 + (lane & 31)) * EPI_PITCH + (tn * 32 + 8 * g4 + 4 * (lane >> 5)) * 4) = v;
+                }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 8 + rr;
+            const int m = mw0 + pass * 64 + row;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(strip + row * EPI_PITCH + cc * 32);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(strip + row * EPI_PITCH + cc * 32 + 16);
+            if (m >= M || n >= N) continue;
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            const bool full = vec_ok && (n + 8 <= N);
+            if (flags & EPI_BIAS) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (n + e < N) v[e] += bf2f(bias[n + e]);
+            }
+            if (act) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gemm_act(bf2f(f2bf(v[e])), act);
+            }
+            bf16_t* cp = C + (long)m * ldc + n;
+            if (full) {
+                if (flags & EPI_RESIDUAL) {
+                    const u32x4 rv = *reinterpret_cast<const u32x4*>(res + (long)m * ldr + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[2 * e] = bf2f(f2bf(v[2 * e])) + bf2f_lo(rv[e]);
+                        v[2 * e + 1] = bf2f(f2bf(v[2 * e + 1])) + bf2f_hi(rv[e]);
+                    }
+                }
+                if (flags & EPI_ACCUM) {
+                    const u32x4 cv = *reinterpret_cast<const u32x4*>(cp);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[2 * e] += bf2f_lo(cv[e]);
+                        v[2 * e + 1] += bf2f_hi(cv[e]);
+                    }
+                }
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+                *reinterpret_cast<u32x4*>(cp) = o;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (n + e < N) {
+                        float x = v[e];
+                        if (flags & EPI_RESIDUAL) x = bf2f(f2bf(x)) + bf2f(res[(long)m * ldr + n + e]);
+                        if (flags & EPI_ACCUM) x += bf2f(cp[e]);
+                        cp[e] = f2bf(x);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // Generic kernel (compiler-scheduled inner loop): 128x128 tiles for small / badly quantised shapes, any operand layout.
 template <int BM, int BN, int WM, int WN, bool AKM = false, bool BKM = false>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_nt_kernel(
@@ -327,20 +410,72 @@ __device__ __forceinline__ void read_frags_km(bf16x8 (&dst)[N_], unsigned slab, 
 // four freed slots are refilled with parts 2,3 of step t+1 and parts 0,1 of step t+2, so 64-96 KiB of global_load_lds are
 // always in flight per CU and the loads get 1-2 K-steps of lead; the only vector-memory wait is a COUNTED
 // s_waitcnt vmcnt(4) (this wave's newest two slabs may still be in flight) -- the queue is never drained in the loop.
+//
+// Work split: one workgroup per tile in XCD-grouped order, dispatched in rounds of #CU.  The tiles of an incomplete last round
+// (M = 5624 x N = 4096 is 352 tiles = 1.375 rounds, 69 % efficient as whole tiles) are split S ways along K, S = #CU / #remainder
+// tiles, so that round lasts 1/S of a tile time (split-K confined to the remainder; a full stream-K schedule was measured
+// slower: its skewed K phases stop the workgroups of an XCD from sharing A/B panels in L2).  The S workgroups of a split tile
+// write fp32 partials to slabs, publish (agent-scope release) and take a ticket; the last arriver acquires and sums the slabs in
+// part order -- the result does not depend on who is last (bitwise reproducible), nobody waits (no co-residency assumption),
+// and the counter is left at zero for the next launch.
+#define SK_SLAB_FLOATS (256 * 256)
+
+template <int TM, int TN>
+__device__ __forceinline__ void sk_store(const f32x16 (&acc)[TN][TM], float* __restrict__ slab, int tid) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                f32x4 v = {acc[tn][tm][4 * g4], acc[tn][tm][4 * g4 + 1], acc[tn][tm][4 * g4 + 2], acc[tn][tm][4 * g4 + 3]};
+                reinterpret_cast<f32x4*>(slab)[((tn * TM + tm) * 4 + g4) * 512 + tid] = v;
+            }
+}
+template <int TM, int TN>
+__device__ __forceinline__ void sk_add(f32x16 (&acc)[TN][TM], const float* __restrict__ slab, int tid) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 v = reinterpret_cast<const f32x4*>(slab)[((tn * TM + tm) * 4 + g4) * 512 + tid];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[tn][tm][4 * g4 + e] += v[e];
+            }
+}
+
 template <bool AKM, bool BKM>
 __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C, int M, int N, int K, long lda, long ldb,
-    long ldc, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res, long ldr, int flags, int tiles_m, int tiles_n) {
+    long ldc, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res, long ldr, int flags, int tiles_m, int tiles_n,
+    int full, int S, float* __restrict__ sk_slabs, unsigned int* __restrict__ sk_cnt) {
     constexpr int TM = 4, TN = 2, SLAB = 16384, PPW = 2;   // 8 waves: 2 (M) x 4 (N), each 128 x 64
     __shared__ __attribute__((aligned(16))) char smem[10 * SLAB];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
 
-    const int nwg = tiles_m * tiles_n;
+    // workgroup -> unit: the workgroups of one XCD (blockIdx % 8) take a contiguous range of tile ids, so the tiles resident on
+    // an XCD share A/B panels in its private L2; units [0, full) are whole tiles, the rest are (remainder tile, K part) pairs
+    // with all tiles of one K part adjacent
+    const int nk = (K + BK - 1) / BK;
     const int bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    const int tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    int tile_id, part = 0;
+    if (bid < full) {
+        const int q = full >> 3, r = full & 7, xcd = bid & 7;
+        tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    } else {
+        const int j = bid - full, nu = gridDim.x - full, rem = nu / S;
+        const int q = nu >> 3, r = nu & 7, xcd = j & 7;
+        const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (j >> 3);
+        part = lin / rem;
+        tile_id = full + lin - part * rem;
+    }
+    const int t0 = (bid < full) ? 0 : (int)((long)nk * part / S);
+    const int t1 = (bid < full) ? nk : (int)((long)nk * (part + 1) / S);
+    // tile id -> (m0, n0): groups of 8 tile rows, column-major inside a group
     const int GROUP = 8;
     const int per_group = GROUP * tiles_n;
     const int g = tile_id / per_group;
@@ -348,6 +483,7 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(
     const int gsz = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
     const int in_g = tile_id - g * per_group;
     const int m0 = (first_m + in_g % gsz) * 256, n0 = (in_g / gsz) * 256;
+    const int Kseg = (t1 * BK < K) ? t1 * BK : K;     // K-steps past this unit's range read the zero page
 
     f32x16 acc[TN][TM];
 #pragma unroll
@@ -357,25 +493,23 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // slab (t, p): two global_load_lds per wave (pieces 2w, 2w+1 of the 16 eight-row pieces); K-steps past the end read zeros
+    // slab (t, p): two global_load_lds per wave (pieces 2w, 2w+1 of the 16 eight-row pieces)
     auto issue = [&](int t, int p) {
         char* dst = smem + ((4 * t + p) % 10) * SLAB;
         const int half = p >> 1;
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
             if (p & 1) {
-                if constexpr (BKM) stage_piece_km<128>(B, ldb, n0 + half * 128, t * BK, K, dst, PPW * wave + j, lane);
-                else stage_piece(B, ldb, n0 + half * 128, N, t * BK, K, dst, PPW * wave + j, lane);
+                if constexpr (BKM) stage_piece_km<128>(B, ldb, n0 + half * 128, t * BK, Kseg, dst, PPW * wave + j, lane);
+                else stage_piece(B, ldb, n0 + half * 128, N, t * BK, Kseg, dst, PPW * wave + j, lane);
             } else {
-                if constexpr (AKM) stage_piece_km<128>(A, lda, m0 + half * 128, t * BK, K, dst, PPW * wave + j, lane);
-                else stage_piece(A, lda, m0 + half * 128, M, t * BK, K, dst, PPW * wave + j, lane);
+                if constexpr (AKM) stage_piece_km<128>(A, lda, m0 + half * 128, t * BK, Kseg, dst, PPW * wave + j, lane);
+                else stage_piece(A, lda, m0 + half * 128, M, t * BK, Kseg, dst, PPW * wave + j, lane);
             }
         }
     };
-
-    const int nk = (K + BK - 1) / BK;
-    issue(0, 0); issue(0, 1); issue(0, 2); issue(0, 3);
-    issue(1, 0); issue(1, 1);
+    issue(t0, 0); issue(t0, 1); issue(t0, 2); issue(t0, 3);
+    issue(t0 + 1, 0); issue(t0 + 1, 1);
 
     const unsigned rowoff = (unsigned)(lane & 31) * 128u;
     const unsigned f = ((unsigned)(lane & 31) >> 1) & 7u;
@@ -393,7 +527,7 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(
 #pragma unroll
     for (int i = 0; i < TN; ++i) kxb[i] = klane + ((((unsigned)((wn & 1) * 2 + i)) ^ kj) << 6);
 
-    for (int t = 0; t < nk; ++t) {
+    for (int t = t0; t < t1; ++t) {
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but step t+1's parts 0,1 (this wave's 4 newest loads) landed
         __builtin_amdgcn_s_barrier();
         const unsigned a_base = lds0 + (unsigned)((4 * t + 2 * wm) % 10) * SLAB;                                  // A half wm
@@ -441,20 +575,133 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the trailing zero-page loads before the LDS is released
-    gemm_epilogue<TM, TN>(acc, C, M, N, ldc, bias, res, ldr, flags, m0 + wm * 128, n0 + wn * 64, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the trailing zero-page loads ...
+    __syncthreads();                                   // ... and every wave's fragment reads: the LDS becomes epilogue scratch
+
+    if (bid >= full) {
+        // one of the S K-parts of a remainder tile: publish the partial, take a ticket, the last arriver sums in part order
+        const int rt = tile_id - full;
+        float* slabs = sk_slabs + (size_t)rt * S * SK_SLAB_FLOATS;
+        sk_store<TM, TN>(acc, slabs + (size_t)part * SK_SLAB_FLOATS, tid);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned int ticket = __hip_atomic_fetch_add(sk_cnt + rt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ticket == (unsigned)(S - 1)) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __hip_atomic_store(sk_cnt + rt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            *reinterpret_cast<volatile unsigned int*>(smem) = ticket;
+        }
+        __syncthreads();
+        const unsigned int ticket = *reinterpret_cast<volatile unsigned int*>(smem);
+        if (__builtin_amdgcn_readfirstlane(ticket) != (unsigned)(S - 1)) return;
+        __syncthreads();                               // the ticket word lies in wave 0's epilogue strip
+        if (S == 2) {
+            sk_add<TM, TN>(acc, slabs + (size_t)(part ^ 1) * SK_SLAB_FLOATS, tid);      // a + b == b + a
+        } else {                                   // fixed association ((p0 + p1) + p2) + ... whoever is last: re-read every slab
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int p = 0; p < S; ++p) sk_add<TM, TN>(acc, slabs + (size_t)p * SK_SLAB_FLOATS, tid);
+        }
+    }
+    gemm_epilogue_lds<TM, TN>(acc, smem + wave * EPI_STRIP, C, M, N, ldc, bias, res, ldr, flags, m0 + wm * 128, n0 + wn * 64, lane);
+}
+
+// split-K workspace: #CU fp32 slabs + ticket counters, one set per (device, stream); launches that share a set are stream-ordered
+#include <map>
+#include <mutex>
+struct SkWorkspace { float* slabs = nullptr; unsigned int* cnt = nullptr; int G = 0; };
+static std::mutex g_sk_mu;
+static std::map<std::pair<int, void*>, SkWorkspace> g_sk;
+static int g_num_cu[64];
+
+static int sk_workspace(hipStream_t s, int G, SkWorkspace* out) {
+    std::lock_guard<std::mutex> lock(g_sk_mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return MANTIS_ELAUNCH;
+    SkWorkspace& w = g_sk[std::make_pair(dev, (void*)s)];
+    if (w.G < G) {
+        if (w.slabs) { (void)hipFree(w.slabs); (void)hipFree(w.cnt); w = SkWorkspace(); }
+        if (hipMalloc((void**)&w.slabs, (size_t)G * SK_SLAB_FLOATS * sizeof(float)) != hipSuccess) return MANTIS_ELAUNCH;
+        if (hipMalloc((void**)&w.cnt, (size_t)(G + 1) * sizeof(unsigned int)) != hipSuccess) return MANTIS_ELAUNCH;
+        if (hipMemsetAsync(w.cnt, 0, (size_t)(G + 1) * sizeof(unsigned int), s) != hipSuccess) return MANTIS_ELAUNCH;
+        w.G = G;
+    }
+    *out = w;
+    return MANTIS_OK;
+}
+static int num_cus() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (g_num_cu[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        g_num_cu[dev] = n;
+    }
+    return g_num_cu[dev];
+}
+
+// K parts for the tiles of the ring kernel's incomplete last round: minimise K-steps per part + the measured reduction cost
+// (slab write, publish, S slab reads by the last arriver ~ 8 + 3 S K-step equivalents)
+static int ring_split(long ntiles, int nk, int cus) {
+    const int rem = (int)(ntiles % cus);
+    if (!rem) return 1;
+    int smax = cus / rem;
+    if (smax > 8) smax = 8;
+    if (smax > nk / 8) smax = nk / 8;
+    int best = 1;
+    double cost = nk;
+    for (int S = 2; S <= smax; ++S) {
+        const double c = (double)nk / S + 8.0 + 3.0 * S;
+        if (c < cost) { cost = c; best = S; }
+    }
+    return best;
+}
+// tile variant by a cost model fitted to measurements (profiles/r01_gemm_experiments.md), in microseconds:
+//   ring 256x256, 1 workgroup/CU: 1.76 per K-step + 8.9 K-step equivalents per round (prologue, epilogue, launch)
+//   generic 128x128, 2 workgroups/CU: 1.05 per K-step per round of 2 x #CU tiles + 5.2 equivalents
+static int gemm_pick_variant(int M, int N, int K) {
+    if (M < 512 || N < 512) return 1;
+    const int cus = num_cus(), nk = cdiv(K, BK);
+    const long t256 = (long)cdiv(M, 256) * cdiv(N, 256), t128 = (long)cdiv(M, 128) * cdiv(N, 128);
+    const int S = ring_split(t256, nk, cus);
+    const long rem = t256 % cus;
+    const double ring = 1.76 * ((double)(t256 / cus) * (nk + 8.9) + (rem ? (double)nk / S + 8.9 + (S > 1 ? 8.0 + 3.0 * S : 0.0) : 0.0));
+    const double gen = 1.05 * (double)((t128 + 2 * cus - 1) / (2 * cus)) * (nk + 5.2);
+    return ring <= gen ? 12 : 1;
 }
 
 template <bool AKM, bool BKM>
 static int launch_gemm_ring(hipStream_t s, const bf16_t* A, const bf16_t* B, bf16_t* C, int M, int N, int K, long lda, long ldb,
                             long ldc, const bf16_t* bias, const bf16_t* res, long ldr, int flags) {
-    const int tiles_m = cdiv(M, 256), tiles_n = cdiv(N, 256);
-    hipLaunchKernelGGL((gemm_nt_ring_kernel<AKM, BKM>), dim3(tiles_m * tiles_n), dim3(512), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias,
-                       res, ldr, flags, tiles_m, tiles_n);
+    const int tiles_m = cdiv(M, 256), tiles_n = cdiv(N, 256), nk = cdiv(K, BK);
+    const long ntiles = (long)tiles_m * tiles_n;
+    const int cus = num_cus();
+    const int rem = (int)(ntiles % cus);
+    const int S = ring_split(ntiles, nk, cus);
+    const int full = S > 1 ? (int)(ntiles - rem) : (int)ntiles;
+    const int grid = S > 1 ? full + S * rem : (int)ntiles;
+    SkWorkspace w;
+    if (S > 1) {
+        const int rc = sk_workspace(s, cus, &w);
+        if (rc != MANTIS_OK) return rc;
+    }
+    hipLaunchKernelGGL((gemm_nt_ring_kernel<AKM, BKM>), dim3(grid), dim3(512), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias, res, ldr, flags,
+                       tiles_m, tiles_n, full, S, w.slabs, w.cnt);
     return mantis_check_launch();
 }
 
 extern "C" {
+
+// tile variant the auto heuristic picks for C[M,N] over K (12 = 256x256 ring kernel, 1 = 128x128 generic kernel)
+int mantis_gemm_pick_variant(int M, int N, int K) { return gemm_pick_variant(M, N, K); }
 
 // C[M,N] (bf16, row stride ldc) = epilogue(A[M,K] . B[N,K]^T); A,B,C 16-B aligned, lda/ldb % 8 == 0, K % 8 == 0.
 // flags: bit0 bias[n] add | bits1-3 activation (1 gelu-erf, 2 gelu-tanh, 3 quick-gelu) | bit4 + residual[m,n] (stride ldr)
@@ -474,13 +721,7 @@ int mantis_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, 
     if ((flags & EPI_RESIDUAL) && !residual) return MANTIS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     int variant = (flags & EPI_VARIANT_MASK) >> EPI_VARIANT_SHIFT;
-    if (variant == 0) {
-        // tile choice by wave quantisation: 256x256 tiles run 1 workgroup per CU (256 slots), 128x128 tiles 2 per CU (512 slots);
-        // the 256x256 ring kernel is ~15 % faster per tile-flop (measured, profiles/), so it wins unless its last round is empty-ish
-        const double r256 = (double)cdiv(M, 256) * cdiv(N, 256) / 256.0, r128 = (double)cdiv(M, 128) * cdiv(N, 128) / 512.0;
-        const double e256 = r256 / (double)(long)(r256 + 0.999999) * 1.15, e128 = r128 / (double)(long)(r128 + 0.999999);
-        variant = (M >= 512 && N >= 512 && e256 >= e128) ? 12 : 1;
-    }
+    if (variant == 0) variant = gemm_pick_variant(M, N, K);
 #define GEMM_ARGS s, (const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C, M, N, K, (long)lda, (long)ldb, (long)ldc, \
                   (const bf16_t*)bias, (const bf16_t*)residual, (long)ldr, flags
     // variant 1 = 128x128 generic kernel, 2 = 256x256 generic kernel, 12 = 256x256 ring kernel (default for well-quantised shapes)

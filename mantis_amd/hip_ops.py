@@ -98,18 +98,15 @@ def linear_fwd(x, w, bias=None, act=None, residual=None):
     return gemm_nt(x, w, bias=bias, act=act, residual=residual)
 
 
-def _prefers_256(M, N):
-    """Mirror of the tile heuristic in csrc/gemm.hip (wave quantisation of 256x256 vs 128x128 tiles)."""
-    cd = lambda a, b: (a + b - 1) // b
-    r256, r128 = cd(M, 256) * cd(N, 256) / 256.0, cd(M, 128) * cd(N, 128) / 512.0
-    e256, e128 = r256 / math.ceil(r256) * 1.15, r128 / math.ceil(r128)
-    return M >= 512 and N >= 512 and e256 >= e128
+def _prefers_256(M, N, K):
+    """True when the library's tile heuristic (csrc/gemm.hip, gemm_pick_variant) takes the 256x256 ring kernel."""
+    return _L.mantis_gemm_pick_variant(M, N, K) == 12
 
 
 def linear_dx(dy, w, k=None):
     """dx[M, in] = dy[M, out] @ w[out, in].  Shapes that tile well at 256x256 consume the weight K-major as stored (ring kernel
     with transposing fragment reads); badly quantised ones run the faster 128x128 NT kernel on a transposed weight copy."""
-    if _prefers_256(dy.shape[0], w.shape[1]):
+    if _prefers_256(dy.shape[0], w.shape[1], w.shape[0]):
         return gemm_nt(dy, w, b_kmajor=True, k=w.shape[0])
     wt = transpose(w)                       # [in, pad8(out)]
     return gemm_nt(dy, wt, k=wt.shape[1] if k is None else k)

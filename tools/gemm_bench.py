@@ -18,6 +18,9 @@ SHAPES = {  # name: (M, N, K)
 
 
 def main():
+    for spec in filter(None, os.environ.get("GEMM_BENCH_SHAPES", "").split(";")):      # extra shapes "name:M,N,K;..."
+        nm, dims = spec.split(":")
+        SHAPES[nm] = tuple(int(x) for x in dims.split(","))
     variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1, 2, 12]
     names = sys.argv[2].split(",") if len(sys.argv) > 2 else list(SHAPES)
     res = {}
@@ -48,6 +51,7 @@ def main():
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / it
             row[v] = round(2.0 * M * N * Kd / ms / 1e9, 1)
+            row[f"us{v}"] = round(ms * 1e3, 1)
         if os.environ.get("GEMM_BENCH_VENDOR") == "1":     # context only: the vendor library (hipBLASLt via torch) on the same operands
             bt = b.t()
             for _ in range(2):
@@ -60,7 +64,7 @@ def main():
             torch.cuda.synchronize()
             row["vendor"] = round(2.0 * M * N * Kd / (e0.elapsed_time(e1) / 8) / 1e9, 1)
         res[name] = row
-        print(f"{name:10s} {M}x{N}x{Kd}: " + "  ".join(f"{('v' + str(v)) if not isinstance(v, str) else v}={t:7.1f}TF" for v, t in row.items()), flush=True)
+        print(f"{name:10s} {M}x{N}x{Kd}: " + "  ".join(f"{('v' + str(v)) if not isinstance(v, str) else v}={t:7.1f}{'' if str(v).startswith('us') else 'TF'}" for v, t in row.items()), flush=True)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(res, open(os.path.join(ROOT, "gpurun_out", "gemm_bench.json"), "w"), indent=1)
 
