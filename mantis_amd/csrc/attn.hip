@@ -125,6 +125,20 @@ __device__ __forceinline__ bf16x8 pack_frag(const f32x16& s, int cp) {
     return as_bf16x8(u);
 }
 
+// Workgroup -> (x = tile, y = head, z = batch) for a 1-D launch of gx * H * B workgroups.  Hardware sends workgroup i to XCD i % 8
+// (each XCD has a private 4 MiB L2); giving every XCD a CONTIGUOUS range of the (batch, head, tile) order keeps all tiles of a
+// head on one XCD, adjacent in time, so the K/V (forward, dQ) or Q/dO (dK/dV) rows they all stream are fetched from HBM once
+// instead of once per tile (rocprofv3 FETCH_SIZE of the dK/dV kernel at L = 2812: 2.0 GB per launch with the plain 3-D grid).
+__device__ __forceinline__ void xcd_tile_map(int gx, int gy, int& x, int& y, int& z) {
+    const int total = gridDim.x, lin = blockIdx.x;
+    const int q = total >> 3, r = total & 7, xcd = lin & 7;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+    x = v % gx;
+    const int t = v / gx;
+    y = t % gy;
+    z = t / gy;
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 // grid (ceil(L/128), H, B); 4 waves x 32 query rows; KV tiles of 64 keys, double buffered.
 template <int HD, bool CAUSAL>
@@ -139,8 +153,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hh = lane >> 5, lq = lane & 31;
-    const int b = blockIdx.z, h = blockIdx.y, hk = h / (H / Hkv);
-    const int qb = CAUSAL ? (gridDim.x - 1 - blockIdx.x) : blockIdx.x;   // causal: longest rows first
+    const int gx = (L + 127) >> 7;
+    int bx, h, b;
+    xcd_tile_map(gx, H, bx, h, b);
+    const int hk = h / (H / Hkv);
+    const int qb = CAUSAL ? (gx - 1 - bx) : bx;   // causal: longest rows first
     const int qblk0 = qb * 128, q0 = qblk0 + wave * 32, q = q0 + lq;
     const int qc = q < L ? q : L - 1;
     const float c = scale * LOG2E;
@@ -335,8 +352,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hh = lane >> 5, lq = lane & 31;
-    const int b = blockIdx.z, h = blockIdx.y, hk = h / (H / Hkv);
-    const int qb = CAUSAL ? (gridDim.x - 1 - blockIdx.x) : blockIdx.x;
+    const int gx = (L + 127) >> 7;
+    int bx, h, b;
+    xcd_tile_map(gx, H, bx, h, b);
+    const int hk = h / (H / Hkv);
+    const int qb = CAUSAL ? (gx - 1 - bx) : bx;
     const int qblk0 = qb * 128, q0 = qblk0 + wave * 32, q = q0 + lq;
     const int qc = q < L ? q : L - 1;
     const float c = scale * LOG2E;
@@ -501,8 +521,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hh = lane >> 5, lk = lane & 31;
     const int kg = wave / D::DS, dh = wave % D::DS;
-    const int b = blockIdx.z, h = blockIdx.y, hk = h / (H / Hkv);
-    const int kblk0 = blockIdx.x * D::KEYS, k0 = kblk0 + kg * 32, key = k0 + lk;   // causal: key block 0 is the heaviest, first
+    int bx, h, b;
+    xcd_tile_map((L + D::KEYS - 1) / D::KEYS, H, bx, h, b);
+    const int hk = h / (H / Hkv);
+    const int kblk0 = bx * D::KEYS, k0 = kblk0 + kg * 32, key = k0 + lk;   // causal: key block 0 is the heaviest, first
     const int keyc = key < L ? key : L - 1;
     const float c = scale * LOG2E;
     const bool key_ok = key < L && (kmask == nullptr || kmask[(long)b * L + keyc] != 0);
@@ -687,7 +709,7 @@ template <int HD>
 static int launch_bwd(bool causal, hipStream_t s, const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* dO,
                       const int* kmask, const float* LSE, const float* Dsum, bf16_t* dQ, bf16_t* dK, bf16_t* dV, bf16_t* ws, int B,
                       int L, int H, int Hkv, long ldq, long ldk, long ldv, long ldo, long lddq, long lddk, long lddv, float scale) {
-    const dim3 gq(cdiv(L, 128), H, B), gk(cdiv(L, DkvCfg<HD>::KEYS), H, B);
+    const dim3 gq(cdiv(L, 128) * H * B), gk(cdiv(L, DkvCfg<HD>::KEYS) * H * B);
     const int G = H / Hkv;
     const long rows = (long)B * L;
     bf16_t* pk = G == 1 ? dK : ws;
@@ -722,7 +744,7 @@ int mantis_attn_fwd(const void* Q, const void* K, const void* V, const int32_t* 
                     int Hkv, int hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale, int causal, void* stream) {
     if (B <= 0 || L <= 0 || H <= 0 || Hkv <= 0 || H % Hkv) return MANTIS_EINVAL;
     if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4) return MANTIS_EUNSUPPORTED;
-    const dim3 grid(cdiv(L, 128), H, B);
+    const dim3 grid(cdiv(L, 128) * H * B);
     hipStream_t s = (hipStream_t)stream;
 #define FWD(HD) return launch_fwd<HD>(causal != 0, grid, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, kmask, \
                                       (bf16_t*)O, LSE, L, H, Hkv, (long)ldq, (long)ldk, (long)ldv, (long)ldo, scale)
