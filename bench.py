@@ -26,6 +26,10 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_SAMPLE = 1.351e14      # SURVEY.md section 8d (ViT fwd x1, projector + LLM fwd+bwd x3, causal attention at 1/2)
 PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+# memory-side bytes per GEMM launch (rocprofv3 --pmc FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE, separate passes, averaged over
+# the 497 GEMM launches of one cfg2 step): profiles/r01_e_pmc_hbm.md.  Offline PMC measurement of this same command, not live.
+GEMM_HBM_BYTES_PER_LAUNCH_CFG2 = 9.28e8
+GEMM_ALGO_BYTES_PER_LAUNCH_CFG2 = 3.04e8
 
 
 def synthetic_batch(cfg, B, T, n_img, img_hw, rank, step=0):
@@ -177,7 +181,11 @@ def main():
             tot_fl = sum(f for _, f, _, _ in timer)
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
             roof = dict(bound="mfma", kernel="gemm_nt_ring_kernel + gemm_nt_kernel (bf16 MFMA GEMM family, csrc/gemm.hip)", achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=None, launches_per_step=len(timer) // args.steps,
+                        frac=round(ach / PEAK_BF16_TFLOPS, 4),
+                        traffic=None if tiny else GEMM_HBM_BYTES_PER_LAUNCH_CFG2,
+                        traffic_note=None if tiny else "bytes/launch on the L2 memory side (Infinity-Cache hits included), rocprofv3 PMC "
+                        "profiles/r01_e_pmc_hbm.md; algorithmic operand+result bytes/launch = %.3g" % GEMM_ALGO_BYTES_PER_LAUNCH_CFG2,
+                        launches_per_step=len(timer) // args.steps,
                         avg_launch_us=round(1e3 * tot_ms / len(timer), 1), gemm_ms_per_step=round(tot_ms / args.steps, 1),
                         step_model_tflops=round(FLOP_PER_SAMPLE * B / (ms * 1e-3) / 1e12, 1) if not tiny else None,
                         step_frac_of_peak=round(FLOP_PER_SAMPLE * B / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if not tiny else None)
@@ -190,6 +198,8 @@ def main():
                    ms_per_step=round(ms, 2),
                    ms_training_step=round(sum(e[0].elapsed_time(e[1]) for e in split) / len(split), 2) if split else None,
                    ms_optimizer=round(sum(e[1].elapsed_time(e[2]) for e in split) / len(split), 2) if split else None,
+                   samples_per_s_training_step_only=round(world * B / (1e-3 * sum(e[0].elapsed_time(e[1]) for e in split) / len(split)), 4)
+                   if split else None,
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="bf16",
                    data="synthetic", loss=round(loss_val, 4),
                    config=dict(workload=f"{args.config}: ViT fwd + projector + packing + Llama fwd/bwd"

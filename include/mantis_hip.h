@@ -78,6 +78,7 @@ int mantis_transpose(const void* in, void* out, int R, int C, int Rpad, int64_t 
 
 /* ---- GEMM: every nn.Linear of the path (see csrc/gemm.hip).  C = epi(A[M,K] . B[N,K]^T).
  * flags: 1 bias | act<<1 (1 gelu-erf, 2 gelu-tanh, 3 quick-gelu) | 16 residual add | 32 accumulate into C
+ *        | 64 SwiGLU backward fused behind dact = A.B^T: residual = [gate | up][M, 2N], C = [dgate | dup][M, 2N]
  *        | bits 8-11 tile variant (0 = auto) | 4096 A is K-major ([K,M], row stride lda) | 8192 B is K-major ([K,N]):
  *        dX = dY.W uses B K-major (the weight as stored), dW = dY^T.X uses both K-major -- no transposed copies. */
 int mantis_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,

@@ -34,6 +34,7 @@
 #define EPI_ACT_MASK (7 << EPI_ACT_SHIFT)  // 0 none, 1 gelu(erf), 2 gelu(tanh), 3 quick_gelu
 #define EPI_RESIDUAL 16
 #define EPI_ACCUM 32
+#define EPI_SWIGLU_BWD 64                   // C = [dgate | dup][M, 2N] from dact = A.B^T and residual = [gate | up][M, 2N] (ring kernel)
 #define EPI_VARIANT_SHIFT 8                 // bits 8-11: tile variant (0 = auto)
 #define EPI_VARIANT_MASK (15 << EPI_VARIANT_SHIFT)
 #define EPI_A_KMAJOR 4096                   // A given as [K, M] (element (m,k) at A[k*lda + m])
@@ -215,13 +216,14 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TN][TM], bf16_t* __r
 // every global instruction covers 8 whole 128-B lines.  Arithmetic and rounding order are those of gemm_epilogue (bit-identical).
 #define EPI_PITCH 272
 #define EPI_STRIP (64 * EPI_PITCH)
-template <int TM, int TN>
+template <int TM, int TN, bool SWIGLU>
 __device__ __forceinline__ void gemm_epilogue_lds(f32x16 (&acc)[TN][TM], char* __restrict__ strip, bf16_t* __restrict__ C, int M,
                                                   int N, long ldc, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
                                                   long ldr, int flags, int mw0, int nw0, int lane) {
     static_assert(TN == 2 && (TM % 2) == 0, "strip is 64 columns wide, two 32-row blocks per pass");
     const int act = (flags & EPI_ACT_MASK) >> EPI_ACT_SHIFT;
-    const bool vec_ok = !(ldc & 7) && !((uintptr_t)C & 15) && (!(flags & EPI_RESIDUAL) || (!(ldr & 7) && !((uintptr_t)res & 15)));
+    const bool vec_ok = !(ldc & 7) && !((uintptr_t)C & 15) && (!(flags & (EPI_RESIDUAL | EPI_SWIGLU_BWD)) || (!(ldr & 7) && !((uintptr_t)res & 15)))
+                        && (!(flags & EPI_SWIGLU_BWD) || !(N & 7));
     const int rr = lane >> 3, cc = lane & 7;
     const int n = nw0 + cc * 8;
 #pragma unroll
@@ -236,7 +238,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x16 (&acc)[TN][TM], char* _
                                      acc[tn][pass * 2 + t2][4 * g4 + 3]};
                     *reinterpret_cast<f32x4*>(strip + (t2 * 32 + (lane & 31)) * EPI_PITCH + (tn * 32 + 8 * g4 + 4 * (lane >> 5)) * 4) = v;
                 }
-#pragma unroll
+#pragma unroll 2
         for (int it = 0; it < 8; ++it) {
             const int row = it * 8 + rr;
             const int m = mw0 + pass * 64 + row;
@@ -255,6 +257,47 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x16 (&acc)[TN][TM], char* _
                 for (int e = 0; e < 8; ++e) v[e] = gemm_act(bf2f(f2bf(v[e])), act);
             }
             bf16_t* cp = C + (long)m * ldc + n;
+            if constexpr (SWIGLU) {
+                // SwiGLU backward fused behind dact = dY . W_down (transformers/models/llama/modeling_llama.py:163-176, autograd):
+                // dgate = dact * up * silu'(gate), dup = dact * silu(gate); dact rounded to bf16 first, as the unfused path stores it
+                if (full) {
+                    const u32x4 g = *reinterpret_cast<const u32x4*>(res + (long)m * ldr + n);
+                    const u32x4 u = *reinterpret_cast<const u32x4*>(res + (long)m * ldr + N + n);
+                    u32x4 og, ou;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float gv[2] = {bf2f_lo(g[e]), bf2f_hi(g[e])};
+                        const float uv[2] = {bf2f_lo(u[e]), bf2f_hi(u[e])};
+                        float rg[2], ru[2];
+#pragma unroll
+                        for (int h2 = 0; h2 < 2; ++h2) {
+                            const float dv = bf2f(f2bf(v[2 * e + h2]));
+                            const float sg = 1.f / (1.f + __expf(-gv[h2]));
+                            const float silu = gv[h2] * sg;
+                            rg[h2] = dv * uv[h2] * (sg + silu * (1.f - sg));
+                            ru[h2] = dv * silu;
+                        }
+                        og[e] = pack_bf2(rg[0], rg[1]);
+                        ou[e] = pack_bf2(ru[0], ru[1]);
+                    }
+                    *reinterpret_cast<u32x4*>(cp) = og;
+                    *reinterpret_cast<u32x4*>(cp + N) = ou;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        if (n + e < N) {
+                            const float gv = bf2f(res[(long)m * ldr + n + e]), uv = bf2f(res[(long)m * ldr + N + n + e]);
+                            const float dv = bf2f(f2bf(v[e]));
+                            const float sg = 1.f / (1.f + __expf(-gv));
+                            const float silu = gv * sg;
+                            cp[e] = f2bf(dv * uv * (sg + silu * (1.f - sg)));
+                            cp[N + e] = f2bf(dv * silu);
+                        }
+                    }
+                }
+                continue;
+            }
+            if (SWIGLU) continue;
             if (full) {
                 if (flags & EPI_RESIDUAL) {
                     const u32x4 rv = *reinterpret_cast<const u32x4*>(res + (long)m * ldr + n);
@@ -446,7 +489,7 @@ __device__ __forceinline__ void sk_add(f32x16 (&acc)[TN][TM], const float* __res
             }
 }
 
-template <bool AKM, bool BKM>
+template <bool AKM, bool BKM, bool SWIGLU = false>
 __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C, int M, int N, int K, long lda, long ldb,
     long ldc, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res, long ldr, int flags, int tiles_m, int tiles_n,
@@ -611,7 +654,7 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(
             for (int p = 0; p < S; ++p) sk_add<TM, TN>(acc, slabs + (size_t)p * SK_SLAB_FLOATS, tid);
         }
     }
-    gemm_epilogue_lds<TM, TN>(acc, smem + wave * EPI_STRIP, C, M, N, ldc, bias, res, ldr, flags, m0 + wm * 128, n0 + wn * 64, lane);
+    gemm_epilogue_lds<TM, TN, SWIGLU>(acc, smem + wave * EPI_STRIP, C, M, N, ldc, bias, res, ldr, flags, m0 + wm * 128, n0 + wn * 64, lane);
 }
 
 // split-K workspace: #CU fp32 slabs + ticket counters, one set per (device, stream); launches that share a set are stream-ordered
@@ -678,7 +721,7 @@ static int gemm_pick_variant(int M, int N, int K) {
     return ring <= gen ? 12 : 1;
 }
 
-template <bool AKM, bool BKM>
+template <bool AKM, bool BKM, bool SWIGLU = false>
 static int launch_gemm_ring(hipStream_t s, const bf16_t* A, const bf16_t* B, bf16_t* C, int M, int N, int K, long lda, long ldb,
                             long ldc, const bf16_t* bias, const bf16_t* res, long ldr, int flags) {
     const int tiles_m = cdiv(M, 256), tiles_n = cdiv(N, 256), nk = cdiv(K, BK);
@@ -693,7 +736,7 @@ static int launch_gemm_ring(hipStream_t s, const bf16_t* A, const bf16_t* B, bf1
         const int rc = sk_workspace(s, cus, &w);
         if (rc != MANTIS_OK) return rc;
     }
-    hipLaunchKernelGGL((gemm_nt_ring_kernel<AKM, BKM>), dim3(grid), dim3(512), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias, res, ldr, flags,
+    hipLaunchKernelGGL((gemm_nt_ring_kernel<AKM, BKM, SWIGLU>), dim3(grid), dim3(512), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias, res, ldr, flags,
                        tiles_m, tiles_n, full, S, w.slabs, w.cnt);
     return mantis_check_launch();
 }
@@ -719,9 +762,14 @@ int mantis_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, 
     if (((uintptr_t)A | (uintptr_t)B) & 15) return MANTIS_EUNSUPPORTED;
     if ((flags & EPI_BIAS) && !bias) return MANTIS_EINVAL;
     if ((flags & EPI_RESIDUAL) && !residual) return MANTIS_EINVAL;
+    if (flags & EPI_SWIGLU_BWD) {      // residual = [gate | up], C = [dgate | dup], both [M, 2N]; only the ring kernel's epilogue has it
+        if (!residual || (flags & (EPI_BIAS | EPI_ACT_MASK | EPI_RESIDUAL | EPI_ACCUM)) || ldc < 2 * (long)N || ldr < 2 * (long)N)
+            return MANTIS_EINVAL;
+    }
     hipStream_t s = (hipStream_t)stream;
     int variant = (flags & EPI_VARIANT_MASK) >> EPI_VARIANT_SHIFT;
-    if (variant == 0) variant = gemm_pick_variant(M, N, K);
+    if (variant == 0) variant = (flags & EPI_SWIGLU_BWD) ? 12 : gemm_pick_variant(M, N, K);
+    if ((flags & EPI_SWIGLU_BWD) && (variant != 12 || akm || !bkm)) return MANTIS_EUNSUPPORTED;
 #define GEMM_ARGS s, (const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C, M, N, K, (long)lda, (long)ldb, (long)ldc, \
                   (const bf16_t*)bias, (const bf16_t*)residual, (long)ldr, flags
     // variant 1 = 128x128 generic kernel, 2 = 256x256 generic kernel, 12 = 256x256 ring kernel (default for well-quantised shapes)
@@ -730,6 +778,7 @@ int mantis_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, 
     if (akm && bkm)
         return ring ? launch_gemm_ring<true, true>(GEMM_ARGS)
                     : big ? launch_gemm<256, 256, 128, 64, true, true>(GEMM_ARGS) : launch_gemm<128, 128, 64, 64, true, true>(GEMM_ARGS);
+    if (flags & EPI_SWIGLU_BWD) return launch_gemm_ring<false, true, true>(GEMM_ARGS);
     if (bkm)
         return ring ? launch_gemm_ring<false, true>(GEMM_ARGS)
                     : big ? launch_gemm<256, 256, 128, 64, false, true>(GEMM_ARGS) : launch_gemm<128, 128, 64, 64, false, true>(GEMM_ARGS);

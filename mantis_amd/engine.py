@@ -199,10 +199,8 @@ class LlavaEngine:
             x_in, rstd1, qkv, o, lse, x_mid, rstd2, gu, n1, n2, a = saved.pop()
             if lg_["down"] is not None:
                 K.linear_dw(dx, a, lg_["down"], acc)
-            da = K.linear_dx(dx, lw["down"])
-            del a
-            dgu = K.swiglu_bwd(da, gu)
-            del da, gu
+            dgu = K.linear_dx_swiglu(dx, lw["down"], gu)     # dact = dx . W_down and the SwiGLU backward in one launch
+            del a, gu
             if lg_["gu"] is not None:
                 K.linear_dw(dgu, n2, lg_["gu"], acc)
             dn2 = K.linear_dx(dgu, lw["gu"])

@@ -112,6 +112,29 @@ def linear_dx(dy, w, k=None):
     return gemm_nt(dy, wt, k=wt.shape[1] if k is None else k)
 
 
+def linear_dx_swiglu(dy, w_down, gu):
+    """dgu[M, 2I] = swiglu_bwd(dy[M, d] @ w_down[d, I], gu[M, 2I]) in one launch: the SwiGLU backward runs in the GEMM epilogue
+    (the [M, I] activation gradient never goes to HBM)."""
+    _chk2d(dy, "dy"), _chk2d(w_down, "w_down"), _chk2d(gu, "gu")
+    M, d = dy.shape
+    I = w_down.shape[1]
+    if gu.shape != (M, 2 * I) or w_down.shape[0] != d:
+        raise ValueError(f"linear_dx_swiglu: dy {tuple(dy.shape)} w_down {tuple(w_down.shape)} gu {tuple(gu.shape)}")
+    dgu = torch.empty_like(gu)
+    prof = KERNEL_TIMER
+    if prof is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = _L.mantis_gemm_bf16_nt(_p(dy), dy.stride(0), _p(w_down), w_down.stride(0), _p(dgu), dgu.stride(0), M, I, d, None, _p(gu),
+                                gu.stride(0), 64 | 8192, _stream())
+    _lib.check(rc, f"gemm+swiglu_bwd M={M} I={I} d={d}")
+    if prof is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        prof.append(("gemm_nt_kernel", 2.0 * M * I * d, e0, e1))
+    return dgu
+
+
 def linear_dw(dy, x, grad_w, accumulate):
     """grad_w[out, in] (+)= dy[M, out]^T @ x[M, in]: both activations are consumed K-major as stored."""
     gemm_nt(dy[:, : grad_w.shape[0]], x, out=grad_w, accumulate=accumulate, a_kmajor=True, b_kmajor=True)

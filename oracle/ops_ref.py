@@ -68,6 +68,10 @@ def linear_dx(dy, w, k=None):
     return (_f(dy)[:, :n] @ _f(w)).to(dy.dtype)
 
 
+def linear_dx_swiglu(dy, w_down, gu):
+    return swiglu_bwd(linear_dx(dy, w_down), gu)
+
+
 def linear_dw(dy, x, grad_w, accumulate):
     n = grad_w.shape[0]
     g = _f(dy)[:, :n].t() @ _f(x)

@@ -107,6 +107,17 @@ def check_linear_dx_dw():
     return max(r1, r2)
 
 
+def check_linear_dx_swiglu(M, d, I):
+    """dact = dy . W_down with the SwiGLU backward fused into the epilogue: vs the oracle, and bit-identical to the unfused kernels."""
+    k = K()
+    dy, w, gu = rnd(M, d, seed=21), rnd(d, I, seed=22, scale=0.1), rnd(M, 2 * I, seed=23)
+    fused = k.linear_dx_swiglu(dy.to(DEV), w.to(DEV), gu.to(DEV))
+    r = close(fused, R.linear_dx_swiglu(dy, w, gu), 1e-2, f"linear_dx_swiglu {M}x{d}x{I}")
+    unfused = k.swiglu_bwd(k.gemm_nt(dy.to(DEV), w.to(DEV), b_kmajor=True, variant=12), gu.to(DEV))
+    assert torch.equal(fused, unfused), "fused SwiGLU-backward epilogue differs from GEMM + swiglu_bwd"
+    return r
+
+
 # ------------------------------------------------------------------------------------------------------------- norms / acts
 def check_rmsnorm(rows=323, d=768):
     k = K()
@@ -414,6 +425,9 @@ def all_checks():
                                     (600, 520, 1000, True, False, 12), (520, 600, 54, True, True, 2), (640, 768, 512, False, True, 2)]:
         c[f"gemm_kmajor_{M}x{N}x{K_}_{int(akm)}{int(bkm)}_v{v}"] = (lambda M=M, N=N, K_=K_, akm=akm, bkm=bkm, v=v: check_gemm_kmajor(M, N, K_, akm, bkm, v))
     c["linear_dx_dw"] = check_linear_dx_dw
+    c["linear_dx_swiglu_333x64x176"] = lambda: check_linear_dx_swiglu(333, 64, 176)
+    c["linear_dx_swiglu_700x768x3072"] = lambda: check_linear_dx_swiglu(700, 768, 3072)
+    c["linear_dx_swiglu_520x256x1000"] = lambda: check_linear_dx_swiglu(520, 256, 1000)
     c["rmsnorm"] = check_rmsnorm
     c["rmsnorm_4096"] = lambda: check_rmsnorm(100, 4096)
     c["layernorm"] = check_layernorm
