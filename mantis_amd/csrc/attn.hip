@@ -73,17 +73,22 @@ struct TileRegs {
 };
 
 // LDS tile layouts.  hd == 128: rows are exactly one 256-B bank row, tiles are filled by global_load_lds (fully asynchronous, no
-// staging registers) and 16-B chunk c of row r sits at slot c ^ ((r & 7) << 1): the four consecutive rows of a transposing read
-// hit four different 32-B bank segments and the 16 rows of a ds_read_b128 group are at most 2-way conflicted.
+// staging registers) and 16-B chunk c of row r sits at slot c ^ swz(r), swz(r) = ((r & 3) << 2) | ((r >> 2) & 3):
+//   * the 16 rows of a ds_read_b128 lane group have 16 distinct r & 15 -> 16 distinct slots = all 64 banks once;
+//   * the 4 consecutive rows x 4 consecutive chunks of a ds_read_b64_tr_b16 lane group differ in r & 3 = the slot's upper two
+//     bits -> 16 distinct slots as well (the previous c ^ ((r & 7) << 1) was 2-way conflicted for both: rocprofv3
+//     SQ_LDS_BANK_CONFLICT = 40-50 % of SQ_LDS_IDX_ACTIVE in all three kernels).
 // Other head sizes: padded rows (pitch = row bytes + 16), staged through registers.
 typedef __attribute__((address_space(3))) void lds_void_t;
+
+__device__ __forceinline__ int lds_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
 template <int HD>
 struct Lay {
     static constexpr bool DMA = (HD == 128);
     static constexpr int PITCH = DMA ? 256 : AttnCfg<HD>::PITCH;
     __device__ static __forceinline__ int chunk_off(int row, int chunk) {
-        return row * PITCH + (DMA ? ((chunk ^ ((row & 7) << 1)) << 4) : (chunk << 4));
+        return row * PITCH + (DMA ? ((chunk ^ lds_swz(row)) << 4) : (chunk << 4));
     }
 };
 
@@ -97,7 +102,7 @@ __device__ __forceinline__ void stage_tile_dma(const bf16_t* __restrict__ g, lon
     for (int j = 0; j < PER; ++j) {
         const int piece = wave * PER + j;
         int row = piece * 4 + (lane >> 4);
-        const int c = (lane & 15) ^ ((row & 7) << 1);
+        const int c = (lane & 15) ^ lds_swz(row);
         row = row < rows_valid ? row : rows_valid - 1;
         __builtin_amdgcn_global_load_lds(g + (long)row * gstride + c * 8, (lds_void_t*)(lds + piece * 1024), 16, 0, 0);
     }
@@ -109,9 +114,11 @@ template <int HD>
 __device__ __forceinline__ bf16x8 read_tr_frag(const char* tile, int row0, int col0, int lane) {
     const int s = lane & 15, g16 = (lane >> 4) & 1, h = lane >> 5;
     const int row = row0 + 4 * h + (s >> 2), col = col0 + 16 * g16 + (s & 3) * 4;
-    const char* p = tile + Lay<HD>::chunk_off(row, col >> 3) + (col & 7) * 2;
-    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
-    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 8 * Lay<HD>::PITCH));   // (row + 8) & 7 == row & 7
+    const int off = Lay<HD>::chunk_off(row, col >> 3) + (col & 7) * 2;
+    // row + 8: same r & 3, (r >> 2) & 3 flips its upper bit -> slot ^ 2 -> byte offset ^ 32 (tile bases are 256-B aligned)
+    const int off8 = Lay<HD>::DMA ? ((off + 8 * Lay<HD>::PITCH) ^ 32) : off + 8 * Lay<HD>::PITCH;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + off));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + off8));
     union { s16x4 s2[2]; bf16x8 f; } u;
     u.s2[0] = a;
     u.s2[1] = b;
