@@ -49,25 +49,31 @@ __global__ __launch_bounds__(64 * NORM_WAVES) void rmsnorm_fwd_kernel(const bf16
     }
 }
 
-// dx = rstd * (g - xhat * mean(g * xhat)) [+ dres],  g = dy * w, xhat = x * rstd;   dW partial[wave] += dy * xhat
-__global__ __launch_bounds__(64 * NORM_WAVES) void rmsnorm_bwd_kernel(
+// dx = rstd * (g - xhat * mean(g * xhat)) [+ dres],  g = dy * w, xhat = x * rstd;   dW partial[workgroup] += dy * xhat
+// One wave per row, 8 waves per workgroup, 2 workgroups per CU (4 waves/SIMD: at 1 wave/SIMD the kernel was latency bound --
+// 75 us for 5624 x 4096 = 2.5 TB/s); the 8 waves' column sums are folded through one LDS row in wave order (deterministic), so
+// a workgroup emits ONE fp32 partial row for reduce_partials_kernel.
+#define RMSB_WAVES 8
+template <int MAXC>
+__global__ __launch_bounds__(64 * RMSB_WAVES, MAXC <= 8 ? 4 : 2) void rmsnorm_bwd_kernel(
     const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
     const float* __restrict__ rstd_in, const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
     float* __restrict__ dw_partial, long rows, int d) {
-    const int lane = threadIdx.x & 63;
-    const long wave = (long)blockIdx.x * NORM_WAVES + (threadIdx.x >> 6);
-    const long nwaves = (long)gridDim.x * NORM_WAVES;
+    __shared__ float fold[MAXC * 64 * 8];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long wave = (long)blockIdx.x * RMSB_WAVES + wv;
+    const long nwaves = (long)gridDim.x * RMSB_WAVES;
     const int cpr = d >> 3;
-    float dwacc[NORM_MAXC][8];
+    float dwacc[MAXC][8];
 #pragma unroll
-    for (int k = 0; k < NORM_MAXC; ++k)
+    for (int k = 0; k < MAXC; ++k)
 #pragma unroll
         for (int e = 0; e < 8; ++e) dwacc[k][e] = 0.f;
     for (long r = wave; r < rows; r += nwaves) {
         const float rstd = rstd_in[r];
         float dot = 0.f;
 #pragma unroll
-        for (int k = 0; k < NORM_MAXC; ++k) {
+        for (int k = 0; k < MAXC; ++k) {
             const int c = lane + 64 * k;
             if (c < cpr) {
                 const u32x4 vd = *reinterpret_cast<const u32x4*>(dy + r * d + c * 8);
@@ -85,7 +91,7 @@ __global__ __launch_bounds__(64 * NORM_WAVES) void rmsnorm_bwd_kernel(
         }
         dot = wave_sum(dot) / (float)d;
 #pragma unroll
-        for (int k = 0; k < NORM_MAXC; ++k) {
+        for (int k = 0; k < MAXC; ++k) {
             const int c = lane + 64 * k;
             if (c < cpr) {
                 const u32x4 vd = *reinterpret_cast<const u32x4*>(dy + r * d + c * 8);
@@ -106,14 +112,23 @@ __global__ __launch_bounds__(64 * NORM_WAVES) void rmsnorm_bwd_kernel(
         }
     }
     if (dw_partial) {
-        float* out = dw_partial + wave * d;
+        // fold[k][e][lane]: lanes hit consecutive banks; waves add in index order
+        for (int wq = 0; wq < RMSB_WAVES; ++wq) {
+            if (wv == wq) {
 #pragma unroll
-        for (int k = 0; k < NORM_MAXC; ++k) {
-            const int c = lane + 64 * k;
-            if (c < cpr) {
-                *reinterpret_cast<f32x4*>(out + c * 8) = f32x4{dwacc[k][0], dwacc[k][1], dwacc[k][2], dwacc[k][3]};
-                *reinterpret_cast<f32x4*>(out + c * 8 + 4) = f32x4{dwacc[k][4], dwacc[k][5], dwacc[k][6], dwacc[k][7]};
+                for (int k = 0; k < MAXC; ++k)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float* f = fold + (k * 8 + e) * 64 + lane;
+                        *f = (wq == 0) ? dwacc[k][e] : *f + dwacc[k][e];
+                    }
             }
+            __syncthreads();
+        }
+        float* out = dw_partial + (long)blockIdx.x * d;
+        for (int j = threadIdx.x; j < d; j += 64 * RMSB_WAVES) {
+            const int c = j >> 3, e = j & 7;            // column j = chunk c (lane c & 63, k = c >> 6), element e
+            out[j] = fold[((c >> 6) * 8 + e) * 64 + (c & 63)];
         }
     }
 }
@@ -201,9 +216,8 @@ int mantis_rmsnorm_fwd(const void* x, const void* weight, void* y, float* rstd, 
 
 // workspace: >= mantis_rmsnorm_bwd_partials(rows) * d floats.  grad_weight (+)= dW (bf16).  dres optional (fused residual-grad add).
 int mantis_rmsnorm_bwd_partials(int64_t rows) {
-    long g = (rows + NORM_WAVES - 1) / NORM_WAVES;
-    g = g < 1 ? 1 : (g > 256 ? 256 : g);
-    return (int)(g * NORM_WAVES);
+    long g = (rows + RMSB_WAVES - 1) / RMSB_WAVES;
+    return (int)(g < 1 ? 1 : (g > 512 ? 512 : g));      // one partial row per workgroup, 2 workgroups per CU
 }
 
 int mantis_rmsnorm_bwd(const void* dy, const void* x, const void* weight, const float* rstd, const void* dres, void* dx,
@@ -211,9 +225,13 @@ int mantis_rmsnorm_bwd(const void* dy, const void* x, const void* weight, const 
     if (d % 8 || d <= 0 || d > 64 * 8 * NORM_MAXC) return MANTIS_EUNSUPPORTED;
     if (rows == 0) return MANTIS_OK;
     const int P = mantis_rmsnorm_bwd_partials(rows);
-    hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(P / NORM_WAVES), dim3(64 * NORM_WAVES), 0, (hipStream_t)stream,
-                       (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)weight, rstd, (const bf16_t*)dres, (bf16_t*)dx,
-                       grad_weight ? workspace : nullptr, (long)rows, d);
+#define RMSB_LAUNCH(MAXC) hipLaunchKernelGGL(rmsnorm_bwd_kernel<MAXC>, dim3(P), dim3(64 * RMSB_WAVES), 0, (hipStream_t)stream, \
+                       (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)weight, rstd, (const bf16_t*)dres, (bf16_t*)dx, \
+                       grad_weight ? workspace : nullptr, (long)rows, d)
+    if (d <= 64 * 8 * 2) RMSB_LAUNCH(2);
+    else if (d <= 64 * 8 * 8) RMSB_LAUNCH(8);
+    else RMSB_LAUNCH(NORM_MAXC);
+#undef RMSB_LAUNCH
     if (grad_weight)
         hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(d, 64)), dim3(1024), 0, (hipStream_t)stream, workspace, P, d,
                            (bf16_t*)grad_weight, accumulate);

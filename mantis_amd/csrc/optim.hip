@@ -43,7 +43,7 @@ __global__ void adamw_kernel(bf16_t* __restrict__ p16, const bf16_t* __restrict_
     }
 }
 
-#define SUMSQ_BLOCKS 1024
+#define SUMSQ_BLOCKS 8192
 __global__ void sumsq_partial_kernel(const bf16_t* __restrict__ x, long n8, float* __restrict__ partial) {
     __shared__ float red[16];
     float s = 0.f;
@@ -78,7 +78,7 @@ int mantis_adamw(void* param_bf16, const void* grad_bf16, float* master, float* 
     if (n % 8) return MANTIS_EUNSUPPORTED;
     if (n == 0) return MANTIS_OK;
     long g = (n / 8 + 255) / 256;
-    g = g > 4096 ? 4096 : g;
+    g = g > 131072 ? 131072 : g;      // measured: 4096 blocks 5.6-5.8 TB/s, 65536-262144 blocks 6.0 TB/s (grid-stride loop, 28 B/element)
     hipLaunchKernelGGL(adamw_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (bf16_t*)param_bf16,
                        (const bf16_t*)grad_bf16, master, exp_avg, exp_avg_sq, (long)(n / 8), lr, beta1, beta2, eps,
                        weight_decay, bias_corr1, bias_corr2, grad_scale_dev);
