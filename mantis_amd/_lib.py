@@ -6,7 +6,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmantis_hip.so")
+LIB_PATH = os.environ.get("MANTIS_HIP_LIB") or os.path.join(_HERE, "libmantis_hip.so")   # override: A/B a differently built library (debugging only)
 
 P = ctypes.c_void_p
 I = ctypes.c_int

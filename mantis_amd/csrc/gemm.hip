@@ -536,18 +536,75 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // slab (t, p): two global_load_lds per wave (pieces 2w, 2w+1 of the 16 eight-row pieces)
+    // slab (t, p): two LDS-DMA pieces per wave (pieces 2w, 2w+1 of the 16 eight-row pieces), issued as
+    // buffer_load_dwordx4 ... lds: descriptor + per-lane 32-bit offset fixed for the whole tile + scalar K-step offset, so the
+    // K loop carries no address arithmetic; lanes whose chunk lies beyond the K range get an out-of-range offset (-> zeros)
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)A, 0, (int)(unsigned)(((long)(AKM ? K : M) * lda) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)B, 0, (int)(unsigned)(((long)(BKM ? K : N) * ldb) * 2), 0x00020000);
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    unsigned voA[2][PPW], voB[2][PPW];
+    int kcA[PPW], kcB[PPW];          // k index (within a K-step) this lane's chunk starts at, per piece
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int piece = PPW * wave + j;
+        {   // row-major piece geometry (stage_piece): 8 rows x 128 B, chunk swizzled with the row pair
+            const int rl = lane >> 3, fz = (piece * 4 + (rl >> 1)) & 7, chunk = (lane & 7) ^ fz;
+            if constexpr (!AKM) {
+                kcA[j] = chunk * 8;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    int grow = m0 + half * 128 + piece * 8 + rl;
+                    grow = grow < M ? grow : M - 1;
+                    voA[half][j] = (unsigned)(((long)grow * lda + chunk * 8) * 2);
+                }
+            }
+            if constexpr (!BKM) {
+                kcB[j] = chunk * 8;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    int grow = n0 + half * 128 + piece * 8 + rl;
+                    grow = grow < N ? grow : N - 1;
+                    voB[half][j] = (unsigned)(((long)grow * ldb + chunk * 8) * 2);
+                }
+            }
+        }
+        {   // K-major piece geometry (stage_piece_km<128>): 4 k-rows x 256 B, column chunk swizzled with k & 3
+            const int kk = piece * 4 + (lane >> 4), slot = lane & 15, cc = slot ^ ((kk & 3) << 2);
+            if constexpr (AKM) {
+                kcA[j] = kk;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const long col = (long)m0 + half * 128 + cc * 8;
+                    voA[half][j] = (col + 8 <= lda) ? (unsigned)(((long)kk * lda + col) * 2) : OOB;
+                }
+            }
+            if constexpr (BKM) {
+                kcB[j] = kk;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const long col = (long)n0 + half * 128 + cc * 8;
+                    voB[half][j] = (col + 8 <= ldb) ? (unsigned)(((long)kk * ldb + col) * 2) : OOB;
+                }
+            }
+        }
+    }
     auto issue = [&](int t, int p) {
         char* dst = smem + ((4 * t + p) % 10) * SLAB;
         const int half = p >> 1;
+        const int krem = Kseg - t * BK;            // K elements of this K-step inside the range (<= 0: the whole step reads zeros)
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
+            lds_void* d = (lds_void*)(dst + (PPW * wave + j) * 1024);
             if (p & 1) {
-                if constexpr (BKM) stage_piece_km<128>(B, ldb, n0 + half * 128, t * BK, Kseg, dst, PPW * wave + j, lane);
-                else stage_piece(B, ldb, n0 + half * 128, N, t * BK, Kseg, dst, PPW * wave + j, lane);
+                const unsigned vo = (kcB[j] < krem) ? voB[half][j] : OOB;
+                const unsigned so = BKM ? (unsigned)t * (unsigned)(BK * 2) * (unsigned)ldb : (unsigned)t * (BK * 2);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, d, 16, vo, so, 0, 0);
             } else {
-                if constexpr (AKM) stage_piece_km<128>(A, lda, m0 + half * 128, t * BK, Kseg, dst, PPW * wave + j, lane);
-                else stage_piece(A, lda, m0 + half * 128, M, t * BK, Kseg, dst, PPW * wave + j, lane);
+                const unsigned vo = (kcA[j] < krem) ? voA[half][j] : OOB;
+                const unsigned so = AKM ? (unsigned)t * (unsigned)(BK * 2) * (unsigned)lda : (unsigned)t * (BK * 2);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, d, 16, vo, so, 0, 0);
             }
         }
     };
