@@ -590,23 +590,24 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(
             }
         }
     }
-    auto issue = [&](int t, int p) {
+    auto issue1 = [&](int t, int p, int j) {
         char* dst = smem + ((4 * t + p) % 10) * SLAB;
         const int half = p >> 1;
         const int krem = Kseg - t * BK;            // K elements of this K-step inside the range (<= 0: the whole step reads zeros)
-#pragma unroll
-        for (int j = 0; j < PPW; ++j) {
-            lds_void* d = (lds_void*)(dst + (PPW * wave + j) * 1024);
-            if (p & 1) {
-                const unsigned vo = (kcB[j] < krem) ? voB[half][j] : OOB;
-                const unsigned so = BKM ? (unsigned)t * (unsigned)(BK * 2) * (unsigned)ldb : (unsigned)t * (BK * 2);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, d, 16, vo, so, 0, 0);
-            } else {
-                const unsigned vo = (kcA[j] < krem) ? voA[half][j] : OOB;
-                const unsigned so = AKM ? (unsigned)t * (unsigned)(BK * 2) * (unsigned)lda : (unsigned)t * (BK * 2);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, d, 16, vo, so, 0, 0);
-            }
+        lds_void* d = (lds_void*)(dst + (PPW * wave + j) * 1024);
+        if (p & 1) {
+            const unsigned vo = (kcB[j] < krem) ? voB[half][j] : OOB;
+            const unsigned so = BKM ? (unsigned)t * (unsigned)(BK * 2) * (unsigned)ldb : (unsigned)t * (BK * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, d, 16, vo, so, 0, 0);
+        } else {
+            const unsigned vo = (kcA[j] < krem) ? voA[half][j] : OOB;
+            const unsigned so = AKM ? (unsigned)t * (unsigned)(BK * 2) * (unsigned)lda : (unsigned)t * (BK * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, d, 16, vo, so, 0, 0);
         }
+    };
+    auto issue = [&](int t, int p) {
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) issue1(t, p, j);
     };
     issue(t0, 0); issue(t0, 1); issue(t0, 2); issue(t0, 3);
     issue(t0 + 1, 0); issue(t0 + 1, 1);
@@ -641,38 +642,99 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(
             if constexpr (AKM) read_frags_km<TM>(dst, a_base, kxa, ks);
             else read_frags<TM>(dst, a_base + xo[ks]);
         };
-        constexpr int NRD = (AKM ? 2 * TM : TM) + (BKM ? 2 * TN : TN);   // DS instructions per k-step
-        rdB(fb[0], 0);
-        rdA(fa[0], 0);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int cb = ks & 1, nb = cb ^ 1;
-            if (ks < 3) {
-                rdB(fb[nb], ks + 1);
-                rdA(fa[nb], ks + 1);
-                if constexpr (NRD == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-                else if constexpr (NRD == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-                else if constexpr (NRD == 10) asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory");
-                else if constexpr (NRD == 12) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
-                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // one fragment (i-th 32-row block) of k-chunk ks
+        auto rdA1 = [&](bf16x8& dst, int i, int ks) {
+            if constexpr (AKM) {
+                if (ks == 0) read_frag_km_asm<0>(dst, a_base + kxa[i]);
+                else if (ks == 1) read_frag_km_asm<1>(dst, a_base + kxa[i]);
+                else if (ks == 2) read_frag_km_asm<2>(dst, a_base + kxa[i]);
+                else read_frag_km_asm<3>(dst, a_base + kxa[i]);
             } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (i == 0) lds_read_b128<0>(dst, a_base + xo[ks]);
+                else if (i == 1) lds_read_b128<4096>(dst, a_base + xo[ks]);
+                else if (i == 2) lds_read_b128<8192>(dst, a_base + xo[ks]);
+                else lds_read_b128<12288>(dst, a_base + xo[ks]);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm)
+        };
+        auto rdB1 = [&](bf16x8& dst, int i, int ks) {
+            if constexpr (BKM) {
+                if (ks == 0) read_frag_km_asm<0>(dst, b_slab + kxb[i]);
+                else if (ks == 1) read_frag_km_asm<1>(dst, b_slab + kxb[i]);
+                else if (ks == 2) read_frag_km_asm<2>(dst, b_slab + kxb[i]);
+                else read_frag_km_asm<3>(dst, b_slab + kxb[i]);
+            } else {
+                if (i == 0) lds_read_b128<0>(dst, b_base + xo[ks]);
+                else lds_read_b128<4096>(dst, b_base + xo[ks]);
+            }
+        };
+        // dW (both operands K-major) needs 12 transposing reads per k-chunk: two per MFMA shadow delay the MFMAs (measured -4 %),
+        // so that layout keeps the reads in front of the cluster; every other layout interleaves (measured +2-4 %)
+        if constexpr (!(AKM && BKM)) {
+            rdB(fb[0], 0);
+            rdA(fa[0], 0);
+    #pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int cb = ks & 1, nb = cb ^ 1;
+                // the fragments of k-chunk ks were requested a whole MFMA cluster ago (or right after the barrier for ks = 0)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+                // 8 MFMAs; in the shadow of each one an independent instruction: the 6 fragment reads of k-chunk ks + 1 and the two
+                // LDS-DMA pieces that refill a freed slab (pinned by sched_barrier: one MFMA + one memory instruction per slot)
+    #pragma unroll
+                for (int i = 0; i < TN * TM; ++i) {
+                    const int tn = i / TM, tm = i % TM;
                     acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cb][tn], fa[cb][tm], acc[tn][tm], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            // refill one freed slab per k-step: the DMA issue slots hide under the partner wave's MFMA cluster
-            if (ks == 0) issue(t + 1, 2);
-            if (ks == 1) issue(t + 1, 3);
-            if (ks == 2) issue(t + 2, 0);
-            if (ks == 3) issue(t + 2, 1);
-            __builtin_amdgcn_sched_barrier(0);
+                    if (ks < 3) {
+                        if (i < TN) rdB1(fb[nb][i], i, ks + 1);
+                        else if (i < TN + TM) rdA1(fa[nb][i - TN], i - TN, ks + 1);
+                    }
+                    if (i == TN * TM - 2 || i == TN * TM - 1) {
+                        const int j = i - (TN * TM - 2);
+                        if (ks == 0) issue1(t + 1, 2, j);
+                        if (ks == 1) issue1(t + 1, 3, j);
+                        if (ks == 2) issue1(t + 2, 0, j);
+                        if (ks == 3) issue1(t + 2, 1, j);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            constexpr int NRD = (AKM ? 2 * TM : TM) + (BKM ? 2 * TN : TN);   // DS instructions per k-step
+            rdB(fb[0], 0);
+            rdA(fa[0], 0);
+    #pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int cb = ks & 1, nb = cb ^ 1;
+                if (ks < 3) {
+                    rdB(fb[nb], ks + 1);
+                    rdA(fa[nb], ks + 1);
+                    if constexpr (NRD == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+                    else if constexpr (NRD == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                    else if constexpr (NRD == 10) asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory");
+                    else if constexpr (NRD == 12) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+    #pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+    #pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+                        acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cb][tn], fa[cb][tm], acc[tn][tm], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                // refill one freed slab per k-step: the DMA issue slots hide under the partner wave's MFMA cluster
+                if (ks == 0) issue(t + 1, 2);
+                if (ks == 1) issue(t + 1, 3);
+                if (ks == 2) issue(t + 2, 0);
+                if (ks == 3) issue(t + 2, 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the trailing zero-page loads ...
