@@ -689,12 +689,12 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(
                         if (i < TN) rdB1(fb[nb][i], i, ks + 1);
                         else if (i < TN + TM) rdA1(fa[nb][i - TN], i - TN, ks + 1);
                     }
-                    if (i == TN * TM - 2 || i == TN * TM - 1) {
-                        const int j = i - (TN * TM - 2);
-                        if (ks == 0) issue1(t + 1, 2, j);
-                        if (ks == 1) issue1(t + 1, 3, j);
-                        if (ks == 2) issue1(t + 2, 0, j);
-                        if (ks == 3) issue1(t + 2, 1, j);
+                    // the four slabs freed at the barrier are all refilled during the first two clusters: the data of step t + 1
+                    // gets ~0.9 K-steps of lead instead of 0.5-0.65 (the counted vmcnt wait at the barrier was 11 % of the loop)
+                    if (i >= 4 && ks < 2) {
+                        const int q = i - 4;
+                        if (ks == 0) issue1(t + 1, 2 + (q >> 1), q & 1);
+                        else issue1(t + 2, (q >> 1), q & 1);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -728,11 +728,9 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(
                         acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cb][tn], fa[cb][tm], acc[tn][tm], 0, 0, 0);
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
-                // refill one freed slab per k-step: the DMA issue slots hide under the partner wave's MFMA cluster
-                if (ks == 0) issue(t + 1, 2);
-                if (ks == 1) issue(t + 1, 3);
-                if (ks == 2) issue(t + 2, 0);
-                if (ks == 3) issue(t + 2, 1);
+                // refill the four freed slabs right after the first two clusters (early issue = longer lead for the data of step t + 1)
+                if (ks == 0) { issue(t + 1, 2); issue(t + 1, 3); }
+                if (ks == 1) { issue(t + 2, 0); issue(t + 2, 1); }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
