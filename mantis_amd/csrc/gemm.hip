@@ -809,7 +809,8 @@ static int num_cus() {
 }
 
 // K parts for the tiles of the ring kernel's incomplete last round: minimise K-steps per part + the measured reduction cost
-// (slab write, publish, S slab reads by the last arriver ~ 8 + 3 S K-step equivalents)
+// (slab write, publish, S slab reads by the last arriver ~ 8 + 1.7 S K-step equivalents; sc1 write-through slabs instead of the
+// release/acquire pair were measured equal at S = 2 and 12 % slower at S = 8)
 static int ring_split(long ntiles, int nk, int cus) {
     const int rem = (int)(ntiles % cus);
     if (!rem) return 1;
@@ -819,13 +820,13 @@ static int ring_split(long ntiles, int nk, int cus) {
     int best = 1;
     double cost = nk;
     for (int S = 2; S <= smax; ++S) {
-        const double c = (double)nk / S + 8.0 + 3.0 * S;
+        const double c = (double)nk / S + 8.0 + 1.7 * S;
         if (c < cost) { cost = c; best = S; }
     }
     return best;
 }
 // tile variant by a cost model fitted to measurements (profiles/r01_gemm_experiments.md), in microseconds:
-//   ring 256x256, 1 workgroup/CU: 1.76 per K-step + 8.9 K-step equivalents per round (prologue, epilogue, launch)
+//   ring 256x256, 1 workgroup/CU: 1.6 per K-step + 5 K-step equivalents per round (prologue, epilogue, launch)
 //   generic 128x128, 2 workgroups/CU: 1.05 per K-step per round of 2 x #CU tiles + 5.2 equivalents
 static int gemm_pick_variant(int M, int N, int K) {
     if (M < 512 || N < 512) return 1;
@@ -833,7 +834,7 @@ static int gemm_pick_variant(int M, int N, int K) {
     const long t256 = (long)cdiv(M, 256) * cdiv(N, 256), t128 = (long)cdiv(M, 128) * cdiv(N, 128);
     const int S = ring_split(t256, nk, cus);
     const long rem = t256 % cus;
-    const double ring = 1.76 * ((double)(t256 / cus) * (nk + 8.9) + (rem ? (double)nk / S + 8.9 + (S > 1 ? 8.0 + 3.0 * S : 0.0) : 0.0));
+    const double ring = 1.6 * ((double)(t256 / cus) * (nk + 5.0) + (rem ? (double)nk / S + 5.0 + (S > 1 ? 8.0 + 1.7 * S : 0.0) : 0.0));
     const double gen = 1.05 * (double)((t128 + 2 * cus - 1) / (2 * cus)) * (nk + 5.2);
     return ring <= gen ? 12 : 1;
 }
