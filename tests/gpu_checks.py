@@ -118,6 +118,24 @@ def check_linear_dx_swiglu(M, d, I):
     return r
 
 
+def check_gemm_ksplit_deterministic():
+    """Shapes whose last tile round is incomplete run the K-split path (slab reduction by the last arriver): results must not
+    depend on which workgroup arrives last -> repeated launches are bit-identical, and agree with the oracle; S = 2 and S > 2."""
+    k = K()
+    worst = 0.0
+    for (M, N, K_) in ((2000, 2100, 1024),      # 8 x 9 = 72 tiles on 256 CUs -> S = 3
+                       (5624, 4096, 1024),      # 352 tiles -> remainder 96 -> S = 2
+                       (2816, 2816, 2048)):     # 121 tiles -> S = 2
+        a, b = rnd(M, K_, seed=31), rnd(N, K_, seed=32, scale=0.1)
+        ad, bd = a.to(DEV), b.to(DEV)
+        outs = [k.gemm_nt(ad, bd, variant=12) for _ in range(4)]
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0]), f"K-split GEMM {M}x{N}x{K_} is not bitwise reproducible"
+        worst = max(worst, close(outs[0][:300], R.gemm_nt(a[:300], b), 1e-2, f"gemm k-split {M}x{N}x{K_}"))
+        assert k._L.mantis_gemm_pick_variant(M, N, K_) in (1, 12)
+    return worst
+
+
 # ------------------------------------------------------------------------------------------------------------- norms / acts
 def check_rmsnorm(rows=323, d=768):
     k = K()
@@ -424,6 +442,7 @@ def all_checks():
                                     (1000, 520, 333 * 8, True, True, 12), (1000, 1152, 4304, False, True, 12),
                                     (600, 520, 1000, True, False, 12), (520, 600, 54, True, True, 2), (640, 768, 512, False, True, 2)]:
         c[f"gemm_kmajor_{M}x{N}x{K_}_{int(akm)}{int(bkm)}_v{v}"] = (lambda M=M, N=N, K_=K_, akm=akm, bkm=bkm, v=v: check_gemm_kmajor(M, N, K_, akm, bkm, v))
+    c["gemm_ksplit_deterministic"] = check_gemm_ksplit_deterministic
     c["linear_dx_dw"] = check_linear_dx_dw
     c["linear_dx_swiglu_333x64x176"] = lambda: check_linear_dx_swiglu(333, 64, 176)
     c["linear_dx_swiglu_700x768x3072"] = lambda: check_linear_dx_swiglu(700, 768, 3072)
