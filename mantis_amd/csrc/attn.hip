@@ -259,25 +259,33 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 #pragma unroll
                 for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float v = s[sb][r] * c;
-                        s[sb][r] = v;
-                        mx = fmaxf(mx, v);
-                    }
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[sb][r]);      // raw scores: the scale is folded into the exp below
+                mx *= c;                                                        // c > 0: max commutes with the scaling
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run, mx);
             const float msafe = (m_new == -INFINITY) ? 0.f : m_new;
             const float alpha = (m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m_run - m_new);
             float psum = 0.f;
+            if (need_mask) {
 #pragma unroll
-            for (int sb = 0; sb < 2; ++sb)
+                for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(s[sb][r] - msafe);
-                    s[sb][r] = p;
-                    psum += p;
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        const float p = __builtin_amdgcn_exp2f(s[sb][r] - msafe);
+                        s[sb][r] = p;
+                        psum += p;
+                    }
+            } else {
+#pragma unroll
+                for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sb][r], c, -msafe));
+                        s[sb][r] = p;
+                        psum += p;
+                    }
+            }
             l_run = l_run * alpha + psum;
             m_run = m_new;
             if (__any(alpha != 1.f)) {     // wave-uniform: once the running maxima have settled nothing needs rescaling
@@ -456,13 +464,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
                         float v = s[r] * c + sBias[kl];
                         if (CAUSAL && key0 + kl > q) v = -INFINITY;
                         const float p = __builtin_amdgcn_exp2f(v - lse2);  // lse = +inf for fully masked rows -> p = 0
-                        s[r] = p * (dp[r] - dsum) * scale;
+                        s[r] = p * (dp[r] - dsum);             // the softmax scale is applied once, to the dQ accumulators
                     }
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float p = __builtin_amdgcn_exp2f(s[r] * c - lse2);
-                        s[r] = p * (dp[r] - dsum) * scale;
+                        s[r] = p * (dp[r] - dsum);             // the softmax scale is applied once, to the dQ accumulators
                     }
                 }
 #pragma unroll
@@ -488,8 +496,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
                 const int dd = d * 32 + 8 * g4 + 4 * hh;
                 if (dd < HD) {
                     u32x2 o;
-                    o[0] = pack_bf2(acc[d][4 * g4], acc[d][4 * g4 + 1]);
-                    o[1] = pack_bf2(acc[d][4 * g4 + 2], acc[d][4 * g4 + 3]);
+                    o[0] = pack_bf2(acc[d][4 * g4] * scale, acc[d][4 * g4 + 1] * scale);
+                    o[1] = pack_bf2(acc[d][4 * g4 + 2] * scale, acc[d][4 * g4 + 3] * scale);
                     *reinterpret_cast<u32x2*>(op + dd) = o;
                 }
             }
@@ -619,7 +627,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
                     if (CAUSAL && key > q0 + ql) v = -INFINITY;
                     const float p = __builtin_amdgcn_exp2f(v - sLse[ql]);
                     s[r] = p;
-                    ds[r] = p * (dp[r] - sDs[ql]) * scale;
+                    ds[r] = p * (dp[r] - sDs[ql]);       // the softmax scale is applied once, to the dK accumulators
                 }
             } else {
 #pragma unroll
@@ -627,7 +635,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
                     const int ql = (r & 3) + 8 * (r >> 2) + 4 * hh;
                     const float p = __builtin_amdgcn_exp2f(s[r] * c - sLse[ql]);
                     s[r] = p;
-                    ds[r] = p * (dp[r] - sDs[ql]) * scale;
+                    ds[r] = p * (dp[r] - sDs[ql]);       // the softmax scale is applied once, to the dK accumulators
                 }
             }
 #pragma unroll
@@ -658,8 +666,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
                 const int dd = (dh * D::NDW + d) * 32 + 8 * g4 + 4 * hh;
                 if (dd < HD) {
                     u32x2 o, w;
-                    o[0] = pack_bf2(dkacc[d][4 * g4], dkacc[d][4 * g4 + 1]);
-                    o[1] = pack_bf2(dkacc[d][4 * g4 + 2], dkacc[d][4 * g4 + 3]);
+                    o[0] = pack_bf2(dkacc[d][4 * g4] * scale, dkacc[d][4 * g4 + 1] * scale);
+                    o[1] = pack_bf2(dkacc[d][4 * g4 + 2] * scale, dkacc[d][4 * g4 + 3] * scale);
                     w[0] = pack_bf2(dvacc[d][4 * g4], dvacc[d][4 * g4 + 1]);
                     w[1] = pack_bf2(dvacc[d][4 * g4 + 2], dvacc[d][4 * g4 + 3]);
                     *reinterpret_cast<u32x2*>(kp + dd) = o;
