@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="mantis_8b_siglip_llama3", choices=["mantis_8b_siglip_llama3", "mantis_tiny"])
+    ap.add_argument("--config", default="mantis_8b_siglip_llama3", choices=["mantis_8b_siglip_llama3", "mantis_8b_clip_llama3", "mantis_tiny"])
     ap.add_argument("--batch-per-gpu", type=int, default=2)
     ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -192,7 +192,8 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.config)
-        out = dict(metric="train samples/sec (4 img x 336^2 + 512 tok) Mantis-8B-SigLIP-Llama-3" if not tiny
+        names = dict(mantis_8b_siglip_llama3="Mantis-8B-SigLIP-Llama-3", mantis_8b_clip_llama3="Mantis-8B-CLIP-L/14-336-Llama-3")
+        out = dict(metric=f"train samples/sec (4 img x 336^2 + 512 tok) {names[args.config]}" if not tiny
                    else "train samples/sec Mantis-tiny (1 img 224^2 + 128 tok)",
                    value=round(value, 4), unit="samples/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=round(ms, 2),

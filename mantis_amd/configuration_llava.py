@@ -104,6 +104,18 @@ def mantis_8b_siglip_llama3():
         image_token_index=128256, pad_token_id=128257, vocab_size=128258, vision_feature_select_strategy="full")
 
 
+def mantis_8b_clip_llama3():
+    """The scripts' default tower (/root/reference/mantis/train/scripts/pretrain_mllava.sh:34, openai/clip-vit-large-patch14-336:
+    CLS token, pre-LN, quick_gelu, eps 1e-5, "default" select strategy = drop CLS) + Llama-3-8B; SURVEY appendix B."""
+    return LlavaConfig(
+        vision_config=dict(model_type="clip_vision_model", hidden_size=1024, intermediate_size=4096, num_hidden_layers=24,
+                           num_attention_heads=16, image_size=336, patch_size=14),
+        text_config=dict(model_type="llama", hidden_size=4096, intermediate_size=14336, num_hidden_layers=32,
+                         num_attention_heads=32, num_key_value_heads=8, vocab_size=128258, rope_theta=500000.0,
+                         rms_norm_eps=1e-5),
+        image_token_index=128256, pad_token_id=128257, vocab_size=128258, vision_feature_select_strategy="default")
+
+
 def mantis_tiny():
     """cfg1: SigLIP-base/16-224 + Llama-68M (V = 32000 + 2)."""
     return LlavaConfig(

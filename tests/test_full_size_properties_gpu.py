@@ -137,3 +137,27 @@ def test_step_full_width_is_reproducible_and_accumulates():
     assert torch.equal(l3, l1)
     num = (model.grad_arena.float() - 2 * g1.float()).norm()
     assert float(num / (2 * g1.float()).norm()) < 5e-3
+
+
+def test_clip_flavour_full_width_step_runs_and_is_reproducible():
+    """The scripts' default tower (CLIP ViT-L/14-336: CLS token, pre-LN, quick_gelu, head dim 64, "default" select) at full width
+    and reduced depth: packed length 4 * 576 + 512 - 4 = 2812 (the CLS row is dropped), finite loss near ln(V), bitwise reproducible."""
+    from mantis_amd import configuration_llava as C
+    from mantis_amd.modeling_llava import LlavaForConditionalGeneration
+    from mantis_amd.trainer import MantisHipTrainer
+    import bench
+    cfg = C.mantis_8b_clip_llama3()
+    cfg.vision_config.num_hidden_layers = 3
+    cfg.text_config.num_hidden_layers = 1
+    model = LlavaForConditionalGeneration(cfg, device=DEV, seed=0)
+    batch = bench.synthetic_batch(cfg, 2, 512, 4, 336, 0)
+    tr = MantisHipTrainer(model, gradient_accumulation_steps=1)
+    l1 = tr.training_step(model, batch)
+    g1 = model.grad_arena.clone()
+    for p in model.parameters():
+        p.grad = None
+    l2 = tr.training_step(model, batch)
+    assert torch.equal(l1, l2) and torch.equal(g1, model.grad_arena)
+    assert math.isfinite(float(l1)) and 10.0 < float(l1) < 13.5
+    out = model.engine.step(batch["input_ids"], batch["attention_mask"], batch["labels"], batch["pixel_values"], compute_grads=False)
+    assert out["plan"].L == 2812
