@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="mantis_8b_siglip_llama3", choices=["mantis_8b_siglip_llama3", "mantis_8b_clip_llama3", "mantis_tiny"])
     ap.add_argument("--batch-per-gpu", type=int, default=2)
+    ap.add_argument("--stage", default="finetune", choices=["finetune", "pretrain"],
+                    help="finetune: projector + LLM trainable (the headline metric); pretrain: only multi_modal_projector "
+                         "(the reference's stage 1, train_mllava.py:177-181)")
     ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
@@ -123,6 +126,10 @@ def main():
     B = args.batch_per_gpu
     T, n_img = (128, 1) if tiny else (512, 4)
     model = LlavaForConditionalGeneration(cfg, device=f"cuda:{local_rank}", seed=0)      # same seed -> identical replicas
+    if args.stage == "pretrain":
+        for n, p in model.named_parameters():
+            if "multi_modal_projector" not in n:
+                p.requires_grad = False
     reducer = GradReducer(model) if (world > 1 or force_dp) else None
     trainer = MantisHipTrainer(model, gradient_accumulation_steps=1, reducer=reducer)
     opt = None if args.no_optimizer else FusedAdamW(model, lr=1e-5, weight_decay=0.0, max_grad_norm=1.0)
@@ -207,7 +214,7 @@ def main():
                                         f"{'' if args.no_optimizer else ' + clip + fused AdamW'}; {B} samples/GPU, "
                                         f"{n_img} img + {T} tok per sample; random-init weights",
                                global_batch=world * B, seq_len=T, merged_seq_len=T - n_img + n_img * (cfg.vision_config.image_size // cfg.vision_config.patch_size) ** 2,
-                               parallelism=f"dp{world}", optimizer=not args.no_optimizer),
+                               parallelism=f"dp{world}", optimizer=not args.no_optimizer, stage=args.stage),
                    roofline=roof, cpu_baseline=cpu)
         print(json.dumps(out), flush=True)
     if world > 1 or force_dp:

@@ -429,6 +429,27 @@ def check_model_step(case):
     return 1.0 - min(c for c, _ in rep.values())
 
 
+def check_model_step_projector_only(case):
+    """Pre-training stage (train_mllava.py:177-181): only multi_modal_projector is trainable; the dX chain still runs through the
+    frozen decoder on the HIP kernels; the gradient arena is the projector alone."""
+    flavour = case.split("_")[0]
+    z = Hh.load_case(case)
+    model, _, _ = Hh.build_product_model(flavour, DEV)
+    oracle = Hh.build_oracle_bf16_weights(flavour)
+    for n, p in model.named_parameters():
+        if "multi_modal_projector" not in n:
+            p.requires_grad = False
+    assert model._ensure_grad_arena()
+    rec = {}
+    out = model.engine.step(torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"]), torch.from_numpy(z["labels"]),
+                            Hh.pixels_list(z), compute_grads=True, overwrite_grads=True, need_logits=True, record=rec)
+    torch.cuda.synchronize()
+    rep = Hh.check_step_against_oracle(model, oracle, z, out, rec)
+    assert len(rep) == 4 and all("multi_modal_projector" in n for n in rep)
+    assert all(p.grad is None for n, p in model.named_parameters() if "multi_modal_projector" not in n)
+    return 1.0 - min(c for c, _ in rep.values())
+
+
 def all_checks():
     """name -> thunk, in dependency order (cheap and fundamental first)."""
     c = {}
@@ -467,4 +488,6 @@ def all_checks():
     c["optim"] = check_optim
     for case in MODEL_CASES:
         c["model_step_" + case] = (lambda case=case: check_model_step(case))
+    c["model_step_projector_only_siglip"] = lambda: check_model_step_projector_only("siglip_b2_equal_rightpad")
+    c["model_step_projector_only_clip"] = lambda: check_model_step_projector_only("clip_b2_equal_rightpad")
     return c

@@ -45,6 +45,33 @@ def test_step_matches_oracle(cpu_backend, case):
             assert p.grad is None
 
 
+@pytest.mark.parametrize("case", ["siglip_b2_equal_rightpad", "clip_b2_equal_rightpad"])
+def test_projector_only_stage(cpu_backend, case):
+    """The reference's pre-training stage tunes only multi_modal_projector (train_mllava.py:177-181): same training_step, every
+    other parameter frozen.  Gradient arena = the projector alone; its gradients still match the oracle (the dX chain runs through
+    the frozen decoder); nothing else receives a .grad."""
+    flavour = case.split("_")[0]
+    z = Hh.load_case(case)
+    model, meta, _ = Hh.build_product_model(flavour, "cpu")
+    oracle = Hh.build_oracle_bf16_weights(flavour)
+    for n, p in model.named_parameters():
+        if "multi_modal_projector" not in n:
+            p.requires_grad = False
+    assert model._ensure_grad_arena()
+    n_proj = sum((p.numel() + 7) // 8 * 8 for n, p in model.named_parameters() if p.requires_grad)
+    assert model.grad_arena.numel() == n_proj
+    rec = {}
+    out = model.engine.step(torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"]),
+                            torch.from_numpy(z["labels"]), Hh.pixels_list(z), compute_grads=True, overwrite_grads=True,
+                            need_logits=True, record=rec)
+    rep = Hh.check_step_against_oracle(model, oracle, z, out, rec)
+    assert set(rep) == {n for n, p in model.named_parameters() if p.requires_grad} and len(rep) == 4
+    for n, p in model.named_parameters():
+        if "multi_modal_projector" not in n:
+            assert p.grad is None, n
+    assert list(model.grad_buckets()) and sum(b.numel() for b in model.grad_buckets().values()) == n_proj
+
+
 def test_count_mismatch_raises_value_error(cpu_backend):
     z = Hh.load_case("siglip_b1_img2_adjacent")
     model, _, _ = Hh.build_product_model("siglip", "cpu")
