@@ -435,6 +435,10 @@ __device__ __forceinline__ void read_frag_km_asm(bf16x8& dst, unsigned addr) {
     lds_read_tr64<KS * 4096 + 1024>(u.h[1], addr);
     dst = u.f;
 }
+template <int KS, int H>
+__device__ __forceinline__ void read_half_km_asm(bf16x8& dst, unsigned addr) {
+    lds_read_tr64<KS * 4096 + H * 1024>(reinterpret_cast<gs16x4*>(&dst)[H], addr);
+}
 template <int N_>
 __device__ __forceinline__ void read_frags_km(bf16x8 (&dst)[N_], unsigned slab, const unsigned (&xb)[N_], int ks) {
 #pragma unroll
@@ -667,12 +671,49 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(
                 else lds_read_b128<4096>(dst, b_base + xo[ks]);
             }
         };
-        // dW (both operands K-major) needs 12 transposing reads per k-chunk: two per MFMA shadow delay the MFMAs (measured -4 %),
-        // so that layout keeps the reads in front of the cluster; every other layout interleaves (measured +2-4 %)
-        if constexpr (!(AKM && BKM)) {
+        // every memory instruction of the K loop sits in the shadow of an MFMA (pinned by sched_barrier): fragment reads of the next
+        // k-chunk and, in the first two clusters, the LDS-DMA pieces that refill the four slabs freed at the barrier
+        if constexpr (AKM && BKM) {
+            // TN: 12 transposing half-reads per k-chunk: two in each of the first four MFMA shadows, one (+ a DMA piece) in the rest
+            auto half = [&](int op, int ks) {       // op 0..11: B0lo B0hi B1lo B1hi A0lo A0hi ... A3hi
+                const int f = op >> 1, h = op & 1;
+                bf16x8& dst = f < TN ? fb[(ks & 1)][f] : fa[(ks & 1)][f - TN];
+                const unsigned addr = f < TN ? b_slab + kxb[f] : a_base + kxa[f - TN];
+                if (ks == 0) { if (h) read_half_km_asm<0, 1>(dst, addr); else read_half_km_asm<0, 0>(dst, addr); }
+                else if (ks == 1) { if (h) read_half_km_asm<1, 1>(dst, addr); else read_half_km_asm<1, 0>(dst, addr); }
+                else if (ks == 2) { if (h) read_half_km_asm<2, 1>(dst, addr); else read_half_km_asm<2, 0>(dst, addr); }
+                else { if (h) read_half_km_asm<3, 1>(dst, addr); else read_half_km_asm<3, 0>(dst, addr); }
+            };
             rdB(fb[0], 0);
             rdA(fa[0], 0);
-    #pragma unroll
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int cb = ks & 1;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < TN * TM; ++i) {
+                    const int tn = i / TM, tm = i % TM;
+                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cb][tn], fa[cb][tm], acc[tn][tm], 0, 0, 0);
+                    if (ks < 3) {
+                        if (i < 4) { half(2 * i, ks + 1); half(2 * i + 1, ks + 1); }
+                        else half(4 + i, ks + 1);
+                    }
+                    if (i >= 4 && ks < 2) {
+                        const int q = i - 4;
+                        if (ks == 0) issue1(t + 1, 2 + (q >> 1), q & 1);
+                        else issue1(t + 2, (q >> 1), q & 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            rdB(fb[0], 0);
+            rdA(fa[0], 0);
+#pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int cb = ks & 1, nb = cb ^ 1;
                 // the fragments of k-chunk ks were requested a whole MFMA cluster ago (or right after the barrier for ks = 0)
@@ -681,7 +722,7 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(
                 __builtin_amdgcn_s_setprio(1);
                 // 8 MFMAs; in the shadow of each one an independent instruction: the 6 fragment reads of k-chunk ks + 1 and the two
                 // LDS-DMA pieces that refill a freed slab (pinned by sched_barrier: one MFMA + one memory instruction per slot)
-    #pragma unroll
+#pragma unroll
                 for (int i = 0; i < TN * TM; ++i) {
                     const int tn = i / TM, tm = i % TM;
                     acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cb][tn], fa[cb][tm], acc[tn][tm], 0, 0, 0);
@@ -699,38 +740,6 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
-            constexpr int NRD = (AKM ? 2 * TM : TM) + (BKM ? 2 * TN : TN);   // DS instructions per k-step
-            rdB(fb[0], 0);
-            rdA(fa[0], 0);
-    #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int cb = ks & 1, nb = cb ^ 1;
-                if (ks < 3) {
-                    rdB(fb[nb], ks + 1);
-                    rdA(fa[nb], ks + 1);
-                    if constexpr (NRD == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-                    else if constexpr (NRD == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-                    else if constexpr (NRD == 10) asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory");
-                    else if constexpr (NRD == 12) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
-                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(1);
-    #pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-    #pragma unroll
-                    for (int tm = 0; tm < TM; ++tm)
-                        acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cb][tn], fa[cb][tm], acc[tn][tm], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_sched_barrier(0);
-                // refill the four freed slabs right after the first two clusters (early issue = longer lead for the data of step t + 1)
-                if (ks == 0) { issue(t + 1, 2); issue(t + 1, 3); }
-                if (ks == 1) { issue(t + 2, 0); issue(t + 2, 1); }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
