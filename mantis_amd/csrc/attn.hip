@@ -22,6 +22,7 @@
 //    reduction sums the GQA group, so the grid is H/Hkv times larger than a per-kv-head walk.
 // Algorithmic FLOPs: forward 4*L*Lk*hd per head (half for causal); backward 2.5x forward (+1x recompute of S and dP here).
 #include "common.h"
+#include <type_traits>
 
 #define LOG2E 1.4426950408889634f
 #define LN2 0.6931471805599453f
@@ -123,6 +124,46 @@ __device__ __forceinline__ bf16x8 read_tr_frag(const char* tile, int row0, int c
     u.s2[0] = a;
     u.s2[1] = b;
     return u.f;
+}
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// Hand-placed LDS fragment reads for the hd == 128 kernels (the compiler neither counts nor moves them; every use is guarded by an
+// explicit counted s_waitcnt lgkmcnt): they sit in the shadow of the MFMAs, 2-3 fragments ahead of their consumer.
+template <int OFF>
+__device__ __forceinline__ void asm_read_b128(bf16x8& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ void asm_read_tr64(s16x4& dst, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+union FragU { s16x4 h[2]; bf16x8 f; };
+template <int N> __device__ __forceinline__ void wait_lgkm() {
+    if constexpr (N == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+    else if constexpr (N == 5) asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+}
+// K-fragment i = sb * 8 + ks of a 64-key tile: row sb * 32 + (lane & 31), chunk ks * 2 + h; kaddr[ks] holds the sb = 0 address
+template <int I>
+__device__ __forceinline__ void issue_kfrag(bf16x8& dst, const unsigned (&kaddr)[8]) {
+    asm_read_b128<(I >> 3) * 32 * 256>(dst, kaddr[I & 7]);
+}
+// V^T fragment j = (sb * 2 + cp) * 4 + d: rows (sb * 2 + cp) * 16 + ..., d-block d; vaddr / vaddr8 hold the row-block-0 addresses
+template <int J>
+__device__ __forceinline__ void issue_vfrag(FragU& dst, const unsigned (&vaddr)[4], const unsigned (&vaddr8)[4]) {
+    asm_read_tr64<(J >> 2) * 16 * 256>(dst.h[0], vaddr[J & 3]);
+    asm_read_tr64<(J >> 2) * 16 * 256>(dst.h[1], vaddr8[J & 3]);
 }
 
 __device__ __forceinline__ bf16x8 pack_frag(const f32x16& s, int cp) {
@@ -232,14 +273,51 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
         if (!(CAUSAL && key0 > q0 + 31)) {   // wave-uniform: skip tiles entirely in this wave's future
             f32x16 s[2];
 #pragma unroll
-            for (int sb = 0; sb < 2; ++sb) {
+            for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) s[sb][e] = 0.f;
+            FragU fb4[4];                       // fragment ring shared by the S phase (K rows) and the P.V phase (V^T)
+            unsigned vaddr[4], vaddr8[4];
+            if constexpr (Y::DMA) {
+                const unsigned ldsK = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)sK;
+                unsigned kaddr[8];
 #pragma unroll
-                for (int ks = 0; ks < C::NKS; ++ks) {
-                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + Y::chunk_off(sb * 32 + lq, ks * 2 + hh));
-                    s[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[sb], 0, 0, 0);
+                for (int ks = 0; ks < 8; ++ks) kaddr[ks] = ldsK + Y::chunk_off(lq, ks * 2 + hh);
+                {
+                    const int sl = lane & 15, g16 = (lane >> 4) & 1;
+                    const int row = 4 * hh + (sl >> 2);
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const int col = d * 32 + 16 * g16 + (sl & 3) * 4;
+                        const int off = Y::chunk_off(row, col >> 3) + (col & 7) * 2;
+                        vaddr[d] = ldsK + TILE + off;
+                        vaddr8[d] = ldsK + TILE + ((off + 8 * Y::PITCH) ^ 32);
+                    }
                 }
+                // S = K.Q^T: 16 MFMAs, K fragment i + 3 requested in the shadow of MFMA i
+                issue_kfrag<0>(fb4[0].f, kaddr);
+                issue_kfrag<1>(fb4[1].f, kaddr);
+                issue_kfrag<2>(fb4[2].f, kaddr);
+                static_for<0, 16>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    wait_lgkm<(15 - i) < 2 ? (15 - i) : 2>();      // requested so far: fragments <= i + 2
+                    __builtin_amdgcn_sched_barrier(0);
+                    s[i >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb4[i & 3].f, qf[i & 7], s[i >> 3], 0, 0, 0);
+                    if constexpr (i + 3 < 16) issue_kfrag<i + 3>(fb4[(i + 3) & 3].f, kaddr);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                // the first three V^T fragments travel while the softmax runs
+                issue_vfrag<0>(fb4[0], vaddr, vaddr8);
+                issue_vfrag<1>(fb4[1], vaddr, vaddr8);
+                issue_vfrag<2>(fb4[2], vaddr, vaddr8);
+            } else {
+#pragma unroll
+                for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                    for (int ks = 0; ks < C::NKS; ++ks) {
+                        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + Y::chunk_off(sb * 32 + lq, ks * 2 + hh));
+                        s[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[sb], 0, 0, 0);
+                    }
             }
             float mx = -INFINITY;
             // wave-uniform: only tiles that touch the diagonal or contain masked keys pay for per-element masking
@@ -294,17 +372,32 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 #pragma unroll
                     for (int e = 0; e < 16; ++e) oacc[d][e] *= alpha;
             }
+            if constexpr (Y::DMA) {
+                // O^T += V^T.P: 16 MFMAs, V^T fragment j + 3 (two transposing reads) requested in the shadow of MFMA j
+                bf16x8 pfr[4];
 #pragma unroll
-            for (int sb = 0; sb < 2; ++sb)
+                for (int g = 0; g < 4; ++g) pfr[g] = pack_frag(s[g >> 1], g & 1);
+                static_for<0, 16>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    wait_lgkm<((15 - j) < 2 ? (15 - j) : 2) * 2>();      // requested so far: fragments <= j + 2 (two reads each)
+                    __builtin_amdgcn_sched_barrier(0);
+                    oacc[j & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb4[j & 3].f, pfr[j >> 2], oacc[j & 3], 0, 0, 0);
+                    if constexpr (j + 3 < 16) issue_vfrag<j + 3>(fb4[(j + 3) & 3], vaddr, vaddr8);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            } else {
 #pragma unroll
-                for (int cp = 0; cp < 2; ++cp) {
-                    const bf16x8 pf = pack_frag(s[sb], cp);
+                for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
-                    for (int d = 0; d < C::NDB; ++d) {
-                        const bf16x8 vf = read_tr_frag<HD>(sV, sb * 32 + 16 * cp, d * 32, lane);
-                        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[d], 0, 0, 0);
+                    for (int cp = 0; cp < 2; ++cp) {
+                        const bf16x8 pf = pack_frag(s[sb], cp);
+#pragma unroll
+                        for (int d = 0; d < C::NDB; ++d) {
+                            const bf16x8 vf = read_tr_frag<HD>(sV, sb * 32 + 16 * cp, d * 32, lane);
+                            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[d], 0, 0, 0);
+                        }
                     }
-                }
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile's DMA landed (this wave's pieces)
         __syncthreads();
