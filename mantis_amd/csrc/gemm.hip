@@ -614,7 +614,7 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(
         for (int j = 0; j < PPW; ++j) issue1(t, p, j);
     };
     issue(t0, 0); issue(t0, 1); issue(t0, 2); issue(t0, 3);
-    issue(t0 + 1, 0); issue(t0 + 1, 1);
+    issue(t0 + 1, 0); issue(t0 + 1, 1); issue(t0 + 1, 2); issue(t0 + 1, 3);
 
     const unsigned rowoff = (unsigned)(lane & 31) * 128u;
     const unsigned f = ((unsigned)(lane & 31) >> 1) & 7u;
@@ -632,116 +632,96 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(
 #pragma unroll
     for (int i = 0; i < TN; ++i) kxb[i] = klane + ((((unsigned)((wn & 1) * 2 + i)) ^ kj) << 6);
 
-    for (int t = t0; t < t1; ++t) {
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // all but step t+1's parts 0,1 (this wave's 4 newest loads) landed
-        __builtin_amdgcn_s_barrier();
-        const unsigned a_base = lds0 + (unsigned)((4 * t + 2 * wm) % 10) * SLAB;                                  // A half wm
-        const unsigned b_slab = lds0 + (unsigned)((4 * t + 1 + 2 * (wn >> 1)) % 10) * SLAB;                     // B half wn >> 1
-        const unsigned b_base = b_slab + (unsigned)(wn & 1) * 8192u;
-        auto rdB = [&](bf16x8 (&dst)[TN], int ks) {
-            if constexpr (BKM) read_frags_km<TN>(dst, b_slab, kxb, ks);
-            else read_frags<TN>(dst, b_base + xo[ks]);
-        };
-        auto rdA = [&](bf16x8 (&dst)[TM], int ks) {
-            if constexpr (AKM) read_frags_km<TM>(dst, a_base, kxa, ks);
-            else read_frags<TM>(dst, a_base + xo[ks]);
-        };
-        // one fragment (i-th 32-row block) of k-chunk ks
-        auto rdA1 = [&](bf16x8& dst, int i, int ks) {
-            if constexpr (AKM) {
-                if (ks == 0) read_frag_km_asm<0>(dst, a_base + kxa[i]);
-                else if (ks == 1) read_frag_km_asm<1>(dst, a_base + kxa[i]);
-                else if (ks == 2) read_frag_km_asm<2>(dst, a_base + kxa[i]);
-                else read_frag_km_asm<3>(dst, a_base + kxa[i]);
-            } else {
-                if (i == 0) lds_read_b128<0>(dst, a_base + xo[ks]);
-                else if (i == 1) lds_read_b128<4096>(dst, a_base + xo[ks]);
-                else if (i == 2) lds_read_b128<8192>(dst, a_base + xo[ks]);
-                else lds_read_b128<12288>(dst, a_base + xo[ks]);
-            }
-        };
-        auto rdB1 = [&](bf16x8& dst, int i, int ks) {
+    // K loop.  The K-step barrier sits in front of the LAST MFMA cluster of a step, not after it: by then every wave has issued (and,
+    // with the lgkmcnt(0) in front of it, received) all fragment reads of step t, so (a) the slabs of step t are free for refill at
+    // once, (b) the data of step t + 1 -- requested a full K-step earlier -- is visible, and (c) the first fragments of step t + 1
+    // are read in the shadows of cluster 3, so no wave ever waits on LDS latency or barrier skew with an empty MFMA pipe.
+    // Ring state in front of cluster 3 of step t: step t + 1 complete (4 slabs), step t + 2 parts 0,1 in flight (2), step t's 4
+    // slabs released -> refilled with (t+2: 2,3) in cluster 3 and (t+3: 0,1) in the next cluster 0.
+    auto slab_base = [&](int t, unsigned& a_base, unsigned& b_slab, unsigned& b_base) {
+        a_base = lds0 + (unsigned)((4 * t + 2 * wm) % 10) * SLAB;                                  // A half wm
+        b_slab = lds0 + (unsigned)((4 * t + 1 + 2 * (wn >> 1)) % 10) * SLAB;                     // B half wn >> 1
+        b_base = b_slab + (unsigned)(wn & 1) * 8192u;
+    };
+    // memory instruction `op` of the fragment set of k-chunk ks (6 row-major fragments, or up to 12 transposing half reads)
+    constexpr int NOPS = (AKM ? 2 * TM : TM) + (BKM ? 2 * TN : TN);
+    auto frag_op = [&](int op, int ks, int buf, unsigned a_base, unsigned b_slab, unsigned b_base) {
+        constexpr int NB_OPS = BKM ? 2 * TN : TN;
+        if (op < NB_OPS) {
             if constexpr (BKM) {
-                if (ks == 0) read_frag_km_asm<0>(dst, b_slab + kxb[i]);
-                else if (ks == 1) read_frag_km_asm<1>(dst, b_slab + kxb[i]);
-                else if (ks == 2) read_frag_km_asm<2>(dst, b_slab + kxb[i]);
-                else read_frag_km_asm<3>(dst, b_slab + kxb[i]);
-            } else {
-                if (i == 0) lds_read_b128<0>(dst, b_base + xo[ks]);
-                else lds_read_b128<4096>(dst, b_base + xo[ks]);
-            }
-        };
-        // every memory instruction of the K loop sits in the shadow of an MFMA (pinned by sched_barrier): fragment reads of the next
-        // k-chunk and, in the first two clusters, the LDS-DMA pieces that refill the four slabs freed at the barrier
-        if constexpr (AKM && BKM) {
-            // TN: 12 transposing half-reads per k-chunk: two in each of the first four MFMA shadows, one (+ a DMA piece) in the rest
-            auto half = [&](int op, int ks) {       // op 0..11: B0lo B0hi B1lo B1hi A0lo A0hi ... A3hi
-                const int f = op >> 1, h = op & 1;
-                bf16x8& dst = f < TN ? fb[(ks & 1)][f] : fa[(ks & 1)][f - TN];
-                const unsigned addr = f < TN ? b_slab + kxb[f] : a_base + kxa[f - TN];
+                bf16x8& dst = fb[buf][op >> 1];
+                const unsigned addr = b_slab + kxb[op >> 1];
+                const int h = op & 1;
                 if (ks == 0) { if (h) read_half_km_asm<0, 1>(dst, addr); else read_half_km_asm<0, 0>(dst, addr); }
                 else if (ks == 1) { if (h) read_half_km_asm<1, 1>(dst, addr); else read_half_km_asm<1, 0>(dst, addr); }
                 else if (ks == 2) { if (h) read_half_km_asm<2, 1>(dst, addr); else read_half_km_asm<2, 0>(dst, addr); }
                 else { if (h) read_half_km_asm<3, 1>(dst, addr); else read_half_km_asm<3, 0>(dst, addr); }
-            };
-            rdB(fb[0], 0);
-            rdA(fa[0], 0);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int cb = ks & 1;
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int i = 0; i < TN * TM; ++i) {
-                    const int tn = i / TM, tm = i % TM;
-                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cb][tn], fa[cb][tm], acc[tn][tm], 0, 0, 0);
-                    if (ks < 3) {
-                        if (i < 4) { half(2 * i, ks + 1); half(2 * i + 1, ks + 1); }
-                        else half(4 + i, ks + 1);
-                    }
-                    if (i >= 4 && ks < 2) {
-                        const int q = i - 4;
-                        if (ks == 0) issue1(t + 1, 2 + (q >> 1), q & 1);
-                        else issue1(t + 2, (q >> 1), q & 1);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                if (op == 0) lds_read_b128<0>(fb[buf][0], b_base + xo[ks]);
+                else lds_read_b128<4096>(fb[buf][1], b_base + xo[ks]);
             }
         } else {
-            rdB(fb[0], 0);
-            rdA(fa[0], 0);
+            const int o = op - NB_OPS;
+            if constexpr (AKM) {
+                bf16x8& dst = fa[buf][o >> 1];
+                const unsigned addr = a_base + kxa[o >> 1];
+                const int h = o & 1;
+                if (ks == 0) { if (h) read_half_km_asm<0, 1>(dst, addr); else read_half_km_asm<0, 0>(dst, addr); }
+                else if (ks == 1) { if (h) read_half_km_asm<1, 1>(dst, addr); else read_half_km_asm<1, 0>(dst, addr); }
+                else if (ks == 2) { if (h) read_half_km_asm<2, 1>(dst, addr); else read_half_km_asm<2, 0>(dst, addr); }
+                else { if (h) read_half_km_asm<3, 1>(dst, addr); else read_half_km_asm<3, 0>(dst, addr); }
+            } else {
+                if (o == 0) lds_read_b128<0>(fa[buf][0], a_base + xo[ks]);
+                else if (o == 1) lds_read_b128<4096>(fa[buf][1], a_base + xo[ks]);
+                else if (o == 2) lds_read_b128<8192>(fa[buf][2], a_base + xo[ks]);
+                else lds_read_b128<12288>(fa[buf][3], a_base + xo[ks]);
+            }
+        }
+    };
+    // ops spread over the 8 MFMA shadows of a cluster: two per slot first if there are more than 8, then one per slot
+    auto slot_ops = [&](int i, int ks, int buf, unsigned a_base, unsigned b_slab, unsigned b_base) {
+        constexpr int DBL = NOPS > 8 ? NOPS - 8 : 0;     // slots that carry two ops
+        if (i < DBL) { frag_op(2 * i, ks, buf, a_base, b_slab, b_base); frag_op(2 * i + 1, ks, buf, a_base, b_slab, b_base); }
+        else if (DBL + i < NOPS) frag_op(DBL + i, ks, buf, a_base, b_slab, b_base);
+    };
+
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // step t0 landed (this wave's pieces); step t0 + 1 may be in flight
+    __builtin_amdgcn_s_barrier();
+    {
+        unsigned a0, bs0, bb0;
+        slab_base(t0, a0, bs0, bb0);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int cb = ks & 1, nb = cb ^ 1;
-                // the fragments of k-chunk ks were requested a whole MFMA cluster ago (or right after the barrier for ks = 0)
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_setprio(1);
-                // 8 MFMAs; in the shadow of each one an independent instruction: the 6 fragment reads of k-chunk ks + 1 and the two
-                // LDS-DMA pieces that refill a freed slab (pinned by sched_barrier: one MFMA + one memory instruction per slot)
+        for (int op = 0; op < NOPS; ++op) frag_op(op, 0, 0, a0, bs0, bb0);
+    }
+    for (int t = t0; t < t1; ++t) {
+        unsigned a_base, b_slab, b_base, a_next, bs_next, bb_next;
+        slab_base(t, a_base, b_slab, b_base);
+        slab_base(t + 1, a_next, bs_next, bb_next);
 #pragma unroll
-                for (int i = 0; i < TN * TM; ++i) {
-                    const int tn = i / TM, tm = i % TM;
-                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cb][tn], fa[cb][tm], acc[tn][tm], 0, 0, 0);
-                    if (ks < 3) {
-                        if (i < TN) rdB1(fb[nb][i], i, ks + 1);
-                        else if (i < TN + TM) rdA1(fa[nb][i - TN], i - TN, ks + 1);
-                    }
-                    // the four slabs freed at the barrier are all refilled during the first two clusters: the data of step t + 1
-                    // gets ~0.9 K-steps of lead instead of 0.5-0.65 (the counted vmcnt wait at the barrier was 11 % of the loop)
-                    if (i >= 4 && ks < 2) {
-                        const int q = i - 4;
-                        if (ks == 0) issue1(t + 1, 2 + (q >> 1), q & 1);
-                        else issue1(t + 2, (q >> 1), q & 1);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+        for (int ks = 0; ks < 4; ++ks) {
+            const int cb = ks & 1, nb = cb ^ 1;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // fragments of k-chunk ks (requested a cluster ago)
+            if (ks == 3) {
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // all but step t+2's parts 0,1 (this wave's 4 newest pieces) landed
+                __builtin_amdgcn_s_barrier();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < TN * TM; ++i) {
+                const int tn = i / TM, tm = i % TM;
+                acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cb][tn], fa[cb][tm], acc[tn][tm], 0, 0, 0);
+                if (ks < 3) slot_ops(i, ks + 1, nb, a_base, b_slab, b_base);
+                else slot_ops(i, 0, nb, a_next, bs_next, bb_next);            // first fragments of step t + 1, behind the barrier
+                if (i >= 4) {
+                    const int q = i - 4;
+                    if (ks == 3) issue1(t + 2, 2 + (q >> 1), q & 1);         // the slabs of step t were released by the barrier
+                    if (ks == 0) issue1(t + 2, (q >> 1), q & 1);             // (t+2: 0,1) -> slabs (t-1: 2,3), released one barrier ago
                 }
-                __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the trailing zero-page loads ...
