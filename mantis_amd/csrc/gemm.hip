@@ -815,7 +815,7 @@ static int ring_split(long ntiles, int nk, int cus) {
     return best;
 }
 // tile variant by a cost model fitted to measurements (profiles/r01_gemm_experiments.md), in microseconds:
-//   ring 256x256, 1 workgroup/CU: 1.6 per K-step + 5 K-step equivalents per round (prologue, epilogue, launch)
+//   ring 256x256, 1 workgroup/CU: 1.45 per K-step + 5 K-step equivalents per round (prologue, epilogue, launch)
 //   generic 128x128, 2 workgroups/CU: 1.05 per K-step per round of 2 x #CU tiles + 5.2 equivalents
 static int gemm_pick_variant(int M, int N, int K) {
     if (M < 512 || N < 512) return 1;
@@ -823,7 +823,7 @@ static int gemm_pick_variant(int M, int N, int K) {
     const long t256 = (long)cdiv(M, 256) * cdiv(N, 256), t128 = (long)cdiv(M, 128) * cdiv(N, 128);
     const int S = ring_split(t256, nk, cus);
     const long rem = t256 % cus;
-    const double ring = 1.6 * ((double)(t256 / cus) * (nk + 5.0) + (rem ? (double)nk / S + 5.0 + (S > 1 ? 8.0 + 1.7 * S : 0.0) : 0.0));
+    const double ring = 1.45 * ((double)(t256 / cus) * (nk + 5.0) + (rem ? (double)nk / S + 5.0 + (S > 1 ? 8.0 + 1.7 * S : 0.0) : 0.0));
     const double gen = 1.05 * (double)((t128 + 2 * cus - 1) / (2 * cus)) * (nk + 5.2);
     return ring <= gen ? 12 : 1;
 }
