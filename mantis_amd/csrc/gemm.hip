@@ -713,11 +713,11 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(
                 acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cb][tn], fa[cb][tm], acc[tn][tm], 0, 0, 0);
                 if (ks < 3) slot_ops(i, ks + 1, nb, a_base, b_slab, b_base);
                 else slot_ops(i, 0, nb, a_next, bs_next, bb_next);            // first fragments of step t + 1, behind the barrier
-                if (i >= 4) {
-                    const int q = i - 4;
-                    if (ks == 3) issue1(t + 2, 2 + (q >> 1), q & 1);         // the slabs of step t were released by the barrier
-                    if (ks == 0) issue1(t + 2, (q >> 1), q & 1);             // (t+2: 0,1) -> slabs (t-1: 2,3), released one barrier ago
-                }
+                // refill: (t+2: 2,3) right behind the barrier that released the slabs of step t (needed one step later: a full K-step
+                // of lead); (t+2: 0,1), which go to slabs released one barrier earlier, two pieces each in clusters 1 and 2
+                if (i >= 4 && ks == 3) { const int q = i - 4; issue1(t + 2, 2 + (q >> 1), q & 1); }
+                if (i >= 6 && ks == 1) issue1(t + 2, 0, i - 6);
+                if (i >= 6 && ks == 2) issue1(t + 2, 1, i - 6);
                 __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_s_setprio(0);
