@@ -6,23 +6,24 @@
 // (transformers/models/llama/modeling_llama.py:163-176,229-280,438-492) -- which today run in cuBLAS/hipBLASLt.
 //
 // Structure (MFMA-bound, fp32 accumulate):
-//   * BM x BN output tile per workgroup (256x256 with 8 waves of 128x64, or 128x128 with 4 waves of 64x64 for small / badly
-//     quantised shapes); every wave tile is built from v_mfma_f32_32x32x16_bf16 blocks
-//   * K step 64; A/B tiles go HBM -> LDS with global_load_lds (16 B per lane, no VGPR round trip), double buffered,
-//     one barrier per K step
-//   * LDS image [rows][64 k]: 16-B chunk c of row r sits at slot c ^ ((r >> 1) & 7): two rows share a 256-B bank row, so the
-//     16 rows of a ds_read_b128 lane group hit 16 distinct slots (conflict free).  global_load_lds writes lane-linearly,
-//     so the swizzle is applied on the SOURCE address and again on the fragment read (cdna guide rule 21)
-//   * ring kernel (256x256): fragment reads are issued one k-step ahead of the MFMAs that consume them (hand-placed
-//     ds_read_b128 / ds_read_b64_tr_b16 + counted lgkmcnt), MFMA clusters run at raised wave priority, the next tiles'
-//     global_load_lds are spread between the MFMA clusters, and the only vector-memory wait is a counted vmcnt(4)
+//   * BM x BN output tile per workgroup: 256x256 with 8 waves of 128x64 (ring kernel, 1 workgroup/CU), or 128x128 with 4 waves
+//     of 64x64 (generic kernel, 2 workgroups/CU) for small shapes; every wave tile is built from v_mfma_f32_32x32x16_bf16 blocks
+//   * K step 64; A/B tiles go HBM -> LDS by LDS-DMA (16 B per lane, no VGPR round trip).  LDS image [rows][64 k]: 16-B chunk c
+//     of row r sits at slot c ^ ((r >> 1) & 7) (conflict-free ds_read_b128); the DMA writes lane-linearly, so the swizzle is
+//     applied on the SOURCE address and again on the fragment read (cdna guide rule 21)
+//   * ring kernel: the whole 160 KiB LDS is a ring of ten 16-KiB slabs.  DMA = buffer_load_dwordx4 ... lds with a descriptor,
+//     per-lane offsets fixed per tile and a scalar K-step offset (no address arithmetic in the loop, out-of-range lanes read
+//     zeros).  Every memory instruction of the loop sits in the shadow of an MFMA (hand-placed asm reads, sched_barrier pins,
+//     counted vmcnt / lgkmcnt), the K-step barrier stands in front of the LAST MFMA cluster of a step so the next step's first
+//     fragments and the slab refill ride behind it, and the data of a step is requested a full K-step before it is needed
 //   * operands may be K-major ([K, rows]): dX = dY.W reads the weight as stored, dW = dY^T.X reads both activations as
 //     stored; fragments then come from a [k][rows] LDS image through the hardware-transposing ds_read_b64_tr_b16
-//   * measured dead ends (profiles/r01_gemm_experiments.md): BK=32 ping-pong / strictly alternating wave groups with a
-//     20-slab ring, one 128x128 wave tile per SIMD, 256x128 and 128x256 tiles -- all slower than the ring kernel
-//   * operands are fed swapped (mfma(a = B rows, b = A rows)) so each lane owns ONE output row m and 4 consecutive n:
-//     the epilogue (bias, GELU variants, residual add, grad accumulation) is 8-byte vector loads/stores
-//   * edges: rows beyond M/N are clamped on load and predicated on store; K tails read a zero page (K % 8 == 0)
+//   * tiles of an incomplete last round are split along K (deterministic slab reduction); epilogue through wave-private LDS
+//     strips (bias, GELUs, residual, grad accumulation, fused SwiGLU backward) with 16-B coalesced global accesses
+//   * measured dead ends (profiles/r01_gemm_experiments.md): BK=32 ping-pong / strictly alternating wave groups, one 128x128
+//     wave tile per SIMD, 256x128 / 128x256 tiles, persistent workgroups, stream-K, explicit L2 prefetch, sc1 slabs
+//   * operands are fed swapped (mfma(a = B rows, b = A rows)) so each lane owns ONE output row m and 4 consecutive n
+//   * edges: rows beyond M/N are clamped on load and predicated on store; K tails read zeros (K % 8 == 0)
 //   * workgroup -> tile map is XCD-aware (contiguous tile range per XCD, 8-row groups) so the tiles resident on one XCD
 //     share A/B panels in that XCD's private 4 MiB L2
 // Algorithmic FLOPs per launch: 2*M*N*K.
