@@ -725,7 +725,7 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // retire the trailing zero-page loads ...
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // retire the trailing DMA pieces and the last cluster's fragment reads ...
     __syncthreads();                                   // ... and every wave's fragment reads: the LDS becomes epilogue scratch
 
     if (bid >= full) {
