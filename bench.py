@@ -28,7 +28,7 @@ FLOP_PER_SAMPLE = 1.351e14      # SURVEY.md section 8d (ViT fwd x1, projector + 
 PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 # memory-side bytes per GEMM launch (rocprofv3 --pmc FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE, separate passes, averaged over
 # the 497 GEMM launches of one cfg2 step): profiles/r01_e_pmc_hbm.md.  Offline PMC measurement of this same command, not live.
-GEMM_HBM_BYTES_PER_LAUNCH_CFG2 = 9.28e8
+GEMM_HBM_BYTES_PER_LAUNCH_CFG2 = 9.74e8
 GEMM_ALGO_BYTES_PER_LAUNCH_CFG2 = 3.04e8
 
 
