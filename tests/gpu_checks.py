@@ -257,9 +257,11 @@ def check_attn_bwd(B, L, H, Hkv, hd, causal, mask):
 
 ATTN_FWD_CASES = [(2, 54, 4, 2, 16, True, "right"), (2, 54, 4, 2, 16, True, "left"), (3, 17, 4, 4, 16, False, None),
                   (2, 197, 12, 12, 64, False, None), (2, 577, 16, 16, 72, False, None), (1, 323, 12, 12, 64, True, None),
-                  (1, 700, 8, 2, 128, True, "right"), (1, 128, 4, 1, 128, True, None), (1, 129, 2, 2, 64, True, "left")]
+                  (1, 700, 8, 2, 128, True, "right"), (1, 128, 4, 1, 128, True, None), (1, 129, 2, 2, 64, True, "left"),
+                  (1, 300, 4, 4, 128, False, "right"), (2, 193, 4, 2, 128, False, None)]
 ATTN_BWD_CASES = [(2, 54, 4, 2, 16, True, "right"), (2, 54, 4, 2, 16, True, "left"), (1, 323, 12, 12, 64, True, None),
-                  (1, 300, 8, 2, 128, True, "right"), (1, 129, 2, 2, 64, True, None), (2, 40, 2, 2, 16, False, None)]
+                  (1, 300, 8, 2, 128, True, "right"), (1, 129, 2, 2, 64, True, None), (2, 40, 2, 2, 16, False, None),
+                  (1, 200, 4, 2, 128, False, "left"), (2, 130, 4, 4, 128, False, None)]
 
 
 # ------------------------------------------------------------------------------------------------------------- packing / CE
