@@ -90,11 +90,13 @@ int mantis_gemm_pick_variant(int M, int N, int K);
 int mantis_attn_fwd(const void* Q, const void* K, const void* V, const int32_t* kmask, void* O, float* LSE, int B, int L, int H,
                     int Hkv, int hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale, int causal, void* stream);
 int mantis_attn_dsum(const void* dO, const void* O, float* Dsum, int B, int L, int H, int hd, int64_t ldo, void* stream);
-/* workspace: 2*B*L*H*hd bf16 when H > Hkv (per-query-head dK/dV partials, reduced over the GQA group), else unused */
-int mantis_attn_bwd(const void* Q, const void* K, const void* V, const void* dO, const int32_t* kmask, const float* LSE,
-                    const float* Dsum, void* dQ, void* dK, void* dV, void* workspace, int B, int L, int H, int Hkv, int hd,
-                    int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, float scale,
-                    int causal, void* stream);
+/* workspace: 2*B*L*H*hd bf16 when H > Hkv (per-query-head dK/dV partials, reduced over the GQA group), else unused.
+ * O (forward output, row stride ld_out) optional: if given, Dsum = rowsum(dO * O) is computed inside the dQ kernel and written to
+ * Dsum ([B,H,L] fp32); if NULL, Dsum must already hold it (mantis_attn_dsum). */
+int mantis_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const int32_t* kmask,
+                    const float* LSE, float* Dsum, void* dQ, void* dK, void* dV, void* workspace, int B, int L, int H, int Hkv,
+                    int hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ld_out, int64_t ldo, int64_t lddq, int64_t lddk,
+                    int64_t lddv, float scale, int causal, void* stream);
 
 /* ---- loss: modeling_llava.py:521-537 (shift + mask filter resolved by mantis_pack_plan into ce_row / ce_tgt) */
 int mantis_ce_fwd_bwd(void* logits, const int32_t* targets, int R, int V, int64_t ld, float grad_scale, float loss_scale,

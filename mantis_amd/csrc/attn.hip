@@ -451,8 +451,9 @@ template <int HD, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                           const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
                                                           const int* __restrict__ kmask, const float* __restrict__ LSE,
-                                                          const float* __restrict__ Dsum, bf16_t* __restrict__ dQ, int L, int H,
-                                                          int Hkv, long ldq, long ldk, long ldv, long ldo, long lddq, float scale) {
+                                                          float* __restrict__ Dsum, bf16_t* __restrict__ dQ, int L, int H,
+                                                          int Hkv, long ldq, long ldk, long ldv, long ldo, long lddq, float scale,
+                                                          const bf16_t* __restrict__ Ofwd, long ldout) {
     using C = AttnCfg<HD>;
     using Y = Lay<HD>;
     constexpr int TILE = 64 * Y::PITCH;
@@ -482,7 +483,27 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
         dof[ks] = as_bf16x8(w);
     }
     const float lse2 = LSE[((long)b * H + h) * L + qc] * LOG2E;
-    const float dsum = Dsum[((long)b * H + h) * L + qc];
+    // D = rowsum(dO * O): given, or (Ofwd != nullptr) computed here from the dO fragments already in registers -- the lane pair
+    // (l, l + 32) covers the row's head dimension -- and published for the dK/dV kernel that runs after this one
+    float dsum;
+    if (Ofwd != nullptr) {
+        float part = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < C::NKS; ++ks) {
+            const int ch = ks * 2 + hh;
+            if (ch * 8 < HD) {
+                const u32x4 o = *reinterpret_cast<const u32x4*>(Ofwd + ((long)b * L + qc) * ldout + (long)h * HD + ch * 8);
+                union { bf16x8 f; u32x4 u; } dv;
+                dv.f = dof[ks];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) part += bf2f_lo(o[e]) * bf2f_lo(dv.u[e]) + bf2f_hi(o[e]) * bf2f_hi(dv.u[e]);
+            }
+        }
+        dsum = part + __shfl_xor(part, 32, 64);
+        if (hh == 0 && q < L) Dsum[((long)b * H + h) * L + q] = dsum;
+    } else {
+        dsum = Dsum[((long)b * H + h) * L + qc];
+    }
     f32x16 acc[C::NDB];
 #pragma unroll
     for (int d = 0; d < C::NDB; ++d)
@@ -815,8 +836,9 @@ static int launch_fwd(bool causal, dim3 grid, hipStream_t s, const bf16_t* Q, co
 
 template <int HD>
 static int launch_bwd(bool causal, hipStream_t s, const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* dO,
-                      const int* kmask, const float* LSE, const float* Dsum, bf16_t* dQ, bf16_t* dK, bf16_t* dV, bf16_t* ws, int B,
-                      int L, int H, int Hkv, long ldq, long ldk, long ldv, long ldo, long lddq, long lddk, long lddv, float scale) {
+                      const int* kmask, const float* LSE, float* Dsum, bf16_t* dQ, bf16_t* dK, bf16_t* dV, bf16_t* ws, int B,
+                      int L, int H, int Hkv, long ldq, long ldk, long ldv, long ldo, long lddq, long lddk, long lddv, float scale,
+                      const bf16_t* Ofwd, long ldout) {
     const dim3 gq(cdiv(L, 128) * H * B), gk(cdiv(L, DkvCfg<HD>::KEYS) * H * B);
     const int G = H / Hkv;
     const long rows = (long)B * L;
@@ -825,12 +847,12 @@ static int launch_bwd(bool causal, hipStream_t s, const bf16_t* Q, const bf16_t*
     const long ldpk = G == 1 ? lddk : (long)H * HD, ldpv = G == 1 ? lddv : (long)H * HD;
     if (causal) {
         hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, true>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, L, H, Hkv, ldq,
-                           ldk, ldv, ldo, lddq, scale);
+                           ldk, ldv, ldo, lddq, scale, Ofwd, ldout);
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, true>), gk, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, pk, pv, L, H, Hkv,
                            ldq, ldk, ldv, ldo, ldpk, ldpv, scale);
     } else {
         hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, false>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, L, H, Hkv, ldq,
-                           ldk, ldv, ldo, lddq, scale);
+                           ldk, ldv, ldo, lddq, scale, Ofwd, ldout);
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, false>), gk, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, pk, pv, L, H, Hkv,
                            ldq, ldk, ldv, ldo, ldpk, ldpv, scale);
     }
@@ -877,17 +899,20 @@ int mantis_attn_dsum(const void* dO, const void* O, float* Dsum, int B, int L, i
 
 // dQ/dK/dV written with row strides lddq/lddk/lddv (head h at column h*hd).  workspace: 2 * B*L*H*hd bf16 when H > Hkv
 // (per-query-head dK/dV partials, summed over the GQA group afterwards), unused otherwise.
-int mantis_attn_bwd(const void* Q, const void* K, const void* V, const void* dO, const int32_t* kmask, const float* LSE,
-                    const float* Dsum, void* dQ, void* dK, void* dV, void* workspace, int B, int L, int H, int Hkv, int hd,
-                    int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, float scale,
-                    int causal, void* stream) {
-    if (B <= 0 || L <= 0 || H <= 0 || Hkv <= 0 || H % Hkv) return MANTIS_EINVAL;
-    if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8 || lddq % 4 || lddk % 8 || lddv % 8) return MANTIS_EUNSUPPORTED;
+// O (optional): the forward output [B*L, H*hd] (row stride ld_out).  If given, D = rowsum(dO * O) is computed inside the dQ kernel and
+// written to Dsum (then a [B,H,L] fp32 scratch/output); if NULL, Dsum must hold it already (mantis_attn_dsum).
+int mantis_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const int32_t* kmask,
+                    const float* LSE, float* Dsum, void* dQ, void* dK, void* dV, void* workspace, int B, int L, int H, int Hkv,
+                    int hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ld_out, int64_t ldo, int64_t lddq, int64_t lddk,
+                    int64_t lddv, float scale, int causal, void* stream) {
+    if (B <= 0 || L <= 0 || H <= 0 || Hkv <= 0 || H % Hkv || !Dsum) return MANTIS_EINVAL;
+    if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8 || lddq % 4 || lddk % 8 || lddv % 8 || (O && ld_out % 8)) return MANTIS_EUNSUPPORTED;
     if (H != Hkv && !workspace) return MANTIS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
 #define BWD(HD) return launch_bwd<HD>(causal != 0, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dO, \
                                       kmask, LSE, Dsum, (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV, (bf16_t*)workspace, B, L, H, Hkv, \
-                                      (long)ldq, (long)ldk, (long)ldv, (long)ldo, (long)lddq, (long)lddk, (long)lddv, scale)
+                                      (long)ldq, (long)ldk, (long)ldv, (long)ldo, (long)lddq, (long)lddk, (long)lddv, scale, \
+                                      (const bf16_t*)O, (long)ld_out)
     switch (hd) {
         case 16: BWD(16);
         case 64: BWD(64);

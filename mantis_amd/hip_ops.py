@@ -244,8 +244,7 @@ def attn_fwd(qkv, B, Lseq, H, Hkv, hd, kmask, scale, causal, want_lse=True):
 def attn_bwd(qkv, o, do, lse, B, Lseq, H, Hkv, hd, kmask, scale, causal):
     """Returns dqkv [B*L, (H+2Hkv)*hd] (gradient w.r.t. the post-RoPE q, k and v)."""
     ld = qkv.stride(0)
-    dsum = torch.empty((B, H, Lseq), dtype=torch.float32, device=qkv.device)
-    _lib.check(_L.mantis_attn_dsum(_p(do), _p(o), _p(dsum), B, Lseq, H, hd, do.stride(0), _stream()), "attn_dsum")
+    dsum = torch.empty((B, H, Lseq), dtype=torch.float32, device=qkv.device)     # rowsum(dO * O): filled by the dQ kernel
     dqkv = torch.empty_like(qkv)
     ws = torch.empty((2, B * Lseq, H * hd), dtype=BF16, device=qkv.device) if H != Hkv else None
     q_ptr = qkv.data_ptr()
@@ -255,8 +254,8 @@ def attn_bwd(qkv, o, do, lse, B, Lseq, H, Hkv, hd, kmask, scale, causal):
     dk_ptr = dq_ptr + H * hd * 2
     dv_ptr = dq_ptr + (H + Hkv) * hd * 2
     ldd = dqkv.stride(0)
-    rc = _L.mantis_attn_bwd(q_ptr, k_ptr, v_ptr, _p(do), _p(kmask), _p(lse), _p(dsum), dq_ptr, dk_ptr, dv_ptr, _p(ws), B, Lseq, H,
-                            Hkv, hd, ld, ld, ld, do.stride(0), ldd, ldd, ldd, float(scale), int(causal), _stream())
+    rc = _L.mantis_attn_bwd(q_ptr, k_ptr, v_ptr, _p(o), _p(do), _p(kmask), _p(lse), _p(dsum), dq_ptr, dk_ptr, dv_ptr, _p(ws), B, Lseq,
+                            H, Hkv, hd, ld, ld, ld, o.stride(0), do.stride(0), ldd, ldd, ldd, float(scale), int(causal), _stream())
     _lib.check(rc, f"attn_bwd hd={hd}")
     return dqkv
 

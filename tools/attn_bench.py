@@ -33,7 +33,7 @@ def main():
     fl = 4.0 * L * L * hd / 2 * B * H          # causal forward FLOPs
     tf = timed(lambda: K.attn_fwd(qkv, B, L, H, Hkv, hd, kmask, scale, True))
     tb = timed(lambda: K.attn_bwd(qkv, o, do, lse, B, L, H, Hkv, hd, kmask, scale, True))
-    print(f"attn fwd {tf:7.1f} us = {fl / tf / 1e6:6.0f} TF | bwd (dsum+dq+dkv+reduce) {tb:7.1f} us = {2.5 * fl / tb / 1e6:6.0f} TF")
+    print(f"attn fwd {tf:7.1f} us = {fl / tf / 1e6:6.0f} TF | bwd (dq incl. rowsum(dO*O) + dkv + reduce) {tb:7.1f} us = {2.5 * fl / tb / 1e6:6.0f} TF")
 
 
 if __name__ == "__main__":
