@@ -92,8 +92,11 @@ class LlavaEngine:
         I = 0
         N = 1
         if pixel_values is not None and T != 1:
-            if isinstance(pixel_values, (list, tuple)):        # modeling_llava.py:431-432
-                pixel_values = torch.cat([p for p in pixel_values if p is not None], dim=0)
+            if isinstance(pixel_values, (list, tuple)):        # modeling_llava.py:431-432 (torch.cat of the per-sample list)
+                # H2D per sample, concatenation on the device: a host-side torch.cat of a few MB costs ~30 ms on a 128-core host
+                # (thread-pool start-up) -- more than the whole tiny-config step
+                parts = [p.to(dev, non_blocking=True) for p in pixel_values if p is not None]
+                pixel_values = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
             pix = pixel_values.to(dev, non_blocking=True).to(torch.float32).contiguous()
             I = pix.shape[0]
             feats, N = self.vision_forward(pix, record)
