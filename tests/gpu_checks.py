@@ -452,6 +452,36 @@ def check_model_step_projector_only(case):
     return 1.0 - min(c for c, _ in rep.values())
 
 
+def check_training_step_contract(ga):
+    """Trainer.training_step on the HIP path vs the values the reference returned (goldens): loss / GA per micro-batch, gradients
+    accumulated over the GA window (EPI_ACCUM epilogues), then the fused clip + AdamW step runs."""
+    from mantis_amd.trainer import MantisHipTrainer
+    from mantis_amd.optim import FusedAdamW
+    z = Hh.load_case(f"siglip_training_step_ga{ga}")
+    model, _, _ = Hh.build_product_model("siglip", DEV)
+    tr = MantisHipTrainer(model, gradient_accumulation_steps=ga)
+    losses = []
+    for i in range(ga):
+        batch = dict(input_ids=torch.from_numpy(z[f"mb{i}.input_ids"]), attention_mask=torch.from_numpy(z[f"mb{i}.attention_mask"]),
+                     labels=torch.from_numpy(z[f"mb{i}.labels"]), pixel_values=Hh.pixels_list(z, f"mb{i}."))
+        out = tr.training_step(model, batch)
+        assert out.dim() == 0 and not out.requires_grad and out.is_cuda
+        losses.append(float(out))
+    assert np.allclose(losses, z["returned_losses"], rtol=2e-2), (losses, z["returned_losses"])
+    worst = 1.0
+    for k in z.files:
+        if k.startswith("grad."):
+            worst = min(worst, Hh.cosine(model._param(k[5:]).grad.float().cpu().numpy(), z[k]))
+    assert worst > 0.98, worst
+    before = model.arena.clone()
+    opt = FusedAdamW(model, lr=1e-3, weight_decay=0.0, max_grad_norm=1.0)
+    opt.step()
+    opt.zero_grad(set_to_none=True)
+    assert torch.isfinite(model.arena.float()).all() and not torch.equal(before, model.arena)
+    assert all(p.grad is None for p in model.parameters())
+    return 1.0 - worst
+
+
 def all_checks():
     """name -> thunk, in dependency order (cheap and fundamental first)."""
     c = {}
@@ -490,6 +520,8 @@ def all_checks():
     c["optim"] = check_optim
     for case in MODEL_CASES:
         c["model_step_" + case] = (lambda case=case: check_model_step(case))
+    c["training_step_contract_ga1"] = lambda: check_training_step_contract(1)
+    c["training_step_contract_ga4"] = lambda: check_training_step_contract(4)
     c["model_step_projector_only_siglip"] = lambda: check_model_step_projector_only("siglip_b2_equal_rightpad")
     c["model_step_projector_only_clip"] = lambda: check_model_step_projector_only("clip_b2_equal_rightpad")
     return c
