@@ -137,3 +137,22 @@ def test_state_dict_names_match_reference():
     own = {n for n, _ in model.named_parameters()}
     ref = {k for k in sd if ".head." not in k}
     assert own == ref
+
+
+def test_stock_hf_trainer_subclass(cpu_backend, tmp_path):
+    """`as_hf_trainer()` is a transformers.Trainer whose training_step is the fused one: constructed like the reference does
+    (train_mllava.py:312-319), it returns the value the reference's Trainer returned for the same micro-batch (golden)."""
+    transformers = pytest.importorskip("transformers")
+    from mantis_amd.trainer import as_hf_trainer
+    z = Hh.load_case("siglip_training_step_ga1")
+    model, _, _ = Hh.build_product_model("siglip", "cpu")
+    args = transformers.TrainingArguments(output_dir=str(tmp_path), use_cpu=True, report_to=[], remove_unused_columns=False,
+                                          gradient_accumulation_steps=1)
+    trainer = as_hf_trainer()(model=model, args=args)
+    trainer.current_gradient_accumulation_steps = 1
+    batch = dict(input_ids=torch.from_numpy(z["mb0.input_ids"]), attention_mask=torch.from_numpy(z["mb0.attention_mask"]),
+                 labels=torch.from_numpy(z["mb0.labels"]), pixel_values=Hh.pixels_list(z, "mb0."))
+    out = trainer.training_step(model, batch)
+    assert out.dim() == 0 and not out.requires_grad
+    assert abs(float(out) - float(z["returned_losses"][0])) < 2e-2 * float(z["returned_losses"][0])
+    assert model._param("multi_modal_projector.linear_1.weight").grad is not None
