@@ -28,7 +28,8 @@ extern "C" {
  *   /root/reference/mantis/models/mllava/modeling_llava.py:293-360 (integer plan, bit-exact) and the loss row filter
  *   of :521-527.  L = max_b (#<image> in row b) * (num_patches-1) + T is computed by the caller (:301).
  * src[B,L]: -1 padding slot | t (text token column) | (1<<30)|r (image-feature row r).
- * status[0]: 0 ok, 1 image-slot count mismatch (reference raises ValueError :347-351), 2 L mismatch;
+ * status[0]: 0 ok, 1 image-slot count mismatch (reference raises ValueError :347-351), 2 L mismatch (every plan
+ * output is then left in a safe all-padding state: nothing to gather, no CE rows);
  * status[1] = slots found, status[2] = #<image> tokens, status[3] = left_padding (:296). */
 int mantis_pack_plan(const int64_t* input_ids, const int64_t* attention_mask, const int64_t* labels /*nullable*/, int B,
                      int T, int num_patches, int num_images, int64_t image_token_index, int64_t pad_token_id,
@@ -98,7 +99,9 @@ int mantis_attn_bwd(const void* Q, const void* K, const void* V, const void* O, 
                     int hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ld_out, int64_t ldo, int64_t lddq, int64_t lddk,
                     int64_t lddv, float scale, int causal, void* stream);
 
-/* ---- loss: modeling_llava.py:521-537 (shift + mask filter resolved by mantis_pack_plan into ce_row / ce_tgt) */
+/* ---- loss: modeling_llava.py:521-537 (shift + mask filter resolved by mantis_pack_plan into ce_row / ce_tgt).
+ * count_out is int32[2]: [0] rows with 0 <= target < V (the mean's denominator), [1] rows with target >= V (torch's
+ * CrossEntropyLoss raises on those; here they are excluded from loss, gradient and denominator and reported). */
 int mantis_ce_fwd_bwd(void* logits, const int32_t* targets, int R, int V, int64_t ld, float grad_scale, float loss_scale,
                       int write_grad, float* row_loss_ws, float* row_lse_out /*nullable*/, int32_t* count_out,
                       float* loss_out, void* stream);

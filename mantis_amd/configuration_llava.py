@@ -54,8 +54,15 @@ class LlavaConfig:
             text_config = text_config.to_dict()
         if text_config:
             t.update(text_config)
-            if "rope_parameters" in text_config and "rope_theta" in text_config["rope_parameters"]:
-                t["rope_theta"] = text_config["rope_parameters"]["rope_theta"]
+            rp = text_config.get("rope_parameters") or {}
+            if "rope_theta" in rp:
+                t["rope_theta"] = rp["rope_theta"]
+            # only the default rotary embedding is built (HF:models/llama/modeling_llama.py:95-110); llama3 / linear / dynamic /
+            # yarn scaling would silently change the numerics, so refuse instead of ignoring
+            scaling = text_config.get("rope_scaling")
+            kinds = [rp.get("rope_type"), rp.get("type")] + ([scaling.get("rope_type"), scaling.get("type")] if scaling else [])
+            if any(k not in (None, "default") for k in kinds) or (scaling and not any(kinds)):
+                raise NotImplementedError(f"rope scaling {scaling or rp!r}: only the default RoPE is implemented on this path")
             self.vocab_size = t["vocab_size"]          # configuration_llava.py:125
         if t["num_key_value_heads"] is None:
             t["num_key_value_heads"] = t["num_attention_heads"]

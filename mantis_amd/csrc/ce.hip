@@ -12,12 +12,20 @@
 
 #define CE_THREADS 1024
 
-__global__ void ce_count_kernel(const int* __restrict__ tgt, int R, int* __restrict__ count) {
+// count[0] = rows with a usable target (0 <= t < V): the mean's denominator.  count[1] = rows whose target is >= V: the
+// reference (torch CrossEntropyLoss) raises on those; here they contribute neither loss nor gradient nor to the denominator and
+// are reported so the host can raise.
+__global__ void ce_count_kernel(const int* __restrict__ tgt, int R, int V, int* __restrict__ count) {
     __shared__ float red[16];
-    float c = 0.f;
-    for (int i = threadIdx.x; i < R; i += blockDim.x) c += (tgt[i] >= 0) ? 1.f : 0.f;
+    float c = 0.f, bad = 0.f;
+    for (int i = threadIdx.x; i < R; i += blockDim.x) {
+        const int t = tgt[i];
+        c += (t >= 0 && t < V) ? 1.f : 0.f;
+        bad += (t >= V) ? 1.f : 0.f;
+    }
     c = block_sum(c, red);
-    if (threadIdx.x == 0) *count = (int)(c + 0.5f);
+    bad = block_sum(bad, red);
+    if (threadIdx.x == 0) { count[0] = (int)(c + 0.5f); count[1] = (int)(bad + 0.5f); }
 }
 
 // logits: [R, ld] bf16, overwritten with dlogits = (softmax - onehot) * gscale / count (zeros for ignored rows)
@@ -95,14 +103,15 @@ __global__ void ce_finish_kernel(const float* __restrict__ row_loss, const int* 
 extern "C" {
 
 // logits [R, ld] bf16 (ld % 8 == 0, columns >= V are scratch); targets int32 (<0 = ignored).  Writes
-//   loss_out[0] = loss_scale * mean_over_valid(lse - logit[target]),   count_out[0] = number of valid rows,
+//   loss_out[0] = loss_scale * mean_over_valid(lse - logit[target]),   count_out[0] = number of valid rows (0 <= t < V),
+//   count_out[1] = number of rows with an out-of-range target (t >= V; the reference raises on those),
 //   and (write_grad) overwrites logits with d(loss_scale_grad * mean CE)/dlogits.
 int mantis_ce_fwd_bwd(void* logits, const int32_t* targets, int R, int V, int64_t ld, float grad_scale, float loss_scale,
                       int write_grad, float* row_loss_ws, float* row_lse_out, int32_t* count_out, float* loss_out,
                       void* stream) {
     if (R <= 0 || V <= 0 || ld % 8 || ld < V) return MANTIS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(1024), 0, s, targets, R, count_out);
+    hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(1024), 0, s, targets, R, V, count_out);
     hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(R), dim3(CE_THREADS), 0, s, (bf16_t*)logits, targets, count_out, row_loss_ws,
                        row_lse_out, V, (long)ld, grad_scale, write_grad);
     hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(1024), 0, s, row_loss_ws, count_out, R, loss_out, loss_scale);

@@ -71,7 +71,14 @@ __global__ __launch_bounds__(PLAN_THREADS) void pack_plan_kernel(
     const int Lc = sh_kmax * (N - 1) + T;
     if (tid == 0) { status[2] = total_img_tokens; status[3] = left; status[1] = 0; status[0] = 0; }
     if (Lc != L) {
+        // host/device disagreement on the merged length: leave every plan output in a SAFE state (all padding, nothing to
+        // gather, no CE rows) so that downstream gather/scatter kernels cannot index out of bounds; the host sees status 2.
         if (tid == 0) status[0] = 2;
+        for (long i = tid; i < (long)B * L; i += PLAN_THREADS) {
+            src[i] = -1; out_mask[i] = 0; out_labels[i] = IGN; out_pos[i] = 1; kmask[i] = 0;
+        }
+        for (long i = tid; i < (long)B * T; i += PLAN_THREADS) { text_pos[i] = -1; ce_row[i] = -1; ce_tgt[i] = -100; }
+        for (long i = tid; i < (long)num_images * N; i += PLAN_THREADS) img_slot[i] = -1;
         return;
     }
     const int perT = (T + PLAN_THREADS - 1) / PLAN_THREADS;

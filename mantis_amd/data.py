@@ -9,6 +9,11 @@ Reference behaviour:
       right-pad input_ids with pad_token_id, attention_mask with 0, labels with -100; `pixel_values` stays a LIST with one
       [n_i, 3, H, W] tensor per sample.  The reference asserts a single sample per batch (:279); this collator accepts
       any batch size (vectorised numpy), which is what configs[1]/[2] (bs = 2 per GPU) need.
+  * sample packing                           /root/reference/mantis/train/data.py:1546-1671 (PackingDataset.pack_batch)
+      several samples concatenated into ONE row: ids [1, sum T_i], a block-diagonal 4-D attention mask (block i = sample i's
+      key mask broadcast over its query rows), position ids restarting at 0 per sample, labels concatenated.
+      `pack_samples` reproduces those outputs and adds the compact form the gfx950 attention kernels consume instead of the
+      O(L^2) mask: `segment_ids` [1, sum T_i] (+ `cu_seqlens`).
 String-level work (chat templates, tokenisation, PIL) stays with the caller's tokenizer/processor: inputs here are token ids."""
 import numpy as np
 import torch
@@ -69,3 +74,47 @@ class Collator:
         batch = dict(input_ids=torch.from_numpy(out_ids), attention_mask=torch.from_numpy(mask), labels=torch.from_numpy(labels))
         batch["pixel_values"] = pix if pix else None
         return batch
+
+
+def _row(x, dtype=np.int64):
+    a = np.asarray(x.numpy() if isinstance(x, torch.Tensor) else x, dtype=dtype)
+    return a.reshape(-1)
+
+
+def pack_samples(samples, materialize_mask=True):
+    """PackingDataset.pack_batch (data.py:1609-1671) for samples with `input_ids` [1,T_i] or [T_i], optional `attention_mask`,
+    `labels`, `pixel_values`.  Returns
+        input_ids      int64 [1, S]            S = sum T_i                                   (:1612)
+        attention_mask int32 [1, 1, S, S]      block-diagonal; block i = sample i's key mask on every query row (:1627-1638);
+                                               None when materialize_mask=False (S = 5624 would be 126 MB nobody reads)
+        position_ids   int64 [S]               arange(T_i) per sample                        (:1641-1648)
+        labels         int64 [1, S]            the reference concatenates along dim 0, which for its [1,T] items only works for
+                                               equal T_i and yields [n, T]; row-major that is this [1, S] vector
+        pixel_values   tensor [sum n_i, ...] (tensors concatenated, :1619-1621) / list / None
+        segment_ids    int32 [1, S], cu_seqlens int32 [n+1], key_mask int64 [1, S]  -- compact equivalents of the 4-D mask"""
+    ids = [_row(s["input_ids"]) for s in samples]
+    lens = [len(x) for x in ids]
+    S = int(sum(lens))
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    keym = [(_row(s["attention_mask"]) if s.get("attention_mask") is not None else np.ones(t, np.int64)) for s, t in zip(samples, lens)]
+    labels = [(_row(s["labels"]) if s.get("labels") is not None else np.full(t, IGNORE_INDEX, np.int64)) for s, t in zip(samples, lens)]
+    out = dict(input_ids=torch.from_numpy(np.concatenate(ids))[None],
+               position_ids=torch.from_numpy(np.concatenate([np.arange(t, dtype=np.int64) for t in lens])),
+               labels=torch.from_numpy(np.concatenate(labels))[None],
+               segment_ids=torch.from_numpy(np.repeat(np.arange(len(lens), dtype=np.int32), lens))[None],
+               cu_seqlens=torch.from_numpy(cu), key_mask=torch.from_numpy(np.concatenate(keym))[None])
+    mask = None
+    if materialize_mask:
+        mask = torch.zeros((1, 1, S, S), dtype=torch.int32)
+        for i, t in enumerate(lens):
+            a, b = int(cu[i]), int(cu[i + 1])
+            mask[0, 0, a:b, a:b] = torch.from_numpy(keym[i]).to(torch.int32)[None, :].expand(t, t)
+    out["attention_mask"] = mask
+    pv = [s.get("pixel_values") for s in samples]
+    if all(p is None for p in pv):
+        out["pixel_values"] = None
+    elif isinstance(next(p for p in pv if p is not None), (list, tuple)):
+        out["pixel_values"] = sum([list(p or []) for p in pv], []) or None
+    else:
+        out["pixel_values"] = torch.cat([torch.as_tensor(p) for p in pv if p is not None], dim=0)
+    return out

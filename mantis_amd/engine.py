@@ -11,10 +11,15 @@ autograd graph.  Reference control flow being reproduced:
 Work the reference does that this engine does not (results identical): the last ViT layer + post_layernorm + pooling head
 (dead), the [B,L,V] logits tensor (only rows that can carry a label reach lm_head), 27 kept ViT hidden states.
 """
+import os
+
 import numpy as np
 import torch
 
 from . import hip_ops as K   # the ONLY compute backend; tests may monkeypatch `engine.K` with the oracle to test host logic
+
+
+_DEBUG_SYNC = os.environ.get("MANTIS_DEBUG_SYNC") == "1"
 
 
 class PackCountError(ValueError):
@@ -30,6 +35,24 @@ class LlavaEngine:
     def __init__(self, model):
         self.m = model
         self.cfg = model.config
+        # device-side status words (pack plan status, out-of-range CE targets) are read back -- one host sync -- on the first
+        # step of an engine and on every step under MANTIS_DEBUG_SYNC=1; the hot loop otherwise never syncs.
+        self._verified = False
+
+    def _verify_device_status(self, plan, count):
+        st = plan.status.cpu().tolist()
+        if st[0] == 2:
+            raise RuntimeError(f"pack_plan: host and device disagree on the merged length (host L={plan.L}); plan left in the safe "
+                               f"all-padding state")
+        if st[0] == 1:
+            raise PackCountError(
+                f"The input provided to the model are wrong. The number of image tokens is {st[2]} while the number of image "
+                f"given to the model is {plan.I} ({st[1]} image slots found for {plan.I * plan.N} feature rows). This prevents "
+                f"correct indexing and breaks batch generation.")
+        if count is not None and int(count[1]) != 0:
+            raise IndexError(f"{int(count[1])} label(s) are >= vocab_size {self.cfg.text_config.vocab_size} "
+                             f"(torch.nn.CrossEntropyLoss: 'Target out of bounds')")
+        self._verified = True
 
     # ------------------------------------------------------------------------------------------------ vision tower (frozen)
     def vision_forward(self, pixels, record=None):
@@ -175,6 +198,8 @@ class LlavaEngine:
             nf, rstdf = K.rmsnorm_fwd(h_ce, m.lm["norm"], eps)
             logits = K.gemm_nt(nf, m.lm["head"], ldc=Vp)              # [B*T, Vp]
             loss, count = K.ce_fwd_bwd(logits, plan.ce_tgt, V, grad_scale, loss_scale, write_grad=compute_grads)
+            if not self._verified or _DEBUG_SYNC:
+                self._verify_device_status(plan, count)
         out = dict(loss=loss, logits=logits_full, plan=plan)
         if not compute_grads:
             return out

@@ -326,10 +326,11 @@ def embed_grad(dmerged, input_ids, plan, grad_weight, accumulate):
 
 
 def ce_fwd_bwd(logits, targets, V, grad_scale, loss_scale, write_grad=True):
-    """logits [R, ld>=pad8(V)] bf16 -> overwritten with dlogits; returns (loss[1] fp32, count[1] int32)."""
+    """logits [R, ld>=pad8(V)] bf16 -> overwritten with dlogits; returns (loss[1] fp32, count[2] int32 = [valid rows,
+    rows with an out-of-range target])"""
     R = logits.shape[0]
     ws = torch.empty((R,), dtype=torch.float32, device=logits.device)
-    count = torch.empty((1,), dtype=torch.int32, device=logits.device)
+    count = torch.empty((2,), dtype=torch.int32, device=logits.device)
     loss = torch.empty((1,), dtype=torch.float32, device=logits.device)
     rc = _L.mantis_ce_fwd_bwd(_p(logits), _p(targets), R, V, logits.stride(0), float(grad_scale), float(loss_scale),
                               int(write_grad), _p(ws), None, _p(count), _p(loss), _stream())

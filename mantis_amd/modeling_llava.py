@@ -118,6 +118,7 @@ class LlavaForConditionalGeneration(nn.Module):
             self._attach(name, p)
         self.grad_arena = None
         self._grad_offs = None
+        self._param_version = 0      # bumped whenever parameter VALUES are replaced wholesale (init / checkpoint load)
         self.engine = _engine.LlavaEngine(self)
         self._build_views()
         if init == "normal":
@@ -207,6 +208,7 @@ class LlavaForConditionalGeneration(nn.Module):
     def reset_parameters(self, seed=0):
         """normal(0, initializer_range), norm weights 1, biases 0 (modeling_llava.py:150-170 / HF _init_weights)."""
         std = self.config.text_config.get("initializer_range", 0.02)
+        self._param_version += 1
         gen = torch.Generator(device=self.device).manual_seed(seed)
         for name, p in self.named_parameters():
             if p.dim() == 1 and "class_embedding" not in name:
@@ -246,6 +248,7 @@ class LlavaForConditionalGeneration(nn.Module):
                 t = torch.as_tensor(v)
                 own[k2].copy_(t.to(own[k2].dtype).reshape(own[k2].shape))
                 seen.add(k2)
+        self._param_version += 1          # optimizers holding fp32 master copies re-snapshot (optim.FusedAdamW.step)
         missing = [k for k in own if k not in seen]
         if strict and missing:
             raise KeyError(f"missing keys: {missing[:5]}...")
@@ -383,13 +386,18 @@ class LlavaForConditionalGeneration(nn.Module):
 
 class _FusedStep(torch.autograd.Function):
     """Bridge for callers that drive the model through autograd (stock `Trainer.training_step`: `loss.backward()`).
-    forward runs the fused forward+backward into a scratch gradient arena; backward adds `grad_output * scratch` to
-    `.grad`.  (MantisHipTrainer bypasses this and accumulates in place with the right scale.)"""
+    forward runs the fused forward+backward into a scratch gradient arena (and clears the live arena when it follows a
+    `zero_grad(set_to_none=True)`); backward adds `grad_output * scratch` to `.grad`.  (MantisHipTrainer bypasses this
+    and accumulates in place with the right scale.)"""
 
     @staticmethod
     def forward(ctx, model, input_ids, attention_mask, labels, pixel_values, need_logits, record, anchor):
-        model._ensure_grad_arena()
+        # True = every trainable .grad was None (the state after Trainer's model.zero_grad()): the arena views that were just
+        # re-attached still hold the PREVIOUS step's gradients and this backward must overwrite them, not add to them.
+        overwrite = model._ensure_grad_arena()
         live = model.grad_arena
+        if overwrite:
+            live.zero_()
         scratch = torch.zeros_like(live)
         # run the step with gradients redirected into `scratch`
         model.grad_arena = scratch
@@ -412,5 +420,7 @@ class _FusedStep(torch.autograd.Function):
     def backward(ctx, grad_out):
         model, scratch = ctx.model, ctx.scratch
         model._ensure_grad_arena()
-        model.grad_arena.add_(scratch, alpha=float(grad_out))   # compatibility path only (one host sync)
+        # grad_out stays on the device (0-d fp32; torch multiplies the bf16 arena by it in fp32): no host sync
+        model.grad_arena.add_(scratch.mul_(grad_out.to(torch.float32)))
+        ctx.scratch = None
         return (None,) * 8

@@ -23,8 +23,7 @@ class FusedAdamW:
         self.master = torch.empty(n, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
-        for p_off, g_off, cnt in self._segments:
-            self.master[g_off:g_off + cnt].copy_(model.arena[p_off:p_off + cnt])
+        self.resync_master()
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.last_grad_norm = None
 
@@ -41,8 +40,20 @@ class FusedAdamW:
                 segs.append((po, go, cnt))
         return segs
 
+    def resync_master(self):
+        """Re-snapshot the fp32 master weights from the bf16 parameter arena.  Needed whenever parameter values are replaced
+        behind the optimizer's back (`load_reference_state_dict`, `reset_parameters`): `step()` writes bf16(master) over
+        the parameters, so a stale master would silently undo the load.  `step()` calls this itself when the model's
+        `_param_version` moved; Adam moments are kept."""
+        m = self.model
+        for p_off, g_off, cnt in self._segments:
+            self.master[g_off:g_off + cnt].copy_(m.arena[p_off:p_off + cnt])
+        self._seen_version = getattr(m, "_param_version", 0)
+
     def step(self):
         m = self.model
+        if getattr(m, "_param_version", 0) != self._seen_version:
+            self.resync_master()
         self.step_count += 1
         scale = None
         if self.max_grad_norm is not None and self.max_grad_norm > 0:

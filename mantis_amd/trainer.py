@@ -28,21 +28,30 @@ class MantisHipTrainer:
                              "(input_ids, attention_mask, labels, pixel_values)")
         return inputs
 
-    def training_step(self, model, inputs, num_items_in_batch=None):
-        """-> 0-dim detached loss tensor on the model's device, already divided by the accumulation steps."""
+    def training_step(self, model, inputs, num_items_in_batch=None, sync=None):
+        """-> 0-dim detached loss tensor on the model's device, already divided by the accumulation steps.
+
+        sync: is this micro-batch the accumulation boundary (gradients are all-reduced across ranks during its backward)?
+        None = count micro-batches (`micro % GA == 0`), which is right for loops that always run whole GA windows; loops that
+        can close a window early (HF closes one on the last batch of an epoch, trainer.py `do_sync_step`) must pass it --
+        `as_hf_trainer()` passes `accelerator.sync_gradients`, the flag torch DDP's `no_sync` follows in the reference
+        (HF:trainer.py:1744-1757)."""
         model.train()
         inputs = self._prepare_inputs(inputs)
         ga = max(1, int(self.current_gradient_accumulation_steps))
         overwrite = model._ensure_grad_arena()
         self._micro += 1
-        sync = self.reducer is not None and (self._micro % ga == 0)
-        hook = self.reducer.bucket_ready if sync else None
-        if sync:
+        boundary = (self._micro % ga == 0) if sync is None else bool(sync)
+        if boundary:
+            self._micro = 0                 # the optimizer steps after this micro-batch: the next window starts at 0
+        reduce_now = self.reducer is not None and boundary
+        hook = self.reducer.bucket_ready if reduce_now else None
+        if reduce_now:
             self.reducer.begin()
         out = model.engine.step(inputs["input_ids"], inputs["attention_mask"], inputs.get("labels"),
                                 inputs.get("pixel_values"), grad_scale=1.0 / ga, loss_scale=1.0 / ga, compute_grads=True,
                                 overwrite_grads=overwrite, on_bucket_ready=hook)
-        if sync:
+        if reduce_now:
             self.reducer.finish()
         return out["loss"].reshape(()).detach()
 
@@ -59,6 +68,10 @@ def as_hf_trainer():
                 impl = self._mantis_impl = MantisHipTrainer(model, ga, getattr(self, "mantis_reducer", None))
             impl.current_gradient_accumulation_steps = ga
             inner = model.module if hasattr(model, "module") else model
-            return impl.training_step(inner, inputs, num_items_in_batch)
+            # the loop's own notion of the accumulation boundary (set before every training_step call by HF's inner loop,
+            # including the short window at the end of an epoch) -- never a private counter
+            acc = getattr(self, "accelerator", None)
+            sync = None if acc is None else bool(acc.sync_gradients)
+            return impl.training_step(inner, inputs, num_items_in_batch, sync=sync)
 
     return MantisHipHFTrainer

@@ -278,9 +278,22 @@ class LlavaRef:
         return loss.detach()
 
 
-def random_weights(cfg, seed=0, std=0.02, dtype=torch.float32):
+def random_weights(cfg, seed=0, std=0.02, dtype=torch.float32, perturb_1d=0.0):
     """Random-init weights with the reference's shapes/names (normal(0, initializer_range), norm weights 1, biases 0;
-    /root/reference/mantis/models/mllava/modeling_llava.py:150-170) for the CPU-baseline leg of bench.py."""
+    /root/reference/mantis/models/mllava/modeling_llava.py:150-170) for the CPU-baseline leg of bench.py.
+    perturb_1d > 0 (cfg1 fixture): afterwards every bias gets N(0, perturb_1d) and every norm weight 1 + N(0, perturb_1d) from a
+    second seeded stream, so a dropped bias / norm weight shows up in parity (the main stream is unchanged)."""
+    w = _random_weights(cfg, seed, std, dtype)
+    if perturb_1d:
+        g2 = torch.Generator().manual_seed(seed + 7919)
+        for k in sorted(w):
+            if w[k].dim() == 1 and "class_embedding" not in k:
+                base = 1.0 if ("norm" in k and k.endswith("weight")) else 0.0
+                w[k] = (base + perturb_1d * torch.randn(w[k].shape, generator=g2)).to(dtype)
+    return w
+
+
+def _random_weights(cfg, seed, std, dtype):
     g = torch.Generator().manual_seed(seed)
     vc, tc = cfg["vision"], cfg["text"]
     dv, iv, P, C = vc["hidden_size"], vc["intermediate_size"], vc["patch_size"], vc.get("num_channels", 3)

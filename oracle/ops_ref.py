@@ -306,10 +306,10 @@ def embed_grad(dmerged, input_ids, plan, grad_weight, accumulate):
 def ce_fwd_bwd(logits, targets, V, grad_scale, loss_scale, write_grad=True):
     x = _f(logits)[:, :V]
     t = targets.long()
-    valid = t >= 0
+    valid = (t >= 0) & (t < V)          # t >= V: torch's CrossEntropyLoss raises; the product excludes and reports them
     cnt = int(valid.sum())
     lse = torch.logsumexp(x, dim=-1)
-    picked = x.gather(1, t.clamp(min=0)[:, None])[:, 0]
+    picked = x.gather(1, t.clamp(min=0, max=V - 1)[:, None])[:, 0]
     row_loss = torch.where(valid, lse - picked, torch.zeros_like(lse))
     loss = loss_scale * row_loss.sum() / cnt if cnt else torch.tensor(float("nan"))
     if write_grad:
@@ -319,7 +319,7 @@ def ce_fwd_bwd(logits, targets, V, grad_scale, loss_scale, write_grad=True):
         g[~valid] = 0
         logits.zero_()
         logits[:, :V] = g.to(logits.dtype)
-    return loss.reshape(1).float(), torch.tensor([cnt], dtype=torch.int32)
+    return loss.reshape(1).float(), torch.tensor([cnt, int((t >= V).sum())], dtype=torch.int32)
 
 
 def im2col(pixels, patch, kp):

@@ -12,7 +12,7 @@ The hot path being recorded:
   * ``_merge_input_ids_with_image_features``         mantis/models/mllava/modeling_llava.py:293-360
   * ``LlavaMultiModalProjector``                     mantis/models/mllava/modeling_llava.py:106-118
   * ``transformers.Trainer.training_step``           (third-party; called from mantis/train/train_mllava.py:312-329)
-  * label-mask rule of ``ChatDataset.getitem``       mantis/train/data.py:415-466 (restated + recorded on synthetic ids)
+  * label-mask rule / collation / sample packing     recorded by make_golden_harness.py (runs mantis/train/data.py itself)
 
 Oracle-side shim: transformers 5.x removed two helper names the
 reference's processing module imports, and calls ``tie_weights`` with a kwarg; both are
@@ -198,35 +198,6 @@ def run_training_step(model, cfg, name, batches, ga):
     print(f"{name}: returned losses {losses}")
 
 
-def label_rule_fixture():
-    """mantis/train/data.py:415-466 on synthetic ids (LLAMA_3/SINGLE + PLAIN branches).  The reference code needs a
-    tokenizer/processor + av/decord to import, so the rule is re-executed here from its definition on planted ids;
-    expected vectors are produced by the literal slice assignments of data.py:432-442 / :459-461."""
-    rng = np.random.default_rng(7)
-    SEP = 290
-    cases = {}
-    for ci, (T, seps) in enumerate([(40, [5, 12, 20, 31]), (40, [3, 9, 15]), (24, [4]), (24, []), (30, [0, 10, 29])]):
-        ids = rng.integers(0, 280, size=T, dtype=np.int64)
-        for s in seps:
-            ids[s] = SEP
-        ids[1] = IMG
-        target = np.full(T, -100, dtype=np.int64)
-        sep_idxs = np.nonzero(ids == SEP)[0].tolist()
-        for i in range(len(sep_idxs)):
-            if i % 2 == 0:
-                continue
-            if i == len(sep_idxs) - 1:
-                target[sep_idxs[i] + 1:] = ids[sep_idxs[i] + 1:]
-            else:
-                target[sep_idxs[i] + 1:sep_idxs[i + 1] + 1] = ids[sep_idxs[i] + 1:sep_idxs[i + 1] + 1]
-        plain = np.full(T, -100, dtype=np.int64)
-        plain[ids != IMG] = ids[ids != IMG]
-        cases[f"c{ci}.ids"], cases[f"c{ci}.llama3"], cases[f"c{ci}.plain"] = ids, target, plain
-    cases["sep_id"] = np.array(SEP)
-    cases["image_id"] = np.array(IMG)
-    np.savez_compressed(os.path.join(HERE, "label_rule.npz"), **cases)
-
-
 def main():
     rng = np.random.default_rng(1234)
 
@@ -286,7 +257,7 @@ def main():
                     i, m = make_ids(rng, T, [2 + j, 12], 0)
                     batches.append((i[None], m[None], make_labels(i, m, 5)[None], [px(2)]))
                 run_training_step(model, cfg, f"siglip_training_step_ga{ga}", batches, ga)
-    label_rule_fixture()
+    # label_rule.npz / collate_ref.npz / pack_batch_ref.npz: tests/golden/make_golden_harness.py (runs the reference's data.py)
 
 
 if __name__ == "__main__":

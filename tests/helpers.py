@@ -90,3 +90,23 @@ def check_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-3, grad_c
             continue
         assert c >= grad_cos and r <= grad_rel, (name, c, r)
     return report
+
+
+def load_cfg1():
+    """cfg1 (Mantis-tiny) fixture recorded from the reference (tests/golden/make_golden_cfg1.py): returns (meta, weights as
+    bf16-rounded fp32 tensors regenerated from the stored seed, a z-like dict with the inputs, the fixture itself)."""
+    from oracle.llava_ref import random_weights
+    f = np.load(os.path.join(G, "cfg1_mantis_tiny_step.npz"))
+    meta = json.loads(str(f["meta"]))
+    w = {k: v.to(torch.bfloat16).float() for k, v in random_weights(meta, seed=int(f["weight_seed"]), perturb_1d=0.05).items()}
+    pix = torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(int(f["pixel_seed"])))
+    z = dict(input_ids=f["input_ids"], attention_mask=f["attention_mask"], labels=f["labels"], pixel_values=pix.numpy(),
+             pixel_counts=np.array([1]))
+    return meta, w, z, f
+
+
+class ZDict(dict):
+    """dict with the `.files` attribute of an NpzFile (pixels_list / check_step_against_oracle accept either)."""
+    @property
+    def files(self):
+        return list(self.keys())

@@ -1,0 +1,170 @@
+"""CPU regression tests for the round-1 advisor findings and for the optimizer oracle pin.
+
+Host logic runs on the product code with the oracle operators monkeypatched in place of the HIP backend (as in
+tests/test_engine_host_logic.py); the `-m gpu` twins of the stateful ones live in tests/gpu_checks.py."""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as Hh
+
+
+@pytest.fixture()
+def cpu_backend(monkeypatch):
+    import mantis_amd.engine as eng
+    import mantis_amd.optim as opt
+    from oracle import ops_ref
+    monkeypatch.setattr(eng, "K", ops_ref)
+    monkeypatch.setattr(opt, "K", ops_ref)
+    return eng
+
+
+def _batch(z, prefix=""):
+    return dict(input_ids=torch.from_numpy(z[prefix + "input_ids"]), attention_mask=torch.from_numpy(z[prefix + "attention_mask"]),
+                labels=torch.from_numpy(z[prefix + "labels"]), pixel_values=Hh.pixels_list(z, prefix))
+
+
+def test_autograd_bridge_does_not_accumulate_across_zero_grad(cpu_backend):
+    """ADVICE high: backward, zero_grad(set_to_none=True), backward on the same batch must give the SAME gradients, not 2x
+    (stock HF loop: trainer.py:1796 `model.zero_grad()` between optimizer steps)."""
+    z = Hh.load_case("siglip_b1_img2_adjacent")
+    model, _, _ = Hh.build_product_model("siglip", "cpu")
+    batch = _batch(z)
+    model(**batch).loss.backward()
+    g1 = {n: p.grad.float().clone() for n, p in model.named_parameters() if p.requires_grad}
+    model.zero_grad(set_to_none=True)
+    model(**batch).loss.backward()
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            assert torch.equal(p.grad.float(), g1[n]), f"{n}: stale gradient leaked through zero_grad (ratio "\
+                f"{float(p.grad.float().norm() / (g1[n].norm() + 1e-30)):.3f})"
+    # and WITHOUT zero_grad the bridge accumulates like autograd does (GA inside a stock loop)
+    model(**batch).loss.backward()
+    n = "language_model.lm_head.weight"
+    assert abs(float(model._param(n).grad.float().norm() / g1[n].norm()) - 2.0) < 2e-2
+
+
+class _FakeReducer:
+    def __init__(self):
+        self.log = []
+
+    def begin(self):
+        self.log.append("begin")
+
+    def bucket_ready(self, key):
+        pass
+
+    def finish(self):
+        self.log.append("finish")
+
+
+def test_explicit_sync_boundary_overrides_and_resets_the_counter(cpu_backend):
+    """ADVICE medium: with GA=4, HF closes a short window on the last batch of an epoch (do_sync_step).  That micro-batch must be
+    reduced, and the next window must again be 4 micro-batches long (counter back in phase)."""
+    from mantis_amd.trainer import MantisHipTrainer
+    z = Hh.load_case("siglip_training_step_ga1")
+    model, _, _ = Hh.build_product_model("siglip", "cpu")
+    red = _FakeReducer()
+    tr = MantisHipTrainer(model, gradient_accumulation_steps=4, reducer=red)
+    b = _batch(z, "mb0.")
+    tr.training_step(model, b, sync=False)
+    tr.training_step(model, b, sync=True)            # short window closes after 2 micro-batches
+    assert red.log == ["begin", "finish"]
+    for _ in range(3):                               # private counter now: 3 micro-batches do not sync ...
+        tr.training_step(model, b)
+    assert red.log == ["begin", "finish"]
+    tr.training_step(model, b)                       # ... the 4th does
+    assert red.log == ["begin", "finish"] * 2
+
+
+def test_hf_trainer_subclass_takes_the_boundary_from_the_accelerator(cpu_backend, tmp_path):
+    transformers = pytest.importorskip("transformers")
+    from mantis_amd.trainer import as_hf_trainer
+    z = Hh.load_case("siglip_training_step_ga1")
+    model, _, _ = Hh.build_product_model("siglip", "cpu")
+    args = transformers.TrainingArguments(output_dir=str(tmp_path), use_cpu=True, report_to=[], remove_unused_columns=False,
+                                          gradient_accumulation_steps=4)
+    trainer = as_hf_trainer()(model=model, args=args)
+    trainer.current_gradient_accumulation_steps = 4
+    red = trainer.mantis_reducer = _FakeReducer()
+    b = _batch(z, "mb0.")
+    trainer.accelerator.gradient_state._set_sync_gradients(False)
+    trainer.training_step(model, dict(b))
+    assert red.log == []
+    trainer.accelerator.gradient_state._set_sync_gradients(True)      # what HF's loop does on the last batch of an epoch
+    trainer.training_step(model, dict(b))
+    assert red.log == ["begin", "finish"]
+
+
+def test_rope_scaling_is_refused():
+    from mantis_amd.configuration_llava import LlavaConfig
+    base = dict(model_type="llama", hidden_size=64, intermediate_size=176, num_hidden_layers=1, num_attention_heads=4, vocab_size=300)
+    LlavaConfig(text_config=dict(base, rope_scaling=None))
+    LlavaConfig(text_config=dict(base, rope_parameters=dict(rope_theta=5e5, rope_type="default")))
+    for bad in (dict(rope_scaling=dict(rope_type="llama3", factor=8.0)), dict(rope_scaling=dict(type="linear", factor=2.0)),
+                dict(rope_parameters=dict(rope_theta=5e5, rope_type="dynamic", factor=2.0))):
+        with pytest.raises(NotImplementedError):
+            LlavaConfig(text_config=dict(base, **bad))
+
+
+def test_out_of_range_label_is_reported_not_averaged_in(cpu_backend):
+    """ADVICE low: a label >= vocab_size must not silently enlarge the CE denominator; the engine raises like torch does."""
+    z = Hh.load_case("siglip_b1_img1")
+    model, _, _ = Hh.build_product_model("siglip", "cpu")
+    b = _batch(z)
+    lab = b["labels"].clone()
+    t = int(torch.nonzero(lab[0] >= 0)[0])
+    lab[0, t] = 300 + 5
+    with pytest.raises(IndexError):
+        model.engine.step(b["input_ids"], b["attention_mask"], lab, b["pixel_values"], compute_grads=False)
+
+
+def test_optimizer_master_follows_a_checkpoint_loaded_after_construction(cpu_backend):
+    """ADVICE low: FusedAdamW snapshots fp32 masters at construction; a later load_reference_state_dict must not be undone by
+    the first step()."""
+    from mantis_amd.optim import FusedAdamW
+    model, _, sd = Hh.build_product_model("siglip", "cpu")
+    model._ensure_grad_arena()
+    opt = FusedAdamW(model, lr=1e-3, max_grad_norm=None)
+    sd2 = {k: v * 0.5 for k, v in sd.items()}
+    model.load_reference_state_dict(sd2)
+    want = model._param("language_model.lm_head.weight").detach().float().clone()
+    model.grad_arena.zero_()                          # zero gradient: the step must leave the (new) parameters where they are
+    opt.step()
+    got = model._param("language_model.lm_head.weight").detach().float()
+    assert torch.equal(got, want)
+
+
+# ------------------------------------------------------------------------------------------------ optimizer oracle pin (row f2)
+def test_adamw_and_clip_oracle_match_torch():
+    """The reference's optimizer step is `clip_grad_norm_(1.0)` + `torch.optim.AdamW` (HF:trainer.py:2535-2545, :1785-1796;
+    hyper-parameters of mantis/train/scripts/train_mllava.sh:162-165: lr 1e-5, wd 0).  Pin oracle/ops_ref.adamw_flat +
+    clip_scale to torch itself over 4 steps, with and without weight decay, on fp32 parameters (the fp32 master copy is what
+    torch would hold)."""
+    from oracle import ops_ref as R
+    for wd, lr in ((0.0, 1e-5), (0.01, 1e-3)):
+        g = torch.Generator().manual_seed(3)
+        shapes = [(37, 16), (64,), (8, 8, 3)]
+        params = [torch.randn(s, generator=g) for s in shapes]
+        tp = [torch.nn.Parameter(p.clone()) for p in params]
+        opt = torch.optim.AdamW(tp, lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
+        n = sum(p.numel() for p in params)
+        master = torch.cat([p.reshape(-1) for p in params]).clone()
+        m, v = torch.zeros(n), torch.zeros(n)
+        pbf = master.to(torch.bfloat16)
+        for step in (1, 2, 3, 4):
+            grads = [torch.randn(s, generator=g) * (3.0 if step % 2 else 0.01) for s in shapes]     # clipped and unclipped steps
+            gb = [x.to(torch.bfloat16) for x in grads]                                               # the arena holds bf16 gradients
+            for p, x in zip(tp, gb):
+                p.grad = x.float().clone()
+            total = torch.nn.utils.clip_grad_norm_(tp, 1.0)
+            opt.step()
+            flat = torch.cat([x.reshape(-1) for x in gb])
+            ss = torch.zeros(1)
+            R.grad_sumsq(flat, ss)
+            scale, norm = R.clip_scale(ss, 1.0)
+            assert abs(float(norm) - float(total)) <= 1e-6 * float(total)
+            R.adamw_flat(pbf, flat, master, m, v, lr, 0.9, 0.999, 1e-8, wd, step, grad_scale=scale)
+            ref = torch.cat([p.detach().reshape(-1) for p in tp])
+            assert torch.allclose(master, ref, rtol=2e-6, atol=1e-7), (wd, step, float((master - ref).abs().max()))
+            assert torch.equal(pbf, master.to(torch.bfloat16))

@@ -1,4 +1,4 @@
-"""CPU tests: batch producer (label rule vs the reference-derived fixture, collation) and the data-parallel gradient
+"""CPU tests: batch producer (label rule, collation and sample packing vs fixtures recorded from the reference's own data.py) and the data-parallel gradient
 reducer on 2 ranks over gloo (the N > 1 path of bench.py / MantisHipTrainer)."""
 import os
 import socket
@@ -33,6 +33,38 @@ def test_collator_right_pads_ragged_samples():
     assert b["labels"].tolist() == [[-100, -100, 3, 4, 5], [-100, 8, -100, -100, -100]]
     assert isinstance(b["pixel_values"], list) and [p.shape[0] for p in b["pixel_values"]] == [1, 1]   # surplus image dropped
     assert b["input_ids"].dtype == torch.int64
+
+
+def test_collator_matches_the_reference_collator_fixture():
+    """collate_ref.npz = output of the reference's Collator (data.py:1392-1527) on three ragged samples."""
+    from mantis_amd.data import Collator
+    z = Hh.load_case("collate_ref")
+    n = int(z["n"])
+    samples = [dict(input_ids=z[f"s{i}.input_ids"][0], labels=z[f"s{i}.labels"][0], pixel_values=z[f"s{i}.pixel_values"]) for i in range(n)]
+    b = Collator(pad_token_id=int(z["pad_token_id"]), image_token_id=298)(samples)
+    for k in ("input_ids", "attention_mask", "labels"):
+        assert np.array_equal(b[k].numpy(), z[f"out.{k}"]), k
+    assert np.array_equal(torch.cat(b["pixel_values"], 0).numpy(), z["out.pixel_values"])
+
+
+@pytest.mark.parametrize("case", ["eq", "ragged"])
+def test_pack_samples_matches_the_reference_pack_batch_fixture(case):
+    """pack_batch_ref.npz = output of the reference's PackingDataset.pack_batch (data.py:1609-1671)."""
+    from mantis_amd.data import pack_samples
+    z = Hh.load_case("pack_batch_ref")
+    n = int(z[f"{case}.n"])
+    samples = [{k: torch.from_numpy(z[f"{case}.s{i}.{k}"]) for k in ("input_ids", "attention_mask", "labels", "pixel_values")}
+               for i in range(n)]
+    out = pack_samples(samples)
+    for k in ("input_ids", "attention_mask", "position_ids", "pixel_values"):
+        assert np.array_equal(out[k].numpy(), z[f"{case}.out.{k}"]), k
+        assert out[k].dtype == torch.from_numpy(z[f"{case}.out.{k}"]).dtype, k
+    assert np.array_equal(out["labels"].numpy().reshape(-1), z[f"{case}.out.labels"].reshape(-1))
+    # the compact form carries the same information as the 4-D mask
+    seg, km = out["segment_ids"][0], out["key_mask"][0]
+    dense = ((seg[:, None] == seg[None, :]) & (km[None, :] != 0)).to(torch.int32)
+    assert torch.equal(dense, out["attention_mask"][0, 0])
+    assert pack_samples(samples, materialize_mask=False)["attention_mask"] is None
 
 
 def _free_port():

@@ -15,7 +15,7 @@ from oracle.llava_ref import LlavaRef
 
 G = os.path.join(os.path.dirname(__file__), "golden")
 CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(G, "*.npz"))
-               if not os.path.basename(p).startswith(("weights_", "label_rule", "siglip_training_step")))
+               if not os.path.basename(p).startswith(("weights_", "label_rule", "siglip_training_step", "cfg1_", "collate_ref", "pack_batch_ref", "idefics2_")))
 
 
 def _pixels(z):
@@ -120,3 +120,27 @@ def test_pack_rows_copy_is_bit_exact():
     assert np.array_equal(plan["attention_mask"], z["merged_attention_mask"])
     assert np.array_equal(plan["position_ids"], z["merged_position_ids"])
     assert np.array_equal(plan["labels"], z["merged_labels"])
+
+
+def test_oracle_matches_cfg1_reference_fixture():
+    """cfg1 = BASELINE.json configs[0] at full size (SigLIP-base/16-224 + Llama-68M, 1 image, 128 tokens): the oracle reproduces the
+    loss, logits statistics and every per-parameter gradient norm the REFERENCE's Trainer.training_step produced on the same
+    seeded weights and batch (tests/golden/make_golden_cfg1.py)."""
+    import json
+    from oracle.llava_ref import LlavaRef
+    from tests import helpers as Hh
+    meta, w, z, f = Hh.load_cfg1()
+    model = LlavaRef(w, meta)
+    model.zero_grad()
+    loss, logits = model.forward(z["input_ids"], [torch.from_numpy(z["pixel_values"])], z["attention_mask"], z["labels"])
+    loss.backward()
+    assert abs(float(loss) - float(f["loss"])) <= 2e-6 * float(f["loss"]) and float(f["loss"]) == pytest.approx(float(f["returned_loss"]), rel=1e-6)
+    assert tuple(logits.shape) == tuple(f["logits_shape"])
+    lg = logits.detach().double()
+    assert abs(float(lg.abs().mean()) - float(f["logits_abs_mean"])) <= 1e-5 * float(f["logits_abs_mean"])
+    assert np.allclose(lg[0, -1, :64].numpy(), f["logits_row0"], atol=2e-5)
+    names = json.loads(str(f["grad_names"]))
+    for n, want in zip(names, f["grad_norms"]):
+        got = float(model.w[n].grad.double().norm())
+        assert abs(got - want) <= 2e-4 * want + 1e-9, (n, got, want)
+    assert {n for n in model.w if model.w[n].grad is not None} == set(names)
