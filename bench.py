@@ -8,12 +8,18 @@
 One step = one `MantisHipTrainer.training_step` (ViT forward, projector, packing, 32-layer Llama-3 forward + backward,
 gradient all-reduce over RCCL when N > 1) followed by the fused clip + AdamW update (`--no-optimizer` times the bare
 training_step boundary of the reference, transformers/trainer.py:1892-1963).  Weak scaling: 2 samples per GPU
-(4 images 336x336 + 512 text tokens each -> merged length 2812), synthetic inputs and random-init weights.
+(4 images 336x336 + 512 text tokens each -> merged length 2812), random-init weights, and a FRESH synthetic batch every step
+(the loss stays at ~ln V = 11.76, it cannot be memorised away, so the timed backward sees random-init operands).
 
 Prints ONE JSON line (rank 0) with the driver's fields plus
-  roofline      dominant kernel (the bf16 MFMA GEMM): algorithmic FLOPs / HIP-event time per launch, live in the timed steps
+  ms_per_step_median / p10 / p90   per-step HIP-event durations over the K timed steps
+  roofline      dominant kernel (the bf16 MFMA GEMM family): algorithmic FLOPs / HIP-event time per launch, live in the timed
+                steps; `traffic` (memory-side bytes per launch) and `mfma_busy_pct` come from the tracked PMC summary
+                profiles/r02_pmc_step.json written by tools/pmc_step_report.py from rocprofv3 passes of this same command
   cpu_baseline  the oracle's CPU restatement of the same training_step ("port"), timed on this host's cores on a bounded
-                sample (1 sample, 1 ViT + {1,2} LLM layers + lm_head) and extrapolated linearly in depth
+                sample (1 sample, 1 ViT + {1,2} LLM layers + lm_head) and extrapolated linearly in depth; fp32 is `value`,
+                the bf16 leg is reported beside it
+  dp            (N > 1) buckets / bytes per step and the time the compute stream waited for RCCL (exposed communication)
 """
 import argparse
 import json
@@ -26,10 +32,7 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_SAMPLE = 1.351e14      # SURVEY.md section 8d (ViT fwd x1, projector + LLM fwd+bwd x3, causal attention at 1/2)
 PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
-# memory-side bytes per GEMM launch (rocprofv3 --pmc FETCH_SIZE x2 [gfx950 correction] + WRITE_SIZE, separate passes, averaged over
-# the 497 GEMM launches of one cfg2 step): profiles/r01_e_pmc_hbm.md.  Offline PMC measurement of this same command, not live.
-GEMM_HBM_BYTES_PER_LAUNCH_CFG2 = 9.74e8
-GEMM_ALGO_BYTES_PER_LAUNCH_CFG2 = 3.04e8
+PMC_JSON = os.path.join(ROOT, "profiles", "r02_pmc_step.json")   # tools/pmc_step_report.py output (offline PMC passes, tracked)
 
 
 def synthetic_batch(cfg, B, T, n_img, img_hw, rank, step=0):
@@ -46,6 +49,15 @@ def synthetic_batch(cfg, B, T, n_img, img_hw, rank, step=0):
     return dict(input_ids=ids, attention_mask=torch.ones_like(ids), labels=labels, pixel_values=pix)
 
 
+def _pct(xs, q):
+    xs = sorted(xs)
+    if not xs:
+        return None
+    i = q * (len(xs) - 1)
+    lo, hi = int(i), min(int(i) + 1, len(xs) - 1)
+    return xs[lo] + (xs[hi] - xs[lo]) * (i - lo)
+
+
 def cpu_baseline(cfg_name):
     """Oracle ("port") timing on the host cores; bounded sample, depth extrapolated.  Returns the cpu_baseline object."""
     import torch
@@ -58,29 +70,41 @@ def cpu_baseline(cfg_name):
                 vision_feature_layer=cfg.vision_feature_layer, projector_hidden_act=cfg.projector_hidden_act)
     meta["vision"]["num_hidden_layers"] = 2
     meta["text"]["num_hidden_layers"] = 2
-    w = random_weights(meta, seed=0)
-    model = LlavaRef(w, meta)
-    del w
     tiny = cfg_name == "mantis_tiny"
     batch = synthetic_batch(cfg, 1, 128 if tiny else 512, 1 if tiny else 4, cfg.vision_config.image_size, 0)
 
-    def run(nv, nl):
-        model.zero_grad()
-        t0 = time.perf_counter()
-        model.training_step(batch, n_vit_layers=nv, n_llm_layers=nl)
-        return time.perf_counter() - t0
-    with torch.no_grad():
-        pv = torch.cat(batch["pixel_values"], 0)
-        t0 = time.perf_counter(); model.vision_tower(pv, 1); tv1 = time.perf_counter() - t0
-        t0 = time.perf_counter(); model.vision_tower(pv, 2); tv2 = time.perf_counter() - t0
-    t11 = run(1, 1)
-    t12 = run(1, 2)
-    per_llm, per_vit = max(t12 - t11, 1e-9), max(tv2 - tv1, 1e-9)
-    total = t11 + (full_l - 1) * per_llm + (full_v - 1) * per_vit
-    return dict(value=1.0 / total, unit="samples/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"oracle/llava_ref.py training_step, fp32, 1 sample ({'1 img 224^2 + 128' if tiny else '4 img 336^2 + 512'} "
-                       f"tok), measured 1 ViT + 1 and 2 LLM layers + lm_head ({t11:.1f}s, {t12:.1f}s; ViT layer {per_vit:.2f}s), "
-                       f"extrapolated linearly to {full_v} ViT / {full_l} LLM layers = {total:.0f}s per sample")
+    def leg(dtype):
+        w = random_weights(meta, seed=0, dtype=dtype)
+        model = LlavaRef(w, meta, dtype=dtype)
+        del w
+
+        def run(nv, nl):
+            model.zero_grad()
+            t0 = time.perf_counter()
+            model.training_step(batch, n_vit_layers=nv, n_llm_layers=nl)
+            return time.perf_counter() - t0
+        with torch.no_grad():
+            pv = torch.cat(batch["pixel_values"], 0).to(dtype)
+            t0 = time.perf_counter(); model.vision_tower(pv, 1); tv1 = time.perf_counter() - t0
+            t0 = time.perf_counter(); model.vision_tower(pv, 2); tv2 = time.perf_counter() - t0
+        t11 = run(1, 1)
+        t12 = run(1, 2)
+        per_llm, per_vit = max(t12 - t11, 1e-9), max(tv2 - tv1, 1e-9)
+        total = t11 + (full_l - 1) * per_llm + (full_v - 1) * per_vit
+        return total, t11, t12, per_vit
+    total, t11, t12, per_vit = leg(torch.float32)
+    out = dict(value=1.0 / total, unit="samples/s", cores=torch.get_num_threads(), kind="port",
+               sample=f"oracle/llava_ref.py training_step, fp32, 1 sample ({'1 img 224^2 + 128' if tiny else '4 img 336^2 + 512'} "
+                      f"tok), measured 1 ViT + 1 and 2 LLM layers + lm_head ({t11:.1f}s, {t12:.1f}s; ViT layer {per_vit:.2f}s), "
+                      f"extrapolated linearly to {full_v} ViT / {full_l} LLM layers = {total:.0f}s per sample")
+    try:
+        tb, b11, b12, _ = leg(torch.bfloat16)
+        out["value_bf16"] = 1.0 / tb
+        out["sample_bf16"] = f"same sample and extrapolation with bf16 weights/activations on the CPU ({b11:.1f}s, {b12:.1f}s) = {tb:.0f}s per sample"
+    except Exception as e:  # a CPU without usable bf16 kernels must not take the bench line down
+        out["value_bf16"] = None
+        out["sample_bf16"] = f"bf16 leg failed: {type(e).__name__}: {e}"
+    return out
 
 
 def main():
@@ -96,6 +120,7 @@ def main():
     ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--recycle-batches", type=int, default=0, help="0 = a fresh synthetic batch every step (default); n > 0 = cycle n batches")
     args = ap.parse_args()
 
     import torch
@@ -133,11 +158,13 @@ def main():
     reducer = GradReducer(model) if (world > 1 or force_dp) else None
     trainer = MantisHipTrainer(model, gradient_accumulation_steps=1, reducer=reducer)
     opt = None if args.no_optimizer else FusedAdamW(model, lr=1e-5, weight_decay=0.0, max_grad_norm=1.0)
-    batches = [synthetic_batch(cfg, B, T, n_img, cfg.vision_config.image_size, rank, s) for s in range(2)]
+    n_batches = args.recycle_batches or (args.warmup + args.steps)
+    batches = [synthetic_batch(cfg, B, T, n_img, cfg.vision_config.image_size, rank, s) for s in range(n_batches)]
     for bt in batches:      # pinned host buffers, as dataloader_pin_memory does in the reference loop
         bt["pixel_values"] = [p.pin_memory() for p in bt["pixel_values"]]
 
     split = []          # (start, after training_step, after optimizer) events per timed step
+    losses = []
 
     def one_step(i, timed=False):
         if timed:
@@ -146,19 +173,25 @@ def main():
         loss = trainer.training_step(model, batches[i % len(batches)])
         if timed:
             ev[1].record()
+            losses.append(loss)
         if opt is not None:
             opt.step()
             opt.zero_grad(set_to_none=True)
-            if timed:
-                ev[2].record()
-                split.append(ev)
         else:
             for p in model.parameters():
                 p.grad = None
+        if timed:
+            ev[2].record()
+            split.append(ev)
         return loss
 
     for i in range(args.warmup):
         loss = one_step(i)
+    first_loss = float(loss) if args.warmup else None
+    if reducer is not None:
+        torch.cuda.synchronize()
+        reducer.collect_exposed_ms()
+        reducer.stats.update(buckets=0, bytes=0, exposed_ms=[], steps=0)
     timer = None if args.no_kernel_timer else []
     K.KERNEL_TIMER = timer
     torch.cuda.synchronize()
@@ -178,44 +211,67 @@ def main():
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
-    loss_val = float(loss)
+    loss_vals = [float(x) for x in losses]
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
         value = world * B * args.steps / elapsed
+        step_ms = [e[0].elapsed_time(e[2]) for e in split]
+        ts_ms = [e[0].elapsed_time(e[1]) for e in split]
+        pmc = None
+        if not tiny and os.path.exists(PMC_JSON):
+            with open(PMC_JSON) as fh:
+                pmc = json.load(fh)
         roof = None
         if timer:
-            tot_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in timer)
-            tot_fl = sum(f for _, f, _, _ in timer)
+            tot_ms = sum(e0.elapsed_time(e1) for _, _, _, e0, e1 in timer)
+            tot_fl = sum(f for _, f, _, _, _ in timer)
+            tot_by = sum(b for _, _, b, _, _ in timer)
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
-            roof = dict(bound="mfma", kernel="gemm_nt_ring_kernel + gemm_nt_kernel (bf16 MFMA GEMM family, csrc/gemm.hip)", achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / PEAK_BF16_TFLOPS, 4),
-                        traffic=None if tiny else GEMM_HBM_BYTES_PER_LAUNCH_CFG2,
-                        traffic_note=None if tiny else "bytes/launch on the L2 memory side (Infinity-Cache hits included), rocprofv3 PMC "
-                        "profiles/r01_e_pmc_hbm.md; algorithmic operand+result bytes/launch = %.3g" % GEMM_ALGO_BYTES_PER_LAUNCH_CFG2,
+            gf = (pmc or {}).get("gemm_family") or {}
+            roof = dict(bound="mfma", kernel="gemm_nt_ring_kernel + gemm_nt_kernel (bf16 MFMA GEMM family, csrc/gemm.hip)", achieved=round(ach, 1),
+                        peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4),
+                        traffic=gf.get("traffic_bytes_per_launch"),
+                        traffic_note=None if not gf else "bytes/launch on the L2 memory side (Infinity-Cache hits included), rocprofv3 PMC passes of "
+                        "this command summarised in profiles/r02_pmc_step.json by tools/pmc_step_report.py",
+                        algorithmic_bytes_per_launch=round(tot_by / len(timer)),
+                        mfma_busy_pct=((pmc or {}).get("step") or {}).get("mfma_busy_pct"),
                         launches_per_step=len(timer) // args.steps,
                         avg_launch_us=round(1e3 * tot_ms / len(timer), 1), gemm_ms_per_step=round(tot_ms / args.steps, 1),
                         step_model_tflops=round(FLOP_PER_SAMPLE * B / (ms * 1e-3) / 1e12, 1) if not tiny else None,
-                        step_frac_of_peak=round(FLOP_PER_SAMPLE * B / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if not tiny else None)
+                        step_frac_of_peak=round(FLOP_PER_SAMPLE * B / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if not tiny else None,
+                        training_step_frac_of_peak=round(FLOP_PER_SAMPLE * B / (_pct(ts_ms, 0.5) * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if not tiny else None)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.config)
+        dp = None
+        if reducer is not None:
+            ex = reducer.collect_exposed_ms()
+            dp = dict(algo=reducer.algo, buckets_per_step=reducer.stats["buckets"] // max(1, args.steps),
+                      bytes_per_step=reducer.stats["bytes"] // max(1, args.steps),
+                      exposed_comm_ms_median=None if not ex else round(_pct(ex, 0.5), 3),
+                      exposed_comm_ms_max=None if not ex else round(max(ex), 3),
+                      nccl_env={k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_"))})
         names = dict(mantis_8b_siglip_llama3="Mantis-8B-SigLIP-Llama-3", mantis_8b_clip_llama3="Mantis-8B-CLIP-L/14-336-Llama-3")
         out = dict(metric=f"train samples/sec (4 img x 336^2 + 512 tok) {names[args.config]}" if not tiny
                    else "train samples/sec Mantis-tiny (1 img 224^2 + 128 tok)",
                    value=round(value, 4), unit="samples/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=round(ms, 2),
-                   ms_training_step=round(sum(e[0].elapsed_time(e[1]) for e in split) / len(split), 2) if split else None,
-                   ms_optimizer=round(sum(e[1].elapsed_time(e[2]) for e in split) / len(split), 2) if split else None,
-                   samples_per_s_training_step_only=round(world * B / (1e-3 * sum(e[0].elapsed_time(e[1]) for e in split) / len(split)), 4)
-                   if split else None,
+                   ms_per_step_median=round(_pct(step_ms, 0.5), 2), ms_per_step_p10=round(_pct(step_ms, 0.1), 2),
+                   ms_per_step_p90=round(_pct(step_ms, 0.9), 2),
+                   ms_training_step=round(_pct(ts_ms, 0.5), 2),
+                   ms_training_step_p10=round(_pct(ts_ms, 0.1), 2), ms_training_step_p90=round(_pct(ts_ms, 0.9), 2),
+                   ms_optimizer=round(_pct([e[1].elapsed_time(e[2]) for e in split], 0.5), 2) if opt is not None else None,
+                   samples_per_s_training_step_only=round(world * B / (1e-3 * _pct(ts_ms, 0.5)), 4),
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="bf16",
-                   data="synthetic", loss=round(loss_val, 4),
+                   data="synthetic" + ("" if args.recycle_batches else " (fresh batch every step)"),
+                   loss=round(loss_vals[-1], 4), loss_first_timed=round(loss_vals[0], 4), loss_after_warmup=first_loss,
+                   loss_min=round(min(loss_vals), 4), loss_max=round(max(loss_vals), 4),
                    config=dict(workload=f"{args.config}: ViT fwd + projector + packing + Llama fwd/bwd"
                                         f"{'' if args.no_optimizer else ' + clip + fused AdamW'}; {B} samples/GPU, "
                                         f"{n_img} img + {T} tok per sample; random-init weights",
                                global_batch=world * B, seq_len=T, merged_seq_len=T - n_img + n_img * (cfg.vision_config.image_size // cfg.vision_config.patch_size) ** 2,
                                parallelism=f"dp{world}", optimizer=not args.no_optimizer, stage=args.stage),
-                   roofline=roof, cpu_baseline=cpu)
+                   roofline=roof, cpu_baseline=cpu, dp=dp)
         print(json.dumps(out), flush=True)
     if world > 1 or force_dp:
         dist.barrier()

@@ -4,7 +4,7 @@
  * driving mantis/models/mllava/modeling_llava.py:364-549 -- reaches native code only through torch/ATen, flash-attn and
  * NCCL.  There is no reference FFI to mirror, so this header DEFINES the operator boundary a maintainer binds from Python
  * (ctypes): plain device pointers, sizes, element strides and a hipStream_t passed as void*.  No torch
- * types, no allocation inside (workspaces are passed in), no hidden global state, re-entrant per stream.
+ * types, no device allocation inside (every workspace is passed in by the caller), no mutable global state, re-entrant per stream.
  * Every function returns 0 on success, MANTIS_EINVAL (-1) for invalid arguments, MANTIS_EUNSUPPORTED (-2) for a shape or
  * alignment the kernels do not cover, MANTIS_ELAUNCH (-3) if the HIP launch failed.  All tensors are bf16 (raw 16-bit)
  * unless stated, row-major, 16-byte aligned; "ld*" are row strides in ELEMENTS.
@@ -81,9 +81,16 @@ int mantis_transpose(const void* in, void* out, int R, int C, int Rpad, int64_t 
  * flags: 1 bias | act<<1 (1 gelu-erf, 2 gelu-tanh, 3 quick-gelu) | 16 residual add | 32 accumulate into C
  *        | 64 SwiGLU backward fused behind dact = A.B^T: residual = [gate | up][M, 2N], C = [dgate | dup][M, 2N]
  *        | bits 8-11 tile variant (0 = auto) | 4096 A is K-major ([K,M], row stride lda) | 8192 B is K-major ([K,N]):
- *        dX = dY.W uses B K-major (the weight as stored), dW = dY^T.X uses both K-major -- no transposed copies. */
+ *        dX = dY.W uses B K-major (the weight as stored), dW = dY^T.X uses both K-major -- no transposed copies.
+ * The ring kernel (variant 12) addresses operands through 32-bit buffer descriptors: an operand of >= 2 GiB is routed to the
+ * generic kernel when the variant is auto and returns MANTIS_EUNSUPPORTED when variant 12 (or the SwiGLU epilogue) was forced. */
 int mantis_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
-                        const void* bias, const void* residual, int64_t ldr, int flags, void* stream);
+                        const void* bias, const void* residual, int64_t ldr, int flags, void* workspace /*nullable*/,
+                        int64_t workspace_bytes, void* stream);
+/* bytes of caller-owned, 256-B aligned, ZERO-INITIALISED device workspace a launch of C[M,N] over K may need (0 = none; only the
+ * ring kernel's deterministic split-K remainder round uses it; every launch leaves it zeroed-for-reuse, so one buffer per stream
+ * serves all stream-ordered launches).  M = N = K = 0: the largest requirement of any shape on the current device (~64 MB). */
+int mantis_gemm_workspace_bytes(int M, int N, int K);
 /* tile variant the auto heuristic (flags bits 8-11 == 0) picks: 12 = 256x256 ring kernel, 1 = 128x128 generic kernel */
 int mantis_gemm_pick_variant(int M, int N, int K);
 

@@ -34,7 +34,8 @@ SIGNATURES = {
     "mantis_rope_table": [P, P, P, P, L, I, P],
     "mantis_rope_apply": [P, P, P, L, I, I, L, I, P],
     "mantis_transpose": [P, P, I, I, I, L, L, I, I, L, L, L, L, P],
-    "mantis_gemm_bf16_nt": [P, L, P, L, P, L, I, I, I, P, P, L, I, P],
+    "mantis_gemm_bf16_nt": [P, L, P, L, P, L, I, I, I, P, P, L, I, P, L, P],
+    "mantis_gemm_workspace_bytes": [I, I, I],
     "mantis_gemm_pick_variant": [I, I, I],
     "mantis_attn_fwd": [P, P, P, P, P, P, I, I, I, I, I, L, L, L, L, F, I, P],
     "mantis_attn_dsum": [P, P, P, I, I, I, I, L, P],

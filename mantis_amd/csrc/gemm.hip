@@ -764,29 +764,13 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(
     gemm_epilogue_lds<TM, TN, SWIGLU>(acc, smem + wave * EPI_STRIP, C, M, N, ldc, bias, res, ldr, flags, m0 + wm * 128, n0 + wn * 64, lane);
 }
 
-// split-K workspace: #CU fp32 slabs + ticket counters, one set per (device, stream); launches that share a set are stream-ordered
-#include <map>
-#include <mutex>
-struct SkWorkspace { float* slabs = nullptr; unsigned int* cnt = nullptr; int G = 0; };
-static std::mutex g_sk_mu;
-static std::map<std::pair<int, void*>, SkWorkspace> g_sk;
+// split-K workspace (caller-owned, see mantis_gemm_workspace_bytes): [ticket counters: (#CU + 1) u32, padded to 256 B][#CU fp32
+// slabs of 256 x 256].  Zero-initialised by the caller ONCE; every launch leaves the counters at zero (the last arriver of a
+// tile resets its ticket), so one workspace serves any number of stream-ordered launches.  No allocation, no global state here.
 static int g_num_cu[64];
+static inline size_t sk_cnt_bytes(int cus) { return (((size_t)(cus + 1) * sizeof(unsigned int)) + 255) / 256 * 256; }
+static inline size_t sk_ws_bytes(int cus) { return sk_cnt_bytes(cus) + (size_t)cus * SK_SLAB_FLOATS * sizeof(float); }
 
-static int sk_workspace(hipStream_t s, int G, SkWorkspace* out) {
-    std::lock_guard<std::mutex> lock(g_sk_mu);
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return MANTIS_ELAUNCH;
-    SkWorkspace& w = g_sk[std::make_pair(dev, (void*)s)];
-    if (w.G < G) {
-        if (w.slabs) { (void)hipFree(w.slabs); (void)hipFree(w.cnt); w = SkWorkspace(); }
-        if (hipMalloc((void**)&w.slabs, (size_t)G * SK_SLAB_FLOATS * sizeof(float)) != hipSuccess) return MANTIS_ELAUNCH;
-        if (hipMalloc((void**)&w.cnt, (size_t)(G + 1) * sizeof(unsigned int)) != hipSuccess) return MANTIS_ELAUNCH;
-        if (hipMemsetAsync(w.cnt, 0, (size_t)(G + 1) * sizeof(unsigned int), s) != hipSuccess) return MANTIS_ELAUNCH;
-        w.G = G;
-    }
-    *out = w;
-    return MANTIS_OK;
-}
 static int num_cus() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
@@ -831,7 +815,7 @@ static int gemm_pick_variant(int M, int N, int K) {
 
 template <bool AKM, bool BKM, bool SWIGLU = false>
 static int launch_gemm_ring(hipStream_t s, const bf16_t* A, const bf16_t* B, bf16_t* C, int M, int N, int K, long lda, long ldb,
-                            long ldc, const bf16_t* bias, const bf16_t* res, long ldr, int flags) {
+                            long ldc, const bf16_t* bias, const bf16_t* res, long ldr, int flags, void* ws, long ws_bytes) {
     const int tiles_m = cdiv(M, 256), tiles_n = cdiv(N, 256), nk = cdiv(K, BK);
     const long ntiles = (long)tiles_m * tiles_n;
     const int cus = num_cus();
@@ -839,13 +823,15 @@ static int launch_gemm_ring(hipStream_t s, const bf16_t* A, const bf16_t* B, bf1
     const int S = ring_split(ntiles, nk, cus);
     const int full = S > 1 ? (int)(ntiles - rem) : (int)ntiles;
     const int grid = S > 1 ? full + S * rem : (int)ntiles;
-    SkWorkspace w;
+    float* slabs = nullptr;
+    unsigned int* cnt = nullptr;
     if (S > 1) {
-        const int rc = sk_workspace(s, cus, &w);
-        if (rc != MANTIS_OK) return rc;
+        if (!ws || ((uintptr_t)ws & 255) || ws_bytes < (long)sk_ws_bytes(cus)) return MANTIS_EINVAL;   // see mantis_gemm_workspace_bytes
+        cnt = (unsigned int*)ws;
+        slabs = (float*)((char*)ws + sk_cnt_bytes(cus));
     }
     hipLaunchKernelGGL((gemm_nt_ring_kernel<AKM, BKM, SWIGLU>), dim3(grid), dim3(512), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias, res, ldr, flags,
-                       tiles_m, tiles_n, full, S, w.slabs, w.cnt);
+                       tiles_m, tiles_n, full, S, slabs, cnt);
     return mantis_check_launch();
 }
 
@@ -857,8 +843,20 @@ int mantis_gemm_pick_variant(int M, int N, int K) { return gemm_pick_variant(M, 
 // C[M,N] (bf16, row stride ldc) = epilogue(A[M,K] . B[N,K]^T); A,B,C 16-B aligned, lda/ldb % 8 == 0, K % 8 == 0.
 // flags: bit0 bias[n] add | bits1-3 activation (1 gelu-erf, 2 gelu-tanh, 3 quick-gelu) | bit4 + residual[m,n] (stride ldr)
 //        | bit5 accumulate into C (C += result, used for gradient accumulation) | bits8-11 tile variant (0 = auto)
+// Bytes of caller-owned, 256-B aligned, ZERO-INITIALISED device workspace the launch of C[M,N] over K needs (0 = none): only the
+// 256x256 ring kernel's split-K remainder round uses it.  M = N = K = 0 returns the largest requirement of any shape on this
+// device, so a caller can allocate one buffer per stream up front (launches sharing a workspace must be stream-ordered).
+int mantis_gemm_workspace_bytes(int M, int N, int K) {
+    const int cus = num_cus();
+    if (M <= 0 && N <= 0 && K <= 0) return (int)sk_ws_bytes(cus);
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
+    return ring_split(t256, cdiv(K, BK), cus) > 1 ? (int)sk_ws_bytes(cus) : 0;
+}
+
 int mantis_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
-                        const void* bias, const void* residual, int64_t ldr, int flags, void* stream) {
+                        const void* bias, const void* residual, int64_t ldr, int flags, void* workspace, int64_t workspace_bytes,
+                        void* stream) {
     if (M <= 0 || N <= 0 || K <= 0) return MANTIS_EINVAL;
     const bool akm = flags & EPI_A_KMAJOR, bkm = flags & EPI_B_KMAJOR;
     if (lda % 8 || ldb % 8 || ldc < N) return MANTIS_EUNSUPPORTED;
@@ -878,23 +876,35 @@ int mantis_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, 
     int variant = (flags & EPI_VARIANT_MASK) >> EPI_VARIANT_SHIFT;
     if (variant == 0) variant = (flags & EPI_SWIGLU_BWD) ? 12 : gemm_pick_variant(M, N, K);
     if ((flags & EPI_SWIGLU_BWD) && (variant != 12 || akm || !bkm)) return MANTIS_EUNSUPPORTED;
+    // the ring kernel addresses its operands through buffer descriptors: 32-bit num_records, 32-bit lane offset + 32-bit scalar
+    // K-step offset.  An operand of 2 GiB or more would wrap silently -> such shapes go to the generic kernel (64-bit addresses)
+    // when the choice is ours, and are refused when the ring kernel was asked for explicitly.
+    if (variant == 12) {
+        const long a_bytes = (long)(akm ? K : M) * (long)lda * 2, b_bytes = (long)(bkm ? K : N) * (long)ldb * 2;
+        if (a_bytes >= (1L << 31) || b_bytes >= (1L << 31)) {
+            if ((flags & EPI_VARIANT_MASK) || (flags & EPI_SWIGLU_BWD)) return MANTIS_EUNSUPPORTED;
+            variant = 1;
+        }
+    }
 #define GEMM_ARGS s, (const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C, M, N, K, (long)lda, (long)ldb, (long)ldc, \
                   (const bf16_t*)bias, (const bf16_t*)residual, (long)ldr, flags
+#define RING_ARGS GEMM_ARGS, workspace, (long)workspace_bytes
     // variant 1 = 128x128 generic kernel, 2 = 256x256 generic kernel, 12 = 256x256 ring kernel (default for well-quantised shapes)
     const bool ring = variant == 12, big = variant == 2;
     if (!ring && !big && variant != 1) return MANTIS_EINVAL;
     if (akm && bkm)
-        return ring ? launch_gemm_ring<true, true>(GEMM_ARGS)
+        return ring ? launch_gemm_ring<true, true>(RING_ARGS)
                     : big ? launch_gemm<256, 256, 128, 64, true, true>(GEMM_ARGS) : launch_gemm<128, 128, 64, 64, true, true>(GEMM_ARGS);
-    if (flags & EPI_SWIGLU_BWD) return launch_gemm_ring<false, true, true>(GEMM_ARGS);
+    if (flags & EPI_SWIGLU_BWD) return launch_gemm_ring<false, true, true>(RING_ARGS);
     if (bkm)
-        return ring ? launch_gemm_ring<false, true>(GEMM_ARGS)
+        return ring ? launch_gemm_ring<false, true>(RING_ARGS)
                     : big ? launch_gemm<256, 256, 128, 64, false, true>(GEMM_ARGS) : launch_gemm<128, 128, 64, 64, false, true>(GEMM_ARGS);
     if (akm)
-        return ring ? launch_gemm_ring<true, false>(GEMM_ARGS)
+        return ring ? launch_gemm_ring<true, false>(RING_ARGS)
                     : big ? launch_gemm<256, 256, 128, 64, true, false>(GEMM_ARGS) : launch_gemm<128, 128, 64, 64, true, false>(GEMM_ARGS);
-    return ring ? launch_gemm_ring<false, false>(GEMM_ARGS)
+    return ring ? launch_gemm_ring<false, false>(RING_ARGS)
                 : big ? launch_gemm<256, 256, 128, 64, false, false>(GEMM_ARGS) : launch_gemm<128, 128, 64, 64, false, false>(GEMM_ARGS);
+#undef RING_ARGS
 #undef GEMM_ARGS
 }
 

@@ -227,10 +227,14 @@ class LlavaEngine:
             x_in, rstd1, qkv, o, lse, x_mid, rstd2, gu, n1, n2, a = saved.pop()
             if lg_["down"] is not None:
                 K.linear_dw(dx, a, lg_["down"], acc)
+            if on_bucket_ready is not None:
+                on_bucket_ready(("layer", i, "down"))
             dgu = K.linear_dx_swiglu(dx, lw["down"], gu)     # dact = dx . W_down and the SwiGLU backward in one launch
             del a, gu
             if lg_["gu"] is not None:
                 K.linear_dw(dgu, n2, lg_["gu"], acc)
+            if on_bucket_ready is not None:
+                on_bucket_ready(("layer", i, "gu"))
             dn2 = K.linear_dx(dgu, lw["gu"])
             del dgu, n2
             dx_mid = K.rmsnorm_bwd(dn2, x_mid, lw["ln2"], rstd2, dx, lg_["ln2"], acc)
@@ -248,7 +252,7 @@ class LlavaEngine:
             dx = K.rmsnorm_bwd(dn1, x_in, lw["ln1"], rstd1, dx_mid, lg_["ln1"], acc)
             del dn1, dx_mid, x_in
             if on_bucket_ready is not None:
-                on_bucket_ready(("layer", i))
+                on_bucket_ready(("layer", i, "attn"))
 
         # ---- rows G, F, E backward: merged-row grads -> embedding rows + image-feature rows -> projector
         if gw("embed") is not None:

@@ -12,7 +12,7 @@ _L = _lib.load()
 BF16 = torch.bfloat16
 ACT_KIND = {"gelu": 0, "gelu_pytorch_tanh": 1, "quick_gelu": 2, "silu": 3}
 GEMM_ACT = {None: 0, "gelu": 1, "gelu_pytorch_tanh": 2, "quick_gelu": 3}
-# bench.py sets this to a list to collect (kernel, algorithmic flops, start event, end event) per GEMM launch
+# bench.py sets this to a list to collect (kernel, algorithmic flops, algorithmic bytes, start event, end event) per GEMM launch
 KERNEL_TIMER = None
 
 
@@ -39,6 +39,21 @@ def _chk2d(t, name):
 
 def pad8(n):
     return (n + 7) // 8 * 8
+
+
+_GEMM_WS = {}
+
+
+def _gemm_workspace():
+    """Caller-owned split-K workspace of the ring GEMM (include/mantis_hip.h: mantis_gemm_workspace_bytes): one zero-initialised
+    buffer per (device, stream); launches on a stream are ordered, and every launch leaves the ticket counters at zero."""
+    key = (torch.cuda.current_device(), _stream())
+    ws = _GEMM_WS.get(key)
+    if ws is None:
+        n = _L.mantis_gemm_workspace_bytes(0, 0, 0)
+        ws = _GEMM_WS[key] = torch.zeros(n + 256, dtype=torch.uint8, device="cuda")
+    off = (-ws.data_ptr()) % 256
+    return ws.data_ptr() + off, ws.numel() - 256
 
 
 # ----------------------------------------------------------------------------------------------------------- GEMM family
@@ -68,13 +83,16 @@ def gemm_nt(a, b, bias=None, act=None, residual=None, out=None, accumulate=False
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()          # torch's current stream == the stream handed to the kernel below
+    wsp, wsn = _gemm_workspace()
     rc = _L.mantis_gemm_bf16_nt(_p(a), a.stride(0), _p(b), b.stride(0), _p(C), C.stride(0), M, N, K, _p(bias), _p(residual),
-                                0 if residual is None else residual.stride(0), flags, _stream())
+                                0 if residual is None else residual.stride(0), flags, wsp, wsn, _stream())
     _lib.check(rc, f"gemm M={M} N={N} K={K} akm={a_kmajor} bkm={b_kmajor}")
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        prof.append(("gemm_nt_kernel", 2.0 * M * N * K, e0, e1))
+        # algorithmic bytes: both operands read once, the result written once (+ residual / accumulate read)
+        by = 2.0 * (M * K + N * K + M * N * (1 + (residual is not None) + bool(accumulate)))
+        prof.append(("gemm_nt_kernel", 2.0 * M * N * K, by, e0, e1))
     return out
 
 
@@ -132,13 +150,14 @@ def linear_dx_swiglu(dy, w_down, gu):
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
+    wsp, wsn = _gemm_workspace()
     rc = _L.mantis_gemm_bf16_nt(_p(dy), dy.stride(0), _p(w_down), w_down.stride(0), _p(dgu), dgu.stride(0), M, I, d, None, _p(gu),
-                                gu.stride(0), 64 | 8192, _stream())
+                                gu.stride(0), 64 | 8192, wsp, wsn, _stream())
     _lib.check(rc, f"gemm+swiglu_bwd M={M} I={I} d={d}")
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        prof.append(("gemm_nt_kernel", 2.0 * M * I * d, e0, e1))
+        prof.append(("gemm_nt_kernel", 2.0 * M * I * d, 2.0 * (M * d + I * d + 4 * M * I), e0, e1))
     return dgu
 
 
@@ -233,37 +252,45 @@ def rope_apply_(x, cos, sin, nheads, hd, backward=False):
     return x
 
 
-def attn_fwd(qkv, B, Lseq, H, Hkv, hd, kmask, scale, causal, want_lse=True):
-    """qkv: [B*L, (H+2Hkv)*hd] fused projection output (q | k | v).  Returns o [B*L, H*hd], lse [B,H,L]."""
-    _chk2d(qkv, "qkv")
-    ld = qkv.stride(0)
-    o = torch.empty((B * Lseq, H * hd), dtype=BF16, device=qkv.device)
-    lse = torch.empty((B, H, Lseq), dtype=torch.float32, device=qkv.device) if want_lse else None
-    q_ptr = qkv.data_ptr()
-    k_ptr = q_ptr + H * hd * 2
-    v_ptr = q_ptr + (H + Hkv) * hd * 2
-    rc = _L.mantis_attn_fwd(q_ptr, k_ptr, v_ptr, _p(kmask), _p(o), _p(lse), B, Lseq, H, Hkv, hd, ld, ld, ld, H * hd,
-                            float(scale), int(causal), _stream())
+def attn_fwd_qkv(q, k, v, B, Lseq, H, Hkv, hd, kmask, scale, causal, want_lse=True):
+    """q [B*L, >=H*hd], k / v [B*L, >=Hkv*hd] bf16 row views (any row stride, heads contiguous inside a row; they may be column
+    slices of one fused projection output).  Returns o [B*L, H*hd], lse [B,H,L] fp32."""
+    _chk2d(q, "q"), _chk2d(k, "k"), _chk2d(v, "v")
+    o = torch.empty((B * Lseq, H * hd), dtype=BF16, device=q.device)
+    lse = torch.empty((B, H, Lseq), dtype=torch.float32, device=q.device) if want_lse else None
+    rc = _L.mantis_attn_fwd(_p(q), _p(k), _p(v), _p(kmask), _p(o), _p(lse), B, Lseq, H, Hkv, hd, q.stride(0), k.stride(0), v.stride(0),
+                            H * hd, float(scale), int(causal), _stream())
     _lib.check(rc, f"attn_fwd hd={hd}")
     return o, lse
 
 
+def attn_bwd_qkv(q, k, v, o, do, lse, dq, dk, dv, B, Lseq, H, Hkv, hd, kmask, scale, causal):
+    """Gradients w.r.t. q, k, v written into the given row views dq [B*L, H*hd], dk / dv [B*L, Hkv*hd] (any row stride)."""
+    dsum = torch.empty((B, H, Lseq), dtype=torch.float32, device=q.device)     # rowsum(dO * O): filled by the dQ kernel
+    ws = torch.empty((2, B * Lseq, H * hd), dtype=BF16, device=q.device) if H != Hkv else None
+    rc = _L.mantis_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(do), _p(kmask), _p(lse), _p(dsum), _p(dq), _p(dk), _p(dv), _p(ws), B, Lseq,
+                            H, Hkv, hd, q.stride(0), k.stride(0), v.stride(0), o.stride(0), do.stride(0), dq.stride(0), dk.stride(0),
+                            dv.stride(0), float(scale), int(causal), _stream())
+    _lib.check(rc, f"attn_bwd hd={hd}")
+
+
+def _split_qkv(qkv, H, Hkv, hd):
+    return qkv[:, : H * hd], qkv[:, H * hd: (H + Hkv) * hd], qkv[:, (H + Hkv) * hd: (H + 2 * Hkv) * hd]
+
+
+def attn_fwd(qkv, B, Lseq, H, Hkv, hd, kmask, scale, causal, want_lse=True):
+    """qkv: [B*L, (H+2Hkv)*hd] fused projection output (q | k | v).  Returns o [B*L, H*hd], lse [B,H,L]."""
+    _chk2d(qkv, "qkv")
+    q, k, v = _split_qkv(qkv, H, Hkv, hd)
+    return attn_fwd_qkv(q, k, v, B, Lseq, H, Hkv, hd, kmask, scale, causal, want_lse)
+
+
 def attn_bwd(qkv, o, do, lse, B, Lseq, H, Hkv, hd, kmask, scale, causal):
     """Returns dqkv [B*L, (H+2Hkv)*hd] (gradient w.r.t. the post-RoPE q, k and v)."""
-    ld = qkv.stride(0)
-    dsum = torch.empty((B, H, Lseq), dtype=torch.float32, device=qkv.device)     # rowsum(dO * O): filled by the dQ kernel
     dqkv = torch.empty_like(qkv)
-    ws = torch.empty((2, B * Lseq, H * hd), dtype=BF16, device=qkv.device) if H != Hkv else None
-    q_ptr = qkv.data_ptr()
-    k_ptr = q_ptr + H * hd * 2
-    v_ptr = q_ptr + (H + Hkv) * hd * 2
-    dq_ptr = dqkv.data_ptr()
-    dk_ptr = dq_ptr + H * hd * 2
-    dv_ptr = dq_ptr + (H + Hkv) * hd * 2
-    ldd = dqkv.stride(0)
-    rc = _L.mantis_attn_bwd(q_ptr, k_ptr, v_ptr, _p(o), _p(do), _p(kmask), _p(lse), _p(dsum), dq_ptr, dk_ptr, dv_ptr, _p(ws), B, Lseq,
-                            H, Hkv, hd, ld, ld, ld, o.stride(0), do.stride(0), ldd, ldd, ldd, float(scale), int(causal), _stream())
-    _lib.check(rc, f"attn_bwd hd={hd}")
+    q, k, v = _split_qkv(qkv, H, Hkv, hd)
+    dq, dk, dv = _split_qkv(dqkv, H, Hkv, hd)
+    attn_bwd_qkv(q, k, v, o, do, lse, dq, dk, dv, B, Lseq, H, Hkv, hd, kmask, scale, causal)
     return dqkv
 
 

@@ -76,11 +76,13 @@ def _param_specs(cfg: LlavaConfig):
     s.append(("language_model.model.embed_tokens.weight", (V, d)))
     for i in range(tc.num_hidden_layers):
         p = f"language_model.model.layers.{i}."
-        s += [(p + "self_attn.q_proj.weight", (H * hd, d)), (p + "self_attn.k_proj.weight", (Hkv * hd, d)),
+        # order inside a layer = REVERSE of backward completion, so that the three DP sub-buckets of a layer are contiguous
+        # slices: [norms | q k v o] (done last), [gate up], [down] (done first) -- see grad_buckets()
+        s += [(p + "input_layernorm.weight", (d,)), (p + "post_attention_layernorm.weight", (d,)),
+              (p + "self_attn.q_proj.weight", (H * hd, d)), (p + "self_attn.k_proj.weight", (Hkv * hd, d)),
               (p + "self_attn.v_proj.weight", (Hkv * hd, d)), (p + "self_attn.o_proj.weight", (d, H * hd)),
               (p + "mlp.gate_proj.weight", (it, d)), (p + "mlp.up_proj.weight", (it, d)),
-              (p + "mlp.down_proj.weight", (d, it)),
-              (p + "input_layernorm.weight", (d,)), (p + "post_attention_layernorm.weight", (d,))]
+              (p + "mlp.down_proj.weight", (d, it))]
     s += [("language_model.model.norm.weight", (d,)), ("language_model.lm_head.weight", (V, d))]
     return s
 
@@ -324,7 +326,10 @@ class LlavaForConditionalGeneration(nn.Module):
 
     def grad_buckets(self):
         """Contiguous slices of the gradient arena in the order backward completes them (for the DP reducer):
-        'head' (final norm + lm_head), ('layer', n-1) .. ('layer', 0), 'front' (projector + embedding)."""
+        'head' (final norm + lm_head); per decoder layer n-1 .. 0 three sub-buckets fired as their last dW lands --
+        ('layer', i, 'down') after dW(down_proj), ('layer', i, 'gu') after dW(gate|up), ('layer', i, 'attn') = norms + q|k|v|o at
+        the end of the layer -- so the first byte of a layer moves after its first GEMM, not after its last; 'front'
+        (projector + embedding)."""
         self._ensure_grad_arena()
         offs = self._grad_offs
         names = list(self._grad_key)
@@ -335,10 +340,14 @@ class LlavaForConditionalGeneration(nn.Module):
                 return None
             a = min(offs[n] for n in sel)
             b = max(offs[n] + (self._param(n).numel() + 7) // 8 * 8 for n in sel)
+            assert b - a == sum((self._param(n).numel() + 7) // 8 * 8 for n in sel), "bucket is not contiguous"
             return self.grad_arena[a:b]
         out = {"head": span(lambda n: n.startswith("language_model.model.norm") or n.startswith("language_model.lm_head"))}
         for i in range(self.config.text_config.num_hidden_layers):
-            out[("layer", i)] = span(lambda n, i=i: n.startswith(f"language_model.model.layers.{i}."))
+            p = f"language_model.model.layers.{i}."
+            out[("layer", i, "down")] = span(lambda n: n == p + "mlp.down_proj.weight")
+            out[("layer", i, "gu")] = span(lambda n: n in (p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight"))
+            out[("layer", i, "attn")] = span(lambda n: n.startswith(p) and ".mlp." not in n)
         out["front"] = span(lambda n: n.startswith("multi_modal_projector.") or n.startswith("language_model.model.embed_tokens"))
         return {k: v for k, v in out.items() if v is not None}
 

@@ -221,6 +221,15 @@ def attn_bwd(qkv, o, do, lse, B, Lseq, H, Hkv, hd, kmask, scale, causal):
     return out
 
 
+def attn_fwd_qkv(q, k, v, B, Lseq, H, Hkv, hd, kmask, scale, causal, want_lse=True):
+    return attn_fwd(torch.cat([q[:, : H * hd], k[:, : Hkv * hd], v[:, : Hkv * hd]], dim=1), B, Lseq, H, Hkv, hd, kmask, scale, causal, want_lse)
+
+
+def attn_bwd_qkv(q, k, v, o, do, lse, dq, dk, dv, B, Lseq, H, Hkv, hd, kmask, scale, causal):
+    d = attn_bwd(torch.cat([q[:, : H * hd], k[:, : Hkv * hd], v[:, : Hkv * hd]], dim=1), o, do, lse, B, Lseq, H, Hkv, hd, kmask, scale, causal)
+    dq.copy_(d[:, : H * hd]), dk.copy_(d[:, H * hd: (H + Hkv) * hd]), dv.copy_(d[:, (H + Hkv) * hd:])
+
+
 class PackPlan:
     pass
 

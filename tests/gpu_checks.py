@@ -482,6 +482,252 @@ def check_training_step_contract(ga):
     return 1.0 - worst
 
 
+# ------------------------------------------------------------------------------------------------------------- cfg1 / boundary
+def check_model_step_cfg1():
+    """BASELINE.json configs[0] at FULL size (Mantis-tiny: SigLIP-base/16-224 + Llama-68M, 1 image 224^2, 128 tokens) on the HIP path:
+    vs the oracle (every activation / gradient) and vs the values the REFERENCE's Trainer.training_step produced on the same seeded
+    weights and batch (tests/golden/cfg1_mantis_tiny_step.npz: loss, per-parameter gradient norms)."""
+    import json
+    from mantis_amd.configuration_llava import LlavaConfig
+    from mantis_amd.modeling_llava import LlavaForConditionalGeneration
+    from oracle.llava_ref import LlavaRef
+    meta, w, z, f = Hh.load_cfg1()
+    model = LlavaForConditionalGeneration(LlavaConfig.from_oracle_meta(meta), device=DEV, init=None)
+    model.load_reference_state_dict(w)
+    oracle = LlavaRef(w, meta)
+    assert model._ensure_grad_arena()
+    rec = {}
+    zz = Hh.ZDict(z)
+    out = model.engine.step(torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"]), torch.from_numpy(z["labels"]),
+                            Hh.pixels_list(zz), compute_grads=True, overwrite_grads=True, need_logits=True, record=rec)
+    torch.cuda.synchronize()
+    rep = Hh.check_step_against_oracle(model, oracle, zz, out, rec)
+    loss = float(out["loss"].cpu())
+    assert abs(loss - float(f["returned_loss"])) <= 5e-3 * float(f["returned_loss"]), (loss, float(f["returned_loss"]))
+    assert tuple(out["logits"].shape) == tuple(f["logits_shape"])
+    names = json.loads(str(f["grad_names"]))
+    for n, want in zip(names, f["grad_norms"]):
+        got = float(model._param(n).grad.float().norm())
+        assert abs(got - want) <= 3e-2 * want + 1e-8, (n, got, want)
+    return 1.0 - min(c for c, _ in rep.values())
+
+
+def _golden_batch(z, prefix=""):
+    return dict(input_ids=torch.from_numpy(z[prefix + "input_ids"]), attention_mask=torch.from_numpy(z[prefix + "attention_mask"]),
+                labels=torch.from_numpy(z[prefix + "labels"]), pixel_values=Hh.pixels_list(z, prefix))
+
+
+def check_forward_contract_hip():
+    """Contract (2) on the HIP path: `model(**batch)` in train mode returns a loss whose `.backward()` (the stock-Trainer route through
+    `_FusedStep`) publishes gradients BIT-IDENTICAL to `MantisHipTrainer.training_step`; a second step after
+    `zero_grad(set_to_none=True)` does not inherit the first one's gradients (ADVICE high); eval forward returns [B, L, V] logits that
+    match the oracle; `return_dict=False` gives the (loss, logits) tuple (modeling_llava.py:539-549)."""
+    from mantis_amd.trainer import MantisHipTrainer
+    case = "siglip_b2_equal_rightpad"
+    z = Hh.load_case(case)
+    batch = _golden_batch(z)
+    m1, _, _ = Hh.build_product_model("siglip", DEV)
+    m2, _, _ = Hh.build_product_model("siglip", DEV)
+    l1 = MantisHipTrainer(m1, 1).training_step(m1, batch)
+    out = m2(**batch)
+    assert out.logits is None and out["loss"] is out.loss and out.loss.requires_grad
+    out.loss.backward()
+    assert torch.equal(l1, out.loss.detach())
+    assert torch.equal(m1.grad_arena, m2.grad_arena), "autograd bridge and fused training_step disagree"
+    g1 = m2.grad_arena.clone()
+    m2.zero_grad(set_to_none=True)
+    m2(**batch).loss.backward()
+    assert torch.equal(m2.grad_arena, g1), "stale gradients leaked through zero_grad(set_to_none=True)"
+    (m2(**batch).loss * 0.5).backward()                   # no zero_grad: accumulates, scaled by the incoming gradient
+    ratio = float(m2.grad_arena.float().norm() / g1.float().norm())
+    assert abs(ratio - 1.5) < 1e-2, ratio
+    # eval: logits for every merged position, against the oracle
+    oracle = Hh.build_oracle_bf16_weights("siglip")
+    m2.eval()
+    with torch.no_grad():
+        ev = m2(**batch)
+        tup = m2(**batch, return_dict=False)
+    _, ologits = oracle.forward(z["input_ids"], Hh.pixels_list(z), z["attention_mask"], z["labels"], record={})
+    am = torch.from_numpy(z["merged_attention_mask"]).bool()
+    r = close(ev.logits.float().cpu()[am], ologits.detach()[am], 3e-2, "eval logits")
+    assert isinstance(tup, tuple) and len(tup) == 2 and torch.equal(tup[0], ev.loss) and torch.equal(tup[1], ev.logits)
+    m2.train()
+    return r
+
+
+def check_hf_trainer_on_hip():
+    """`as_hf_trainer()` (a stock transformers.Trainer subclass, constructed the way train_mllava.py:312-319 does) on the HIP path:
+    returns the value the reference's Trainer returned for the same micro-batches (golden, GA = 4), accumulates the same gradients
+    as `MantisHipTrainer`, bit for bit."""
+    import tempfile
+    import transformers
+    from mantis_amd.trainer import MantisHipTrainer, as_hf_trainer
+    z = Hh.load_case("siglip_training_step_ga4")
+    m1, _, _ = Hh.build_product_model("siglip", DEV)
+    m2, _, _ = Hh.build_product_model("siglip", DEV)
+    args = transformers.TrainingArguments(output_dir=tempfile.mkdtemp(), report_to=[], remove_unused_columns=False,
+                                          gradient_accumulation_steps=4, per_device_train_batch_size=1)
+    tr = as_hf_trainer()(model=m2, args=args)
+    tr.current_gradient_accumulation_steps = 4
+    ref = MantisHipTrainer(m1, 4)
+    losses = []
+    for i in range(4):
+        b = _golden_batch(z, f"mb{i}.")
+        tr.accelerator.gradient_state._set_sync_gradients(i == 3)
+        out = tr.training_step(m2, dict(b))
+        want = ref.training_step(m1, dict(b))
+        assert out.dim() == 0 and not out.requires_grad and out.is_cuda and torch.equal(out, want)
+        losses.append(float(out))
+    assert np.allclose(losses, z["returned_losses"], rtol=2e-2), (losses, z["returned_losses"])
+    assert torch.equal(m1.grad_arena, m2.grad_arena)
+    return 0.0
+
+
+def check_optimizer_step_vs_torch():
+    """Row f2 end to end on HIP: `FusedAdamW.step()` (sum-of-squares, clip coefficient, AdamW over the flat arenas) against
+    `torch.nn.utils.clip_grad_norm_(1.0)` + `torch.optim.AdamW` on fp32 copies of the same parameters and the same bf16 gradients,
+    three optimizer steps of the tiny golden model; parameters compared after every step."""
+    from mantis_amd.trainer import MantisHipTrainer
+    from mantis_amd.optim import FusedAdamW
+    z = Hh.load_case("siglip_training_step_ga4")
+    model, _, _ = Hh.build_product_model("siglip", DEV)
+    tr = MantisHipTrainer(model, 1)
+    opt = FusedAdamW(model, lr=1e-3, weight_decay=0.0, max_grad_norm=1.0)
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    tp = {n: torch.nn.Parameter(model._param(n).detach().float().cpu().clone()) for n in names}
+    topt = torch.optim.AdamW(list(tp.values()), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    worst = 0.0
+    for i in range(3):
+        tr.training_step(model, _golden_batch(z, f"mb{i}."))
+        for n in names:
+            tp[n].grad = model._param(n).grad.detach().float().cpu().clone()
+        total = torch.nn.utils.clip_grad_norm_(list(tp.values()), 1.0)
+        topt.step()
+        opt.step()
+        assert abs(float(opt.last_grad_norm) - float(total)) <= 1e-3 * float(total)
+        opt.zero_grad(set_to_none=True)
+        for n in names:
+            got = model._param(n).detach().float().cpu()
+            assert torch.equal(got, tp[n].detach().to(BF).float()) or rel(got, tp[n].detach()) < 4e-3, n
+        # the fp32 master copy is what torch holds (gradient-arena order, every parameter padded to 8 elements): compare it tightly
+        flat_ref = torch.cat([torch.nn.functional.pad(tp[n].detach().reshape(-1), (0, (-tp[n].numel()) % 8)) for n in names])
+        worst = max(worst, close(opt.master.cpu(), flat_ref, 2e-5, f"fp32 master after step {i + 1}"))
+    return worst
+
+
+# ------------------------------------------------------------------------------------------------------------- full-size parity
+CFG2 = dict(B=2, L=2812, H=32, Hkv=8, hd=128, d=4096, I=14336, V=128258, M=5624)
+
+
+def check_attn_fullsize(mask):
+    """cfg2-shape attention (B=2, L=2812, 32/8 heads x 128, causal, optional right-padded key mask on sample 1) forward AND backward
+    against the oracle on ALL rows: exercises the heavy-first causal order, XCD maps, GQA group handling and the 2812 % 32 != 0 tail."""
+    k = K()
+    B, L, H, Hkv, hd = CFG2["B"], CFG2["L"], CFG2["H"], CFG2["Hkv"], CFG2["hd"]
+    qkv = rnd(B * L, (H + 2 * Hkv) * hd, seed=77)
+    do = rnd(B * L, H * hd, seed=78)
+    km = None
+    if mask:
+        km = torch.ones(B, L, dtype=torch.int32)
+        km[1, L - 301:] = 0
+        do = do * km.reshape(B * L, 1).to(BF)
+    scale = hd ** -0.5
+    qd, kd = qkv.to(DEV), None if km is None else km.to(DEV)
+    o, lse = k.attn_fwd(qd, B, L, H, Hkv, hd, kd, scale, True)
+    d = k.attn_bwd(qd, o, do.to(DEV), lse, B, L, H, Hkv, hd, kd, scale, True)
+    o, lse, d = o.cpu(), lse.cpu(), d.cpu()
+    worst = 0.0
+    cuts = [0, H * hd, (H + Hkv) * hd, (H + 2 * Hkv) * hd]
+    for b in range(B):                                  # one sample at a time bounds the oracle's [H, L, L] fp32 temporaries (1 GB each)
+        rows = slice(b * L, (b + 1) * L)
+        kmb = None if km is None else km[b:b + 1]
+        oref, lref = R.attn_fwd(qkv[rows], 1, L, H, Hkv, hd, kmb, scale, True)
+        dref = R.attn_bwd(qkv[rows], oref, do[rows], lref, 1, L, H, Hkv, hd, kmb, scale, True)
+        valid = torch.ones(L, dtype=torch.bool) if kmb is None else kmb[0].bool()
+        worst = max(worst, close(o[rows][valid], oref[valid], 2e-2, f"attn_fwd full size b={b} mask={mask}"))
+        close(lse[b][:, valid], lref[0][:, valid], 2e-3, "lse full size")
+        for i, n in enumerate(("dq", "dk", "dv")):
+            worst = max(worst, close(d[rows, cuts[i]:cuts[i + 1]], dref[:, cuts[i]:cuts[i + 1]], 3e-2,
+                                     f"attn_bwd {n} full size b={b} mask={mask}"))
+    return worst
+
+
+def check_gemm_fullsize(M, N, K_, a_km, b_km):
+    """The 256x256 ring kernel (incl. its split-K remainder round) at the step's own shapes, ALL rows against the oracle."""
+    k = K()
+    a, b = rnd(M, K_, seed=41), rnd(N, K_, seed=42, scale=0.05)
+    ref = (a.float() @ b.float().t())
+    ad = (a.t().contiguous() if a_km else a).to(DEV)
+    bd = (b.t().contiguous() if b_km else b).to(DEV)
+    assert k._L.mantis_gemm_pick_variant(M, N, K_) == 12
+    out = k.gemm_nt(ad, bd, a_kmajor=a_km, b_kmajor=b_km)
+    r = close(out, ref, 1e-2, f"gemm full size {M}x{N}x{K_} akm={a_km} bkm={b_km}")
+    # per-row check too: a wrong tile (256 rows) must not hide in the global norm
+    err = (out.float().cpu() - ref).norm(dim=1) / (ref.norm(dim=1) + 1e-30)
+    assert float(err.max()) < 2e-2, f"gemm full size {M}x{N}x{K_}: worst row rel err {float(err.max()):.3e} at row {int(err.argmax())}"
+    return r
+
+
+def check_linear_dx_swiglu_fullsize():
+    k = K()
+    M, d, I = CFG2["M"], CFG2["d"], CFG2["I"]
+    dy, w, gu = rnd(M, d, seed=51), rnd(d, I, seed=52, scale=0.05), rnd(M, 2 * I, seed=53)
+    fused = k.linear_dx_swiglu(dy.to(DEV), w.to(DEV), gu.to(DEV))
+    ref = R.linear_dx_swiglu(dy, w, gu)
+    r = close(fused, ref, 1e-2, "linear_dx_swiglu full size")
+    err = (fused.float().cpu() - ref.float()).norm(dim=1) / (ref.float().norm(dim=1) + 1e-30)
+    assert float(err.max()) < 2e-2, float(err.max())
+    return r
+
+
+def check_ce_fullsize():
+    """V = 128258 with RANDOM logits (scale 3) and 30 % ignored rows, loss + every gradient element vs the oracle."""
+    return check_ce(96, CFG2["V"], 0.3)
+
+
+def check_rmsnorm_fullsize():
+    return check_rmsnorm(CFG2["M"], CFG2["d"])
+
+
+def check_dp_rccl_world1():
+    """The RCCL path of the data-parallel reducer (`GradReducer`, torch.distributed backend nccl = RCCL) on one GPU: world size 1 with
+    MANTIS_DP_FORCE=1 issues every bucket's all-reduce(AVG) from inside the backward on RCCL's stream; gradients must come out
+    bit-identical to the un-reduced step (mean over one rank), for GA = 1 and for the boundary micro-batch of GA = 2."""
+    import os
+    import torch.distributed as dist
+    from mantis_amd.trainer import MantisHipTrainer
+    from mantis_amd.dp import GradReducer
+    z = Hh.load_case("siglip_training_step_ga4")
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    old = os.environ.get("MANTIS_DP_FORCE")
+    os.environ["MANTIS_DP_FORCE"] = "1"
+    try:
+        m1, _, _ = Hh.build_product_model("siglip", DEV)
+        m2, _, _ = Hh.build_product_model("siglip", DEV)
+        red = GradReducer(m2)
+        plain, dp = MantisHipTrainer(m1, 2), MantisHipTrainer(m2, 2, reducer=red)
+        for i in range(2):
+            b = _golden_batch(z, f"mb{i}.")
+            l1, l2 = plain.training_step(m1, dict(b)), dp.training_step(m2, dict(b))
+            assert torch.equal(l1, l2)
+        torch.cuda.synchronize()
+        assert red.stats["buckets"] > 0 and red.stats["bytes"] >= m2.grad_arena.numel() * 2, red.stats
+        assert torch.equal(m1.grad_arena, m2.grad_arena), "RCCL mean over one rank changed the gradients"
+    finally:
+        if old is None:
+            os.environ.pop("MANTIS_DP_FORCE", None)
+        else:
+            os.environ["MANTIS_DP_FORCE"] = old
+        if created:
+            dist.destroy_process_group()
+    return 0.0
+
+
 def all_checks():
     """name -> thunk, in dependency order (cheap and fundamental first)."""
     c = {}
@@ -524,4 +770,23 @@ def all_checks():
     c["training_step_contract_ga4"] = lambda: check_training_step_contract(4)
     c["model_step_projector_only_siglip"] = lambda: check_model_step_projector_only("siglip_b2_equal_rightpad")
     c["model_step_projector_only_clip"] = lambda: check_model_step_projector_only("clip_b2_equal_rightpad")
+    c["model_step_cfg1_mantis_tiny"] = check_model_step_cfg1
+    c["forward_contract_hip"] = check_forward_contract_hip
+    c["hf_trainer_on_hip"] = check_hf_trainer_on_hip
+    c["optimizer_step_vs_torch"] = check_optimizer_step_vs_torch
+    c["dp_rccl_world1"] = check_dp_rccl_world1
+    # cfg2 (BASELINE.json configs[1]) shapes, every row against the oracle
+    c["fullsize_attn_causal"] = lambda: check_attn_fullsize(False)
+    c["fullsize_attn_causal_rightpad"] = lambda: check_attn_fullsize(True)
+    M, d, I = CFG2["M"], CFG2["d"], CFG2["I"]
+    for (m, n, k_, akm, bkm) in [(M, d, d, False, False),            # o_proj fwd (NT, 352 tiles + split-K remainder)
+                                 (M, 2 * I, d, False, False),        # gate|up fwd (NT)
+                                 (M, d, 2 * I, False, True),         # dX of gate|up (NN: weight K-major as stored)
+                                 (M, d + 2048, d, False, False),     # q|k|v fwd (NT, N = 6144)
+                                 (2 * I, d, M, True, True),          # dW of gate|up (TN: both activations K-major)
+                                 (d, I, M, True, True)]:             # dW of down_proj (TN)
+        c[f"fullsize_gemm_{m}x{n}x{k_}_{int(akm)}{int(bkm)}"] = (lambda m=m, n=n, k_=k_, akm=akm, bkm=bkm: check_gemm_fullsize(m, n, k_, akm, bkm))
+    c["fullsize_linear_dx_swiglu"] = check_linear_dx_swiglu_fullsize
+    c["fullsize_ce_128258"] = check_ce_fullsize
+    c["fullsize_rmsnorm_5624x4096"] = check_rmsnorm_fullsize
     return c

@@ -137,3 +137,85 @@ def test_dp2_gradients_are_the_mean_of_the_per_rank_gradients():
             assert Hh.rel_l2(g0[k], ref) < 2e-2 or np.abs(ref).max() < 1e-6, k
     finally:
         eng.K = eng_K
+
+
+def _dp_ga_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import mantis_amd.engine as eng
+        from oracle import ops_ref
+        eng.K = ops_ref
+        from mantis_amd.trainer import MantisHipTrainer
+        from mantis_amd.dp import GradReducer
+        model, _, _ = Hh.build_product_model("siglip", "cpu")
+        z = Hh.load_case("siglip_training_step_ga4")
+        red = GradReducer(model)
+        tr = MantisHipTrainer(model, gradient_accumulation_steps=2, reducer=red)
+        snaps = []
+        for j in range(2):
+            i = 2 * rank + j
+            b = dict(input_ids=torch.from_numpy(z[f"mb{i}.input_ids"]), attention_mask=torch.from_numpy(z[f"mb{i}.attention_mask"]),
+                     labels=torch.from_numpy(z[f"mb{i}.labels"]), pixel_values=Hh.pixels_list(z, f"mb{i}."))
+            tr.training_step(model, b)
+            snaps.append((red.stats["buckets"], model.grad_arena.float().clone().numpy()))
+        q.put((rank, snaps, len(model.grad_buckets())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp2_with_gradient_accumulation_reduces_only_on_the_boundary():
+    """2 ranks x GA=2 (HF no_sync semantics, trainer.py:1744-1757): the first micro-batch of a window is NOT reduced (ranks differ,
+    no bucket traffic); after the boundary micro-batch both ranks hold mean_r( sum_j grad(mb_rj) / GA ), and every bucket of the
+    arena was sent exactly once."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_ga_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, s0, nb), (_, s1, _) = res
+    assert s0[0][0] == 0 and s1[0][0] == 0, "a non-boundary micro-batch was reduced"
+    assert not np.array_equal(s0[0][1], s1[0][1])
+    assert s0[1][0] == nb and s1[1][0] == nb, "each bucket must be reduced exactly once per optimizer step"
+    assert np.array_equal(s0[1][1], s1[1][1]), "ranks disagree after the boundary all-reduce"
+    # single-process reference: four micro-batch gradients (scale 1/GA) summed per rank, averaged over ranks
+    import mantis_amd.engine as eng
+    from oracle import ops_ref
+    eng_K = eng.K
+    eng.K = ops_ref
+    try:
+        z = Hh.load_case("siglip_training_step_ga4")
+        model, _, _ = Hh.build_product_model("siglip", "cpu")
+        model._ensure_grad_arena()
+        for i in range(4):
+            model.engine.step(torch.from_numpy(z[f"mb{i}.input_ids"]), torch.from_numpy(z[f"mb{i}.attention_mask"]),
+                              torch.from_numpy(z[f"mb{i}.labels"]), Hh.pixels_list(z, f"mb{i}."), grad_scale=0.5 / 2,
+                              compute_grads=True, overwrite_grads=(i == 0))
+        ref = model.grad_arena.float().numpy()
+        assert Hh.rel_l2(s0[1][1], ref) < 2e-2
+    finally:
+        eng.K = eng_K
+
+
+def test_grad_buckets_tile_the_arena_in_backward_order():
+    """Buckets are disjoint contiguous slices covering the whole gradient arena; within a layer they are ordered down -> gate|up ->
+    attention block, i.e. the order their dW GEMMs complete in the backward."""
+    model, _, _ = Hh.build_product_model("siglip", "cpu")
+    b = model.grad_buckets()
+    spans = sorted((v.data_ptr(), v.numel()) for v in b.values())
+    base = model.grad_arena.data_ptr()
+    pos = base
+    for ptr, n in spans:
+        assert ptr == pos, "gap or overlap between buckets"
+        pos += n * 2
+    assert pos == base + model.grad_arena.numel() * 2
+    keys = list(b)
+    assert keys[0] == "head" and keys[-1] == "front"
+    for i in range(model.config.text_config.num_hidden_layers):
+        d, g, a = b[("layer", i, "down")], b[("layer", i, "gu")], b[("layer", i, "attn")]
+        assert a.data_ptr() < g.data_ptr() < d.data_ptr()
