@@ -98,13 +98,18 @@ int mantis_gemm_pick_variant(int M, int N, int K);
 int mantis_attn_fwd(const void* Q, const void* K, const void* V, const int32_t* kmask, void* O, float* LSE, int B, int L, int H,
                     int Hkv, int hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale, int causal, void* stream);
 int mantis_attn_dsum(const void* dO, const void* O, float* Dsum, int B, int L, int H, int hd, int64_t ldo, void* stream);
-/* workspace: 2*B*L*H*hd bf16 when H > Hkv (per-query-head dK/dV partials, reduced over the GQA group), else unused.
+/* workspace: 2*B*L*H*hd bf16 (per-query-head dK/dV partials, reduced over the GQA group) when
+ * mantis_attn_bwd_needs_workspace(H, Hkv, hd) says so, else unused/NULL: not for H == Hkv, and not for the GQA-aware dK/dV kernel
+ * (hd 128, H = 4 Hkv -- Llama-3: one workgroup per (64-key block, KV head) walks all four query heads, partials meet in LDS).
  * O (forward output, row stride ld_out) optional: if given, Dsum = rowsum(dO * O) is computed inside the dQ kernel and written to
- * Dsum ([B,H,L] fp32); if NULL, Dsum must already hold it (mantis_attn_dsum). */
+ * Dsum ([B,H,L] fp32); if NULL, Dsum must already hold it (mantis_attn_dsum).
+ * kstart / qend (int32 [B,L], both or neither, nullable): segment bounds for packed samples (data.py:1609-1671 block-diagonal mask):
+ * kstart[b,q] = first key position query q attends, qend[b,k] = one past the last query position that attends key k. */
 int mantis_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const int32_t* kmask,
-                    const float* LSE, float* Dsum, void* dQ, void* dK, void* dV, void* workspace, int B, int L, int H, int Hkv,
-                    int hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ld_out, int64_t ldo, int64_t lddq, int64_t lddk,
-                    int64_t lddv, float scale, int causal, void* stream);
+                    const int32_t* kstart, const int32_t* qend, const float* LSE, float* Dsum, void* dQ, void* dK, void* dV,
+                    void* workspace, int B, int L, int H, int Hkv, int hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ld_out,
+                    int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, float scale, int causal, void* stream);
+int mantis_attn_bwd_needs_workspace(int H, int Hkv, int hd);
 
 /* ---- loss: modeling_llava.py:521-537 (shift + mask filter resolved by mantis_pack_plan into ce_row / ce_tgt).
  * count_out is int32[2]: [0] rows with 0 <= target < V (the mean's denominator), [1] rows with target >= V (torch's

@@ -39,7 +39,8 @@ SIGNATURES = {
     "mantis_gemm_pick_variant": [I, I, I],
     "mantis_attn_fwd": [P, P, P, P, P, P, I, I, I, I, I, L, L, L, L, F, I, P],
     "mantis_attn_dsum": [P, P, P, I, I, I, I, L, P],
-    "mantis_attn_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, L, L, L, L, L, L, L, L, F, I, P],
+    "mantis_attn_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, L, L, L, L, L, L, L, L, F, I, P],
+    "mantis_attn_bwd_needs_workspace": [I, I, I],
     "mantis_ce_fwd_bwd": [P, P, I, I, L, F, F, I, P, P, P, P, P],
     "mantis_im2col": [P, P, I, I, I, I, I, I, P],
     "mantis_vit_assemble": [P, P, P, P, I, I, I, P],

@@ -822,6 +822,372 @@ __global__ void attn_group_reduce_kernel(const bf16_t* __restrict__ pk, const bf
     }
 }
 
+// ------------------------------------------------------------------------------------------------ backward: dK, dV for GQA 4:1, hd 128
+// One workgroup per (64-key block, KV head, batch); NO per-query-head partials in HBM, no group-reduce pass, S and dP computed once.
+// Wave (kb, hp): kb = which 32 keys of the block, hp = which PAIR of the group's 4 query heads.  A wave owns its 32 keys over the
+// FULL head dimension (dK and dV accumulators: 128 registers, K and V fragments: 64 registers -> one wave per SIMD, 512-register
+// budget) and walks the 32-row query tiles of its two heads back to back as one stream; the two waves of a stream share the
+// Q / dO tiles (LDS-DMA into a 3-stage ring, requested two tiles ahead, one barrier per tile).  The loop is software pipelined by
+// hand: while the VALU turns tile i's S, dP into P and dS, the matrix pipe already computes S, dP of tile i+1.
+//   MFMAs per (32 keys x 32 queries x head): S 8 + dP 8 + dV 8 + dK 8 = 32   (the per-query-head kernel above: 48, + the reduce)
+// At the end the two streams' partial sums meet in LDS: wave hp = 0 finishes dK, wave hp = 1 finishes dV (fixed order: deterministic).
+// Work per workgroup is at most (L/32 tiles x 4 heads x 2 key groups) / 4 waves, far below the per-CU average, so the causal
+// imbalance is absorbed by the dispatch order (heaviest key block first) -- the reason the key block is 64 and not 128.
+// Optional segment bounds for packed samples: kstart[b, q] = first key position query q may attend (its sample's start),
+// qend[b, key] = one past the last query position that may attend key (its sample's end).
+template <bool CAUSAL, bool SEG>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_g4_kernel(
+    const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
+    const int* __restrict__ kmask, const int* __restrict__ kstart, const int* __restrict__ qend, const float* __restrict__ LSE,
+    const float* __restrict__ Dsum, bf16_t* __restrict__ dK, bf16_t* __restrict__ dV, int L, int H, int Hkv, long ldq, long ldk,
+    long ldv, long ldo, long lddk, long lddv, float scale) {
+    constexpr int HD = 128, QT = 32, NKS = 8, NDB = 4;
+    using Y = Lay<HD>;
+    constexpr int TILE = QT * 256;                 // 8 KiB: 32 rows x 128 bf16
+    constexpr int STREAM = 2 * TILE + 512;         // Q tile | dO tile | lse2[32] dsum[32] kstart[32] (+pad: keeps tile bases 256-B aligned)
+    constexpr int STAGE = 2 * STREAM;              // the two head-pair streams
+    __shared__ __attribute__((aligned(256))) char smem[3 * STAGE];
+
+    const int lane = threadIdx.x & 63, hh = lane >> 5, lk = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kb = wave & 1, hp = wave >> 1;
+    int bx, hk, b;
+    xcd_tile_map((L + 63) >> 6, Hkv, bx, hk, b);
+    const int kblk0 = bx * 64, k0 = kblk0 + kb * 32, key = k0 + lk;
+    const int keyc = key < L ? key : L - 1;
+    const float c = scale * LOG2E;
+    const bool key_ok = key < L && (kmask == nullptr || kmask[(long)b * L + keyc] != 0);
+
+    bf16x8 kf[NKS], vf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const int ch = ks * 2 + hh;
+        kf[ks] = as_bf16x8(*reinterpret_cast<const u32x4*>(K + ((long)b * L + keyc) * ldk + (long)hk * HD + ch * 8));
+        vf[ks] = as_bf16x8(*reinterpret_cast<const u32x4*>(V + ((long)b * L + keyc) * ldv + (long)hk * HD + ch * 8));
+    }
+    f32x16 dkacc[NDB], dvacc[NDB];
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dkacc[d][e] = 0.f; dvacc[d][e] = 0.f; }
+
+    // query tiles that can see this key block: from the block's first key (causal) to the end of the sequence / of the keys' sample
+    const int qstart = CAUSAL ? (kblk0 >> 5) : 0;
+    int qlim = L;
+    if constexpr (SEG) {
+        const int kk = kblk0 + lane;
+        int e = kk < L ? qend[(long)b * L + kk] : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(e, o, 64); e = e > y ? e : y; }
+        e = __builtin_amdgcn_readfirstlane(e);
+        qlim = e < L ? e : L;
+    }
+    const int ntl = ((qlim + QT - 1) >> 5) - qstart;       // tiles per head (may be <= 0)
+    // Tiles that need per-element masking are walked FIRST by a plain loop; the rest -- the bulk: interior tiles of fully valid key
+    // blocks -- by the software-pipelined loop, whose body is one branch-free basic block.  Causal: the first two tiles of a head
+    // touch the diagonal of this 64-key block.  Irregular blocks (padded keys; with segments: keys of more than one sample) mask
+    // every tile.  The order only permutes a sum that is the same for every launch: deterministic.
+    // (decided on all 64 keys of the block by every wave alike: the four waves must agree on the tile split)
+    bool irregular;
+    {
+        const int kk = kblk0 + lane, kkc = kk < L ? kk : L - 1;
+        irregular = !__all(kk < L && (kmask == nullptr || kmask[(long)b * L + kkc] != 0));
+    }
+    if constexpr (SEG) {
+        const int kk = kblk0 + lane, kkc = kk < L ? kk : L - 1;
+        const int e = qend[(long)b * L + kkc], e0 = __builtin_amdgcn_readfirstlane(e);
+        irregular = irregular || !__all(e == e0 || kk >= L);
+    }
+    irregular = __builtin_amdgcn_readfirstlane((int)irregular) != 0;
+    const int ntc = ntl > 0 ? ntl : 0;
+    const int nm = irregular ? ntc : (CAUSAL ? (ntc < 2 ? ntc : 2) : 0);     // masked tiles per head
+    const int nu1 = ntc - nm;                                                // unmasked tiles per head
+
+    // stage = (a) request the tile's lse / rowsum(dO*O) / kstart words into registers FIRST (oldest entries of the vmcnt queue:
+    // their wait does not drain the DMA behind them), (b) issue the LDS-DMA of the Q and dO rows; (c) `stage_finish`, called at the
+    // end of the iteration, puts the words into LDS.  Everything goes through buffer descriptors: the per-lane offsets are fixed for
+    // the whole kernel, a tile adds one wave-uniform offset to them (no 64-bit address arithmetic in the loop), and rows beyond L are
+    // out of range of the descriptor -> the DMA writes zeros (no clamping, no branches: the loop body stays one basic block).
+    // A tile is (gi = which head of the pair, qt = query tile index).
+    const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc((void*)(Q + (long)b * L * ldq), 0, (int)(unsigned)((long)L * ldq * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)(dO + (long)b * L * ldo), 0, (int)(unsigned)((long)L * ldo * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsL = __builtin_amdgcn_make_buffer_rsrc((void*)(LSE + (long)b * H * L), 0, (int)(unsigned)((long)H * L * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void*)(Dsum + (long)b * H * L), 0, (int)(unsigned)((long)H * L * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(SEG ? kstart + (long)b * L : nullptr), 0, SEG ? (int)(unsigned)((long)L * 4) : 0, 0x00020000);
+    unsigned voQ[4], voD[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (kb * 4 + j) * 4 + (lane >> 4);
+        const int cc = (lane & 15) ^ lds_swz(row);
+        voQ[j] = (unsigned)(((long)row * ldq + cc * 8) * 2);
+        voD[j] = (unsigned)(((long)row * ldo + cc * 8) * 2);
+    }
+    auto stage = [&](int gi, int qt, int slot, float& vl, float& vs, int& ksv) {
+        const int q0 = qt * QT;
+        const int h = hk * 4 + hp * 2 + gi;
+        char* base = smem + slot * STAGE + hp * STREAM;
+        // NB the hardware range check of a raw buffer covers the VECTOR offset only (the scalar offset is added after it), so the
+        // tile offset is added into the vector offset: one v_add per access buys "rows beyond L read zeros" for the last tile
+        const unsigned soL = (unsigned)(((long)h * L + q0) * 4);
+        // a query row beyond L reads lse / dsum words of the next head (or zeros past the end): replaced in stage_finish
+        vl = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsL, (unsigned)lk * 4u + soL, 0, 0));
+        vs = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsS, (unsigned)lk * 4u + soL, 0, 0));
+        if constexpr (SEG) ksv = (int)__builtin_amdgcn_raw_buffer_load_b32(rsK, (unsigned)lk * 4u + (unsigned)q0 * 4u, 0, 0);
+        const unsigned soQ = (unsigned)(((long)q0 * ldq + (long)h * HD) * 2), soD = (unsigned)(((long)q0 * ldo + (long)h * HD) * 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int piece = kb * 4 + j;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lds_void_t*)(base + piece * 1024), 16, voQ[j] + soQ, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (lds_void_t*)(base + TILE + piece * 1024), 16, voD[j] + soD, 0, 0, 0);
+        }
+    };
+    auto stage_finish = [&](int qt, int slot, float vl, float vs, int ksv) {
+        const int qq = qt * QT + lk;
+        float* fp = reinterpret_cast<float*>(smem + slot * STAGE + hp * STREAM + 2 * TILE);
+        const float val = hh == 0 ? vl * LOG2E : vs;
+        fp[lane] = qq < L ? val : (hh == 0 ? INFINITY : 0.f);      // +inf beyond L -> p = 0
+        if constexpr (SEG) reinterpret_cast<int*>(fp)[2 * QT + lk] = ksv;
+    };
+    // S, dP of the tile in `slot` -> s, dp   (the first MFMA of each chain takes the constant 0 as its accumulator input)
+    auto scores = [&](int slot, f32x16& s, f32x16& dp) {
+        const char* sQ = smem + slot * STAGE + hp * STREAM;
+        const char* sdO = sQ + TILE;
+        f32x16 z;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) z[e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int off = Y::chunk_off(lk, ks * 2 + hh);
+            const bf16x8 qa = *reinterpret_cast<const bf16x8*>(sQ + off);
+            const bf16x8 da = *reinterpret_cast<const bf16x8*>(sdO + off);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], ks == 0 ? z : s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], ks == 0 ? z : dp, 0, 0, 0);
+        }
+    };
+    // P and dS of a tile from its S, dP (in place: s <- P, dp <- dS)
+    auto softmax_bwd = [&](auto masked, int q0, int slot, f32x16& s, f32x16& dp) {
+        const float* sLse = reinterpret_cast<const float*>(smem + slot * STAGE + hp * STREAM + 2 * TILE);
+        const float* sDs = sLse + QT;
+        const int* sKs = reinterpret_cast<const int*>(sLse + 2 * QT);
+        if constexpr (decltype(masked)::value) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ql = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                float v = key_ok ? s[r] * c : -INFINITY;
+                if (CAUSAL && key > q0 + ql) v = -INFINITY;
+                if constexpr (SEG) { if (key < sKs[ql]) v = -INFINITY; }
+                const float p = __builtin_amdgcn_exp2f(v - sLse[ql]);
+                s[r] = p;
+                dp[r] = p * (dp[r] - sDs[ql]);       // the softmax scale is applied once, to the dK accumulators
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ql = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, -sLse[ql]));
+                s[r] = p;
+                dp[r] = p * (dp[r] - sDs[ql]);
+            }
+        }
+    };
+    // dV^T += dO^T . P, dK^T += Q^T . dS  (transposing reads of the same row-major tiles)
+    auto accumulate = [&](int slot, const f32x16& p, const f32x16& ds) {
+        const char* sQ = smem + slot * STAGE + hp * STREAM;
+        const char* sdO = sQ + TILE;
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp) {
+            const bf16x8 pf = pack_frag(p, cp);
+            const bf16x8 dsf = pack_frag(ds, cp);
+#pragma unroll
+            for (int d = 0; d < NDB; ++d) {
+                const bf16x8 dot = read_tr_frag<HD>(sdO, 16 * cp, d * 32, lane);
+                const bf16x8 qtf = read_tr_frag<HD>(sQ, 16 * cp, d * 32, lane);
+                dvacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot, pf, dvacc[d], 0, 0, 0);
+                dkacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsf, dkacc[d], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- masked tiles: plain double-buffered walk (slots 0 / 1), tile j -> (gi = j / nm, qt = qstart + j % nm)
+    {
+        const int ntot = 2 * nm;
+        auto tile_m = [&](int j, int& gi, int& qt) { gi = j >= nm ? 1 : 0; qt = qstart + j - gi * nm; };
+        if (ntot > 0) {
+            int gi, qt;
+            float vl, vs;
+            int ksv = 0;
+            tile_m(0, gi, qt);
+            stage(gi, qt, 0, vl, vs, ksv);
+            stage_finish(qt, 0, vl, vs, ksv);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            for (int j = 0; j < ntot; ++j) {
+                const int slot = j & 1;
+                int gn, qn;
+                tile_m(j + 1 < ntot ? j + 1 : j, gn, qn);
+                stage(gn, qn, slot ^ 1, vl, vs, ksv);
+                stage_finish(qn, slot ^ 1, vl, vs, ksv);
+                tile_m(j, gi, qt);
+                f32x16 s, dp;
+                scores(slot, s, dp);
+                softmax_bwd(std::true_type{}, qt * QT, slot, s, dp);
+                accumulate(slot, s, dp);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        }
+    }
+    // ---- unmasked tiles: 3-slot ring, software pipelined; tile j -> (gi = j / nu1, qt = qstart + nm + j % nu1)
+    {
+        const int n = 2 * nu1;
+        auto tile_u = [&](int j, int& gi, int& qt) { gi = j >= nu1 ? 1 : 0; qt = qstart + nm + j - gi * nu1; };
+        if (n > 0) {
+            {
+                int g0, q0t, g1, q1t;
+                float v0, w0, v1, w1;
+                int z0 = 0, z1 = 0;
+                tile_u(0, g0, q0t);
+                tile_u(n > 1 ? 1 : 0, g1, q1t);
+                stage(g0, q0t, 0, v0, w0, z0);
+                stage(g1, q1t, 1, v1, w1, z1);
+                stage_finish(q0t, 0, v0, w0, z0);
+                stage_finish(q1t, 1, v1, w1, z1);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            f32x16 sa, dpa, sb, dpb;
+            scores(0, sa, dpa);
+            // one step = tile j held in (sc, dpc); tile j+1's S, dP go to (sn, dpn) on the matrix pipe while the VALU turns tile j
+            // into P, dS; then tile j's 16 accumulation MFMAs.  (Past the end, tile n-1 is re-staged and the ring's next slot
+            // re-scored: harmless, nothing consumes them.)  The issue order is written out slot by slot -- one MFMA per slot, with
+            // the LDS reads it shadows (requested PF slots ahead of their consumer) and one 16th of the softmax work -- and pinned
+            // with sched_barrier: with ONE wave per SIMD nothing else hides LDS latency or fills the matrix pipe.
+            auto step = [&](int j, auto slotc, f32x16& sc, f32x16& dpc, f32x16& sn, f32x16& dpn) {
+                constexpr int slot = decltype(slotc)::value, s1 = (slot + 1) % 3, s2 = (slot + 2) % 3;
+                constexpr int PF = 4;                      // fragment prefetch distance, in MFMA slots
+                const char* cQ = smem + slot * STAGE + hp * STREAM;    // tile j: transposed fragments, lse / dsum words
+                const char* cD = cQ + TILE;
+                const char* nQ = smem + s1 * STAGE + hp * STREAM;      // tile j + 1: row fragments
+                int gi2, qt2;
+                tile_u(j + 2 < n ? j + 2 : n - 1, gi2, qt2);
+                float vl, vs;
+                int ksv = 0;
+                stage(gi2, qt2, s2, vl, vs, ksv);              // slot s2 held tile j-1: released by the barrier that ended step j-1
+                f32x4 lse4[4], dsm4[4];
+                {
+                    const float* sLse = reinterpret_cast<const float*>(cQ + 2 * TILE) + 4 * hh;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        lse4[g] = *reinterpret_cast<const f32x4*>(sLse + 8 * g);
+                        dsm4[g] = *reinterpret_cast<const f32x4*>(sLse + QT + 8 * g);
+                    }
+                }
+                f32x16 z;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) z[e] = 0.f;
+                bf16x8 fr[PF + 1];
+                auto rowfrag = [&](int g) -> bf16x8 {          // g = 2 * ks + which (0: Q for S, 1: dO for dP)
+                    return *reinterpret_cast<const bf16x8*>(nQ + (g & 1) * TILE + Y::chunk_off(lk, (g >> 1) * 2 + hh));
+                };
+#pragma unroll
+                for (int g = 0; g < PF; ++g) fr[g] = rowfrag(g);
+                FragU tf[4];
+                auto trfrag = [&](int g) -> bf16x8 {           // g = cp * 8 + d * 2 + which (0: dO^T for dV, 1: Q^T for dK)
+                    return read_tr_frag<HD>((g & 1) ? cQ : cD, 16 * (g >> 3), ((g >> 1) & 3) * 32, lane);
+                };
+                u32x4 pfu[2], dsu[2];                          // packed P / dS fragments, cp = 0, 1
+                // ---- phase A: S, dP of tile j+1  ||  P, dS of tile j
+                static_for<0, 16>([&](auto gc) {
+                    constexpr int g = decltype(gc)::value, ks = g >> 1;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (g & 1) dpn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g % (PF + 1)], vf[ks], ks == 0 ? z : dpn, 0, 0, 0);
+                    else sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g % (PF + 1)], kf[ks], ks == 0 ? z : sn, 0, 0, 0);
+                    if constexpr (g + PF < 16) fr[(g + PF) % (PF + 1)] = rowfrag(g + PF);
+                    {   // softmax element r = g of tile j
+                        constexpr int r = g;
+                        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], c, -lse4[r >> 2][r & 3]));
+                        sc[r] = p;
+                        dpc[r] = p * (dpc[r] - dsm4[r >> 2][r & 3]);
+                    }
+                    if constexpr (g >= 8) {                    // pack the cp = 0 fragments (elements 0..7 are final since slot 7)
+                        constexpr int e = (g - 8) & 3;
+                        if constexpr (g < 12) pfu[0][e] = pack_bf2(sc[2 * e], sc[2 * e + 1]);
+                        else dsu[0][e] = pack_bf2(dpc[2 * e], dpc[2 * e + 1]);
+                    }
+                    if constexpr (g >= 13) tf[g - 13].f = trfrag(g - 13);
+                });
+                // ---- phase B: dV, dK of tile j
+                static_for<0, 16>([&](auto gc) {
+                    constexpr int g = decltype(gc)::value, cp = g >> 3, d = (g >> 1) & 3;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (g & 1) dkacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[g & 3].f, as_bf16x8(dsu[cp]), dkacc[d], 0, 0, 0);
+                    else dvacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[g & 3].f, as_bf16x8(pfu[cp]), dvacc[d], 0, 0, 0);
+                    if constexpr (g + 3 < 16) tf[(g + 3) & 3].f = trfrag(g + 3);
+                    if constexpr (g < 8) {                     // pack the cp = 1 fragments (elements 8..15)
+                        constexpr int e = g & 3;
+                        if constexpr (g < 4) pfu[1][e] = pack_bf2(sc[8 + 2 * e], sc[8 + 2 * e + 1]);
+                        else dsu[1][e] = pack_bf2(dpc[8 + 2 * e], dpc[8 + 2 * e + 1]);
+                    }
+                });
+                __builtin_amdgcn_sched_barrier(0);
+                stage_finish(qt2, s2, vl, vs, ksv);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile j+2 landed (this wave's pieces)
+                __syncthreads();
+            };
+            using I0 = std::integral_constant<int, 0>;
+            using I1 = std::integral_constant<int, 1>;
+            using I2 = std::integral_constant<int, 2>;
+            // 6 steps per trip: ring slots (3) and register roles (2) both return to where they started -> no copies at the back edge
+            int j = 0;
+            for (; j + 5 < n; j += 6) {
+                step(j, I0{}, sa, dpa, sb, dpb);
+                step(j + 1, I1{}, sb, dpb, sa, dpa);
+                step(j + 2, I2{}, sa, dpa, sb, dpb);
+                step(j + 3, I0{}, sb, dpb, sa, dpa);
+                step(j + 4, I1{}, sa, dpa, sb, dpb);
+                step(j + 5, I2{}, sb, dpb, sa, dpa);
+            }
+            // tail (< 6 steps): same steps, guarded one by one (positions inside a trip keep their slot and role)
+            if (j < n) step(j, I0{}, sa, dpa, sb, dpb);
+            if (j + 1 < n) step(j + 1, I1{}, sb, dpb, sa, dpa);
+            if (j + 2 < n) step(j + 2, I2{}, sa, dpa, sb, dpb);
+            if (j + 3 < n) step(j + 3, I0{}, sb, dpb, sa, dpa);
+            if (j + 4 < n) step(j + 4, I1{}, sa, dpa, sb, dpb);
+        }
+    }
+    // cross-stream reduction: [kb][which][d][r][lane] fp32; hp = 0 hands over its dV partial and finishes dK, hp = 1 the converse
+    __syncthreads();
+    {
+        float* red = reinterpret_cast<float*>(smem);
+        float* mine = red + ((kb * 2 + hp) * 64) * 64;          // region written by this wave
+        const float* theirs = red + ((kb * 2 + (hp ^ 1)) * 64) * 64;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mine[(d * 16 + e) * 64 + lane] = hp == 0 ? dvacc[d][e] : dkacc[d][e];
+        __syncthreads();
+        if (key < L) {
+            bf16_t* op = (hp == 0 ? dK + ((long)b * L + key) * lddk : dV + ((long)b * L + key) * lddv) + (long)hk * HD;
+            const float sc = hp == 0 ? scale : 1.f;
+#pragma unroll
+            for (int d = 0; d < NDB; ++d)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float own = hp == 0 ? dkacc[d][4 * g4 + e] : dvacc[d][4 * g4 + e];
+                        v[e] = (own + theirs[(d * 16 + 4 * g4 + e) * 64 + lane]) * sc;
+                    }
+                    u32x2 o;
+                    o[0] = pack_bf2(v[0], v[1]);
+                    o[1] = pack_bf2(v[2], v[3]);
+                    *reinterpret_cast<u32x2*>(op + d * 32 + 8 * g4 + 4 * hh) = o;
+                }
+        }
+    }
+}
+
 template <int HD>
 static int launch_fwd(bool causal, dim3 grid, hipStream_t s, const bf16_t* Q, const bf16_t* K, const bf16_t* V, const int* kmask,
                       bf16_t* O, float* LSE, int L, int H, int Hkv, long ldq, long ldk, long ldv, long ldo, float scale) {
@@ -838,9 +1204,29 @@ template <int HD>
 static int launch_bwd(bool causal, hipStream_t s, const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* dO,
                       const int* kmask, const float* LSE, float* Dsum, bf16_t* dQ, bf16_t* dK, bf16_t* dV, bf16_t* ws, int B,
                       int L, int H, int Hkv, long ldq, long ldk, long ldv, long ldo, long lddq, long lddk, long lddv, float scale,
-                      const bf16_t* Ofwd, long ldout) {
+                      const bf16_t* Ofwd, long ldout, const int* kstart, const int* qend) {
     const dim3 gq(cdiv(L, 128) * H * B), gk(cdiv(L, DkvCfg<HD>::KEYS) * H * B);
     const int G = H / Hkv;
+    if constexpr (HD == 128) {
+        if (G == 4) {      // Llama-3 geometry: GQA-aware dK/dV (no HBM partials, no group reduce); dQ as before (it also publishes Dsum)
+            if (kstart != nullptr) return MANTIS_EUNSUPPORTED;      // the dQ kernel has no segment bounds yet
+            if (causal)
+                hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, true>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, L, H, Hkv,
+                                   ldq, ldk, ldv, ldo, lddq, scale, Ofwd, ldout);
+            else
+                hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, false>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, L, H, Hkv,
+                                   ldq, ldk, ldv, ldo, lddq, scale, Ofwd, ldout);
+            const dim3 g4(cdiv(L, 64) * Hkv * B);
+#define DKV_G4(C_, S_) hipLaunchKernelGGL((attn_bwd_dkv_g4_kernel<C_, S_>), g4, dim3(256), 0, s, Q, K, V, dO, kmask, kstart, qend, LSE, \
+                                          Dsum, dK, dV, L, H, Hkv, ldq, ldk, ldv, ldo, lddk, lddv, scale)
+            if (causal) { if (kstart) DKV_G4(true, true); else DKV_G4(true, false); }
+            else { if (kstart) DKV_G4(false, true); else DKV_G4(false, false); }
+#undef DKV_G4
+            return mantis_check_launch();
+        }
+    }
+    if (kstart != nullptr || qend != nullptr) return MANTIS_EUNSUPPORTED;
+    if (G > 1 && ws == nullptr) return MANTIS_EINVAL;
     const long rows = (long)B * L;
     bf16_t* pk = G == 1 ? dK : ws;
     bf16_t* pv = G == 1 ? dV : ws + rows * H * HD;
@@ -888,6 +1274,9 @@ int mantis_attn_fwd(const void* Q, const void* K, const void* V, const int32_t* 
 #undef FWD
 }
 
+// 1 if mantis_attn_bwd needs the 2 * B*L*H*hd bf16 workspace for this geometry (per-query-head dK/dV partials), 0 if not
+int mantis_attn_bwd_needs_workspace(int H, int Hkv, int hd) { return (H == Hkv || (hd == 128 && H == 4 * Hkv)) ? 0 : 1; }
+
 // Dsum [B,H,L] = rowsum(dO * O)
 int mantis_attn_dsum(const void* dO, const void* O, float* Dsum, int B, int L, int H, int hd, int64_t ldo, void* stream) {
     if (hd % 8 || ldo % 8) return MANTIS_EUNSUPPORTED;
@@ -898,21 +1287,22 @@ int mantis_attn_dsum(const void* dO, const void* O, float* Dsum, int B, int L, i
 }
 
 // dQ/dK/dV written with row strides lddq/lddk/lddv (head h at column h*hd).  workspace: 2 * B*L*H*hd bf16 when H > Hkv
-// (per-query-head dK/dV partials, summed over the GQA group afterwards), unused otherwise.
+// (per-query-head dK/dV partials, summed over the GQA group afterwards); unused when H == Hkv and on the GQA-aware path
+// (hd 128, H = 4 Hkv; see mantis_attn_bwd_workspace_bytes).  kstart / qend (both or neither): segment bounds of packed samples.
 // O (optional): the forward output [B*L, H*hd] (row stride ld_out).  If given, D = rowsum(dO * O) is computed inside the dQ kernel and
 // written to Dsum (then a [B,H,L] fp32 scratch/output); if NULL, Dsum must hold it already (mantis_attn_dsum).
 int mantis_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const int32_t* kmask,
-                    const float* LSE, float* Dsum, void* dQ, void* dK, void* dV, void* workspace, int B, int L, int H, int Hkv,
-                    int hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ld_out, int64_t ldo, int64_t lddq, int64_t lddk,
-                    int64_t lddv, float scale, int causal, void* stream) {
+                    const int32_t* kstart, const int32_t* qend, const float* LSE, float* Dsum, void* dQ, void* dK, void* dV,
+                    void* workspace, int B, int L, int H, int Hkv, int hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ld_out,
+                    int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, float scale, int causal, void* stream) {
     if (B <= 0 || L <= 0 || H <= 0 || Hkv <= 0 || H % Hkv || !Dsum) return MANTIS_EINVAL;
     if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8 || lddq % 4 || lddk % 8 || lddv % 8 || (O && ld_out % 8)) return MANTIS_EUNSUPPORTED;
-    if (H != Hkv && !workspace) return MANTIS_EINVAL;
+    if ((kstart == nullptr) != (qend == nullptr)) return MANTIS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
 #define BWD(HD) return launch_bwd<HD>(causal != 0, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dO, \
                                       kmask, LSE, Dsum, (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV, (bf16_t*)workspace, B, L, H, Hkv, \
                                       (long)ldq, (long)ldk, (long)ldv, (long)ldo, (long)lddq, (long)lddk, (long)lddv, scale, \
-                                      (const bf16_t*)O, (long)ld_out)
+                                      (const bf16_t*)O, (long)ld_out, kstart, qend)
     switch (hd) {
         case 16: BWD(16);
         case 64: BWD(64);

@@ -264,11 +264,12 @@ def attn_fwd_qkv(q, k, v, B, Lseq, H, Hkv, hd, kmask, scale, causal, want_lse=Tr
     return o, lse
 
 
-def attn_bwd_qkv(q, k, v, o, do, lse, dq, dk, dv, B, Lseq, H, Hkv, hd, kmask, scale, causal):
+def attn_bwd_qkv(q, k, v, o, do, lse, dq, dk, dv, B, Lseq, H, Hkv, hd, kmask, scale, causal, kstart=None, qend=None):
     """Gradients w.r.t. q, k, v written into the given row views dq [B*L, H*hd], dk / dv [B*L, Hkv*hd] (any row stride)."""
     dsum = torch.empty((B, H, Lseq), dtype=torch.float32, device=q.device)     # rowsum(dO * O): filled by the dQ kernel
-    ws = torch.empty((2, B * Lseq, H * hd), dtype=BF16, device=q.device) if H != Hkv else None
-    rc = _L.mantis_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(do), _p(kmask), _p(lse), _p(dsum), _p(dq), _p(dk), _p(dv), _p(ws), B, Lseq,
+    ws = torch.empty((2, B * Lseq, H * hd), dtype=BF16, device=q.device) if _L.mantis_attn_bwd_needs_workspace(H, Hkv, hd) else None
+    rc = _L.mantis_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(do), _p(kmask), _p(kstart), _p(qend), _p(lse), _p(dsum), _p(dq), _p(dk),
+                            _p(dv), _p(ws), B, Lseq,
                             H, Hkv, hd, q.stride(0), k.stride(0), v.stride(0), o.stride(0), do.stride(0), dq.stride(0), dk.stride(0),
                             dv.stride(0), float(scale), int(causal), _stream())
     _lib.check(rc, f"attn_bwd hd={hd}")

@@ -261,7 +261,10 @@ ATTN_FWD_CASES = [(2, 54, 4, 2, 16, True, "right"), (2, 54, 4, 2, 16, True, "lef
                   (1, 300, 4, 4, 128, False, "right"), (2, 193, 4, 2, 128, False, None)]
 ATTN_BWD_CASES = [(2, 54, 4, 2, 16, True, "right"), (2, 54, 4, 2, 16, True, "left"), (1, 323, 12, 12, 64, True, None),
                   (1, 300, 8, 2, 128, True, "right"), (1, 129, 2, 2, 64, True, None), (2, 40, 2, 2, 16, False, None),
-                  (1, 200, 4, 2, 128, False, "left"), (2, 130, 4, 4, 128, False, None)]
+                  (1, 200, 4, 2, 128, False, "left"), (2, 130, 4, 4, 128, False, None),
+                  # GQA 4:1 at hd 128: the GQA-aware dK/dV kernel (one workgroup per 64-key block and KV head, partials meet in LDS)
+                  (2, 200, 4, 1, 128, True, None), (1, 130, 8, 2, 128, False, "left"), (1, 40, 4, 1, 128, True, None),
+                  (1, 256, 4, 1, 128, True, "right"), (2, 97, 8, 2, 128, False, None), (1, 33, 4, 1, 128, True, "left")]
 
 
 # ------------------------------------------------------------------------------------------------------------- packing / CE
