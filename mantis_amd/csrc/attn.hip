@@ -846,7 +846,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_g4_kernel(
     constexpr int TILE = QT * 256;                 // 8 KiB: 32 rows x 128 bf16
     constexpr int STREAM = 2 * TILE + 512;         // Q tile | dO tile | lse2[32] dsum[32] kstart[32] (+pad: keeps tile bases 256-B aligned)
     constexpr int STAGE = 2 * STREAM;              // the two head-pair streams
-    __shared__ __attribute__((aligned(256))) char smem[3 * STAGE];
+    __shared__ __attribute__((aligned(256))) char smem[4 * STAGE];
 
     const int lane = threadIdx.x & 63, hh = lane >> 5, lk = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1037,122 +1037,160 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_g4_kernel(
             }
         }
     }
-    // ---- unmasked tiles: 3-slot ring, software pipelined; tile j -> (gi = j / nu1, qt = qstart + nm + j % nu1)
+    // ---- unmasked tiles: 4-slot ring, three-stage software pipeline; tile j -> (gi = j / nu1, qt = qstart + nm + j % nu1)
+    // Step j runs, on ONE wave per SIMD:   MS(j+2): S, dP of tile j+2 (16 MFMAs, slots 0-15)
+    //                                       SM(j+1): softmax backward of tile j+1 on the VALU, one element per two slots
+    //                                       MA(j):   dV, dK accumulation of tile j (16 MFMAs, slots 16-31)
+    // so every one of the 32 MFMA slots of a step shadows the same small bundle: its LDS fragment reads (requested PF slots ahead),
+    // half a softmax element, a pack.  Register roles rotate with period 3, ring slots with period 4, the packed-fragment buffers
+    // with period 2 -> the loop body is written out for 12 steps (all indices compile-time).  The score MFMAs are issued through
+    // inline asm with VGPR destinations and the K / V fragments as AGPR operands: S and dP then need no v_accvgpr_read per
+    // element (the accumulators proper -- dK, dV -- stay in AGPRs under the compiler's builtin).
     {
         const int n = 2 * nu1;
         auto tile_u = [&](int j, int& gi, int& qt) { gi = j >= nu1 ? 1 : 0; qt = qstart + nm + j - gi * nu1; };
         if (n > 0) {
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) { asm volatile("" : "+a"(kf[ks])); asm volatile("" : "+a"(vf[ks])); }
             {
-                int g0, q0t, g1, q1t;
-                float v0, w0, v1, w1;
-                int z0 = 0, z1 = 0;
-                tile_u(0, g0, q0t);
-                tile_u(n > 1 ? 1 : 0, g1, q1t);
-                stage(g0, q0t, 0, v0, w0, z0);
-                stage(g1, q1t, 1, v1, w1, z1);
-                stage_finish(q0t, 0, v0, w0, z0);
-                stage_finish(q1t, 1, v1, w1, z1);
+                float v[3], w[3];
+                int zz[3] = {0, 0, 0}, g[3], q[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) { tile_u(t < n ? t : n - 1, g[t], q[t]); stage(g[t], q[t], t, v[t], w[t], zz[t]); }
+#pragma unroll
+                for (int t = 0; t < 3; ++t) stage_finish(q[t], t, v[t], w[t], zz[t]);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            f32x16 sa, dpa, sb, dpb;
-            scores(0, sa, dpa);
-            // one step = tile j held in (sc, dpc); tile j+1's S, dP go to (sn, dpn) on the matrix pipe while the VALU turns tile j
-            // into P, dS; then tile j's 16 accumulation MFMAs.  (Past the end, tile n-1 is re-staged and the ring's next slot
-            // re-scored: harmless, nothing consumes them.)  The issue order is written out slot by slot -- one MFMA per slot, with
-            // the LDS reads it shadows (requested PF slots ahead of their consumer) and one 16th of the softmax work -- and pinned
-            // with sched_barrier: with ONE wave per SIMD nothing else hides LDS latency or fills the matrix pipe.
-            auto step = [&](int j, auto slotc, f32x16& sc, f32x16& dpc, f32x16& sn, f32x16& dpn) {
-                constexpr int slot = decltype(slotc)::value, s1 = (slot + 1) % 3, s2 = (slot + 2) % 3;
-                constexpr int PF = 4;                      // fragment prefetch distance, in MFMA slots
-                const char* cQ = smem + slot * STAGE + hp * STREAM;    // tile j: transposed fragments, lse / dsum words
-                const char* cD = cQ + TILE;
-                const char* nQ = smem + s1 * STAGE + hp * STREAM;      // tile j + 1: row fragments
-                int gi2, qt2;
-                tile_u(j + 2 < n ? j + 2 : n - 1, gi2, qt2);
+            f32x16 sv[3], dv[3];          // S / dP -> P / dS of three tiles in flight (roles rotate)
+            u32x4 pk[2][2][2];            // [parity][0: P, 1: dS][cp] packed bf16 fragments
+            auto rowfrag = [&](const char* tq, int g) -> bf16x8 {          // g = 2 * ks + which (0: Q for S, 1: dO for dP)
+                return *reinterpret_cast<const bf16x8*>(tq + (g & 1) * TILE + Y::chunk_off(lk, (g >> 1) * 2 + hh));
+            };
+            auto mfma_s = [&](auto first, f32x16& acc, const bf16x8& a, const bf16x8& bagpr) {
+                if constexpr (decltype(first)::value)
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "a"(bagpr));
+                else
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(bagpr));
+            };
+            // softmax backward of ONE element r (in place) with the lse / dsum words of its tile
+            auto sm_elem = [&](auto rc, f32x16& sx, f32x16& dx, const f32x4 (&lse4)[4], const f32x4 (&dsm4)[4]) {
+                constexpr int r = decltype(rc)::value;
+                float l = lse4[r >> 2][r & 3];
+                asm volatile("" : "+v"(l));            // pins the element's arithmetic behind the slot's (volatile asm) MFMA
+                float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sx[r], c, -l));
+                float ds = p * (dx[r] - dsm4[r >> 2][r & 3]);
+                asm volatile("" : "+v"(p), "+v"(ds));  // ... and in front of the next one (IR sinking would move it to its user's block)
+                sx[r] = p;
+                dx[r] = ds;
+            };
+            auto pack_pinned = [&](float a, float b2) -> unsigned {
+                asm volatile("" : "+v"(a));
+                unsigned u = pack_bf2(a, b2);
+                asm volatile("" : "+v"(u));
+                return u;
+            };
+            auto load_words = [&](int slot, f32x4 (&lse4)[4], f32x4 (&dsm4)[4]) {
+                const float* sLse = reinterpret_cast<const float*>(smem + slot * STAGE + hp * STREAM + 2 * TILE) + 4 * hh;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    lse4[g] = *reinterpret_cast<const f32x4*>(sLse + 8 * g);
+                    dsm4[g] = *reinterpret_cast<const f32x4*>(sLse + QT + 8 * g);
+                }
+            };
+            // ---- prologue: S, dP of tiles 0 and 1; softmax backward + packs of tile 0
+            {
+                const char* t0 = smem + 0 * STAGE + hp * STREAM;
+                const char* t1 = smem + 1 * STAGE + hp * STREAM;
+                static_for<0, 16>([&](auto gc) {
+                    constexpr int g = decltype(gc)::value, ks = g >> 1;
+                    if constexpr (g & 1) mfma_s(std::integral_constant<bool, ks == 0>{}, dv[0], rowfrag(t0, g), vf[ks]);
+                    else mfma_s(std::integral_constant<bool, ks == 0>{}, sv[0], rowfrag(t0, g), kf[ks]);
+                });
+                static_for<0, 16>([&](auto gc) {
+                    constexpr int g = decltype(gc)::value, ks = g >> 1;
+                    if constexpr (g & 1) mfma_s(std::integral_constant<bool, ks == 0>{}, dv[1], rowfrag(t1, g), vf[ks]);
+                    else mfma_s(std::integral_constant<bool, ks == 0>{}, sv[1], rowfrag(t1, g), kf[ks]);
+                });
+                asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // MFMA results -> VALU readers (the asm MFMAs are invisible to hipcc)
+                f32x4 lse4[4], dsm4[4];
+                load_words(0, lse4, dsm4);
+                static_for<0, 16>([&](auto rc) { sm_elem(rc, sv[0], dv[0], lse4, dsm4); });
+#pragma unroll
+                for (int cp = 0; cp < 2; ++cp)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        pk[0][0][cp][e] = pack_bf2(sv[0][8 * cp + 2 * e], sv[0][8 * cp + 2 * e + 1]);
+                        pk[0][1][cp][e] = pack_bf2(dv[0][8 * cp + 2 * e], dv[0][8 * cp + 2 * e + 1]);
+                    }
+            }
+            auto step = [&](int j, auto kc) {
+                constexpr int k = decltype(kc)::value;                 // position inside the 12-step trip
+                constexpr int slot0 = k % 4, slot1 = (k + 1) % 4, slot2 = (k + 2) % 4, slot3 = (k + 3) % 4;
+                constexpr int r0 = k % 3, r1 = (k + 1) % 3, r2 = (k + 2) % 3;     // roles of tiles j, j+1, j+2
+                constexpr int par0 = k % 2, par1 = (k + 1) % 2;
+                constexpr int PF = 4;
+                const char* tq0 = smem + slot0 * STAGE + hp * STREAM;    // tile j: transposed fragments
+                const char* tq2 = smem + slot2 * STAGE + hp * STREAM;    // tile j + 2: row fragments
+                int gi3, qt3;
+                tile_u(j + 3 < n ? j + 3 : n - 1, gi3, qt3);
                 float vl, vs;
                 int ksv = 0;
-                stage(gi2, qt2, s2, vl, vs, ksv);              // slot s2 held tile j-1: released by the barrier that ended step j-1
+                stage(gi3, qt3, slot3, vl, vs, ksv);       // slot3 held tile j-1: released by the barrier that ended step j-1
                 f32x4 lse4[4], dsm4[4];
-                {
-                    const float* sLse = reinterpret_cast<const float*>(cQ + 2 * TILE) + 4 * hh;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        lse4[g] = *reinterpret_cast<const f32x4*>(sLse + 8 * g);
-                        dsm4[g] = *reinterpret_cast<const f32x4*>(sLse + QT + 8 * g);
-                    }
-                }
-                f32x16 z;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) z[e] = 0.f;
+                load_words(slot1, lse4, dsm4);
                 bf16x8 fr[PF + 1];
-                auto rowfrag = [&](int g) -> bf16x8 {          // g = 2 * ks + which (0: Q for S, 1: dO for dP)
-                    return *reinterpret_cast<const bf16x8*>(nQ + (g & 1) * TILE + Y::chunk_off(lk, (g >> 1) * 2 + hh));
-                };
 #pragma unroll
-                for (int g = 0; g < PF; ++g) fr[g] = rowfrag(g);
+                for (int g = 0; g < PF; ++g) fr[g] = rowfrag(tq2, g);
                 FragU tf[4];
                 auto trfrag = [&](int g) -> bf16x8 {           // g = cp * 8 + d * 2 + which (0: dO^T for dV, 1: Q^T for dK)
-                    return read_tr_frag<HD>((g & 1) ? cQ : cD, 16 * (g >> 3), ((g >> 1) & 3) * 32, lane);
+                    return read_tr_frag<HD>(tq0 + ((g & 1) ? 0 : TILE), 16 * (g >> 3), ((g >> 1) & 3) * 32, lane);
                 };
-                u32x4 pfu[2], dsu[2];                          // packed P / dS fragments, cp = 0, 1
-                // ---- phase A: S, dP of tile j+1  ||  P, dS of tile j
+                // slots 0-15: MS(j+2)  ||  SM(j+1) elements 0-7  ||  cp = 1 packs of tile j (its elements 8-15 finished last step)
                 static_for<0, 16>([&](auto gc) {
                     constexpr int g = decltype(gc)::value, ks = g >> 1;
                     __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (g & 1) dpn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g % (PF + 1)], vf[ks], ks == 0 ? z : dpn, 0, 0, 0);
-                    else sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[g % (PF + 1)], kf[ks], ks == 0 ? z : sn, 0, 0, 0);
-                    if constexpr (g + PF < 16) fr[(g + PF) % (PF + 1)] = rowfrag(g + PF);
-                    {   // softmax element r = g of tile j
-                        constexpr int r = g;
-                        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], c, -lse4[r >> 2][r & 3]));
-                        sc[r] = p;
-                        dpc[r] = p * (dpc[r] - dsm4[r >> 2][r & 3]);
+                    if constexpr (g & 1) mfma_s(std::integral_constant<bool, ks == 0>{}, dv[r2], fr[g % (PF + 1)], vf[ks]);
+                    else mfma_s(std::integral_constant<bool, ks == 0>{}, sv[r2], fr[g % (PF + 1)], kf[ks]);
+                    if constexpr (g + PF < 16) fr[(g + PF) % (PF + 1)] = rowfrag(tq2, g + PF);
+                    if constexpr (g < 8) {
+                        constexpr int e = g & 3;
+                        if constexpr (g < 4) pk[par0][0][1][e] = pack_pinned(sv[r0][8 + 2 * e], sv[r0][8 + 2 * e + 1]);
+                        else pk[par0][1][1][e] = pack_pinned(dv[r0][8 + 2 * e], dv[r0][8 + 2 * e + 1]);
                     }
-                    if constexpr (g >= 8) {                    // pack the cp = 0 fragments (elements 0..7 are final since slot 7)
-                        constexpr int e = (g - 8) & 3;
-                        if constexpr (g < 12) pfu[0][e] = pack_bf2(sc[2 * e], sc[2 * e + 1]);
-                        else dsu[0][e] = pack_bf2(dpc[2 * e], dpc[2 * e + 1]);
-                    }
+                    if constexpr (g & 1) sm_elem(std::integral_constant<int, (g >> 1)>{}, sv[r1], dv[r1], lse4, dsm4);
                     if constexpr (g >= 13) tf[g - 13].f = trfrag(g - 13);
                 });
-                // ---- phase B: dV, dK of tile j
+                // slots 16-31: MA(j)  ||  SM(j+1) elements 8-15  ||  cp = 0 packs of tile j+1
                 static_for<0, 16>([&](auto gc) {
                     constexpr int g = decltype(gc)::value, cp = g >> 3, d = (g >> 1) & 3;
                     __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (g & 1) dkacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[g & 3].f, as_bf16x8(dsu[cp]), dkacc[d], 0, 0, 0);
-                    else dvacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[g & 3].f, as_bf16x8(pfu[cp]), dvacc[d], 0, 0, 0);
+                    asm volatile("" ::: "memory");
+                    if constexpr (g & 1) dkacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[g & 3].f, as_bf16x8(pk[par0][1][cp]), dkacc[d], 0, 0, 0);
+                    else dvacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[g & 3].f, as_bf16x8(pk[par0][0][cp]), dvacc[d], 0, 0, 0);
                     if constexpr (g + 3 < 16) tf[(g + 3) & 3].f = trfrag(g + 3);
-                    if constexpr (g < 8) {                     // pack the cp = 1 fragments (elements 8..15)
+                    if constexpr (g & 1) sm_elem(std::integral_constant<int, 8 + (g >> 1)>{}, sv[r1], dv[r1], lse4, dsm4);
+                    if constexpr (g < 8) {
                         constexpr int e = g & 3;
-                        if constexpr (g < 4) pfu[1][e] = pack_bf2(sc[8 + 2 * e], sc[8 + 2 * e + 1]);
-                        else dsu[1][e] = pack_bf2(dpc[8 + 2 * e], dpc[8 + 2 * e + 1]);
+                        if constexpr (g < 4) pk[par1][0][0][e] = pack_pinned(sv[r1][2 * e], sv[r1][2 * e + 1]);
+                        else pk[par1][1][0][e] = pack_pinned(dv[r1][2 * e], dv[r1][2 * e + 1]);
                     }
                 });
                 __builtin_amdgcn_sched_barrier(0);
-                stage_finish(qt2, s2, vl, vs, ksv);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile j+2 landed (this wave's pieces)
+                stage_finish(qt3, slot3, vl, vs, ksv);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile j+3 landed (this wave's pieces)
                 __syncthreads();
             };
-            using I0 = std::integral_constant<int, 0>;
-            using I1 = std::integral_constant<int, 1>;
-            using I2 = std::integral_constant<int, 2>;
-            // 6 steps per trip: ring slots (3) and register roles (2) both return to where they started -> no copies at the back edge
             int j = 0;
-            for (; j + 5 < n; j += 6) {
-                step(j, I0{}, sa, dpa, sb, dpb);
-                step(j + 1, I1{}, sb, dpb, sa, dpa);
-                step(j + 2, I2{}, sa, dpa, sb, dpb);
-                step(j + 3, I0{}, sb, dpb, sa, dpa);
-                step(j + 4, I1{}, sa, dpa, sb, dpb);
-                step(j + 5, I2{}, sb, dpb, sa, dpa);
+            while (true) {
+#define DKV_STEP(K_) step(j, std::integral_constant<int, K_>{}); if (++j >= n) break;
+                DKV_STEP(0) DKV_STEP(1) DKV_STEP(2) DKV_STEP(3) DKV_STEP(4) DKV_STEP(5)
+                DKV_STEP(6) DKV_STEP(7) DKV_STEP(8) DKV_STEP(9) DKV_STEP(10) DKV_STEP(11)
+#undef DKV_STEP
             }
-            // tail (< 6 steps): same steps, guarded one by one (positions inside a trip keep their slot and role)
-            if (j < n) step(j, I0{}, sa, dpa, sb, dpb);
-            if (j + 1 < n) step(j + 1, I1{}, sb, dpb, sa, dpa);
-            if (j + 2 < n) step(j + 2, I2{}, sa, dpa, sb, dpb);
-            if (j + 3 < n) step(j + 3, I0{}, sb, dpb, sa, dpa);
-            if (j + 4 < n) step(j + 4, I1{}, sa, dpa, sb, dpb);
+            // (the asm MFMAs of the final steps wrote registers nothing reads; they retired long ago: 16 accumulation MFMAs and a
+            // barrier follow them inside the step, so no keep-alive is needed -- and one would force the rotating roles to a common
+            // register assignment at all twelve loop exits)
         }
     }
     // cross-stream reduction: [kb][which][d][r][lane] fp32; hp = 0 hands over its dV partial and finishes dK, hp = 1 the converse
