@@ -156,8 +156,12 @@ def main():
             if "multi_modal_projector" not in n:
                 p.requires_grad = False
     reducer = GradReducer(model) if (world > 1 or force_dp) else None
-    trainer = MantisHipTrainer(model, gradient_accumulation_steps=1, reducer=reducer)
     opt = None if args.no_optimizer else FusedAdamW(model, lr=1e-5, weight_decay=0.0, max_grad_norm=1.0)
+    # MANTIS_NORM_OVERLAP=1: the optimizer's gradient-norm pass rides on a side stream inside the backward instead of being a
+    # separate pass.  Measured on 1x MI355X (profiles/r02_experiments.md): the side-stream kernels cost the concurrent GEMMs more
+    # (+3.5 ms) than the separate pass they replace (-3.2 ms), so the default stays off.
+    overlap = opt is not None and os.environ.get("MANTIS_NORM_OVERLAP", "0") == "1"
+    trainer = MantisHipTrainer(model, gradient_accumulation_steps=1, reducer=reducer, optimizer=opt if overlap else None)
     n_batches = args.recycle_batches or (args.warmup + args.steps)
     batches = [synthetic_batch(cfg, B, T, n_img, cfg.vision_config.image_size, rank, s) for s in range(n_batches)]
     for bt in batches:      # pinned host buffers, as dataloader_pin_memory does in the reference loop

@@ -60,7 +60,7 @@ def build(verbose=True):
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     if verbose:
-        print(f"[mantis_amd.build] {'built' if changed else 'up to date'}: {LIB}")
+        print(f"[mantis_amd.build] {'built' if changed else 'up to date'}: {LIB}", file=sys.stderr)
     return LIB
 
 

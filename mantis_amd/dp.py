@@ -83,16 +83,19 @@ class GradReducer:
         return [h], (stage, t)
 
     def bucket_ready(self, key):
+        """Returns the async handles of the bucket's collective (nccl) so that follow-up work on another stream -- the overlapped
+        gradient-norm pass -- can queue behind it; () when nothing was launched."""
         if not self.active:
-            return
+            return ()
         b = self._buckets.get(key)
         if b is None:
-            return
+            return ()
         self._pending.discard(key)
         hs, post = self._reduce_mean(b)
         self._handles.append((hs, post))
         self.stats["buckets"] += 1
         self.stats["bytes"] += b.numel() * b.element_size()
+        return tuple(hs) if post is None else ()
 
     def finish(self):
         if self.active and self._pending:

@@ -398,8 +398,9 @@ def adamw_flat(param, grad, master, m, v, lr, beta1, beta2, eps, wd, step, grad_
     _lib.check(rc, "adamw")
 
 
-def grad_sumsq(x, out, accumulate=False):
-    ws = torch.empty((_L.mantis_sumsq_partials(x.numel()),), dtype=torch.float32, device=x.device)
+def grad_sumsq(x, out, accumulate=False, ws=None):
+    if ws is None:
+        ws = torch.empty((_L.mantis_sumsq_partials(x.numel()),), dtype=torch.float32, device=x.device)
     _lib.check(_L.mantis_sumsq(_p(x), x.numel(), _p(ws), _p(out), int(accumulate), _stream()), "sumsq")
 
 

@@ -26,6 +26,7 @@ class FusedAdamW:
         self.resync_master()
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.last_grad_norm = None
+        self._side, self._norm_ws, self._norm_ready = None, None, False
 
     def _plan(self, names):
         """Maximal runs where the parameter arena and the gradient arena advance together -> (param_off, grad_off, numel)."""
@@ -50,6 +51,47 @@ class FusedAdamW:
             self.master[g_off:g_off + cnt].copy_(m.arena[p_off:p_off + cnt])
         self._seen_version = getattr(m, "_param_version", 0)
 
+    # ---- gradient norm overlapped with the backward (the reference's clip_grad_norm_ is a separate pass over all gradients,
+    # HF:trainer.py:2535-2545).  The engine reports every gradient bucket the moment its last kernel is enqueued (the same hook the
+    # data-parallel reducer uses); each bucket's sum of squares is then taken on a SIDE stream behind that point -- and behind the
+    # bucket's all-reduce when there is one -- while the compute stream carries on with the backward.  The buckets tile the arena
+    # and the side stream runs them in hook order, so the accumulation order is fixed: deterministic.
+    def begin_norm(self):
+        if self.max_grad_norm is None or self.max_grad_norm <= 0 or not torch.cuda.is_available():
+            return False
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+            big = max(b.numel() for b in self.model.grad_buckets().values())
+            with torch.cuda.stream(self._side):
+                self._norm_ws = torch.empty((K._L.mantis_sumsq_partials(big),), dtype=torch.float32, device=self.model.device)
+        self._norm_buckets = self.model.grad_buckets()
+        self._norm_first = True
+        self._norm_seen = 0
+        return True
+
+    def bucket_ready(self, key, after=()):
+        """Called from inside the backward right after the last kernel that writes bucket `key` was enqueued (`after`: async
+        collective handles that must complete first)."""
+        b = self._norm_buckets.get(key)
+        if b is None:
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(ev)
+            for h in after:
+                h.wait()
+            K.grad_sumsq(b, self._sumsq, accumulate=not self._norm_first, ws=self._norm_ws)
+        self._norm_first = False
+        self._norm_seen += b.numel()
+
+    def end_norm(self):
+        if self._norm_seen != self.model.grad_arena.numel():
+            raise RuntimeError("gradient-norm overlap: the backward reported buckets covering "
+                               f"{self._norm_seen} of {self.model.grad_arena.numel()} gradient elements")
+        torch.cuda.current_stream().wait_stream(self._side)
+        self._norm_ready = True
+
     def step(self):
         m = self.model
         if getattr(m, "_param_version", 0) != self._seen_version:
@@ -57,7 +99,9 @@ class FusedAdamW:
         self.step_count += 1
         scale = None
         if self.max_grad_norm is not None and self.max_grad_norm > 0:
-            K.grad_sumsq(m.grad_arena, self._sumsq, accumulate=False)
+            if not self._norm_ready:                       # no overlap this step (GA window not driven through the hooks, CPU tests)
+                K.grad_sumsq(m.grad_arena, self._sumsq, accumulate=False)
+            self._norm_ready = False
             scale, self.last_grad_norm = K.clip_scale(self._sumsq, self.max_grad_norm)
         for p_off, g_off, cnt in self._segments:
             K.adamw_flat(m.arena[p_off:p_off + cnt], m.grad_arena[g_off:g_off + cnt], self.master[g_off:g_off + cnt],

@@ -14,10 +14,13 @@ import torch
 
 
 class MantisHipTrainer:
-    def __init__(self, model=None, gradient_accumulation_steps=1, reducer=None):
+    def __init__(self, model=None, gradient_accumulation_steps=1, reducer=None, optimizer=None):
+        """optimizer (a `FusedAdamW`, optional): its gradient-norm pass is taken bucket by bucket on a side stream during the
+        backward of the boundary micro-batch instead of as a separate pass before the update."""
         self.model = model
         self.current_gradient_accumulation_steps = gradient_accumulation_steps
         self.reducer = reducer
+        self.optimizer = optimizer
         self._micro = 0
 
     def _prepare_inputs(self, inputs):
@@ -45,14 +48,24 @@ class MantisHipTrainer:
         if boundary:
             self._micro = 0                 # the optimizer steps after this micro-batch: the next window starts at 0
         reduce_now = self.reducer is not None and boundary
-        hook = self.reducer.bucket_ready if reduce_now else None
+        norm_now = boundary and self.optimizer is not None and self.optimizer.begin_norm()
         if reduce_now:
             self.reducer.begin()
+        hook = None
+        if reduce_now or norm_now:
+            red, opt = self.reducer, self.optimizer
+
+            def hook(key):
+                handles = red.bucket_ready(key) if reduce_now else ()
+                if norm_now:
+                    opt.bucket_ready(key, after=handles or ())
         out = model.engine.step(inputs["input_ids"], inputs["attention_mask"], inputs.get("labels"),
                                 inputs.get("pixel_values"), grad_scale=1.0 / ga, loss_scale=1.0 / ga, compute_grads=True,
                                 overwrite_grads=overwrite, on_bucket_ready=hook)
         if reduce_now:
             self.reducer.finish()
+        if norm_now:
+            self.optimizer.end_norm()
         return out["loss"].reshape(()).detach()
 
 

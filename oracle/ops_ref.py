@@ -363,7 +363,7 @@ def adamw_flat(param, grad, master, m, v, lr, beta1, beta2, eps, wd, step, grad_
     param.copy_(master.to(param.dtype))
 
 
-def grad_sumsq(x, out, accumulate=False):
+def grad_sumsq(x, out, accumulate=False, ws=None):
     s = _f(x).pow(2).sum()
     out[0] = out[0] + s if accumulate else s
 

@@ -619,6 +619,32 @@ def check_optimizer_step_vs_torch():
     return worst
 
 
+def check_norm_overlap():
+    """The gradient-norm pass taken bucket by bucket on a side stream during the backward (MantisHipTrainer(optimizer=...)) gives the
+    same global norm as the separate pass over the whole arena, and the same parameters after the step."""
+    from mantis_amd.trainer import MantisHipTrainer
+    from mantis_amd.optim import FusedAdamW
+    z = Hh.load_case("siglip_training_step_ga4")
+    m1, _, _ = Hh.build_product_model("siglip", DEV)
+    m2, _, _ = Hh.build_product_model("siglip", DEV)
+    o1 = FusedAdamW(m1, lr=1e-3, max_grad_norm=1.0)
+    o2 = FusedAdamW(m2, lr=1e-3, max_grad_norm=1.0)
+    t1, t2 = MantisHipTrainer(m1, 2), MantisHipTrainer(m2, 2, optimizer=o2)
+    for step in range(2):
+        for i in range(2):
+            b = _golden_batch(z, f"mb{2 * step + i}.")
+            t1.training_step(m1, dict(b))
+            t2.training_step(m2, dict(b))
+        assert torch.equal(m1.grad_arena, m2.grad_arena)
+        assert o2._norm_ready, "the boundary micro-batch did not drive the overlapped norm"
+        o1.step(), o2.step()
+        n1, n2 = float(o1.last_grad_norm), float(o2.last_grad_norm)
+        assert abs(n1 - n2) <= 1e-5 * n1, (n1, n2)
+        o1.zero_grad(set_to_none=True), o2.zero_grad(set_to_none=True)
+        close(o2.master, o1.master, 1e-6, f"fp32 master after step {step + 1}")
+    return 0.0
+
+
 # ------------------------------------------------------------------------------------------------------------- full-size parity
 CFG2 = dict(B=2, L=2812, H=32, Hkv=8, hd=128, d=4096, I=14336, V=128258, M=5624)
 
@@ -778,6 +804,7 @@ def all_checks():
     c["forward_contract_hip"] = check_forward_contract_hip
     c["hf_trainer_on_hip"] = check_hf_trainer_on_hip
     c["optimizer_step_vs_torch"] = check_optimizer_step_vs_torch
+    c["norm_overlap"] = check_norm_overlap
     c["dp_rccl_world1"] = check_dp_rccl_world1
     # cfg2 (BASELINE.json configs[1]) shapes, every row against the oracle
     c["fullsize_attn_causal"] = lambda: check_attn_fullsize(False)
