@@ -36,6 +36,15 @@ int mantis_pack_plan(const int64_t* input_ids, const int64_t* attention_mask, co
                      int64_t ignore_index, int L, int32_t* src, int64_t* out_mask, int64_t* out_labels, int64_t* out_pos,
                      int32_t* kmask, int32_t* text_pos, int32_t* img_slot, int32_t* ce_row, int32_t* ce_tgt,
                      int32_t* status, void* stream);
+/* Packed samples (/root/reference/mantis/train/data.py:1546-1671, PackingDataset.pack_batch: several samples concatenated into one
+ * row with a block-diagonal 4-D attention mask and position ids restarting per sample).  Runs after mantis_pack_plan on the same
+ * arrays; segment_ids int32 [B,T] = sample index of every input token (non-decreasing along a row, rows not padded).  Writes
+ * kstart / qend int32 [B,L] (first / one-past-last merged position of each position's sample: the O(L) form of the block-diagonal
+ * mask, consumed by mantis_attn_fwd / mantis_attn_bwd), rewrites out_pos to restart at 0 per sample and removes the CE row of every
+ * sample's first token (no prediction across a sample boundary).  workspace: int32 [B,L]. */
+int mantis_pack_segments(const int64_t* input_ids, const int32_t* segment_ids, const int64_t* merged_mask, int B, int T,
+                         int num_patches, int64_t image_token_index, int L, int64_t* out_pos, int32_t* ce_row, int32_t* ce_tgt,
+                         int32_t* kstart, int32_t* qend, int32_t* workspace, void* stream);
 /* merged[b,p,:] = embed_weight[ids[b,src]] | image_features[src & ~(1<<30)] | 0     (modeling_llava.py:427,338,353) */
 int mantis_pack_rows_fwd(const int32_t* src, const int64_t* input_ids, const void* embed_weight, const void* image_features,
                          void* out, int B, int T, int L, int d, int64_t vocab, void* stream);
@@ -95,8 +104,12 @@ int mantis_gemm_workspace_bytes(int M, int N, int K);
 int mantis_gemm_pick_variant(int M, int N, int K);
 
 /* ---- attention: HF:models/llama/modeling_llama.py:191-214,262-276; HF:models/siglip/modeling_siglip.py:227-247 */
-int mantis_attn_fwd(const void* Q, const void* K, const void* V, const int32_t* kmask, void* O, float* LSE, int B, int L, int H,
-                    int Hkv, int hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale, int causal, void* stream);
+/* kmask int32 [B,L] (nullable): 1 = key may be attended (key padding).  kstart int32 [B,L] (nullable): packed samples -- query q
+ * attends keys >= kstart[b,q] only (the start of its own sample; non-decreasing in q), i.e. the block-diagonal mask of
+ * /root/reference/mantis/train/data.py:1627-1638 in O(L) form. */
+int mantis_attn_fwd(const void* Q, const void* K, const void* V, const int32_t* kmask, const int32_t* kstart, void* O, float* LSE,
+                    int B, int L, int H, int Hkv, int hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale, int causal,
+                    void* stream);
 int mantis_attn_dsum(const void* dO, const void* O, float* Dsum, int B, int L, int H, int hd, int64_t ldo, void* stream);
 /* workspace: 2*B*L*H*hd bf16 (per-query-head dK/dV partials, reduced over the GQA group) when
  * mantis_attn_bwd_needs_workspace(H, Hkv, hd) says so, else unused/NULL: not for H == Hkv, and not for the GQA-aware dK/dV kernel

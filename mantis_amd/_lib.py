@@ -16,6 +16,7 @@ F = ctypes.c_float
 # name -> argtypes (restype is always int).  Mirrors include/mantis_hip.h one-to-one.
 SIGNATURES = {
     "mantis_pack_plan": [P, P, P, I, I, I, I, L, L, L, I, P, P, P, P, P, P, P, P, P, P, P],
+    "mantis_pack_segments": [P, P, P, I, I, I, L, I, P, P, P, P, P, P, P],
     "mantis_pack_rows_fwd": [P, P, P, P, P, I, I, I, I, L, P],
     "mantis_gather_rows": [P, P, P, L, I, P],
     "mantis_scatter_rows": [P, P, P, L, I, P],
@@ -37,7 +38,7 @@ SIGNATURES = {
     "mantis_gemm_bf16_nt": [P, L, P, L, P, L, I, I, I, P, P, L, I, P, L, P],
     "mantis_gemm_workspace_bytes": [I, I, I],
     "mantis_gemm_pick_variant": [I, I, I],
-    "mantis_attn_fwd": [P, P, P, P, P, P, I, I, I, I, I, L, L, L, L, F, I, P],
+    "mantis_attn_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, L, L, L, L, F, I, P],
     "mantis_attn_dsum": [P, P, P, I, I, I, I, L, P],
     "mantis_attn_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, L, L, L, L, L, L, L, L, F, I, P],
     "mantis_attn_bwd_needs_workspace": [I, I, I],

@@ -193,7 +193,8 @@ template <int HD, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                        const bf16_t* __restrict__ V, const int* __restrict__ kmask,
                                                        bf16_t* __restrict__ O, float* __restrict__ LSE, int L, int H, int Hkv,
-                                                       long ldq, long ldk, long ldv, long ldo, float scale) {
+                                                       long ldq, long ldk, long ldv, long ldo, float scale,
+                                                       const int* __restrict__ kstart) {
     using C = AttnCfg<HD>;
     using Y = Lay<HD>;
     constexpr int TILE = 64 * Y::PITCH;
@@ -209,6 +210,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     const int qblk0 = qb * 128, q0 = qblk0 + wave * 32, q = q0 + lq;
     const int qc = q < L ? q : L - 1;
     const float c = scale * LOG2E;
+    // packed samples: query q attends keys >= kstart[q] only (its own sample; non-decreasing in q).  ks_q = this lane's bound,
+    // ks_hi = the largest bound in the wave's 32 rows (tiles below it need per-element masking), t_first = first tile any row of
+    // the workgroup's 128-query block can see
+    const int ks_q = kstart ? kstart[(long)b * L + qc] : 0;
+    const int ks_hi = kstart ? kstart[(long)b * L + (q0 + 31 < L ? q0 + 31 : L - 1)] : 0;
+    const int t_first = kstart ? (kstart[(long)b * L + (qblk0 < L ? qblk0 : L - 1)] >> 6) : 0;
 
     bf16x8 qf[C::NKS];
 #pragma unroll
@@ -259,18 +266,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
             if (threadIdx.x == 0) bp[64] = (okm == ~0ull) ? 0.f : 1.f;
         }
     };
-    stage(0);
+    stage(t_first);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    for (int t = 0; t < ntiles; ++t) {
+    for (int t = t_first; t < ntiles; ++t) {
         const int key0 = t * 64;
         const char* sK = smem + (t & 1) * BUF;
         const char* sV = sK + TILE;
         const float* sBias = reinterpret_cast<const float*>(sK + 2 * TILE);
         const bool more = t + 1 < ntiles;
         if (more) stage(t + 1);
-        if (!(CAUSAL && key0 > q0 + 31)) {   // wave-uniform: skip tiles entirely in this wave's future
+        if (!(CAUSAL && key0 > q0 + 31)) {   // wave-uniform: skip tiles entirely in this wave's future (tiles wholly before the
+                                             // wave's samples are harmless: fully masked, p = 0, running max stays -inf)
             f32x16 s[2];
 #pragma unroll
             for (int sb = 0; sb < 2; ++sb)
@@ -321,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
             }
             float mx = -INFINITY;
             // wave-uniform: only tiles that touch the diagonal or contain masked keys pay for per-element masking
-            const bool need_mask = (CAUSAL && key0 + 63 > q0) || sBias[64] != 0.f;
+            const bool need_mask = (CAUSAL && key0 + 63 > q0) || sBias[64] != 0.f || key0 < ks_hi;
             if (need_mask) {
 #pragma unroll
                 for (int sb = 0; sb < 2; ++sb)
@@ -330,6 +338,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
                         const int kl = sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
                         float v = s[sb][r] * c + sBias[kl];
                         if (CAUSAL && key0 + kl > q) v = -INFINITY;
+                        if (key0 + kl < ks_q) v = -INFINITY;
                         s[sb][r] = v;
                         mx = fmaxf(mx, v);
                     }
@@ -453,7 +462,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
                                                           const int* __restrict__ kmask, const float* __restrict__ LSE,
                                                           float* __restrict__ Dsum, bf16_t* __restrict__ dQ, int L, int H,
                                                           int Hkv, long ldq, long ldk, long ldv, long ldo, long lddq, float scale,
-                                                          const bf16_t* __restrict__ Ofwd, long ldout) {
+                                                          const bf16_t* __restrict__ Ofwd, long ldout,
+                                                          const int* __restrict__ kstart) {
     using C = AttnCfg<HD>;
     using Y = Lay<HD>;
     constexpr int TILE = 64 * Y::PITCH;
@@ -469,6 +479,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     const int qblk0 = qb * 128, q0 = qblk0 + wave * 32, q = q0 + lq;
     const int qc = q < L ? q : L - 1;
     const float c = scale * LOG2E;
+    // segment bounds of packed samples: see attn_fwd_kernel
+    const int ks_q = kstart ? kstart[(long)b * L + qc] : 0;
+    const int ks_hi = kstart ? kstart[(long)b * L + (q0 + 31 < L ? q0 + 31 : L - 1)] : 0;
+    const int t_first = kstart ? (kstart[(long)b * L + (qblk0 < L ? qblk0 : L - 1)] >> 6) : 0;
 
     bf16x8 qf[C::NKS], dof[C::NKS];
 #pragma unroll
@@ -544,11 +558,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
             if (threadIdx.x == 0) bp[64] = (okm == ~0ull) ? 0.f : 1.f;
         }
     };
-    stage(0);
+    stage(t_first);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    for (int t = 0; t < ntiles; ++t) {
+    for (int t = t_first; t < ntiles; ++t) {
         const int key0 = t * 64;
         const char* sK = smem + (t & 1) * BUF;
         const char* sV = sK + TILE;
@@ -556,7 +570,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
         const bool more = t + 1 < ntiles;
         if (more) stage(t + 1);
         if (!(CAUSAL && key0 > q0 + 31)) {
-            const bool need_mask = (CAUSAL && key0 + 63 > q0) || sBias[64] != 0.f;   // wave-uniform
+            const bool need_mask = (CAUSAL && key0 + 63 > q0) || sBias[64] != 0.f || key0 < ks_hi;   // wave-uniform
             // one 32-key half at a time: S, dP -> dS -> dQ contribution, so only 32 score registers are live (2 waves per SIMD)
 #pragma unroll
             for (int sb = 0; sb < 2; ++sb) {
@@ -577,6 +591,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
                         const int kl = sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
                         float v = s[r] * c + sBias[kl];
                         if (CAUSAL && key0 + kl > q) v = -INFINITY;
+                        if (key0 + kl < ks_q) v = -INFINITY;
                         const float p = __builtin_amdgcn_exp2f(v - lse2);  // lse = +inf for fully masked rows -> p = 0
                         s[r] = p * (dp[r] - dsum);             // the softmax scale is applied once, to the dQ accumulators
                     }
@@ -639,13 +654,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
                                                               const int* __restrict__ kmask, const float* __restrict__ LSE,
                                                               const float* __restrict__ Dsum, bf16_t* __restrict__ dKp,
                                                               bf16_t* __restrict__ dVp, int L, int H, int Hkv, long ldq, long ldk,
-                                                              long ldv, long ldo, long ldpk, long ldpv, float scale) {
+                                                              long ldv, long ldo, long ldpk, long ldpv, float scale,
+                                                              const int* __restrict__ kstart, const int* __restrict__ qend) {
     using C = AttnCfg<HD>;
     using D = DkvCfg<HD>;
     constexpr int QT = 64;                          // query rows staged per barrier (processed as two 32-row passes)
     using Y = Lay<HD>;
     constexpr int TILE = QT * Y::PITCH;
-    constexpr int BUF = 2 * TILE + 2 * QT * 4;
+    constexpr int BUF = 2 * TILE + 3 * QT * 4;      // Q tile | dO tile | lse2[QT] dsum[QT] kstart[QT]
     __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hh = lane >> 5, lk = lane & 31;
@@ -677,7 +693,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
         for (int e = 0; e < 16; ++e) { dkacc[d][e] = 0.f; dvacc[d][e] = 0.f; }
 
     const int qstart = CAUSAL ? (kblk0 / QT) : 0;  // first query tile that can see this key block
-    const int nqt = (L + QT - 1) / QT;
+    int qlim = L;                                   // packed samples: no query at or beyond the end of these keys' sample sees them
+    if (qend != nullptr) {
+        __shared__ int s_qlim;
+        if (threadIdx.x == 0) s_qlim = 0;
+        __syncthreads();
+        if (threadIdx.x < D::KEYS && kblk0 + (int)threadIdx.x < L) atomicMax(&s_qlim, qend[(long)b * L + kblk0 + threadIdx.x]);
+        __syncthreads();
+        qlim = s_qlim < L ? s_qlim : L;
+    }
+    const int nqt = (qlim + QT - 1) / QT;
     const bf16_t* Qb = Q + (long)b * L * ldq + (long)h * HD;
     const bf16_t* dOb = dO + (long)b * L * ldo + (long)h * HD;
 
@@ -703,6 +728,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
             const int qq = q0 + threadIdx.x;
             reinterpret_cast<float*>(base + 2 * TILE)[threadIdx.x] = qq < L ? LSE[((long)b * H + h) * L + qq] * LOG2E : INFINITY;
             reinterpret_cast<float*>(base + 2 * TILE)[QT + threadIdx.x] = qq < L ? Dsum[((long)b * H + h) * L + qq] : 0.f;
+            // rows beyond L: "sees no key" (keeps the wave-uniform need_mask test below, which looks at the pass's LAST row, sound)
+            reinterpret_cast<int*>(base + 2 * TILE)[2 * QT + threadIdx.x] =
+                kstart == nullptr ? 0 : (qq < L ? kstart[(long)b * L + qq] : 0x7fffffff);
         }
     };
     if (qstart < nqt) stage(qstart);
@@ -719,6 +747,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
         const char* sdO = sQ + TILE;
         const float* sLse = reinterpret_cast<const float*>(tQ + 2 * TILE) + pass * 32;
         const float* sDs = sLse + QT;
+        const int* sKs = reinterpret_cast<const int*>(tQ + 2 * TILE) + 2 * QT + pass * 32;
         if (!(CAUSAL && q0 + 31 < k0)) {  // wave-uniform: skip passes whose every query precedes this wave's keys
             f32x16 s, dp;
 #pragma unroll
@@ -732,13 +761,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[ks], dp, 0, 0, 0);
             }
             f32x16 ds;
-            const bool need_mask = (CAUSAL && k0 + 31 > q0) || !__all(key_ok);   // wave-uniform
+            const bool need_mask = (CAUSAL && k0 + 31 > q0) || !__all(key_ok) || sKs[31] > k0;   // wave-uniform
             if (need_mask) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ql = (r & 3) + 8 * (r >> 2) + 4 * hh;
                     float v = key_ok ? s[r] * c : -INFINITY;
                     if (CAUSAL && key > q0 + ql) v = -INFINITY;
+                    if (key < sKs[ql]) v = -INFINITY;
                     const float p = __builtin_amdgcn_exp2f(v - sLse[ql]);
                     s[r] = p;
                     ds[r] = p * (dp[r] - sDs[ql]);       // the softmax scale is applied once, to the dK accumulators
@@ -945,7 +975,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_g4_kernel(
         const int qq = qt * QT + lk;
         float* fp = reinterpret_cast<float*>(smem + slot * STAGE + hp * STREAM + 2 * TILE);
         const float val = hh == 0 ? vl * LOG2E : vs;
-        fp[lane] = qq < L ? val : (hh == 0 ? INFINITY : 0.f);      // +inf beyond L -> p = 0
+        // +inf beyond the last query that can see this key block -> p = 0: beyond L, and (packed samples) beyond the end of the
+        // keys' sample -- for a regular block every key shares that end, so the tile straddling it needs no per-element mask
+        fp[lane] = qq < qlim ? val : (hh == 0 ? INFINITY : 0.f);
         if constexpr (SEG) reinterpret_cast<int*>(fp)[2 * QT + lk] = ksv;
     };
     // S, dP of the tile in `slot` -> s, dp   (the first MFMA of each chain takes the constant 0 as its accumulator input)
@@ -1228,13 +1260,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_g4_kernel(
 
 template <int HD>
 static int launch_fwd(bool causal, dim3 grid, hipStream_t s, const bf16_t* Q, const bf16_t* K, const bf16_t* V, const int* kmask,
-                      bf16_t* O, float* LSE, int L, int H, int Hkv, long ldq, long ldk, long ldv, long ldo, float scale) {
+                      bf16_t* O, float* LSE, int L, int H, int Hkv, long ldq, long ldk, long ldv, long ldo, float scale,
+                      const int* kstart) {
     if (causal)
         hipLaunchKernelGGL((attn_fwd_kernel<HD, true>), grid, dim3(256), 0, s, Q, K, V, kmask, O, LSE, L, H, Hkv, ldq, ldk, ldv,
-                           ldo, scale);
+                           ldo, scale, kstart);
     else
         hipLaunchKernelGGL((attn_fwd_kernel<HD, false>), grid, dim3(256), 0, s, Q, K, V, kmask, O, LSE, L, H, Hkv, ldq, ldk, ldv,
-                           ldo, scale);
+                           ldo, scale, kstart);
     return mantis_check_launch();
 }
 
@@ -1247,13 +1280,12 @@ static int launch_bwd(bool causal, hipStream_t s, const bf16_t* Q, const bf16_t*
     const int G = H / Hkv;
     if constexpr (HD == 128) {
         if (G == 4) {      // Llama-3 geometry: GQA-aware dK/dV (no HBM partials, no group reduce); dQ as before (it also publishes Dsum)
-            if (kstart != nullptr) return MANTIS_EUNSUPPORTED;      // the dQ kernel has no segment bounds yet
             if (causal)
                 hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, true>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, L, H, Hkv,
-                                   ldq, ldk, ldv, ldo, lddq, scale, Ofwd, ldout);
+                                   ldq, ldk, ldv, ldo, lddq, scale, Ofwd, ldout, kstart);
             else
                 hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, false>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, L, H, Hkv,
-                                   ldq, ldk, ldv, ldo, lddq, scale, Ofwd, ldout);
+                                   ldq, ldk, ldv, ldo, lddq, scale, Ofwd, ldout, kstart);
             const dim3 g4(cdiv(L, 64) * Hkv * B);
 #define DKV_G4(C_, S_) hipLaunchKernelGGL((attn_bwd_dkv_g4_kernel<C_, S_>), g4, dim3(256), 0, s, Q, K, V, dO, kmask, kstart, qend, LSE, \
                                           Dsum, dK, dV, L, H, Hkv, ldq, ldk, ldv, ldo, lddk, lddv, scale)
@@ -1263,7 +1295,6 @@ static int launch_bwd(bool causal, hipStream_t s, const bf16_t* Q, const bf16_t*
             return mantis_check_launch();
         }
     }
-    if (kstart != nullptr || qend != nullptr) return MANTIS_EUNSUPPORTED;
     if (G > 1 && ws == nullptr) return MANTIS_EINVAL;
     const long rows = (long)B * L;
     bf16_t* pk = G == 1 ? dK : ws;
@@ -1271,14 +1302,14 @@ static int launch_bwd(bool causal, hipStream_t s, const bf16_t* Q, const bf16_t*
     const long ldpk = G == 1 ? lddk : (long)H * HD, ldpv = G == 1 ? lddv : (long)H * HD;
     if (causal) {
         hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, true>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, L, H, Hkv, ldq,
-                           ldk, ldv, ldo, lddq, scale, Ofwd, ldout);
+                           ldk, ldv, ldo, lddq, scale, Ofwd, ldout, kstart);
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, true>), gk, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, pk, pv, L, H, Hkv,
-                           ldq, ldk, ldv, ldo, ldpk, ldpv, scale);
+                           ldq, ldk, ldv, ldo, ldpk, ldpv, scale, kstart, qend);
     } else {
         hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, false>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, L, H, Hkv, ldq,
-                           ldk, ldv, ldo, lddq, scale, Ofwd, ldout);
+                           ldk, ldv, ldo, lddq, scale, Ofwd, ldout, kstart);
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, false>), gk, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, pk, pv, L, H, Hkv,
-                           ldq, ldk, ldv, ldo, ldpk, ldpv, scale);
+                           ldq, ldk, ldv, ldo, ldpk, ldpv, scale, kstart, qend);
     }
     if (G > 1) {
         const long total = rows * Hkv * (HD / 8);
@@ -1294,14 +1325,16 @@ extern "C" {
 
 // Q [B,L,H,hd] (row stride ldq), K,V [B,L,Hkv,hd] (ldk, ldv), kmask int32[B,L] or NULL, O [B,L,H,hd] (ldo),
 // LSE fp32 [B,H,L] or NULL.  hd in {16, 64, 72, 128}.
-int mantis_attn_fwd(const void* Q, const void* K, const void* V, const int32_t* kmask, void* O, float* LSE, int B, int L, int H,
-                    int Hkv, int hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale, int causal, void* stream) {
+int mantis_attn_fwd(const void* Q, const void* K, const void* V, const int32_t* kmask, const int32_t* kstart, void* O, float* LSE,
+                    int B, int L, int H, int Hkv, int hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale, int causal,
+                    void* stream) {
     if (B <= 0 || L <= 0 || H <= 0 || Hkv <= 0 || H % Hkv) return MANTIS_EINVAL;
     if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4) return MANTIS_EUNSUPPORTED;
+    if (kstart != nullptr && !causal) return MANTIS_EUNSUPPORTED;     // a lower key bound alone is a block-diagonal mask only under causality
     const dim3 grid(cdiv(L, 128) * H * B);
     hipStream_t s = (hipStream_t)stream;
 #define FWD(HD) return launch_fwd<HD>(causal != 0, grid, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, kmask, \
-                                      (bf16_t*)O, LSE, L, H, Hkv, (long)ldq, (long)ldk, (long)ldv, (long)ldo, scale)
+                                      (bf16_t*)O, LSE, L, H, Hkv, (long)ldq, (long)ldk, (long)ldv, (long)ldo, scale, kstart)
     switch (hd) {
         case 16: FWD(16);
         case 64: FWD(64);
@@ -1336,6 +1369,7 @@ int mantis_attn_bwd(const void* Q, const void* K, const void* V, const void* O, 
     if (B <= 0 || L <= 0 || H <= 0 || Hkv <= 0 || H % Hkv || !Dsum) return MANTIS_EINVAL;
     if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8 || lddq % 4 || lddk % 8 || lddv % 8 || (O && ld_out % 8)) return MANTIS_EUNSUPPORTED;
     if ((kstart == nullptr) != (qend == nullptr)) return MANTIS_EINVAL;
+    if (kstart != nullptr && !causal) return MANTIS_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
 #define BWD(HD) return launch_bwd<HD>(causal != 0, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dO, \
                                       kmask, LSE, Dsum, (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV, (bf16_t*)workspace, B, L, H, Hkv, \

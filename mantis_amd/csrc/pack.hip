@@ -8,6 +8,7 @@
 // latency- not bandwidth-bound and a single CU doing block-wide scans in LDS beats ~10 ATen launches.
 // Row kernels: pure HBM-bound 16 B/lane copies (algorithmic bytes: read B*T*d + I*N*d, write B*L*d bf16).
 #include "common.h"
+#include <climits>
 
 #define IMGBIT (1 << 30)
 #define PLAN_THREADS 1024
@@ -284,6 +285,123 @@ static inline int row_grid(long total_chunks) {
     return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
 }
 
+
+// ---- packed samples (sample packing, /root/reference/mantis/train/data.py:1546-1671: several samples in ONE row) --------------
+// Runs after pack_plan_kernel on the same arrays.  seg[B,T]: sample index of every input token (non-decreasing along a row).
+// Produces, per merged position p of a row:   kstart[p] = first merged position of p's sample (the O(L) form of the reference's
+// block-diagonal 4-D mask: a causal query attends keys >= kstart only),   qend[p] = one past the last position of p's sample,
+// and rewrites   position_ids   to restart at 0 in every sample (data.py:1641-1648; pads keep 1 as in modeling_llava.py:355) and
+// ce_row / ce_tgt so that the first token of a sample is NOT predicted from the last hidden state of the previous sample.
+// A token's span in the merged row is [tok_start, tok_end]: one slot for text, num_patches slots for <image>; spans are recovered
+// from an inclusive scan of the span lengths (+ the row's left-padding shift, which is 0 for packed rows).  One workgroup per row.
+__device__ __forceinline__ int block_scan_max_incl(int v, int* lds) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(x, o, 64);
+        if (lane >= o) x = max(x, y);
+    }
+    __syncthreads();
+    if (lane == 63) lds[w] = x;
+    __syncthreads();
+    if (w == 0) {
+        int t = (lane < 16) ? lds[lane] : INT_MIN;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            const int y = __shfl_up(t, o, 64);
+            if (lane >= o) t = max(t, y);
+        }
+        if (lane < 16) lds[16 + lane] = t;
+    }
+    __syncthreads();
+    return (w == 0) ? x : max(x, lds[16 + w - 1]);
+}
+
+__global__ __launch_bounds__(PLAN_THREADS) void pack_segments_kernel(
+    const long* __restrict__ ids, const int* __restrict__ seg, const long* __restrict__ out_mask, int B, int T, int N, long IMG, int L,
+    long* __restrict__ out_pos, int* __restrict__ ce_row, int* __restrict__ ce_tgt, int* __restrict__ kstart,
+    int* __restrict__ qend, int* __restrict__ ws /* [B, L] scratch */) {
+    __shared__ int lds[64];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const long* idb = ids + (long)b * T;
+    const int* sgb = seg + (long)b * T;
+    int* wsb = ws + (long)b * L;
+    int* ksb = kstart + (long)b * L;
+    int* qeb = qend + (long)b * L;
+    const int perT = (T + PLAN_THREADS - 1) / PLAN_THREADS, perL = (L + PLAN_THREADS - 1) / PLAN_THREADS;
+    // 1. span ends by an inclusive scan of span lengths; the row's shift = L - total (left padding, modeling_llava.py:310-312)
+    const int t0 = tid * perT, t1 = min(T, t0 + perT);
+    int local = 0;
+    for (int t = t0; t < t1; ++t) local += (idb[t] == IMG) ? N : 1;
+    int tot;
+    const int incl = block_scan_incl(local, lds, &tot);
+    const int shift = L - tot;          // packed rows: 0.  (right-padded rows never reach here: the host refuses pad + segments)
+    for (int p = tid; p < L; p += PLAN_THREADS) wsb[p] = 0;
+    __syncthreads();
+    // 2. mark the first merged position of every sample with (position + 1); sample starts also lose their CE row
+    int run = incl - local;
+    for (int t = t0; t < t1; ++t) {
+        const int len = (idb[t] == IMG) ? N : 1;
+        const int start = run + shift;
+        run += len;
+        if (t == 0 || sgb[t] != sgb[t - 1]) {
+            if (start >= 0 && start < L) wsb[start] = start + 1;
+            ce_row[(long)b * T + t] = -1;
+            ce_tgt[(long)b * T + t] = -100;
+        }
+    }
+    __syncthreads();
+    // 3. kstart = running maximum of the marks (minus 1); positions before the first mark (left padding) belong to "sample" 0
+    const int p0 = tid * perL, p1 = min(L, p0 + perL);
+    int lm = 0;
+    for (int p = p0; p < p1; ++p) lm = max(lm, wsb[p]);
+    const int pre = block_scan_max_incl(lm, lds);      // inclusive over chunks
+    // exclusive prefix for this chunk = max over earlier chunks: recompute from the inclusive value of the previous thread
+    __shared__ int chunkmax[PLAN_THREADS];
+    chunkmax[tid] = pre;
+    __syncthreads();
+    int cur = tid == 0 ? 0 : chunkmax[tid - 1];
+    for (int p = p0; p < p1; ++p) {
+        cur = max(cur, wsb[p]);
+        ksb[p] = cur > 0 ? cur - 1 : 0;
+    }
+    __syncthreads();
+    // 4. qend[p] = start of the next sample (or L): the smallest mark position > p  ->  reverse running minimum
+    int ln = L;
+    for (int p = p1 - 1; p >= p0; --p) if (wsb[p] > 0 && p > 0) ln = p;      // smallest marked position inside the chunk (p = 0 is no "next")
+    // suffix minimum over later chunks: small serial pass by warp 0 over the 1024 chunk values (once per step, latency irrelevant)
+    chunkmax[tid] = ln;
+    __syncthreads();
+    if (tid == 0) {
+        int m = L;
+        for (int i = PLAN_THREADS - 1; i >= 0; --i) { const int v = chunkmax[i]; chunkmax[i] = m; m = min(m, v); }   // exclusive suffix min
+    }
+    __syncthreads();
+    int nxt = chunkmax[tid];
+    for (int p = p1 - 1; p >= p0; --p) {
+        qeb[p] = nxt;
+        if (wsb[p] > 0 && p > 0) nxt = p;
+    }
+    __syncthreads();
+    // 5. position ids restart per sample: cumsum(mask) - cumsum(mask)[kstart - 1] - 1; pads keep 1 (modeling_llava.py:355)
+    int lc = 0;
+    for (int p = p0; p < p1; ++p) lc += (int)out_mask[(long)b * L + p];
+    int totm;
+    const int inclm = block_scan_incl(lc, lds, &totm);
+    int c = inclm - lc;
+    for (int p = p0; p < p1; ++p) {
+        c += (int)out_mask[(long)b * L + p];
+        wsb[p] = c;                                    // inclusive cumsum of the merged attention mask
+    }
+    __syncthreads();
+    for (int p = p0; p < p1; ++p) {
+        const int ks = ksb[p];
+        const int base = ks > 0 ? wsb[ks - 1] : 0;
+        out_pos[(long)b * L + p] = out_mask[(long)b * L + p] == 0 ? 1 : (long)(wsb[p] - base - 1);
+    }
+}
+
 extern "C" {
 
 int mantis_pack_plan(const int64_t* input_ids, const int64_t* attention_mask, const int64_t* labels, int B, int T,
@@ -297,6 +415,16 @@ int mantis_pack_plan(const int64_t* input_ids, const int64_t* attention_mask, co
                        (const long*)attention_mask, (const long*)labels, B, T, num_patches, num_images,
                        (long)image_token_index, (long)pad_token_id, (long)ignore_index, L, src, (long*)out_mask,
                        (long*)out_labels, (long*)out_pos, kmask, text_pos, img_slot, ce_row, ce_tgt, status);
+    return mantis_check_launch();
+}
+
+int mantis_pack_segments(const int64_t* input_ids, const int32_t* segment_ids, const int64_t* merged_mask, int B, int T,
+                         int num_patches, int64_t image_token_index, int L, int64_t* out_pos, int32_t* ce_row, int32_t* ce_tgt,
+                         int32_t* kstart, int32_t* qend, int32_t* workspace, void* stream) {
+    if (B <= 0 || T <= 0 || L < T || num_patches <= 0) return MANTIS_EINVAL;
+    hipLaunchKernelGGL(pack_segments_kernel, dim3(B), dim3(PLAN_THREADS), 0, (hipStream_t)stream, (const long*)input_ids,
+                       segment_ids, (const long*)merged_mask, B, T, num_patches, (long)image_token_index, L, (long*)out_pos, ce_row,
+                       ce_tgt, kstart, qend, workspace);
     return mantis_check_launch();
 }
 

@@ -118,3 +118,18 @@ def pack_samples(samples, materialize_mask=True):
     else:
         out["pixel_values"] = torch.cat([torch.as_tensor(p) for p in pv if p is not None], dim=0)
     return out
+
+
+def segments_from_packed(batch):
+    """(segment_ids int32 [1,S], key_mask int64 [1,S]) from a batch in the reference's packed format (PackingDataset.pack_batch,
+    data.py:1609-1671): `position_ids` restart at 0 at every sample start (:1641-1648) and the diagonal of the 4-D block-diagonal
+    mask is the per-token key mask (:1627-1638).  `pack_samples` output carries `segment_ids` / `key_mask` directly."""
+    if batch.get("segment_ids") is not None and batch.get("key_mask") is not None:
+        return batch["segment_ids"], batch["key_mask"]
+    if batch.get("position_ids") is None:
+        raise ValueError("a packed batch needs `position_ids` (restarting at 0 per sample) or `segment_ids` + `key_mask`")
+    pos = torch.as_tensor(batch["position_ids"]).reshape(-1)
+    seg = (torch.cumsum((pos == 0).to(torch.int32), 0) - 1).to(torch.int32)[None]
+    m = torch.as_tensor(batch["attention_mask"])
+    key = torch.diagonal(m[0, 0], 0).to(torch.int64)[None]
+    return seg, key

@@ -94,8 +94,12 @@ class LlavaEngine:
 
     # ------------------------------------------------------------------------------------------------ full step
     def step(self, input_ids, attention_mask, labels, pixel_values, grad_scale=1.0, loss_scale=1.0, compute_grads=True,
-             overwrite_grads=True, need_logits=False, record=None, on_bucket_ready=None):
+             overwrite_grads=True, need_logits=False, record=None, on_bucket_ready=None, segment_ids=None):
         """One forward (+ backward).  Returns dict(loss=fp32[1] on device, logits=[B,L,V] or None, plan=...).
+
+        segment_ids (int [B,T], optional): sample packing (/root/reference/mantis/train/data.py:1546-1671) -- several samples in
+        one row; tokens attend inside their own sample only (the reference's block-diagonal 4-D mask, here O(L) segment bounds
+        consumed by the attention kernels), position ids restart per sample, no token is predicted across a sample boundary.
 
         grad_scale multiplies d(loss) (1/GA for Trainer.training_step); loss_scale multiplies the returned loss.
         overwrite_grads: first micro-batch after zero_grad -> gradient kernels overwrite instead of accumulate."""
@@ -147,6 +151,14 @@ class LlavaEngine:
             L = T
             plan = K.pack_plan(ids_d, attn_d, lab_d, 1, 0, -(2 ** 62), pad_id, ign, L)
             plan.position_ids = torch.arange(T, device=dev, dtype=torch.int64)[None].expand(B, T).contiguous()
+        kstart = qend = None
+        if segment_ids is not None:
+            if bool((ids_cpu[:, -1] == pad_id).any()):
+                raise ValueError("packed rows (segment_ids) must not be right-padded: pack them to equal length or pass them one by one")
+            seg_d = segment_ids.to(dev, non_blocking=True).to(torch.int32).contiguous()
+            img_tok = cfg.image_token_index if (pixel_values is not None and T != 1) else -(2 ** 62)
+            K.pack_segments(plan, ids_d, seg_d, img_tok)
+            kstart, qend = plan.kstart, plan.qend
         emb_w = m.lm["embed"]
         x = K.pack_rows_fwd(plan, ids_d, emb_w, img)        # rows F+G fused: [B*L, d]
         if record is not None:
@@ -167,7 +179,7 @@ class LlavaEngine:
             n1, rstd1 = K.rmsnorm_fwd(x, lw["ln1"], eps)
             qkv = K.gemm_nt(n1, lw["qkv"])
             K.rope_apply_(qkv, cos, sin, H + Hkv, hd)
-            o, lse = K.attn_fwd(qkv, B, L, H, Hkv, hd, kmask, scale, True)
+            o, lse = K.attn_fwd(qkv, B, L, H, Hkv, hd, kmask, scale, True, kstart=kstart)
             x_mid = K.gemm_nt(o, lw["o"], residual=x)
             n2, rstd2 = K.rmsnorm_fwd(x_mid, lw["ln2"], eps)
             gu = K.gemm_nt(n2, lw["gu"])
@@ -242,7 +254,7 @@ class LlavaEngine:
             if lg_["o"] is not None:
                 K.linear_dw(dx_mid, o, lg_["o"], acc)
             do = K.linear_dx(dx_mid, lw["o"])
-            dqkv = K.attn_bwd(qkv, o, do, lse, B, L, H, Hkv, hd, kmask, scale, True)
+            dqkv = K.attn_bwd(qkv, o, do, lse, B, L, H, Hkv, hd, kmask, scale, True, kstart=kstart, qend=qend)
             del do, o
             K.rope_apply_(dqkv, cos, sin, H + Hkv, hd, backward=True)
             if lg_["qkv"] is not None:

@@ -252,14 +252,14 @@ def rope_apply_(x, cos, sin, nheads, hd, backward=False):
     return x
 
 
-def attn_fwd_qkv(q, k, v, B, Lseq, H, Hkv, hd, kmask, scale, causal, want_lse=True):
+def attn_fwd_qkv(q, k, v, B, Lseq, H, Hkv, hd, kmask, scale, causal, want_lse=True, kstart=None):
     """q [B*L, >=H*hd], k / v [B*L, >=Hkv*hd] bf16 row views (any row stride, heads contiguous inside a row; they may be column
     slices of one fused projection output).  Returns o [B*L, H*hd], lse [B,H,L] fp32."""
     _chk2d(q, "q"), _chk2d(k, "k"), _chk2d(v, "v")
     o = torch.empty((B * Lseq, H * hd), dtype=BF16, device=q.device)
     lse = torch.empty((B, H, Lseq), dtype=torch.float32, device=q.device) if want_lse else None
-    rc = _L.mantis_attn_fwd(_p(q), _p(k), _p(v), _p(kmask), _p(o), _p(lse), B, Lseq, H, Hkv, hd, q.stride(0), k.stride(0), v.stride(0),
-                            H * hd, float(scale), int(causal), _stream())
+    rc = _L.mantis_attn_fwd(_p(q), _p(k), _p(v), _p(kmask), _p(kstart), _p(o), _p(lse), B, Lseq, H, Hkv, hd, q.stride(0), k.stride(0),
+                            v.stride(0), H * hd, float(scale), int(causal), _stream())
     _lib.check(rc, f"attn_fwd hd={hd}")
     return o, lse
 
@@ -279,26 +279,27 @@ def _split_qkv(qkv, H, Hkv, hd):
     return qkv[:, : H * hd], qkv[:, H * hd: (H + Hkv) * hd], qkv[:, (H + Hkv) * hd: (H + 2 * Hkv) * hd]
 
 
-def attn_fwd(qkv, B, Lseq, H, Hkv, hd, kmask, scale, causal, want_lse=True):
-    """qkv: [B*L, (H+2Hkv)*hd] fused projection output (q | k | v).  Returns o [B*L, H*hd], lse [B,H,L]."""
+def attn_fwd(qkv, B, Lseq, H, Hkv, hd, kmask, scale, causal, want_lse=True, kstart=None):
+    """qkv: [B*L, (H+2Hkv)*hd] fused projection output (q | k | v).  Returns o [B*L, H*hd], lse [B,H,L].
+    kstart int32 [B,L] (packed samples): first key position each query may attend."""
     _chk2d(qkv, "qkv")
     q, k, v = _split_qkv(qkv, H, Hkv, hd)
-    return attn_fwd_qkv(q, k, v, B, Lseq, H, Hkv, hd, kmask, scale, causal, want_lse)
+    return attn_fwd_qkv(q, k, v, B, Lseq, H, Hkv, hd, kmask, scale, causal, want_lse, kstart=kstart)
 
 
-def attn_bwd(qkv, o, do, lse, B, Lseq, H, Hkv, hd, kmask, scale, causal):
+def attn_bwd(qkv, o, do, lse, B, Lseq, H, Hkv, hd, kmask, scale, causal, kstart=None, qend=None):
     """Returns dqkv [B*L, (H+2Hkv)*hd] (gradient w.r.t. the post-RoPE q, k and v)."""
     dqkv = torch.empty_like(qkv)
     q, k, v = _split_qkv(qkv, H, Hkv, hd)
     dq, dk, dv = _split_qkv(dqkv, H, Hkv, hd)
-    attn_bwd_qkv(q, k, v, o, do, lse, dq, dk, dv, B, Lseq, H, Hkv, hd, kmask, scale, causal)
+    attn_bwd_qkv(q, k, v, o, do, lse, dq, dk, dv, B, Lseq, H, Hkv, hd, kmask, scale, causal, kstart=kstart, qend=qend)
     return dqkv
 
 
 # ----------------------------------------------------------------------------------------------------------- packing / loss
 class PackPlan:
     __slots__ = ("B", "T", "L", "N", "I", "src", "attention_mask", "labels", "position_ids", "kmask", "text_pos", "img_slot",
-                 "ce_row", "ce_tgt", "status")
+                 "ce_row", "ce_tgt", "status", "kstart", "qend")
 
 
 def pack_plan(input_ids, attention_mask, labels, num_patches, num_images, image_token_index, pad_token_id, ignore_index, L):
@@ -306,6 +307,7 @@ def pack_plan(input_ids, attention_mask, labels, num_patches, num_images, image_
     dev = input_ids.device
     pl = PackPlan()
     pl.B, pl.T, pl.L, pl.N, pl.I = B, T, L, num_patches, num_images
+    pl.kstart = pl.qend = None
     pl.src = torch.empty((B, L), dtype=torch.int32, device=dev)
     pl.attention_mask = torch.empty((B, L), dtype=torch.int64, device=dev)
     pl.labels = torch.empty((B, L), dtype=torch.int64, device=dev)
@@ -322,6 +324,19 @@ def pack_plan(input_ids, attention_mask, labels, num_patches, num_images, image_
                              _p(pl.status), _stream())
     _lib.check(rc, "pack_plan")
     return pl
+
+
+def pack_segments(plan, input_ids, segment_ids, image_token_index):
+    """Packed samples: adds plan.kstart / plan.qend (int32 [B,L]) and rewrites plan.position_ids / ce_row / ce_tgt in place."""
+    dev = input_ids.device
+    plan.kstart = torch.empty((plan.B, plan.L), dtype=torch.int32, device=dev)
+    plan.qend = torch.empty((plan.B, plan.L), dtype=torch.int32, device=dev)
+    ws = torch.empty((plan.B, plan.L), dtype=torch.int32, device=dev)
+    rc = _L.mantis_pack_segments(_p(input_ids), _p(segment_ids), _p(plan.attention_mask), plan.B, plan.T, plan.N, image_token_index,
+                                 plan.L, _p(plan.position_ids), _p(plan.ce_row), _p(plan.ce_tgt), _p(plan.kstart), _p(plan.qend),
+                                 _p(ws), _stream())
+    _lib.check(rc, "pack_segments")
+    return plan
 
 
 def pack_rows_fwd(plan, input_ids, embed_weight, image_features):

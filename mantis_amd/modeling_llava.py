@@ -355,7 +355,7 @@ class LlavaForConditionalGeneration(nn.Module):
     def forward(self, input_ids=None, pixel_values=None, attention_mask=None, position_ids=None, past_key_values=None,
                 inputs_embeds=None, vision_feature_layer=None, vision_feature_select_strategy=None, labels=None,
                 use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None, return_logits=None,
-                _record=None):
+                _record=None, segment_ids=None):
         if inputs_embeds is not None or past_key_values is not None or use_cache:
             raise NotImplementedError("generation / KV-cache paths are out of scope (SURVEY.md section 2); training forward only")
         if output_attentions or output_hidden_states:
@@ -367,6 +367,11 @@ class LlavaForConditionalGeneration(nn.Module):
                 raise ValueError(f"Unexpected select feature strategy: {vision_feature_select_strategy}")
             raise NotImplementedError("per-call vision_feature_select_strategy override")
         return_dict = return_dict if return_dict is not None else self.config.use_return_dict
+        if attention_mask is not None and attention_mask.dim() == 4:
+            # the reference's packed batch (mantis/train/data.py:1609-1671): block-diagonal 4-D mask + restarting position ids
+            from .data import segments_from_packed
+            segment_ids, attention_mask = segments_from_packed(dict(attention_mask=attention_mask, position_ids=position_ids,
+                                                                    segment_ids=segment_ids))
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids)
         want_grads = self.training and labels is not None and torch.is_grad_enabled() and \
@@ -375,11 +380,11 @@ class LlavaForConditionalGeneration(nn.Module):
             return_logits = not want_grads        # training: the [B,L,V] logits are never materialised unless asked for
         if want_grads:
             loss = _FusedStep.apply(self, input_ids, attention_mask, labels, pixel_values, return_logits, _record,
-                                    self._loss_anchor())
+                                    self._loss_anchor(), segment_ids)
             logits = self._last_logits
         else:
             out = self.engine.step(input_ids, attention_mask, labels, pixel_values, compute_grads=False,
-                                   need_logits=return_logits, record=_record)
+                                   need_logits=return_logits, record=_record, segment_ids=segment_ids)
             loss = None if labels is None else out["loss"].reshape(())
             logits = out["logits"]
         if not return_dict:
@@ -400,7 +405,7 @@ class _FusedStep(torch.autograd.Function):
     and accumulates in place with the right scale.)"""
 
     @staticmethod
-    def forward(ctx, model, input_ids, attention_mask, labels, pixel_values, need_logits, record, anchor):
+    def forward(ctx, model, input_ids, attention_mask, labels, pixel_values, need_logits, record, anchor, segment_ids=None):
         # True = every trainable .grad was None (the state after Trainer's model.zero_grad()): the arena views that were just
         # re-attached still hold the PREVIOUS step's gradients and this backward must overwrite them, not add to them.
         overwrite = model._ensure_grad_arena()
@@ -416,7 +421,8 @@ class _FusedStep(torch.autograd.Function):
         model._build_grad_views()
         try:
             out = model.engine.step(input_ids, attention_mask, labels, pixel_values, grad_scale=1.0, loss_scale=1.0,
-                                    compute_grads=True, overwrite_grads=True, need_logits=need_logits, record=record)
+                                    compute_grads=True, overwrite_grads=True, need_logits=need_logits, record=record,
+                                    segment_ids=segment_ids)
         finally:
             model.grad_arena = live
             model._grad_views = model._grad_views_live
@@ -432,4 +438,4 @@ class _FusedStep(torch.autograd.Function):
         # grad_out stays on the device (0-d fp32; torch multiplies the bf16 arena by it in fp32): no host sync
         model.grad_arena.add_(scratch.mul_(grad_out.to(torch.float32)))
         ctx.scratch = None
-        return (None,) * 8
+        return (None,) * 9

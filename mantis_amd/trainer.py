@@ -59,9 +59,13 @@ class MantisHipTrainer:
                 handles = red.bucket_ready(key) if reduce_now else ()
                 if norm_now:
                     opt.bucket_ready(key, after=handles or ())
-        out = model.engine.step(inputs["input_ids"], inputs["attention_mask"], inputs.get("labels"),
+        seg, attn = inputs.get("segment_ids"), inputs["attention_mask"]
+        if attn is None or attn.dim() == 4:               # the reference's packed batch (data.py:1609-1671): 4-D block-diagonal mask
+            from .data import segments_from_packed
+            seg, attn = segments_from_packed(inputs)
+        out = model.engine.step(inputs["input_ids"], attn, inputs.get("labels"),
                                 inputs.get("pixel_values"), grad_scale=1.0 / ga, loss_scale=1.0 / ga, compute_grads=True,
-                                overwrite_grads=overwrite, on_bucket_ready=hook)
+                                overwrite_grads=overwrite, on_bucket_ready=hook, segment_ids=seg)
         if reduce_now:
             self.reducer.finish()
         if norm_now:

@@ -255,6 +255,7 @@ class LlavaRef:
             attn = torch.from_numpy(plan["attention_mask"])
             pos = torch.from_numpy(plan["position_ids"])
             lab = torch.from_numpy(plan["labels"]) if lab is not None else torch.full_like(attn, cfg.get("ignore_index", -100))
+            self._last_merged_labels, self._last_merged_mask = lab, attn
             if record is not None:
                 record.update(merged_embeds=emb, merged_attention_mask=attn, merged_labels=lab, merged_position_ids=pos)
         if pos is None:
@@ -266,6 +267,41 @@ class LlavaRef:
         if lab is not None:
             loss = masked_shift_ce(logits, lab, attn, cfg.get("ignore_index", -100))
         return loss, logits
+
+    def forward_packed(self, input_ids, pixel_values, segment_ids, labels, attention_mask=None):
+        """Sample packing (/root/reference/mantis/train/data.py:1546-1671) defined through its meaning: the packed row is UNPACKED
+        into its samples, every sample runs through `forward` alone (batch size 1, exactly the reference's mllava collator regime),
+        and the loss is the mean over all label positions of all samples -- what the block-diagonal mask + restarted position ids
+        compute in one pass, with no prediction across a sample boundary.  Independent of the kstart / qend machinery under test."""
+        cfg = self.cfg
+        ids = torch.as_tensor(input_ids)
+        seg = torch.as_tensor(segment_ids)
+        lab = torch.as_tensor(labels)
+        am = torch.ones_like(ids) if attention_mask is None else torch.as_tensor(attention_mask)
+        if isinstance(pixel_values, (list, tuple)):
+            pixel_values = torch.cat([torch.as_tensor(p) for p in pixel_values if p is not None], 0)
+        pv = None if pixel_values is None else torch.as_tensor(pixel_values)
+        total, count, img0 = 0.0, 0, 0
+        ign = cfg.get("ignore_index", -100)
+        for b in range(ids.shape[0]):
+            for sid in torch.unique_consecutive(seg[b]).tolist():
+                sel = seg[b] == sid
+                si, sl, sa = ids[b][sel][None], lab[b][sel][None], am[b][sel][None]
+                n_img = int((si == cfg["image_token_index"]).sum())
+                spv = None if n_img == 0 else pv[img0: img0 + n_img]
+                img0 += n_img
+                _, logits = self.forward(si, spv, sa, sl)
+                # the per-sample numerator / denominator of masked_shift_ce
+                plan_lab = self._last_merged_labels if spv is not None else sl
+                plan_am = self._last_merged_mask if spv is not None else sa
+                keep = plan_am[:, 1:] != 0
+                lg = logits[:, :-1][keep]
+                tg = plan_lab[:, 1:][keep]
+                valid = tg != ign
+                if int(valid.sum()):
+                    total = total + F.cross_entropy(lg[valid].float(), tg[valid], reduction="sum")
+                    count += int(valid.sum())
+        return total / max(count, 1)
 
     # ---- rows A, J, L
     def training_step(self, inputs, gradient_accumulation_steps=1, **fw):

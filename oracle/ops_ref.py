@@ -172,7 +172,7 @@ def _split_qkv(qkv, B, L, H, Hkv, hd):
     return q, k, v
 
 
-def _scores(q, k, scale, causal, kmask, H, Hkv):
+def _scores(q, k, scale, causal, kmask, H, Hkv, kstart=None):
     rep = H // Hkv
     kk = k.repeat_interleave(rep, dim=1) if rep > 1 else k
     s = torch.matmul(_f(q), _f(kk).transpose(-1, -2)) * scale
@@ -181,12 +181,15 @@ def _scores(q, k, scale, causal, kmask, H, Hkv):
         s = s.masked_fill(~torch.ones(L, Lk, dtype=torch.bool).tril(), float("-inf"))
     if kmask is not None:
         s = s.masked_fill(kmask[:, None, None, :] == 0, float("-inf"))
+    if kstart is not None:          # packed samples: query q sees keys >= kstart[b, q] only (block-diagonal mask, data.py:1627-1638)
+        keys = torch.arange(Lk)[None, None, None, :]
+        s = s.masked_fill(keys < kstart.long()[:, None, :, None], float("-inf"))
     return s
 
 
-def attn_fwd(qkv, B, Lseq, H, Hkv, hd, kmask, scale, causal, want_lse=True):
+def attn_fwd(qkv, B, Lseq, H, Hkv, hd, kmask, scale, causal, want_lse=True, kstart=None):
     q, k, v = _split_qkv(qkv, B, Lseq, H, Hkv, hd)
-    s = _scores(q, k, scale, causal, kmask, H, Hkv)
+    s = _scores(q, k, scale, causal, kmask, H, Hkv, kstart)
     lse = torch.logsumexp(s, dim=-1)
     p = torch.exp(s - lse[..., None]).nan_to_num(0.0)
     rep = H // Hkv
@@ -196,10 +199,10 @@ def attn_fwd(qkv, B, Lseq, H, Hkv, hd, kmask, scale, causal, want_lse=True):
     return o, (lse if want_lse else None)
 
 
-def attn_bwd(qkv, o, do, lse, B, Lseq, H, Hkv, hd, kmask, scale, causal):
+def attn_bwd(qkv, o, do, lse, B, Lseq, H, Hkv, hd, kmask, scale, causal, kstart=None, qend=None):
     q, k, v = _split_qkv(qkv, B, Lseq, H, Hkv, hd)
     rep = H // Hkv
-    s = _scores(q, k, scale, causal, kmask, H, Hkv)
+    s = _scores(q, k, scale, causal, kmask, H, Hkv, kstart)
     p = torch.exp(s - lse[..., None]).nan_to_num(0.0)
     dO = _f(do).reshape(B, Lseq, H, hd).transpose(1, 2)
     O = _f(o).reshape(B, Lseq, H, hd).transpose(1, 2)
@@ -221,12 +224,14 @@ def attn_bwd(qkv, o, do, lse, B, Lseq, H, Hkv, hd, kmask, scale, causal):
     return out
 
 
-def attn_fwd_qkv(q, k, v, B, Lseq, H, Hkv, hd, kmask, scale, causal, want_lse=True):
-    return attn_fwd(torch.cat([q[:, : H * hd], k[:, : Hkv * hd], v[:, : Hkv * hd]], dim=1), B, Lseq, H, Hkv, hd, kmask, scale, causal, want_lse)
+def attn_fwd_qkv(q, k, v, B, Lseq, H, Hkv, hd, kmask, scale, causal, want_lse=True, kstart=None):
+    return attn_fwd(torch.cat([q[:, : H * hd], k[:, : Hkv * hd], v[:, : Hkv * hd]], dim=1), B, Lseq, H, Hkv, hd, kmask, scale, causal, want_lse,
+                    kstart=kstart)
 
 
-def attn_bwd_qkv(q, k, v, o, do, lse, dq, dk, dv, B, Lseq, H, Hkv, hd, kmask, scale, causal):
-    d = attn_bwd(torch.cat([q[:, : H * hd], k[:, : Hkv * hd], v[:, : Hkv * hd]], dim=1), o, do, lse, B, Lseq, H, Hkv, hd, kmask, scale, causal)
+def attn_bwd_qkv(q, k, v, o, do, lse, dq, dk, dv, B, Lseq, H, Hkv, hd, kmask, scale, causal, kstart=None, qend=None):
+    d = attn_bwd(torch.cat([q[:, : H * hd], k[:, : Hkv * hd], v[:, : Hkv * hd]], dim=1), o, do, lse, B, Lseq, H, Hkv, hd, kmask, scale, causal,
+                 kstart=kstart)
     dq.copy_(d[:, : H * hd]), dk.copy_(d[:, H * hd: (H + Hkv) * hd]), dv.copy_(d[:, (H + Hkv) * hd:])
 
 
@@ -268,7 +273,19 @@ def pack_plan(input_ids, attention_mask, labels, num_patches, num_images, image_
                     ce_tgt[b * T + t] = lab[b, t]
     out.ce_row, out.ce_tgt = torch.from_numpy(ce_row), torch.from_numpy(ce_tgt)
     out.status = torch.zeros(4, dtype=torch.int32)
+    out.kstart = out.qend = None
     return out
+
+
+def pack_segments(plan, input_ids, segment_ids, image_token_index):
+    pl = dict(L=plan.L, attention_mask=plan.attention_mask.numpy())
+    ks, qe, pos, first = pack_ref.pack_segments(pl, input_ids.numpy(), segment_ids.numpy(), plan.N, image_token_index)
+    plan.kstart, plan.qend = torch.from_numpy(ks), torch.from_numpy(qe)
+    plan.position_ids = torch.from_numpy(pos)
+    f = torch.from_numpy(first.reshape(-1))
+    plan.ce_row[f] = -1
+    plan.ce_tgt[f] = -100
+    return plan
 
 
 def pack_rows_fwd(plan, input_ids, embed_weight, image_features):

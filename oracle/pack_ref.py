@@ -110,3 +110,36 @@ def plain_label_mask(ids, image_token_id, ignore_index=-100):
     keep = ids != image_token_id
     target[keep] = ids[keep]
     return target
+
+
+def pack_segments(plan, input_ids, segment_ids, num_patches, image_token_index):
+    """Packed samples (/root/reference/mantis/train/data.py:1546-1671, PackingDataset.pack_batch: block-diagonal mask :1627-1638,
+    position ids restarting per sample :1641-1648) carried through the image-token expansion of modeling_llava.py:293-360.
+    plan: the dict returned by pack_plan for the packed row(s).  Returns (kstart, qend, position_ids, sample_start_tokens):
+      kstart[b, p] / qend[b, p]   first / one-past-last merged position of p's sample (the O(L) form of the 4-D mask)
+      position_ids                cumsum(mask) restarted at every sample start; 1 where mask == 0 (modeling_llava.py:355)
+      sample_start_tokens[b, t]   True for the first token of a sample (it must not be predicted from the previous sample)."""
+    ids = np.asarray(input_ids, dtype=np.int64)
+    seg = np.asarray(segment_ids, dtype=np.int64)
+    B, T = ids.shape
+    L = plan["L"]
+    N = int(num_patches)
+    mask = plan["attention_mask"]
+    kstart = np.zeros((B, L), dtype=np.int32)
+    qend = np.full((B, L), L, dtype=np.int32)
+    pos = np.ones((B, L), dtype=np.int64)
+    first = np.zeros((B, T), dtype=bool)
+    for b in range(B):
+        lens = np.where(ids[b] == image_token_index, N, 1)
+        ends = np.cumsum(lens)
+        starts = ends - lens + (L - int(ends[-1]))
+        first[b] = np.concatenate([[True], seg[b, 1:] != seg[b, :-1]])
+        marks = sorted(int(s) for s in starts[first[b]] if 0 <= s < L)
+        edges = [0] + [m for m in marks if m > 0] + [L]
+        for a, e in zip(edges[:-1], edges[1:]):
+            kstart[b, a:e] = a
+            qend[b, a:e] = e
+        c = np.cumsum(mask[b])
+        base = np.where(kstart[b] > 0, c[np.maximum(kstart[b] - 1, 0)], 0)
+        pos[b] = np.where(mask[b] == 0, 1, c - base - 1)
+    return kstart, qend, pos, first

@@ -255,6 +255,52 @@ def check_attn_bwd(B, L, H, Hkv, hd, causal, mask):
     return worst
 
 
+def _segment_bounds(B, L, cuts):
+    """cuts: per batch row, sorted interior boundaries.  -> kstart[b, q] (first position of q's segment), qend[b, k] (one past its last)."""
+    ks = torch.zeros(B, L, dtype=torch.int32)
+    qe = torch.zeros(B, L, dtype=torch.int32)
+    for b in range(B):
+        edges = [0] + list(cuts[b]) + [L]
+        for a, e in zip(edges[:-1], edges[1:]):
+            ks[b, a:e] = a
+            qe[b, a:e] = e
+    return ks, qe
+
+
+def check_attn_segments(B, L, H, Hkv, hd, cuts, causal=True, mask=None):
+    """Packed samples (block-diagonal attention, /root/reference/mantis/train/data.py:1627-1638) through the O(L) segment bounds:
+    forward and backward against the oracle's dense-mask restatement, and each segment against a run of that segment alone."""
+    k = K()
+    qkv = rnd(B * L, (H + 2 * Hkv) * hd, seed=L + hd + 3)
+    do = rnd(B * L, H * hd, seed=L + 11)
+    ks, qe = _segment_bounds(B, L, cuts)
+    km = _kmask(B, L, mask, seed=L)
+    if km is not None:
+        do = do * km.reshape(B * L, 1).to(BF)
+    scale = hd ** -0.5
+    oref, lref = R.attn_fwd(qkv, B, L, H, Hkv, hd, km, scale, causal, kstart=ks)
+    dref = R.attn_bwd(qkv, oref, do, lref, B, L, H, Hkv, hd, km, scale, causal, kstart=ks)
+    qd, kd = qkv.to(DEV), None if km is None else km.to(DEV)
+    o, lse = k.attn_fwd(qd, B, L, H, Hkv, hd, kd, scale, causal, kstart=ks.to(DEV))
+    d = k.attn_bwd(qd, o, do.to(DEV), lse, B, L, H, Hkv, hd, kd, scale, causal, kstart=ks.to(DEV), qend=qe.to(DEV))
+    valid = torch.isfinite(lref)
+    vo = valid.transpose(1, 2).reshape(B * L, H, 1).expand(B * L, H, hd).reshape(B * L, H * hd)
+    worst = close(o.cpu().float() * vo, oref.float() * vo, 2e-2, f"segmented attn_fwd L{L} H{H}/{Hkv} hd{hd}")
+    cutsx = [0, H * hd, (H + Hkv) * hd, (H + 2 * Hkv) * hd]
+    for i, n in enumerate(("dq", "dk", "dv")):
+        worst = max(worst, close(d[:, cutsx[i]:cutsx[i + 1]], dref[:, cutsx[i]:cutsx[i + 1]], 3e-2, f"segmented attn_bwd {n} L{L} H{H}/{Hkv} hd{hd}"))
+    if km is None and causal:       # a segment computed alone gives the same rows (same kernels, shifted tiles: to bf16 rounding)
+        b, (a, e) = 0, ([0] + list(cuts[0]) + [L])[1:3] if len(cuts[0]) > 0 else (0, L)
+        sub = qkv[b * L + a: b * L + e].to(DEV)
+        o1, _ = k.attn_fwd(sub, 1, e - a, H, Hkv, hd, None, scale, True)
+        close(o[b * L + a: b * L + e], o1, 1e-2, "segment alone vs inside the pack")
+    return worst
+
+
+ATTN_SEG_CASES = [(1, 300, 8, 2, 128, [[70, 71, 200]], True, None), (2, 200, 4, 2, 16, [[64], [33, 150]], True, None),
+                  (1, 257, 4, 4, 64, [[100, 228]], True, "right"), (1, 450, 4, 1, 128, [[128, 320]], True, None),
+                  (1, 190, 8, 2, 128, [[95]], True, "right"), (2, 130, 4, 2, 16, [[], [65]], True, "left")]
+
 ATTN_FWD_CASES = [(2, 54, 4, 2, 16, True, "right"), (2, 54, 4, 2, 16, True, "left"), (3, 17, 4, 4, 16, False, None),
                   (2, 197, 12, 12, 64, False, None), (2, 577, 16, 16, 72, False, None), (1, 323, 12, 12, 64, True, None),
                   (1, 700, 8, 2, 128, True, "right"), (1, 128, 4, 1, 128, True, None), (1, 129, 2, 2, 64, True, "left"),
@@ -619,6 +665,88 @@ def check_optimizer_step_vs_torch():
     return worst
 
 
+def check_pack_segments_random():
+    """mantis_pack_segments (kstart / qend / per-sample position ids / CE rows of packed rows) bit-exact vs the numpy oracle."""
+    k = K()
+    g = np.random.default_rng(11)
+    for trial in range(8):
+        B, T, N = int(g.integers(1, 3)), int(g.integers(20, 900)), int(g.integers(2, 30))
+        nimg = int(g.integers(0, 6))
+        ids = g.integers(0, 1000, size=(B, T))
+        seg = np.zeros((B, T), np.int32)
+        for b in range(B):
+            ids[b, g.choice(T, size=min(nimg, T), replace=False)] = 5000          # same count per row -> equal merged length
+            cuts = np.sort(g.choice(np.arange(1, T), size=int(g.integers(0, 5)), replace=False))
+            seg[b] = np.searchsorted(cuts, np.arange(T), side="right")
+        am = (g.random((B, T)) < 0.95).astype(np.int64)
+        lab = np.where(g.random((B, T)) < 0.6, ids, -100)
+        I = int((ids == 5000).sum())
+        L = int((ids == 5000).sum(-1).max()) * (N - 1) + T
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+        pl = k.pack_plan(t(ids).to(DEV), t(am).to(DEV), t(lab).to(DEV), N, I, 5000, 5001, -100, L)
+        rp = R.pack_plan(t(ids), t(am), t(lab), N, I, 5000, 5001, -100, L)
+        k.pack_segments(pl, t(ids).to(DEV), t(seg).to(DEV), 5000)
+        R.pack_segments(rp, t(ids), t(seg), 5000)
+        for f in ("kstart", "qend", "position_ids", "ce_row", "ce_tgt"):
+            assert torch.equal(getattr(pl, f).cpu(), getattr(rp, f)), (trial, f)
+    return 0.0
+
+
+def check_packed_model_step():
+    """Sample packing end to end on the HIP path (tiny golden model): two samples packed into one row give the loss and gradients of
+    the oracle running them separately, and of the HIP path running them as a batch of two."""
+    from mantis_amd.data import pack_samples
+    z = Hh.load_case("siglip_b2_equal_nopad")
+    pv = Hh.pixels_list(z)
+    samples = [dict(input_ids=torch.from_numpy(z["input_ids"][[r]]), attention_mask=torch.from_numpy(z["attention_mask"][[r]]),
+                    labels=torch.from_numpy(z["labels"][[r]]), pixel_values=pv[r]) for r in (0, 1, 0)]
+    packed = pack_samples(samples, materialize_mask=False)
+    model, _, _ = Hh.build_product_model("siglip", DEV)
+    oracle = Hh.build_oracle_bf16_weights("siglip")
+    assert model._ensure_grad_arena()
+    out = model.engine.step(packed["input_ids"], packed["key_mask"], packed["labels"], packed["pixel_values"], compute_grads=True,
+                            overwrite_grads=True, segment_ids=packed["segment_ids"])
+    oracle.zero_grad()
+    oloss = oracle.forward_packed(packed["input_ids"], packed["pixel_values"], packed["segment_ids"], packed["labels"], packed["key_mask"])
+    oloss.backward()
+    loss = float(out["loss"].cpu())
+    assert abs(loss - float(oloss)) <= 5e-3 * float(oloss), (loss, float(oloss))
+    worst = 1.0
+    for name, p in model.named_parameters():
+        if p.requires_grad:
+            g, og = p.grad.float().cpu().numpy(), oracle.w[name].grad.numpy()
+            c = Hh.cosine(g, og)
+            assert c > 0.995 and Hh.rel_l2(g, og) < 6e-2, (name, c, Hh.rel_l2(g, og))
+            worst = min(worst, c)
+    return 1.0 - worst
+
+
+def check_packed_fullsize_vs_batched():
+    """cfg2 geometry at reduced depth: the two samples of a bench batch packed into ONE row of 1024 tokens (merged length 5624,
+    GQA-aware dK/dV kernel with segment bounds) against the same two samples as a batch of two: same loss, same gradients."""
+    from mantis_amd import configuration_llava as C
+    from mantis_amd.modeling_llava import LlavaForConditionalGeneration
+    from mantis_amd.data import pack_samples
+    import bench
+    cfg = C.mantis_8b_siglip_llama3()
+    cfg.vision_config.num_hidden_layers = 3
+    cfg.text_config.num_hidden_layers = 2
+    model = LlavaForConditionalGeneration(cfg, device=DEV, seed=0)
+    b = bench.synthetic_batch(cfg, 2, 512, 4, 336, 0)
+    assert model._ensure_grad_arena()
+    o1 = model.engine.step(b["input_ids"], b["attention_mask"], b["labels"], b["pixel_values"], compute_grads=True, overwrite_grads=True)
+    g1 = model.grad_arena.clone()
+    samples = [dict(input_ids=b["input_ids"][[r]], attention_mask=b["attention_mask"][[r]], labels=b["labels"][[r]],
+                    pixel_values=b["pixel_values"][r]) for r in range(2)]
+    packed = pack_samples(samples, materialize_mask=False)
+    o2 = model.engine.step(packed["input_ids"], packed["key_mask"], packed["labels"], packed["pixel_values"], compute_grads=True,
+                           overwrite_grads=True, segment_ids=packed["segment_ids"])
+    assert o2["plan"].L == 2 * 2812
+    l1, l2 = float(o1["loss"].cpu()), float(o2["loss"].cpu())
+    assert abs(l1 - l2) <= 2e-3 * l1, (l1, l2)
+    return close(model.grad_arena, g1, 2e-2, "packed vs batched gradients (cfg2 width, 2 layers)")
+
+
 def check_norm_overlap():
     """The gradient-norm pass taken bucket by bucket on a side stream during the backward (MantisHipTrainer(optimizer=...)) gives the
     same global norm as the separate pass over the whole arena, and the same parameters after the step."""
@@ -785,6 +913,8 @@ def all_checks():
         c["attn_fwd_" + "_".join(map(str, a))] = (lambda a=a: check_attn_fwd(*a))
     for a in ATTN_BWD_CASES:
         c["attn_bwd_" + "_".join(map(str, a))] = (lambda a=a: check_attn_bwd(*a))
+    for i, a in enumerate(ATTN_SEG_CASES):
+        c[f"attn_segments_{i}_L{a[1]}_H{a[2]}_{a[3]}_hd{a[4]}"] = (lambda a=a: check_attn_segments(*a))
     for case in ("siglip_b1_img1", "siglip_b1_img2_adjacent", "siglip_b1_img4", "siglip_b1_img_first_last",
                  "siglip_b2_equal_rightpad", "siglip_b2_equal_nopad", "siglip_b2_unequal_quirk", "clip_b2_equal_rightpad"):
         c["pack_golden_" + case] = (lambda case=case: check_pack_golden(case))
@@ -804,6 +934,9 @@ def all_checks():
     c["forward_contract_hip"] = check_forward_contract_hip
     c["hf_trainer_on_hip"] = check_hf_trainer_on_hip
     c["optimizer_step_vs_torch"] = check_optimizer_step_vs_torch
+    c["pack_segments_random"] = check_pack_segments_random
+    c["packed_model_step"] = check_packed_model_step
+    c["packed_fullsize_vs_batched"] = check_packed_fullsize_vs_batched
     c["norm_overlap"] = check_norm_overlap
     c["dp_rccl_world1"] = check_dp_rccl_world1
     # cfg2 (BASELINE.json configs[1]) shapes, every row against the oracle

@@ -156,3 +156,63 @@ def test_stock_hf_trainer_subclass(cpu_backend, tmp_path):
     assert out.dim() == 0 and not out.requires_grad
     assert abs(float(out) - float(z["returned_losses"][0])) < 2e-2 * float(z["returned_losses"][0])
     assert model._param("multi_modal_projector.linear_1.weight").grad is not None
+
+
+def _packed_from_case(z, rows):
+    """Pack the given batch rows of a golden case (unpadded rows) into one row with pack_samples."""
+    from mantis_amd.data import pack_samples
+    pv = Hh.pixels_list(z)
+    samples = [dict(input_ids=torch.from_numpy(z["input_ids"][[r]]), attention_mask=torch.from_numpy(z["attention_mask"][[r]]),
+                    labels=torch.from_numpy(z["labels"][[r]]), pixel_values=pv[r]) for r in rows]
+    return pack_samples(samples)
+
+
+def test_pack_segments_oracle_matches_the_reference_4d_mask():
+    """oracle/pack_ref.pack_segments: with no images the merged row is the packed row itself, so kstart / qend must reproduce the
+    REFERENCE's block-diagonal 4-D mask (pack_batch_ref.npz, recorded from PackingDataset.pack_batch) and its position ids."""
+    from oracle import pack_ref
+    z = Hh.load_case("pack_batch_ref")
+    for case in ("eq", "ragged"):
+        n = int(z[f"{case}.n"])
+        lens = [z[f"{case}.s{i}.input_ids"].shape[-1] for i in range(n)]
+        ids = z[f"{case}.out.input_ids"]
+        seg = np.repeat(np.arange(n), lens)[None]
+        key = np.concatenate([z[f"{case}.s{i}.attention_mask"].reshape(-1) for i in range(n)])[None]
+        plan = pack_ref.pack_plan(ids, key, None, 0, 1, -(2 ** 62), -1)
+        ks, qe, pos, first = pack_ref.pack_segments(plan, ids, seg, 1, -(2 ** 62))
+        S = ids.shape[1]
+        q = np.arange(S)[:, None]
+        k = np.arange(S)[None, :]
+        dense = ((k >= ks[0][:, None]) & (k < qe[0][:, None]) & (key[0][None, :] != 0)).astype(np.int32)
+        assert np.array_equal(dense, z[f"{case}.out.attention_mask"][0, 0])
+        ref_pos = z[f"{case}.out.position_ids"]
+        assert np.array_equal(pos[0][key[0] != 0], ref_pos[key[0] != 0])      # (masked keys sit at the end of their sample here)
+        assert first[0].sum() == n
+
+
+@pytest.mark.parametrize("case,rows", [("siglip_b2_equal_nopad", [0, 1]), ("siglip_b2_equal_nopad", [1, 0, 1])])
+def test_packed_step_equals_the_separate_samples(cpu_backend, case, rows):
+    """Sample packing through the product's host logic (plan segments, segment-bounded attention, per-sample positions, CE rows):
+    loss and gradients equal those of running the samples separately (oracle `forward_packed` = unpack and run one by one)."""
+    z = Hh.load_case(case)
+    packed = _packed_from_case(z, rows)
+    model, _, _ = Hh.build_product_model("siglip", "cpu")
+    oracle = Hh.build_oracle_bf16_weights("siglip")
+    assert model._ensure_grad_arena()
+    out = model.engine.step(packed["input_ids"], packed["key_mask"], packed["labels"], packed["pixel_values"], compute_grads=True,
+                            overwrite_grads=True, segment_ids=packed["segment_ids"])
+    oracle.zero_grad()
+    oloss = oracle.forward_packed(packed["input_ids"], packed["pixel_values"], packed["segment_ids"], packed["labels"], packed["key_mask"])
+    oloss.backward()
+    assert abs(float(out["loss"]) - float(oloss)) <= 5e-3 * float(oloss), (float(out["loss"]), float(oloss))
+    for name, p in model.named_parameters():
+        if p.requires_grad:
+            g, og = p.grad.float().numpy(), oracle.w[name].grad.numpy()
+            assert Hh.cosine(g, og) > 0.995 and Hh.rel_l2(g, og) < 6e-2, (name, Hh.cosine(g, og), Hh.rel_l2(g, og))
+    # the trainer accepts the reference's packed batch format (4-D mask + position ids) as well
+    from mantis_amd.trainer import MantisHipTrainer
+    m2, _, _ = Hh.build_product_model("siglip", "cpu")
+    ref_fmt = dict(input_ids=packed["input_ids"], attention_mask=packed["attention_mask"], position_ids=packed["position_ids"],
+                   labels=packed["labels"], pixel_values=packed["pixel_values"])
+    l2 = MantisHipTrainer(m2, 1).training_step(m2, ref_fmt)
+    assert abs(float(l2) - float(out["loss"])) < 1e-6
