@@ -49,6 +49,40 @@ def synthetic_batch(cfg, B, T, n_img, img_hw, rank, step=0):
     return dict(input_ids=ids, attention_mask=torch.ones_like(ids), labels=labels, pixel_values=pix)
 
 
+def synthetic_batch_idefics2(cfg, B, T, n_img, img_hw, rank, step=0):
+    """BASELINE.json configs[3]: n_img interleaved images of img_hw^2 pixels per sample, each standing for resampler_n_latents <image>
+    tokens inside a T-token sequence; labels ignore (= image_token_id, train_idefics2.py:164) the first half and the image tokens."""
+    import torch
+    g = torch.Generator().manual_seed(4321 + rank + 1000 * step)
+    nl, IMG = cfg.perceiver_config.resampler_n_latents, cfg.image_token_id
+    ids = torch.randint(3, 32000 if cfg.vocab_size > 32000 else cfg.vocab_size - 3, (B, T), generator=g)
+    gap = (T - n_img * nl) // (n_img + 1)
+    for b in range(B):
+        for j in range(n_img):
+            s = gap + j * (nl + gap)
+            ids[b, s: s + nl] = IMG
+    labels = ids.clone()
+    labels[:, : T // 2] = IMG
+    pix = torch.randn(B, n_img, 3, img_hw, img_hw, generator=g)
+    return dict(input_ids=ids, attention_mask=torch.ones_like(ids), labels=labels, pixel_values=pix, pixel_attention_mask=None)
+
+
+def idefics2_flop_per_sample(cfg, T, n_img, img_hw):
+    """Algorithmic FLOPs of one sample (matmul = 2mnk, causal attention at half, frozen ViT forward only, connector + LLM x3)."""
+    vc, pc, tc = cfg.vision_config, cfg.perceiver_config, cfg.text_config
+    N = (img_hw // vc.patch_size) ** 2
+    dv, iv = vc.hidden_size, vc.intermediate_size
+    vit = n_img * vc.num_hidden_layers * N * (2 * (4 * dv * dv + 2 * dv * iv) + 4 * N * dv)
+    d, it, nl = tc.hidden_size, tc.intermediate_size, pc.resampler_n_latents
+    pq, pkv = pc.resampler_n_heads * pc.resampler_head_dim, pc.num_key_value_heads * pc.resampler_head_dim
+    conn = n_img * (N * 2 * (2 * dv * it + it * d)
+                    + pc.resampler_depth * ((N + nl) * 2 * 2 * pkv * d + nl * 2 * (2 * pq * d) + 4 * nl * (N + nl) * pq + nl * 2 * 12 * d * d))
+    hd = tc.head_dim
+    per_tok = 2 * ((tc.num_attention_heads + 2 * tc.num_key_value_heads) * hd * d + tc.num_attention_heads * hd * d + 3 * d * it)
+    llm = tc.num_hidden_layers * (T * per_tok + 4 * T * T * tc.num_attention_heads * hd / 2) + T * 2 * d * tc.vocab_size
+    return vit + 3 * (conn + llm)
+
+
 def _pct(xs, q):
     xs = sorted(xs)
     if not xs:
@@ -112,8 +146,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="mantis_8b_siglip_llama3", choices=["mantis_8b_siglip_llama3", "mantis_8b_clip_llama3", "mantis_tiny"])
-    ap.add_argument("--batch-per-gpu", type=int, default=2)
+    ap.add_argument("--config", default="mantis_8b_siglip_llama3",
+                    choices=["mantis_8b_siglip_llama3", "mantis_8b_clip_llama3", "mantis_tiny", "mantis_8b_idefics2"],
+                    help="mantis_8b_siglip_llama3 = the headline (BASELINE.json configs[1]/[2]); mantis_8b_idefics2 = configs[3] "
+                         "(8 interleaved images x 448^2, 2048 tokens, 1 sample per GPU)")
+    ap.add_argument("--batch-per-gpu", type=int, default=None, help="default: 2 (LLaVA path) / 1 (Idefics2 path)")
     ap.add_argument("--stage", default="finetune", choices=["finetune", "pretrain"],
                     help="finetune: projector + LLM trainable (the headline metric); pretrain: only multi_modal_projector "
                          "(the reference's stage 1, train_mllava.py:177-181)")
@@ -146,14 +183,26 @@ def main():
     from mantis_amd.dp import GradReducer
     from mantis_amd.optim import FusedAdamW
 
-    cfg = getattr(C, args.config)()
+    idefics = args.config == "mantis_8b_idefics2"
     tiny = args.config == "mantis_tiny"
-    B = args.batch_per_gpu
-    T, n_img = (128, 1) if tiny else (512, 4)
-    model = LlavaForConditionalGeneration(cfg, device=f"cuda:{local_rank}", seed=0)      # same seed -> identical replicas
+    if idefics:
+        from mantis_amd import configuration_idefics2 as C2
+        from mantis_amd.modeling_idefics2 import Idefics2ForConditionalGeneration
+        cfg = C2.mantis_8b_idefics2()
+        B = args.batch_per_gpu or 1
+        T, n_img, img_hw = 2048, 8, 448
+        model = Idefics2ForConditionalGeneration(cfg, device=f"cuda:{local_rank}", seed=0)
+        flop_per_sample = idefics2_flop_per_sample(cfg, T, n_img, img_hw)
+    else:
+        cfg = getattr(C, args.config)()
+        B = args.batch_per_gpu or 2
+        T, n_img = (128, 1) if tiny else (512, 4)
+        img_hw = cfg.vision_config.image_size
+        model = LlavaForConditionalGeneration(cfg, device=f"cuda:{local_rank}", seed=0)      # same seed -> identical replicas
+        flop_per_sample = FLOP_PER_SAMPLE
     if args.stage == "pretrain":
         for n, p in model.named_parameters():
-            if "multi_modal_projector" not in n:
+            if "multi_modal_projector" not in n and "model.connector." not in n:
                 p.requires_grad = False
     reducer = GradReducer(model) if (world > 1 or force_dp) else None
     opt = None if args.no_optimizer else FusedAdamW(model, lr=1e-5, weight_decay=0.0, max_grad_norm=1.0)
@@ -163,9 +212,10 @@ def main():
     overlap = opt is not None and os.environ.get("MANTIS_NORM_OVERLAP", "0") == "1"
     trainer = MantisHipTrainer(model, gradient_accumulation_steps=1, reducer=reducer, optimizer=opt if overlap else None)
     n_batches = args.recycle_batches or (args.warmup + args.steps)
-    batches = [synthetic_batch(cfg, B, T, n_img, cfg.vision_config.image_size, rank, s) for s in range(n_batches)]
+    make = synthetic_batch_idefics2 if idefics else synthetic_batch
+    batches = [make(cfg, B, T, n_img, img_hw, rank, s) for s in range(n_batches)]
     for bt in batches:      # pinned host buffers, as dataloader_pin_memory does in the reference loop
-        bt["pixel_values"] = [p.pin_memory() for p in bt["pixel_values"]]
+        bt["pixel_values"] = bt["pixel_values"].pin_memory() if idefics else [p.pin_memory() for p in bt["pixel_values"]]
 
     split = []          # (start, after training_step, after optimizer) events per timed step
     losses = []
@@ -222,7 +272,7 @@ def main():
         step_ms = [e[0].elapsed_time(e[2]) for e in split]
         ts_ms = [e[0].elapsed_time(e[1]) for e in split]
         pmc = None
-        if not tiny and os.path.exists(PMC_JSON):
+        if not tiny and not idefics and os.path.exists(PMC_JSON):
             with open(PMC_JSON) as fh:
                 pmc = json.load(fh)
         roof = None
@@ -241,11 +291,11 @@ def main():
                         mfma_busy_pct=((pmc or {}).get("step") or {}).get("mfma_busy_pct"),
                         launches_per_step=len(timer) // args.steps,
                         avg_launch_us=round(1e3 * tot_ms / len(timer), 1), gemm_ms_per_step=round(tot_ms / args.steps, 1),
-                        step_model_tflops=round(FLOP_PER_SAMPLE * B / (ms * 1e-3) / 1e12, 1) if not tiny else None,
-                        step_frac_of_peak=round(FLOP_PER_SAMPLE * B / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if not tiny else None,
-                        training_step_frac_of_peak=round(FLOP_PER_SAMPLE * B / (_pct(ts_ms, 0.5) * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if not tiny else None)
+                        step_model_tflops=round(flop_per_sample * B / (ms * 1e-3) / 1e12, 1) if not tiny else None,
+                        step_frac_of_peak=round(flop_per_sample * B / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if not tiny else None,
+                        training_step_frac_of_peak=round(flop_per_sample * B / (_pct(ts_ms, 0.5) * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if not tiny else None)
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not idefics:      # the CPU leg times the headline (LLaVA-path) oracle
             cpu = cpu_baseline(args.config)
         dp = None
         if reducer is not None:
@@ -256,8 +306,10 @@ def main():
                       exposed_comm_ms_max=None if not ex else round(max(ex), 3),
                       nccl_env={k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_"))})
         names = dict(mantis_8b_siglip_llama3="Mantis-8B-SigLIP-Llama-3", mantis_8b_clip_llama3="Mantis-8B-CLIP-L/14-336-Llama-3")
-        out = dict(metric=f"train samples/sec (4 img x 336^2 + 512 tok) {names[args.config]}" if not tiny
-                   else "train samples/sec Mantis-tiny (1 img 224^2 + 128 tok)",
+        metric = ("train samples/sec Mantis-tiny (1 img 224^2 + 128 tok)" if tiny else
+                  "train samples/sec (8 img x 448^2, seq 2048) Mantis-8B-Idefics2" if idefics else
+                  f"train samples/sec (4 img x 336^2 + 512 tok) {names[args.config]}")
+        out = dict(metric=metric,
                    value=round(value, 4), unit="samples/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=round(ms, 2),
                    ms_per_step_median=round(_pct(step_ms, 0.5), 2), ms_per_step_p10=round(_pct(step_ms, 0.1), 2),
@@ -273,7 +325,9 @@ def main():
                    config=dict(workload=f"{args.config}: ViT fwd + projector + packing + Llama fwd/bwd"
                                         f"{'' if args.no_optimizer else ' + clip + fused AdamW'}; {B} samples/GPU, "
                                         f"{n_img} img + {T} tok per sample; random-init weights",
-                               global_batch=world * B, seq_len=T, merged_seq_len=T - n_img + n_img * (cfg.vision_config.image_size // cfg.vision_config.patch_size) ** 2,
+                               global_batch=world * B, seq_len=T,
+                               merged_seq_len=T if idefics else T - n_img + n_img * (cfg.vision_config.image_size // cfg.vision_config.patch_size) ** 2,
+                               flop_per_sample=flop_per_sample,
                                parallelism=f"dp{world}", optimizer=not args.no_optimizer, stage=args.stage),
                    roofline=roof, cpu_baseline=cpu, dp=dp)
         print(json.dumps(out), flush=True)

@@ -1,0 +1,150 @@
+"""Flat-arena module base: every parameter of a model is a VIEW into one flat bf16 tensor in HBM, every gradient a view into one flat
+gradient arena.  Fused projections (q|k|v, gate|up) are zero-copy views over adjacent parameters, data-parallel buckets are contiguous
+slices, the optimizer is one launch over the arena (mantis_amd/optim.py).  Parameter names are the reference's state_dict keys.
+Shared by the LLaVA path (modeling_llava.py) and the Idefics2 path (modeling_idefics2.py)."""
+import torch
+from torch import nn
+
+
+def numel(shape):
+    n = 1
+    for x in shape:
+        n *= x
+    return n
+
+
+class ArenaModule(nn.Module):
+    #: name prefixes of parameters that are frozen on this path (no backward kernels exist for them)
+    frozen_prefixes = ()
+
+    def _init_arena(self, specs, device, dtype=torch.bfloat16):
+        if dtype != torch.bfloat16:
+            raise NotImplementedError("the gfx950 path computes in bf16 (fp32 accumulate); construct with dtype=torch.bfloat16")
+        dev = torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        offs, off = {}, 0
+        for name, shape in specs:
+            offs[name] = off
+            off += (numel(shape) + 7) // 8 * 8       # keep every parameter 16-byte aligned
+        self._specs, self._offs, self._arena_numel = specs, offs, off
+        self.arena = torch.zeros(off, dtype=dtype, device=dev)
+        for name, shape in specs:
+            view = self.arena[offs[name]: offs[name] + numel(shape)].view(shape)
+            self._attach(name, nn.Parameter(view, requires_grad=not name.startswith(tuple(self.frozen_prefixes))))
+        self.grad_arena = None
+        self._grad_offs = None
+        self._param_version = 0      # bumped whenever parameter VALUES are replaced wholesale (init / checkpoint load)
+
+    # ------------------------------------------------------------------ module tree with the reference's parameter names
+    def _attach(self, dotted, param):
+        mod = self
+        parts = dotted.split(".")
+        for p in parts[:-1]:
+            if p not in mod._modules:
+                mod.add_module(p, nn.Module())
+            mod = mod._modules[p]
+        mod.register_parameter(parts[-1], param)
+
+    def _param(self, name):
+        mod = self
+        parts = name.split(".")
+        for p in parts[:-1]:
+            mod = mod._modules[p]
+        return mod._parameters[parts[-1]]
+
+    def _flat(self, first, last_incl, rows, cols):
+        a = self._offs[first]
+        b = self._offs[last_incl] + numel(dict(self._specs)[last_incl])
+        assert b - a == rows * cols, (first, last_incl, b - a, rows, cols)
+        return self.arena[a:b].view(rows, cols)
+
+    @property
+    def device(self):
+        return self.arena.device
+
+    @property
+    def dtype(self):
+        return self.arena.dtype
+
+    def _apply(self, fn, recurse=True):
+        # parameters are views of one arena; moving / casting them individually would break the fused layouts
+        probe = fn(torch.zeros(1, dtype=self.arena.dtype, device=self.arena.device))
+        if probe.dtype != self.arena.dtype or probe.device != self.arena.device:
+            raise RuntimeError(f"{type(self).__name__} lives in a flat bf16 arena: construct it with device=... instead "
+                               "of calling .to()/.half()/.float()")
+        return self
+
+    # ------------------------------------------------------------------ gradients
+    def _ensure_grad_arena(self):
+        """(Re)attach `.grad` views.  Returns True if the gradients are known to be zero-initialised garbage that the
+        next backward may OVERWRITE (i.e. every trainable .grad was None, the state after Trainer's model.zero_grad())."""
+        trainable = [(n, p) for n, p in self.named_parameters() if p.requires_grad]
+        bad = [n for n, _ in trainable if n.startswith(tuple(self.frozen_prefixes))] if self.frozen_prefixes else []
+        if bad:
+            raise NotImplementedError(f"{bad[0].split('.')[0]}...: frozen on this path (no backward kernels for it); "
+                                      f"requires_grad was switched on for {len(bad)} of its parameters")
+        key = tuple(n for n, _ in trainable)
+        if self.grad_arena is None or self._grad_key != key:
+            offs, off = {}, 0
+            for n, p in trainable:
+                offs[n] = off
+                off += (p.numel() + 7) // 8 * 8
+            self.grad_arena = torch.zeros(off, dtype=self.arena.dtype, device=self.device)
+            self._grad_offs, self._grad_key = offs, key
+            self._grad_views = {n: self.grad_arena[offs[n]: offs[n] + p.numel()].view(p.shape) for n, p in trainable}
+            self._build_grad_views()
+            for n, p in trainable:
+                p.grad = None
+        all_none = all(p.grad is None for _, p in trainable)
+        for n, p in trainable:
+            if p.grad is None:
+                if not all_none:
+                    self._grad_views[n].zero_()
+                p.grad = self._grad_views[n]
+            elif p.grad.data_ptr() != self._grad_views[n].data_ptr():
+                # a foreign gradient tensor was installed: fold it into the arena view
+                self._grad_views[n].copy_(p.grad)
+                p.grad = self._grad_views[n]
+        return all_none
+
+    def _gflat(self, first, last_incl, rows, cols):
+        if first not in self._grad_offs:
+            return None
+        if last_incl not in self._grad_offs:
+            raise NotImplementedError(f"{first}..{last_incl} must be trainable together (fused projection)")
+        a = self._grad_offs[first]
+        b = self._grad_offs[last_incl] + self._param(last_incl).numel()
+        assert b - a == rows * cols
+        return self.grad_arena[a:b].view(rows, cols)
+
+    def _bucket_span(self, pred):
+        """Contiguous slice of the gradient arena covering the trainable parameters selected by `pred` (None if none)."""
+        offs = self._grad_offs
+        sel = [n for n in self._grad_key if pred(n)]
+        if not sel:
+            return None
+        a = min(offs[n] for n in sel)
+        b = max(offs[n] + (self._param(n).numel() + 7) // 8 * 8 for n in sel)
+        assert b - a == sum((self._param(n).numel() + 7) // 8 * 8 for n in sel), "bucket is not contiguous"
+        return self.grad_arena[a:b]
+
+    def copy_state_dict(self, sd, rename=lambda k: k, ignorable=lambda k: False, strict=True):
+        """Copy a reference state_dict into the arena views (values rounded to bf16).  Returns the list of missing keys."""
+        own = dict(self.named_parameters())
+        seen = set()
+        with torch.no_grad():
+            for k, v in sd.items():
+                k2 = rename(k)
+                if k2 not in own:
+                    if ignorable(k2):
+                        continue
+                    if strict:
+                        raise KeyError(f"unexpected key {k}")
+                    continue
+                t = torch.as_tensor(v)
+                own[k2].copy_(t.to(own[k2].dtype).reshape(own[k2].shape))
+                seen.add(k2)
+        self._param_version += 1          # optimizers holding fp32 master copies re-snapshot (optim.FusedAdamW.step)
+        missing = [k for k in own if k not in seen]
+        if strict and missing:
+            raise KeyError(f"missing keys: {missing[:5]}...")
+        return missing

@@ -643,7 +643,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 // dKp/dVp: per-QUERY-head outputs [B*L, H*hd] (row stride ldp), or the final dK/dV when H == Hkv.
 template <int HD>
 struct DkvCfg {
-    static constexpr int DS = AttnCfg<HD>::NDB >= 2 ? 2 : 1;   // waves sharing a key group (d-split)
+    static constexpr int DS = (AttnCfg<HD>::NDB >= 2 && AttnCfg<HD>::NDB % 2 == 0) ? 2 : 1;   // waves sharing a key group (d-split)
     static constexpr int NDW = AttnCfg<HD>::NDB / DS;          // 32-wide d-blocks per wave
     static constexpr int KEYS = (4 / DS) * 32;                 // keys per workgroup
 };
@@ -1324,7 +1324,7 @@ static int launch_bwd(bool causal, hipStream_t s, const bf16_t* Q, const bf16_t*
 extern "C" {
 
 // Q [B,L,H,hd] (row stride ldq), K,V [B,L,Hkv,hd] (ldk, ldv), kmask int32[B,L] or NULL, O [B,L,H,hd] (ldo),
-// LSE fp32 [B,H,L] or NULL.  hd in {16, 64, 72, 128}.
+// LSE fp32 [B,H,L] or NULL.  hd in {16, 64, 72, 96, 128} (96: the Idefics2 perceiver resampler).
 int mantis_attn_fwd(const void* Q, const void* K, const void* V, const int32_t* kmask, const int32_t* kstart, void* O, float* LSE,
                     int B, int L, int H, int Hkv, int hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale, int causal,
                     void* stream) {
@@ -1339,6 +1339,7 @@ int mantis_attn_fwd(const void* Q, const void* K, const void* V, const int32_t* 
         case 16: FWD(16);
         case 64: FWD(64);
         case 72: FWD(72);
+        case 96: FWD(96);
         case 128: FWD(128);
         default: return MANTIS_EUNSUPPORTED;
     }
@@ -1378,6 +1379,7 @@ int mantis_attn_bwd(const void* Q, const void* K, const void* V, const void* O, 
     switch (hd) {
         case 16: BWD(16);
         case 64: BWD(64);
+        case 96: BWD(96);
         case 128: BWD(128);
         default: return MANTIS_EUNSUPPORTED;
     }

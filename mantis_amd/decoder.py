@@ -1,0 +1,118 @@
+"""Explicit forward / backward of the decoder-only text model shared by the LLaVA path (Llama-3) and the Idefics2 path (Mistral-7B):
+RMSNorm -> fused q|k|v -> RoPE -> causal GQA attention (+ key mask, + sample-packing segment bounds) -> o_proj -> +res -> RMSNorm ->
+SwiGLU MLP -> +res, then final RMSNorm, lm_head on the rows that can carry a label, masked shifted cross-entropy.
+
+Reference control flow: HF LlamaModel / MistralModel.forward (transformers/models/llama/modeling_llama.py:284-325,367-418; Mistral is
+the same block), invoked from /root/reference/mantis/models/mllava/modeling_llava.py:510-537 and
+/root/reference/mantis/models/idefics2/modeling_idefics2.py:1700-1708,1880-1899.  `K` is the operator backend (mantis_amd.hip_ops; the
+host-logic tests pass the oracle's operator restatement instead).  `lm` = dict(embed, layers=[dict(qkv, o, gu, down, ln1, ln2)], norm,
+head) of arena views; `grads` / `grads_layers` = the same shape over the gradient arena (None where frozen)."""
+import torch
+
+
+def inv_freq(head_dim, theta):
+    # transformers/models/llama/modeling_llama.py:95-110 (default rope), computed on the host in fp32 like the reference
+    return 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+
+
+def decoder_forward(K, lm, tc, x, B, L, position_ids, kmask, kstart=None, compute_grads=True, record=None):
+    """x [B*L, d] merged input embeddings -> (hidden states before the final norm, ctx for decoder_backward)."""
+    H, Hkv, hd = tc.num_attention_heads, tc.num_key_value_heads, tc.head_dim
+    eps = tc.rms_norm_eps
+    scale = hd ** -0.5
+    cos, sin = K.rope_table(position_ids.reshape(-1), inv_freq(hd, tc.rope_theta).to(x.device))
+    saved = []
+    for i in range(tc.num_hidden_layers):
+        lw = lm["layers"][i]
+        n1, rstd1 = K.rmsnorm_fwd(x, lw["ln1"], eps)
+        qkv = K.gemm_nt(n1, lw["qkv"])
+        K.rope_apply_(qkv, cos, sin, H + Hkv, hd)
+        o, lse = K.attn_fwd(qkv, B, L, H, Hkv, hd, kmask, scale, True, kstart=kstart)
+        x_mid = K.gemm_nt(o, lw["o"], residual=x)
+        n2, rstd2 = K.rmsnorm_fwd(x_mid, lw["ln2"], eps)
+        gu = K.gemm_nt(n2, lw["gu"])
+        a = K.swiglu_fwd(gu)
+        x_out = K.gemm_nt(a, lw["down"], residual=x_mid)
+        if compute_grads:
+            # 288 GB of HBM: keep the cheap-to-recompute tensors too (n1, n2, a: +370 MB per layer) instead of re-running
+            # RMSNorm / SwiGLU in the backward
+            saved.append((x, rstd1, qkv, o, lse, x_mid, rstd2, gu, n1, n2, a))
+        x = x_out
+        if record is not None:
+            record[f"llm_layer{i}_out"] = x.view(B, L, -1)
+    return x, dict(saved=saved, cos=cos, sin=sin, scale=scale)
+
+
+def head_and_loss(K, lm, tc, x, plan, B, L, labels_given, grad_scale, loss_scale, compute_grads, need_logits, record=None):
+    """Final norm + lm_head + masked shifted CE.  Only the rows that can carry a label (plan.ce_row) reach lm_head for the loss; the
+    full [B, L, V] logits are produced only on request.  Returns (loss, count, logits_full, ctx)."""
+    eps = tc.rms_norm_eps
+    V = tc.vocab_size
+    Vp = K.pad8(V)
+    logits_full = None
+    if need_logits:
+        nf_all, _ = K.rmsnorm_fwd(x, lm["norm"], eps, want_rstd=False)
+        if record is not None:
+            record["llm_final_norm"] = nf_all.view(B, L, -1)
+        lg = K.gemm_nt(nf_all, lm["head"], ldc=Vp)
+        logits_full = lg.view(B, L, Vp)[:, :, :V]
+    loss = count = ctx = None
+    if labels_given or compute_grads:
+        h_ce = K.gather_rows(x, plan.ce_row)                       # [B*T, d] rows that can carry a label
+        nf, rstdf = K.rmsnorm_fwd(h_ce, lm["norm"], eps)
+        logits = K.gemm_nt(nf, lm["head"], ldc=Vp)                # [B*T, Vp]
+        loss, count = K.ce_fwd_bwd(logits, plan.ce_tgt, V, grad_scale, loss_scale, write_grad=compute_grads)
+        ctx = dict(dlogits=logits, nf=nf, h_ce=h_ce, rstdf=rstdf, Vp=Vp)      # logits were overwritten in place with dlogits
+    return loss, count, logits_full, ctx
+
+
+def decoder_backward(K, lm, grads, grads_layers, tc, ctx, hctx, plan, B, L, kmask, kstart=None, qend=None, accumulate=False,
+                     on_bucket_ready=None):
+    """Backward of head_and_loss + decoder_forward.  Returns dx [B*L, d], the gradient w.r.t. the merged input embeddings.
+    Fires on_bucket_ready("head") and (("layer", i, "down" | "gu" | "attn")) as each gradient bucket completes."""
+    H, Hkv, hd = tc.num_attention_heads, tc.num_key_value_heads, tc.head_dim
+    acc = accumulate
+    saved, cos, sin, scale = ctx["saved"], ctx["cos"], ctx["sin"], ctx["scale"]
+    dlogits, nf, h_ce, rstdf = hctx["dlogits"], hctx["nf"], hctx["h_ce"], hctx["rstdf"]
+    if grads.get("head") is not None:
+        K.linear_dw(dlogits, nf, grads["head"], acc)      # pad columns [V, Vp) are zero
+    dnf = K.linear_dx(dlogits, lm["head"], k=hctx["Vp"])
+    dh_ce = K.rmsnorm_bwd(dnf, h_ce, lm["norm"], rstdf, None, grads.get("norm"), acc)
+    dx = K.scatter_rows(dh_ce, plan.ce_row, B * L)
+    hctx.clear()
+    del dlogits, dnf, nf, h_ce, dh_ce
+    if on_bucket_ready is not None:
+        on_bucket_ready("head")
+    for i in reversed(range(tc.num_hidden_layers)):
+        lw = lm["layers"][i]
+        lg_ = grads_layers[i]
+        x_in, rstd1, qkv, o, lse, x_mid, rstd2, gu, n1, n2, a = saved.pop()
+        if lg_["down"] is not None:
+            K.linear_dw(dx, a, lg_["down"], acc)
+        if on_bucket_ready is not None:
+            on_bucket_ready(("layer", i, "down"))
+        dgu = K.linear_dx_swiglu(dx, lw["down"], gu)     # dact = dx . W_down and the SwiGLU backward in one launch
+        del a, gu
+        if lg_["gu"] is not None:
+            K.linear_dw(dgu, n2, lg_["gu"], acc)
+        if on_bucket_ready is not None:
+            on_bucket_ready(("layer", i, "gu"))
+        dn2 = K.linear_dx(dgu, lw["gu"])
+        del dgu, n2
+        dx_mid = K.rmsnorm_bwd(dn2, x_mid, lw["ln2"], rstd2, dx, lg_["ln2"], acc)
+        del dn2, dx
+        if lg_["o"] is not None:
+            K.linear_dw(dx_mid, o, lg_["o"], acc)
+        do = K.linear_dx(dx_mid, lw["o"])
+        dqkv = K.attn_bwd(qkv, o, do, lse, B, L, H, Hkv, hd, kmask, scale, True, kstart=kstart, qend=qend)
+        del do, o
+        K.rope_apply_(dqkv, cos, sin, H + Hkv, hd, backward=True)
+        if lg_["qkv"] is not None:
+            K.linear_dw(dqkv, n1, lg_["qkv"], acc)
+        dn1 = K.linear_dx(dqkv, lw["qkv"])
+        del dqkv, n1, qkv
+        dx = K.rmsnorm_bwd(dn1, x_in, lw["ln1"], rstd1, dx_mid, lg_["ln1"], acc)
+        del dn1, dx_mid, x_in
+        if on_bucket_ready is not None:
+            on_bucket_ready(("layer", i, "attn"))
+    return dx

@@ -16,6 +16,7 @@ import os
 import numpy as np
 import torch
 
+from . import decoder as D
 from . import hip_ops as K   # the ONLY compute backend; tests may monkeypatch `engine.K` with the oracle to test host logic
 
 
@@ -24,11 +25,6 @@ _DEBUG_SYNC = os.environ.get("MANTIS_DEBUG_SYNC") == "1"
 
 class PackCountError(ValueError):
     pass
-
-
-def _inv_freq(head_dim, theta):
-    # transformers/models/llama/modeling_llama.py:95-110 (default rope), computed on the host in fp32 like the reference
-    return 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
 
 
 class LlavaEngine:
@@ -53,6 +49,10 @@ class LlavaEngine:
             raise IndexError(f"{int(count[1])} label(s) are >= vocab_size {self.cfg.text_config.vocab_size} "
                              f"(torch.nn.CrossEntropyLoss: 'Target out of bounds')")
         self._verified = True
+
+    def step_from_batch(self, inputs, **kw):
+        """The batch dict of the Mantis collator -> step()."""
+        return self.step(inputs["input_ids"], inputs["attention_mask"], inputs.get("labels"), inputs.get("pixel_values"), **kw)
 
     # ------------------------------------------------------------------------------------------------ vision tower (frozen)
     def vision_forward(self, pixels, record=None):
@@ -165,53 +165,13 @@ class LlavaEngine:
             record.update(merged_embeds=x.view(B, L, -1), merged_attention_mask=plan.attention_mask,
                           merged_labels=plan.labels, merged_position_ids=plan.position_ids)
 
-        # ---- row H: Llama decoder
-        d, H, Hkv, hd = tc.hidden_size, tc.num_attention_heads, tc.num_key_value_heads, tc.head_dim
-        eps = tc.rms_norm_eps
-        scale = hd ** -0.5
-        inv_freq = _inv_freq(hd, tc.rope_theta).to(dev)
-        cos, sin = K.rope_table(plan.position_ids.reshape(-1), inv_freq)
+        # ---- rows H, I: Llama decoder, final norm, lm_head, masked shifted CE (decoder.py, shared with the Idefics2 path)
         kmask = plan.kmask
-        saved = []
-        nl = tc.num_hidden_layers
-        for i in range(nl):
-            lw = m.lm["layers"][i]
-            n1, rstd1 = K.rmsnorm_fwd(x, lw["ln1"], eps)
-            qkv = K.gemm_nt(n1, lw["qkv"])
-            K.rope_apply_(qkv, cos, sin, H + Hkv, hd)
-            o, lse = K.attn_fwd(qkv, B, L, H, Hkv, hd, kmask, scale, True, kstart=kstart)
-            x_mid = K.gemm_nt(o, lw["o"], residual=x)
-            n2, rstd2 = K.rmsnorm_fwd(x_mid, lw["ln2"], eps)
-            gu = K.gemm_nt(n2, lw["gu"])
-            a = K.swiglu_fwd(gu)
-            x_out = K.gemm_nt(a, lw["down"], residual=x_mid)
-            if compute_grads:
-                # 288 GB of HBM: keep the cheap-to-recompute tensors too (n1, n2, a: +370 MB per layer) instead of re-running
-                # RMSNorm / SwiGLU in the backward
-                saved.append((x, rstd1, qkv, o, lse, x_mid, rstd2, gu, n1, n2, a))
-            x = x_out
-            if record is not None:
-                record[f"llm_layer{i}_out"] = x.view(B, L, -1)
-        n1 = n2 = a = None
-
-        # ---- row I: final norm, lm_head, masked shifted CE
-        V = tc.vocab_size
-        Vp = K.pad8(V)
-        logits_full = None
-        if need_logits:
-            nf_all, _ = K.rmsnorm_fwd(x, m.lm["norm"], eps, want_rstd=False)
-            if record is not None:
-                record["llm_final_norm"] = nf_all.view(B, L, -1)
-            lg = K.gemm_nt(nf_all, m.lm["head"], ldc=Vp)
-            logits_full = lg.view(B, L, Vp)[:, :, :V]
-        loss = None
-        if labels is not None or compute_grads:
-            h_ce = K.gather_rows(x, plan.ce_row)                       # [B*T, d] rows that can carry a label
-            nf, rstdf = K.rmsnorm_fwd(h_ce, m.lm["norm"], eps)
-            logits = K.gemm_nt(nf, m.lm["head"], ldc=Vp)              # [B*T, Vp]
-            loss, count = K.ce_fwd_bwd(logits, plan.ce_tgt, V, grad_scale, loss_scale, write_grad=compute_grads)
-            if not self._verified or _DEBUG_SYNC:
-                self._verify_device_status(plan, count)
+        x, dctx = D.decoder_forward(K, m.lm, tc, x, B, L, plan.position_ids, kmask, kstart, compute_grads, record)
+        loss, count, logits_full, hctx = D.head_and_loss(K, m.lm, tc, x, plan, B, L, labels is not None, grad_scale, loss_scale,
+                                                         compute_grads, need_logits, record)
+        if count is not None and (not self._verified or _DEBUG_SYNC):
+            self._verify_device_status(plan, count)
         out = dict(loss=loss, logits=logits_full, plan=plan)
         if not compute_grads:
             return out
@@ -223,48 +183,7 @@ class LlavaEngine:
         def gw(key):
             return g.get(key)
 
-        dlogits = logits                 # overwritten in place by the CE kernel
-        if gw("head") is not None:
-            K.linear_dw(dlogits, nf, gw("head"), acc)      # pad columns [V, Vp) are zero
-        dnf = K.linear_dx(dlogits, m.lm["head"], k=Vp)
-        dh_ce = K.rmsnorm_bwd(dnf, h_ce, m.lm["norm"], rstdf, None, gw("norm"), acc)
-        dx = K.scatter_rows(dh_ce, plan.ce_row, B * L)
-        del dlogits, logits, dnf, nf, h_ce, dh_ce
-        if on_bucket_ready is not None:
-            on_bucket_ready("head")
-
-        for i in reversed(range(nl)):
-            lw = m.lm["layers"][i]
-            lg_ = m.grads_layers[i]
-            x_in, rstd1, qkv, o, lse, x_mid, rstd2, gu, n1, n2, a = saved.pop()
-            if lg_["down"] is not None:
-                K.linear_dw(dx, a, lg_["down"], acc)
-            if on_bucket_ready is not None:
-                on_bucket_ready(("layer", i, "down"))
-            dgu = K.linear_dx_swiglu(dx, lw["down"], gu)     # dact = dx . W_down and the SwiGLU backward in one launch
-            del a, gu
-            if lg_["gu"] is not None:
-                K.linear_dw(dgu, n2, lg_["gu"], acc)
-            if on_bucket_ready is not None:
-                on_bucket_ready(("layer", i, "gu"))
-            dn2 = K.linear_dx(dgu, lw["gu"])
-            del dgu, n2
-            dx_mid = K.rmsnorm_bwd(dn2, x_mid, lw["ln2"], rstd2, dx, lg_["ln2"], acc)
-            del dn2, dx
-            if lg_["o"] is not None:
-                K.linear_dw(dx_mid, o, lg_["o"], acc)
-            do = K.linear_dx(dx_mid, lw["o"])
-            dqkv = K.attn_bwd(qkv, o, do, lse, B, L, H, Hkv, hd, kmask, scale, True, kstart=kstart, qend=qend)
-            del do, o
-            K.rope_apply_(dqkv, cos, sin, H + Hkv, hd, backward=True)
-            if lg_["qkv"] is not None:
-                K.linear_dw(dqkv, n1, lg_["qkv"], acc)
-            dn1 = K.linear_dx(dqkv, lw["qkv"])
-            del dqkv, n1, qkv
-            dx = K.rmsnorm_bwd(dn1, x_in, lw["ln1"], rstd1, dx_mid, lg_["ln1"], acc)
-            del dn1, dx_mid, x_in
-            if on_bucket_ready is not None:
-                on_bucket_ready(("layer", i, "attn"))
+        dx = D.decoder_backward(K, m.lm, g, m.grads_layers, tc, dctx, hctx, plan, B, L, kmask, kstart, qend, acc, on_bucket_ready)
 
         # ---- rows G, F, E backward: merged-row grads -> embedding rows + image-feature rows -> projector
         if gw("embed") is not None:

@@ -354,8 +354,10 @@ def gather_rows(x, idx):
     return out
 
 
-def scatter_rows(x, idx, nrows_out):
-    out = torch.zeros((nrows_out, x.shape[1]), dtype=BF16, device=x.device)
+def scatter_rows(x, idx, nrows_out, out=None):
+    """out[idx[r]] = x[r] (unique idx; idx < 0 skipped).  `out`: an existing contiguous [nrows_out, d] buffer to scatter into."""
+    if out is None:
+        out = torch.zeros((nrows_out, x.shape[1]), dtype=BF16, device=x.device)
     _lib.check(_L.mantis_scatter_rows(_p(x), _p(idx), _p(out), idx.numel(), x.shape[1], _stream()), "scatter_rows")
     return out
 

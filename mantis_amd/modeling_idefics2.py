@@ -1,0 +1,465 @@
+"""Drop-in module for the reference fork's `Idefics2ForConditionalGeneration`
+(/root/reference/mantis/models/idefics2/modeling_idefics2.py:1729-1912 over Idefics2Model :1487-1722): same forward keyword arguments,
+same output fields, same parameter names (state_dict-compatible), on the flat-arena layout of `ArenaModule` and the hand-written gfx950
+kernels (no autograd graph): NaViT SigLIP tower (frozen, as under the reference's LoRA target list train_idefics2.py:156), modality
+projection + perceiver resampler, `inputs_merger`, Mistral-7B decoder, fp32 cross-entropy with ignore_index = image_token_id.
+
+Documented divergences: full-parameter training of connector + text model instead of LoRA adapters; the vision tower is frozen;
+`do_image_splitting` / generation / KV-cache paths are out of scope."""
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import decoder as D
+from . import hip_ops as K   # tests may monkeypatch `modeling_idefics2.K` with the oracle's operators to test the host logic
+from .arena import ArenaModule
+from .configuration_idefics2 import Idefics2Config
+
+
+@dataclass
+class Idefics2CausalLMOutputWithPast:
+    """modeling_idefics2.py:119-152"""
+    loss: Optional[torch.Tensor] = None
+    logits: Optional[torch.Tensor] = None
+    past_key_values: Optional[Tuple] = None
+    hidden_states: Optional[Tuple] = None
+    attentions: Optional[Tuple] = None
+    image_hidden_states: Optional[torch.Tensor] = None
+
+    def __getitem__(self, k):
+        if isinstance(k, str):
+            return getattr(self, k)
+        return tuple(v for v in (self.loss, self.logits, self.past_key_values, self.hidden_states, self.attentions,
+                                 self.image_hidden_states) if v is not None)[k]
+
+
+def _param_specs(cfg: Idefics2Config):
+    """(name, shape) in ARENA ORDER: [vision tower | connector | embed | text layer 0..n-1 | final norm | lm_head]."""
+    vc, pc, tc = cfg.vision_config, cfg.perceiver_config, cfg.text_config
+    dv, iv, P, C = vc.hidden_size, vc.intermediate_size, vc.patch_size, vc.num_channels
+    s = []
+    v = "model.vision_model."
+    s += [(v + "embeddings.patch_embedding.weight", (dv, C, P, P)), (v + "embeddings.patch_embedding.bias", (dv,)),
+          (v + "embeddings.position_embedding.weight", ((vc.image_size // P) ** 2, dv))]
+    for i in range(vc.num_hidden_layers):
+        p = f"{v}encoder.layers.{i}."
+        s += [(p + "self_attn.q_proj.weight", (dv, dv)), (p + "self_attn.k_proj.weight", (dv, dv)), (p + "self_attn.v_proj.weight", (dv, dv)),
+              (p + "self_attn.q_proj.bias", (dv,)), (p + "self_attn.k_proj.bias", (dv,)), (p + "self_attn.v_proj.bias", (dv,)),
+              (p + "self_attn.out_proj.weight", (dv, dv)), (p + "self_attn.out_proj.bias", (dv,)),
+              (p + "layer_norm1.weight", (dv,)), (p + "layer_norm1.bias", (dv,)), (p + "layer_norm2.weight", (dv,)), (p + "layer_norm2.bias", (dv,)),
+              (p + "mlp.fc1.weight", (iv, dv)), (p + "mlp.fc1.bias", (iv,)), (p + "mlp.fc2.weight", (dv, iv)), (p + "mlp.fc2.bias", (dv,))]
+    s += [(v + "post_layernorm.weight", (dv,)), (v + "post_layernorm.bias", (dv,))]
+    d, it, V = tc.hidden_size, tc.intermediate_size, tc.vocab_size
+    H, Hkv, hd = tc.num_attention_heads, tc.num_key_value_heads, tc.head_dim
+    c = "model.connector."
+    s += [(c + "modality_projection.gate_proj.weight", (it, dv)), (c + "modality_projection.up_proj.weight", (it, dv)),
+          (c + "modality_projection.down_proj.weight", (d, it)), (c + "perceiver_resampler.latents", (pc.resampler_n_latents, d))]
+    ph, pkv, phd = pc.resampler_n_heads, pc.num_key_value_heads, pc.resampler_head_dim
+    for i in range(pc.resampler_depth):
+        p = f"{c}perceiver_resampler.layers.{i}."
+        s += [(p + "input_latents_norm.weight", (d,)), (p + "input_context_norm.weight", (d,)), (p + "post_attention_layernorm.weight", (d,)),
+              (p + "self_attn.q_proj.weight", (ph * phd, d)), (p + "self_attn.k_proj.weight", (pkv * phd, d)),
+              (p + "self_attn.v_proj.weight", (pkv * phd, d)), (p + "self_attn.o_proj.weight", (d, ph * phd)),
+              (p + "mlp.gate_proj.weight", (4 * d, d)), (p + "mlp.up_proj.weight", (4 * d, d)), (p + "mlp.down_proj.weight", (d, 4 * d))]
+    s += [(c + "perceiver_resampler.norm.weight", (d,))]
+    t = "model.text_model."
+    s.append((t + "embed_tokens.weight", (V, d)))
+    for i in range(tc.num_hidden_layers):
+        p = f"{t}layers.{i}."
+        # same in-layer order as the LLaVA path: [norms | q k v o] [gate up] [down] = reverse of backward completion (DP sub-buckets)
+        s += [(p + "input_layernorm.weight", (d,)), (p + "post_attention_layernorm.weight", (d,)),
+              (p + "self_attn.q_proj.weight", (H * hd, d)), (p + "self_attn.k_proj.weight", (Hkv * hd, d)),
+              (p + "self_attn.v_proj.weight", (Hkv * hd, d)), (p + "self_attn.o_proj.weight", (d, H * hd)),
+              (p + "mlp.gate_proj.weight", (it, d)), (p + "mlp.up_proj.weight", (it, d)), (p + "mlp.down_proj.weight", (d, it))]
+    s += [(t + "norm.weight", (d,)), ("lm_head.weight", (V, d))]
+    return s
+
+
+class Idefics2ForConditionalGeneration(ArenaModule):
+    config_class = Idefics2Config
+    supports_gradient_checkpointing = False
+    frozen_prefixes = ("model.vision_model.",)
+
+    def __init__(self, config: Idefics2Config, device=None, dtype=torch.bfloat16, init="normal", seed=0):
+        super().__init__()
+        self.config = config
+        self.image_token_id = config.image_token_id
+        self.vocab_size = config.vocab_size
+        self._init_arena(_param_specs(config), device, dtype)
+        self.engine = Idefics2Engine(self)
+        self._build_views()
+        if init == "normal":
+            self.reset_parameters(seed)
+        self.train()
+
+    def _build_views(self):
+        cfg, vc, pc, tc = self.config, self.config.vision_config, self.config.perceiver_config, self.config.text_config
+        g = lambda n: self._param(n).data
+        dv, P, C = vc.hidden_size, vc.patch_size, vc.num_channels
+        v = "model.vision_model."
+        kraw = C * P * P
+        kp = (kraw + 7) // 8 * 8
+
+        def patch_w_padded():
+            w = g(v + "embeddings.patch_embedding.weight").view(dv, kraw)
+            if kp == kraw:
+                return w
+            out = torch.zeros((dv, kp), dtype=w.dtype, device=w.device)
+            out[:, :kraw] = w
+            return out
+        layers = []
+        for i in range(vc.num_hidden_layers):
+            p = f"{v}encoder.layers.{i}."
+            layers.append(dict(
+                qkv_w=self._flat(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", 3 * dv, dv),
+                qkv_b=self._flat(p + "self_attn.q_proj.bias", p + "self_attn.v_proj.bias", 1, 3 * dv).view(-1),
+                out_w=g(p + "self_attn.out_proj.weight"), out_b=g(p + "self_attn.out_proj.bias"),
+                ln1_w=g(p + "layer_norm1.weight"), ln1_b=g(p + "layer_norm1.bias"), ln2_w=g(p + "layer_norm2.weight"), ln2_b=g(p + "layer_norm2.bias"),
+                fc1_w=g(p + "mlp.fc1.weight"), fc1_b=g(p + "mlp.fc1.bias"), fc2_w=g(p + "mlp.fc2.weight"), fc2_b=g(p + "mlp.fc2.bias")))
+        self.vt = dict(patch_kp=kp, patch_w_padded=patch_w_padded, patch_b=g(v + "embeddings.patch_embedding.bias"),
+                       pos=g(v + "embeddings.position_embedding.weight"), layers=layers,
+                       post_ln=(g(v + "post_layernorm.weight"), g(v + "post_layernorm.bias")))
+        d, it = tc.hidden_size, tc.intermediate_size
+        c = "model.connector."
+        ph, pkv, phd = pc.resampler_n_heads, pc.num_key_value_heads, pc.resampler_head_dim
+        pl = []
+        for i in range(pc.resampler_depth):
+            p = f"{c}perceiver_resampler.layers.{i}."
+            pl.append(dict(lat_norm=g(p + "input_latents_norm.weight"), ctx_norm=g(p + "input_context_norm.weight"),
+                           post_norm=g(p + "post_attention_layernorm.weight"),
+                           qkv=self._flat(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", (ph + 2 * pkv) * phd, d),
+                           o=g(p + "self_attn.o_proj.weight"),
+                           gu=self._flat(p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight", 8 * d, d), down=g(p + "mlp.down_proj.weight")))
+        self.conn = dict(mp_gu=self._flat(c + "modality_projection.gate_proj.weight", c + "modality_projection.up_proj.weight", 2 * it, dv),
+                         mp_down=g(c + "modality_projection.down_proj.weight"), latents=g(c + "perceiver_resampler.latents"),
+                         layers=pl, norm=g(c + "perceiver_resampler.norm.weight"))
+        H, Hkv, hd = tc.num_attention_heads, tc.num_key_value_heads, tc.head_dim
+        t = "model.text_model."
+        ll = []
+        for i in range(tc.num_hidden_layers):
+            p = f"{t}layers.{i}."
+            ll.append(dict(qkv=self._flat(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", (H + 2 * Hkv) * hd, d),
+                           o=g(p + "self_attn.o_proj.weight"),
+                           gu=self._flat(p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight", 2 * it, d), down=g(p + "mlp.down_proj.weight"),
+                           ln1=g(p + "input_layernorm.weight"), ln2=g(p + "post_attention_layernorm.weight")))
+        self.lm = dict(embed=g(t + "embed_tokens.weight"), layers=ll, norm=g(t + "norm.weight"), head=g("lm_head.weight"))
+
+    def _build_grad_views(self):
+        pc, tc = self.config.perceiver_config, self.config.text_config
+        gv = self._grad_views.get
+        d, it, dv = tc.hidden_size, tc.intermediate_size, self.config.vision_config.hidden_size
+        H, Hkv, hd = tc.num_attention_heads, tc.num_key_value_heads, tc.head_dim
+        t, c = "model.text_model.", "model.connector."
+        self.grads = dict(head=gv("lm_head.weight"), norm=gv(t + "norm.weight"), embed=gv(t + "embed_tokens.weight"))
+        self.grads_layers = []
+        for i in range(tc.num_hidden_layers):
+            p = f"{t}layers.{i}."
+            self.grads_layers.append(dict(
+                qkv=self._gflat(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", (H + 2 * Hkv) * hd, d), o=gv(p + "self_attn.o_proj.weight"),
+                gu=self._gflat(p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight", 2 * it, d), down=gv(p + "mlp.down_proj.weight"),
+                ln1=gv(p + "input_layernorm.weight"), ln2=gv(p + "post_attention_layernorm.weight")))
+        ph, pkv, phd = pc.resampler_n_heads, pc.num_key_value_heads, pc.resampler_head_dim
+        pl = []
+        for i in range(pc.resampler_depth):
+            p = f"{c}perceiver_resampler.layers.{i}."
+            pl.append(dict(lat_norm=gv(p + "input_latents_norm.weight"), ctx_norm=gv(p + "input_context_norm.weight"),
+                           post_norm=gv(p + "post_attention_layernorm.weight"),
+                           qkv=self._gflat(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", (ph + 2 * pkv) * phd, d),
+                           o=gv(p + "self_attn.o_proj.weight"),
+                           gu=self._gflat(p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight", 8 * d, d), down=gv(p + "mlp.down_proj.weight")))
+        self.grads_conn = dict(mp_gu=self._gflat(c + "modality_projection.gate_proj.weight", c + "modality_projection.up_proj.weight", 2 * it, dv),
+                               mp_down=gv(c + "modality_projection.down_proj.weight"), latents=gv(c + "perceiver_resampler.latents"),
+                               layers=pl, norm=gv(c + "perceiver_resampler.norm.weight"))
+
+    @torch.no_grad()
+    def reset_parameters(self, seed=0):
+        """normal(0, initializer_range), norm weights 1, biases 0, latents 1 (modeling_idefics2.py:1366-1387, :1275)."""
+        std = self.config.text_config.get("initializer_range", 0.02)
+        self._param_version += 1
+        gen = torch.Generator(device=self.device).manual_seed(seed)
+        for name, p in self.named_parameters():
+            if name.endswith("perceiver_resampler.latents"):
+                p.fill_(1.0)
+            elif p.dim() == 1:
+                p.fill_(1.0 if ("norm" in name and name.endswith("weight")) else 0.0)
+            else:
+                flat = p.view(-1)
+                step = 1 << 26
+                for a in range(0, flat.numel(), step):
+                    b = min(flat.numel(), a + step)
+                    flat[a:b] = torch.randn(b - a, generator=gen, device=self.device, dtype=torch.float32).mul_(std)
+
+    def get_input_embeddings(self):
+        return self.model.text_model.embed_tokens
+
+    def get_output_embeddings(self):
+        return self.lm_head
+
+    def tie_weights(self, *a, **k):
+        return None
+
+    def load_reference_state_dict(self, sd, strict=True):
+        return self.copy_state_dict(sd, ignorable=lambda k: k.endswith("position_ids") or ".head." in k, strict=strict)
+
+    def grad_buckets(self):
+        """Contiguous gradient-arena slices in backward-completion order: 'head', per text layer n-1..0 ('layer', i, 'down' | 'gu' |
+        'attn'), then 'front' = connector (modality projection + perceiver) + token embedding."""
+        self._ensure_grad_arena()
+        span = self._bucket_span
+        out = {"head": span(lambda n: n.startswith("model.text_model.norm") or n.startswith("lm_head"))}
+        for i in range(self.config.text_config.num_hidden_layers):
+            p = f"model.text_model.layers.{i}."
+            out[("layer", i, "down")] = span(lambda n: n == p + "mlp.down_proj.weight")
+            out[("layer", i, "gu")] = span(lambda n: n in (p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight"))
+            out[("layer", i, "attn")] = span(lambda n: n.startswith(p) and ".mlp." not in n)
+        out["front"] = span(lambda n: n.startswith("model.connector.") or n.startswith("model.text_model.embed_tokens"))
+        return {k: v for k, v in out.items() if v is not None}
+
+    # ------------------------------------------------------------------ forward (modeling_idefics2.py:1797-1912)
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None, pixel_values=None,
+                pixel_attention_mask=None, image_hidden_states=None, labels=None, use_cache=None, output_attentions=None,
+                output_hidden_states=None, return_dict=None, return_logits=None, _record=None):
+        if inputs_embeds is not None or past_key_values is not None or use_cache or image_hidden_states is not None:
+            raise NotImplementedError("generation / KV-cache / precomputed image states are out of scope: training forward only")
+        if output_attentions or output_hidden_states:
+            raise NotImplementedError("output_attentions / output_hidden_states are not produced by the fused kernels")
+        if position_ids is not None:
+            raise NotImplementedError("explicit position_ids (the reference passes None: Mistral's default arange)")
+        return_dict = return_dict if return_dict is not None else self.config.use_return_dict
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)
+        want_grads = self.training and labels is not None and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if want_grads:
+            raise NotImplementedError("drive training through MantisHipTrainer.training_step (the fused forward+backward); "
+                                      "the autograd bridge is implemented for the LLaVA module only")
+        if return_logits is None:
+            return_logits = True
+        out = self.engine.step(input_ids, attention_mask, labels, pixel_values, pixel_attention_mask, compute_grads=False,
+                               need_logits=return_logits, record=_record)
+        loss = None if labels is None else out["loss"].reshape(())
+        logits = None if out["logits"] is None else out["logits"].float()          # :1882 logits.float()
+        if not return_dict:
+            return ((loss,) if loss is not None else ()) + ((logits,) if logits is not None else ())
+        return Idefics2CausalLMOutputWithPast(loss=loss, logits=logits)
+
+
+class Idefics2Engine:
+    """Host side of the Idefics2 step: sequences the gfx950 kernels for the vision tower, the connector (forward + backward), the merger
+    and -- through decoder.py -- the Mistral decoder, head and loss."""
+
+    def __init__(self, model):
+        self.m = model
+        self.cfg = model.config
+        self._verified = False
+
+    def step_from_batch(self, inputs, **kw):
+        return self.step(inputs["input_ids"], inputs["attention_mask"], inputs.get("labels"), inputs.get("pixel_values"),
+                         inputs.get("pixel_attention_mask"), **kw)
+
+    # ------------------------------------------------------------------ host-side integer preparation (tiny, data dependent)
+    def _prepare_images(self, pixel_values, pixel_attention_mask):
+        """Padding-image removal (:1636-1639), pixel mask -> patch mask (:1653-1658), bucketised NaViT position ids (:190-210).
+        Integer / boolean bookkeeping on the host copy of the batch (the shapes of everything downstream depend on it); the
+        fractional-coordinate arithmetic repeats the reference's float32 torch ops so the ids are bit-identical."""
+        vc = self.cfg.vision_config
+        P = vc.patch_size
+        pv = torch.as_tensor(pixel_values)
+        Bm = pv.shape[0] * pv.shape[1]
+        pv = pv.reshape(Bm, *pv.shape[2:])
+        real = torch.count_nonzero(pv.reshape(Bm, -1), dim=1) != 0
+        idx = torch.nonzero(real).reshape(-1)
+        pv = pv[idx]
+        I, _, Hh, Ww = pv.shape
+        if pixel_attention_mask is None:
+            pm = torch.ones((I, Hh, Ww), dtype=torch.bool)
+        else:
+            pm = torch.as_tensor(pixel_attention_mask).bool().reshape(Bm, Hh, Ww)[idx]
+        sub = pm.unfold(1, P, P).unfold(2, P, P)
+        patch_mask = sub.sum(dim=(-1, -2)) > 0                                   # [I, ph, pw]
+        side = vc.image_size // P
+        boundaries = torch.arange(1 / side, 1.0, 1 / side)
+        ph, pw = patch_mask.shape[1:]
+        pos = torch.zeros((I, ph * pw), dtype=torch.int64)
+        for i in range(I):
+            m = patch_mask[i]
+            nh, nw = m[:, 0].sum(), m[0].sum()
+            fh = torch.arange(0, 1 - 1e-6, 1 / nh)
+            fw = torch.arange(0, 1 - 1e-6, 1 / nw)
+            bh = torch.bucketize(fh, boundaries, right=True)
+            bw = torch.bucketize(fw, boundaries, right=True)
+            pos[i][m.reshape(-1)] = (bh[:, None] * side + bw).flatten()
+        km = patch_mask.reshape(I, -1)
+        return pv, pos.to(torch.int32), (None if bool(km.all()) else km.to(torch.int32)), km.to(torch.int32)
+
+    # ------------------------------------------------------------------ vision tower (frozen, forward only)
+    def vision_forward(self, pix, pos_ids, kmask):
+        m, vc = self.m, self.cfg.vision_config
+        vt = m.vt
+        I = pix.shape[0]
+        P, dv = vc.patch_size, vc.hidden_size
+        N = (pix.shape[2] // P) * (pix.shape[3] // P)
+        patches = K.im2col(pix, P, vt["patch_kp"])
+        pe = K.gemm_nt(patches, vt["patch_w_padded"](), bias=vt["patch_b"])
+        x = K.add(pe, K.gather_rows(vt["pos"], pos_ids.reshape(-1)))
+        eps = vc.layer_norm_eps
+        nh = vc.num_attention_heads
+        hd = dv // nh
+        for lw in vt["layers"]:
+            y = K.layernorm_fwd(x, lw["ln1_w"], lw["ln1_b"], eps)
+            qkv = K.gemm_nt(y, lw["qkv_w"], bias=lw["qkv_b"])
+            o, _ = K.attn_fwd(qkv, I, N, nh, nh, hd, kmask, hd ** -0.5, False, want_lse=False)
+            x = K.gemm_nt(o, lw["out_w"], bias=lw["out_b"], residual=x)
+            y = K.layernorm_fwd(x, lw["ln2_w"], lw["ln2_b"], eps)
+            hmid = K.gemm_nt(y, lw["fc1_w"], bias=lw["fc1_b"], act=vc.hidden_act)
+            x = K.gemm_nt(hmid, lw["fc2_w"], bias=lw["fc2_b"], residual=x)
+        return K.layernorm_fwd(x, vt["post_ln"][0], vt["post_ln"][1], eps), N
+
+    # ------------------------------------------------------------------ connector forward (saves what its backward needs)
+    def connector_forward(self, feats, I, N, km_all, record=None):
+        """feats [I*N, d_v] -> image hidden states [I*n_latents, d].  Perceiver attention (:812-912) = attention of the latent queries over
+        concat[context, latents]; run here as ONE self-attention over the concatenated rows with the fused q|k|v projection (context
+        rows get a query too -- their outputs are never read and their output gradient is zero, so they contribute nothing)."""
+        m, pc, tc = self.m, self.cfg.perceiver_config, self.cfg.text_config
+        cw = m.conn
+        dev = feats.device
+        nl, H, Hkv, hd = pc.resampler_n_latents, pc.resampler_n_heads, pc.num_key_value_heads, pc.resampler_head_dim
+        eps = tc.rms_norm_eps
+        gu = K.gemm_nt(feats, cw["mp_gu"])
+        a = K.swiglu_fwd(gu)
+        ctx = K.gemm_nt(a, cw["mp_down"])
+        if record is not None:
+            record["modality_projection_out"] = ctx.view(I, N, -1)
+        Lk = N + nl
+        base = torch.arange(I, dtype=torch.int32)[:, None] * Lk
+        ctx_idx = (base + torch.arange(N, dtype=torch.int32)[None]).reshape(-1).to(dev)
+        lat_idx = (base + N + torch.arange(nl, dtype=torch.int32)[None]).reshape(-1).to(dev)
+        lat_src = torch.arange(nl, dtype=torch.int32).repeat(I).to(dev)
+        kmask = torch.cat([km_all, torch.ones((I, nl), dtype=torch.int32)], dim=1).contiguous().to(dev)     # :1293-1296
+        lat = K.gather_rows(cw["latents"], lat_src)
+        saved = []
+        for lw in cw["layers"]:
+            ln, rstd_l = K.rmsnorm_fwd(lat, lw["lat_norm"], eps)
+            cn, rstd_c = K.rmsnorm_fwd(ctx, lw["ctx_norm"], eps)
+            hs = torch.empty((I * Lk, ctx.shape[1]), dtype=ctx.dtype, device=dev)
+            K.scatter_rows(cn, ctx_idx, I * Lk, out=hs)
+            K.scatter_rows(ln, lat_idx, I * Lk, out=hs)
+            qkv = K.gemm_nt(hs, lw["qkv"])
+            o_all, lse = K.attn_fwd(qkv, I, Lk, H, Hkv, hd, kmask, hd ** -0.5, False)
+            o_lat = K.gather_rows(o_all, lat_idx)
+            lat_mid = K.gemm_nt(o_lat, lw["o"], residual=lat)
+            n2, rstd2 = K.rmsnorm_fwd(lat_mid, lw["post_norm"], eps)
+            gu2 = K.gemm_nt(n2, lw["gu"])
+            a2 = K.swiglu_fwd(gu2)
+            lat_out = K.gemm_nt(a2, lw["down"], residual=lat_mid)
+            saved.append((lat, rstd_l, rstd_c, hs, qkv, o_all, lse, o_lat, lat_mid, rstd2, n2, gu2, a2))
+            lat = lat_out
+        out, rstd_f = K.rmsnorm_fwd(lat, cw["norm"], eps)
+        return out, dict(feats=feats, gu=gu, a=a, ctx=ctx, saved=saved, lat_final=lat, rstd_f=rstd_f, ctx_idx=ctx_idx, lat_idx=lat_idx,
+                         kmask=kmask, I=I, N=N, Lk=Lk)
+
+    def connector_backward(self, dimg, c, acc):
+        m, pc = self.m, self.cfg.perceiver_config
+        cw, g = m.conn, m.grads_conn
+        nl, H, Hkv, hd = pc.resampler_n_latents, pc.resampler_n_heads, pc.num_key_value_heads, pc.resampler_head_dim
+        I, Lk = c["I"], c["Lk"]
+        d_lat = K.rmsnorm_bwd(dimg, c["lat_final"], cw["norm"], c["rstd_f"], None, g["norm"], acc)
+        d_ctx = None
+        for li in reversed(range(len(cw["layers"]))):
+            lw, lg = cw["layers"][li], g["layers"][li]
+            lat_in, rstd_l, rstd_c, hs, qkv, o_all, lse, o_lat, lat_mid, rstd2, n2, gu2, a2 = c["saved"].pop()
+            if lg["down"] is not None:
+                K.linear_dw(d_lat, a2, lg["down"], acc)
+            dgu2 = K.swiglu_bwd(K.linear_dx(d_lat, lw["down"]), gu2)
+            if lg["gu"] is not None:
+                K.linear_dw(dgu2, n2, lg["gu"], acc)
+            dn2 = K.linear_dx(dgu2, lw["gu"])
+            d_mid = K.rmsnorm_bwd(dn2, lat_mid, lw["post_norm"], rstd2, d_lat, lg["post_norm"], acc)
+            if lg["o"] is not None:
+                K.linear_dw(d_mid, o_lat, lg["o"], acc)
+            do_lat = K.linear_dx(d_mid, lw["o"])
+            do_all = K.scatter_rows(do_lat, c["lat_idx"], I * Lk)          # zero output gradient on the context rows
+            dqkv = K.attn_bwd(qkv, o_all, do_all, lse, I, Lk, H, Hkv, hd, c["kmask"], hd ** -0.5, False)
+            if lg["qkv"] is not None:
+                K.linear_dw(dqkv, hs, lg["qkv"], acc)
+            d_hs = K.linear_dx(dqkv, lw["qkv"])
+            d_ln = K.gather_rows(d_hs, c["lat_idx"])
+            d_cn = K.gather_rows(d_hs, c["ctx_idx"])
+            d_lat = K.rmsnorm_bwd(d_ln, lat_in, lw["lat_norm"], rstd_l, d_mid, lg["lat_norm"], acc)
+            d_ctx = K.rmsnorm_bwd(d_cn, c["ctx"], lw["ctx_norm"], rstd_c, d_ctx, lg["ctx_norm"], acc)
+        if g["latents"] is not None:                                       # the latents are broadcast over the images (:1289)
+            K.colsum(d_lat.view(I, -1), g["latents"].view(-1), acc)
+        if g["mp_down"] is not None:
+            K.linear_dw(d_ctx, c["a"], g["mp_down"], acc)
+        dgu = K.swiglu_bwd(K.linear_dx(d_ctx, cw["mp_down"]), c["gu"])
+        if g["mp_gu"] is not None:
+            K.linear_dw(dgu, c["feats"], g["mp_gu"], acc)
+
+    # ------------------------------------------------------------------ full step
+    def step(self, input_ids, attention_mask, labels, pixel_values, pixel_attention_mask=None, grad_scale=1.0, loss_scale=1.0,
+             compute_grads=True, overwrite_grads=True, need_logits=False, record=None, on_bucket_ready=None, segment_ids=None):
+        if segment_ids is not None:
+            raise NotImplementedError("sample packing is wired for the LLaVA path; the Idefics2 path takes batches")
+        m, cfg, tc = self.m, self.cfg, self.cfg.text_config
+        dev = m.device
+        ids_cpu = input_ids.detach().to("cpu") if input_ids.device.type != "cpu" else input_ids
+        B, T = ids_cpu.shape
+        IMG = cfg.image_token_id
+        am_cpu = attention_mask.detach().to("cpu") if attention_mask.device.type != "cpu" else attention_mask
+        ids_d = input_ids.to(dev, non_blocking=True)
+        attn_d = attention_mask.to(dev, non_blocking=True).to(torch.int64)
+        lab_d = None if labels is None else labels.to(dev, non_blocking=True).to(torch.int64)
+        img = cctx = None
+        n_rows = 0
+        is_img = ids_cpu == IMG
+        if pixel_values is not None:
+            pv, pos_ids, vit_kmask, km_all = self._prepare_images(pixel_values, pixel_attention_mask)
+            pix = pv.to(dev, non_blocking=True).to(torch.float32).contiguous()
+            I = pix.shape[0]
+            feats, N = self.vision_forward(pix, pos_ids.to(dev), None if vit_kmask is None else vit_kmask.to(dev))
+            if record is not None:
+                record["vision_last_hidden_state"] = feats.view(I, N, -1)
+            img, cctx = self.connector_forward(feats, I, N, km_all, record)
+            if record is not None:
+                record["connector_out"] = img.view(I, cfg.perceiver_config.resampler_n_latents, -1)
+            n_rows = img.shape[0]
+            n_tok = int(is_img.sum())
+            if n_tok != n_rows:      # torch raises a shape-mismatch error in inputs_merger (:1564) for this
+                raise ValueError(f"{n_tok} <image> tokens in input_ids but {n_rows} image hidden states "
+                                 f"({I} images x {cfg.perceiver_config.resampler_n_latents} latents)")
+            if bool((am_cpu[is_img] == 0).any()):
+                raise NotImplementedError("attention_mask == 0 on an <image> token")
+        # inputs_merger (:1545-1565) = the packing plan with ONE slot per <image> token: slot r takes image-hidden row r in row-major
+        # order; labels equal to image_token_id are the ignored ones (:1898); positions are Mistral's default arange
+        plan = K.pack_plan(ids_d, attn_d, lab_d, 1, n_rows, IMG if img is not None else -(2 ** 62), -1, IMG, T)
+        plan.position_ids = torch.arange(T, device=dev, dtype=torch.int64)[None].expand(B, T).contiguous()
+        x = K.pack_rows_fwd(plan, ids_d, m.lm["embed"], img)
+        if record is not None and img is not None:
+            record["merged_embeds"] = x.view(B, T, -1)
+        kmask = plan.kmask
+        x, dctx = D.decoder_forward(K, m.lm, tc, x, B, T, plan.position_ids, kmask, None, compute_grads, record)
+        loss, count, logits_full, hctx = D.head_and_loss(K, m.lm, tc, x, plan, B, T, labels is not None, grad_scale, loss_scale,
+                                                         compute_grads, need_logits, record)
+        if count is not None and not self._verified:
+            if int(count[1]) != 0:
+                raise IndexError(f"{int(count[1])} label(s) are >= vocab_size {tc.vocab_size}")
+            self._verified = True
+        out = dict(loss=loss, logits=logits_full, plan=plan)
+        if not compute_grads:
+            return out
+        acc = not overwrite_grads
+        g = m.grads
+        dx = D.decoder_backward(K, m.lm, g, m.grads_layers, tc, dctx, hctx, plan, B, T, kmask, None, None, acc, on_bucket_ready)
+        if g.get("embed") is not None:
+            if overwrite_grads:
+                g["embed"].zero_()
+            K.embed_grad(dx, ids_d, plan, g["embed"], True)
+        if img is not None:
+            self.connector_backward(K.gather_rows(dx, plan.img_slot), cctx, acc)
+        elif overwrite_grads:
+            for n, p in m.named_parameters():          # no image in this batch: the connector receives exactly zero gradient
+                if n.startswith("model.connector.") and p.grad is not None:
+                    p.grad.zero_()
+        if on_bucket_ready is not None:
+            on_bucket_ready("front")
+        return out

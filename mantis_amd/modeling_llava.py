@@ -17,6 +17,7 @@ from typing import Optional, Tuple
 import torch
 from torch import nn
 
+from .arena import ArenaModule, numel as _numel
 from .configuration_llava import LlavaConfig
 from . import engine as _engine
 
@@ -87,76 +88,23 @@ def _param_specs(cfg: LlavaConfig):
     return s
 
 
-def _numel(shape):
-    n = 1
-    for x in shape:
-        n *= x
-    return n
-
-
-class LlavaForConditionalGeneration(nn.Module):
+class LlavaForConditionalGeneration(ArenaModule):
     config_class = LlavaConfig
     supports_gradient_checkpointing = False
+    frozen_prefixes = ("vision_tower.",)      # train_mllava.py:240-242
 
     def __init__(self, config: LlavaConfig, device=None, dtype=torch.bfloat16, init="normal", seed=0):
         super().__init__()
-        if dtype != torch.bfloat16:
-            raise NotImplementedError("the gfx950 path computes in bf16 (fp32 accumulate); construct with dtype=torch.bfloat16")
         self.config = config
         self.vocab_size = config.vocab_size
         self.pad_token_id = config.pad_token_id if config.pad_token_id is not None else -1
-        dev = torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
-        specs = _param_specs(config)
-        offs, off = {}, 0
-        for name, shape in specs:
-            offs[name] = off
-            off += (_numel(shape) + 7) // 8 * 8       # keep every parameter 16-byte aligned
-        self._specs, self._offs, self._arena_numel = specs, offs, off
-        self.arena = torch.zeros(off, dtype=dtype, device=dev)
-        self._trainable_start = offs["multi_modal_projector.linear_1.weight"]
-        for name, shape in specs:
-            view = self.arena[offs[name]: offs[name] + _numel(shape)].view(shape)
-            p = nn.Parameter(view, requires_grad=not name.startswith("vision_tower."))   # train_mllava.py:240-242
-            self._attach(name, p)
-        self.grad_arena = None
-        self._grad_offs = None
-        self._param_version = 0      # bumped whenever parameter VALUES are replaced wholesale (init / checkpoint load)
+        self._init_arena(_param_specs(config), device, dtype)
+        self._trainable_start = self._offs["multi_modal_projector.linear_1.weight"]
         self.engine = _engine.LlavaEngine(self)
         self._build_views()
         if init == "normal":
             self.reset_parameters(seed)
         self.train()
-
-    # ------------------------------------------------------------------ module tree with the reference's parameter names
-    def _attach(self, dotted, param):
-        mod = self
-        parts = dotted.split(".")
-        for p in parts[:-1]:
-            if p not in mod._modules:
-                mod.add_module(p, nn.Module())
-            mod = mod._modules[p]
-        mod.register_parameter(parts[-1], param)
-
-    def _param(self, name):
-        mod = self
-        parts = name.split(".")
-        for p in parts[:-1]:
-            mod = mod._modules[p]
-        return mod._parameters[parts[-1]]
-
-    def _flat(self, first, last_incl, rows, cols):
-        a = self._offs[first]
-        b = self._offs[last_incl] + _numel(dict(self._specs)[last_incl])
-        assert b - a == rows * cols, (first, last_incl, b - a, rows, cols)
-        return self.arena[a:b].view(rows, cols)
-
-    @property
-    def device(self):
-        return self.arena.device
-
-    @property
-    def dtype(self):
-        return self.arena.dtype
 
     def _build_views(self):
         cfg, vc, tc = self.config, self.config.vision_config, self.config.text_config
@@ -236,74 +184,8 @@ class LlavaForConditionalGeneration(nn.Module):
     def load_reference_state_dict(self, sd, strict=True):
         """Accepts the reference's state_dict names (HF-5 flat `vision_tower.*` or 4.x `vision_tower.vision_model.*`);
         pooling-head tensors of SigLIP (dead on this path) are ignored."""
-        own = dict(self.named_parameters())
-        seen = set()
-        with torch.no_grad():
-            for k, v in sd.items():
-                k2 = k.replace("vision_tower.vision_model.", "vision_tower.")
-                if k2 not in own:
-                    if ".head." in k2 or k2.endswith("position_ids"):
-                        continue
-                    if strict:
-                        raise KeyError(f"unexpected key {k}")
-                    continue
-                t = torch.as_tensor(v)
-                own[k2].copy_(t.to(own[k2].dtype).reshape(own[k2].shape))
-                seen.add(k2)
-        self._param_version += 1          # optimizers holding fp32 master copies re-snapshot (optim.FusedAdamW.step)
-        missing = [k for k in own if k not in seen]
-        if strict and missing:
-            raise KeyError(f"missing keys: {missing[:5]}...")
-        return missing
-
-    def _apply(self, fn, recurse=True):
-        # parameters are views of one arena; moving / casting them individually would break the fused layouts
-        probe = fn(torch.zeros(1, dtype=self.arena.dtype, device=self.arena.device))
-        if probe.dtype != self.arena.dtype or probe.device != self.arena.device:
-            raise RuntimeError("LlavaForConditionalGeneration lives in a flat bf16 arena: construct it with device=... instead "
-                               "of calling .to()/.half()/.float()")
-        return self
-
-    # ------------------------------------------------------------------ gradients
-    def _ensure_grad_arena(self):
-        """(Re)attach `.grad` views.  Returns True if the gradients are known to be zero-initialised garbage that the
-        next backward may OVERWRITE (i.e. every trainable .grad was None, the state after Trainer's model.zero_grad())."""
-        trainable = [(n, p) for n, p in self.named_parameters() if p.requires_grad]
-        if any(n.startswith("vision_tower.") for n, _ in trainable):
-            raise NotImplementedError("the vision tower is frozen on this path (train_mllava.py:240-242): no backward kernels for it")
-        key = tuple(n for n, _ in trainable)
-        if self.grad_arena is None or self._grad_key != key:
-            offs, off = {}, 0
-            for n, p in trainable:
-                offs[n] = off
-                off += (p.numel() + 7) // 8 * 8
-            self.grad_arena = torch.zeros(off, dtype=self.arena.dtype, device=self.device)
-            self._grad_offs, self._grad_key = offs, key
-            self._grad_views = {n: self.grad_arena[offs[n]: offs[n] + p.numel()].view(p.shape) for n, p in trainable}
-            self._build_grad_views()
-            for n, p in trainable:
-                p.grad = None
-        all_none = all(p.grad is None for _, p in trainable)
-        for n, p in trainable:
-            if p.grad is None:
-                if not all_none:
-                    self._grad_views[n].zero_()
-                p.grad = self._grad_views[n]
-            elif p.grad.data_ptr() != self._grad_views[n].data_ptr():
-                # a foreign gradient tensor was installed: fold it into the arena view
-                self._grad_views[n].copy_(p.grad)
-                p.grad = self._grad_views[n]
-        return all_none
-
-    def _gflat(self, first, last_incl, rows, cols):
-        if first not in self._grad_offs:
-            return None
-        if last_incl not in self._grad_offs:
-            raise NotImplementedError(f"{first}..{last_incl} must be trainable together (fused projection)")
-        a = self._grad_offs[first]
-        b = self._grad_offs[last_incl] + self._param(last_incl).numel()
-        assert b - a == rows * cols
-        return self.grad_arena[a:b].view(rows, cols)
+        return self.copy_state_dict(sd, rename=lambda k: k.replace("vision_tower.vision_model.", "vision_tower."),
+                                    ignorable=lambda k: ".head." in k or k.endswith("position_ids"), strict=strict)
 
     def _build_grad_views(self):
         tc = self.config.text_config
@@ -331,17 +213,7 @@ class LlavaForConditionalGeneration(nn.Module):
         the end of the layer -- so the first byte of a layer moves after its first GEMM, not after its last; 'front'
         (projector + embedding)."""
         self._ensure_grad_arena()
-        offs = self._grad_offs
-        names = list(self._grad_key)
-
-        def span(pred):
-            sel = [n for n in names if pred(n)]
-            if not sel:
-                return None
-            a = min(offs[n] for n in sel)
-            b = max(offs[n] + (self._param(n).numel() + 7) // 8 * 8 for n in sel)
-            assert b - a == sum((self._param(n).numel() + 7) // 8 * 8 for n in sel), "bucket is not contiguous"
-            return self.grad_arena[a:b]
+        span = self._bucket_span
         out = {"head": span(lambda n: n.startswith("language_model.model.norm") or n.startswith("language_model.lm_head"))}
         for i in range(self.config.text_config.num_hidden_layers):
             p = f"language_model.model.layers.{i}."

@@ -63,9 +63,9 @@ class MantisHipTrainer:
         if attn is None or attn.dim() == 4:               # the reference's packed batch (data.py:1609-1671): 4-D block-diagonal mask
             from .data import segments_from_packed
             seg, attn = segments_from_packed(inputs)
-        out = model.engine.step(inputs["input_ids"], attn, inputs.get("labels"),
-                                inputs.get("pixel_values"), grad_scale=1.0 / ga, loss_scale=1.0 / ga, compute_grads=True,
-                                overwrite_grads=overwrite, on_bucket_ready=hook, segment_ids=seg)
+        batch = inputs if attn is inputs["attention_mask"] else dict(inputs, attention_mask=attn)
+        out = model.engine.step_from_batch(batch, grad_scale=1.0 / ga, loss_scale=1.0 / ga, compute_grads=True,
+                                           overwrite_grads=overwrite, on_bucket_ready=hook, segment_ids=seg)
         if reduce_now:
             self.reducer.finish()
         if norm_now:

@@ -309,8 +309,9 @@ def gather_rows(x, idx):
     return out
 
 
-def scatter_rows(x, idx, nrows_out):
-    out = torch.zeros((nrows_out, x.shape[1]), dtype=x.dtype)
+def scatter_rows(x, idx, nrows_out, out=None):
+    if out is None:
+        out = torch.zeros((nrows_out, x.shape[1]), dtype=x.dtype)
     ok = idx >= 0
     out[idx[ok].long()] = x[ok]
     return out

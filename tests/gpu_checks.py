@@ -304,13 +304,16 @@ ATTN_SEG_CASES = [(1, 300, 8, 2, 128, [[70, 71, 200]], True, None), (2, 200, 4, 
 ATTN_FWD_CASES = [(2, 54, 4, 2, 16, True, "right"), (2, 54, 4, 2, 16, True, "left"), (3, 17, 4, 4, 16, False, None),
                   (2, 197, 12, 12, 64, False, None), (2, 577, 16, 16, 72, False, None), (1, 323, 12, 12, 64, True, None),
                   (1, 700, 8, 2, 128, True, "right"), (1, 128, 4, 1, 128, True, None), (1, 129, 2, 2, 64, True, "left"),
-                  (1, 300, 4, 4, 128, False, "right"), (2, 193, 4, 2, 128, False, None)]
+                  (1, 300, 4, 4, 128, False, "right"), (2, 193, 4, 2, 128, False, None),
+                  # head dim 96, GQA 16/4, non-causal with a key mask: the Idefics2 perceiver resampler (modeling_idefics2.py:812-912)
+                  (2, 80, 16, 4, 96, False, "right"), (1, 1088, 16, 4, 96, False, "right"), (1, 200, 4, 2, 96, True, None)]
 ATTN_BWD_CASES = [(2, 54, 4, 2, 16, True, "right"), (2, 54, 4, 2, 16, True, "left"), (1, 323, 12, 12, 64, True, None),
                   (1, 300, 8, 2, 128, True, "right"), (1, 129, 2, 2, 64, True, None), (2, 40, 2, 2, 16, False, None),
                   (1, 200, 4, 2, 128, False, "left"), (2, 130, 4, 4, 128, False, None),
                   # GQA 4:1 at hd 128: the GQA-aware dK/dV kernel (one workgroup per 64-key block and KV head, partials meet in LDS)
                   (2, 200, 4, 1, 128, True, None), (1, 130, 8, 2, 128, False, "left"), (1, 40, 4, 1, 128, True, None),
-                  (1, 256, 4, 1, 128, True, "right"), (2, 97, 8, 2, 128, False, None), (1, 33, 4, 1, 128, True, "left")]
+                  (1, 256, 4, 1, 128, True, "right"), (2, 97, 8, 2, 128, False, None), (1, 33, 4, 1, 128, True, "left"),
+                  (2, 80, 16, 4, 96, False, "right"), (1, 300, 4, 2, 96, True, None), (1, 1088, 16, 4, 96, False, "right")]
 
 
 # ------------------------------------------------------------------------------------------------------------- packing / CE
@@ -747,6 +750,51 @@ def check_packed_fullsize_vs_batched():
     return close(model.grad_arena, g1, 2e-2, "packed vs batched gradients (cfg2 width, 2 layers)")
 
 
+IDEFICS2_CASES = ["idefics2_b1_img2", "idefics2_b1_navit", "idefics2_b2_padimg_rightpad", "idefics2_b1_text_only"]
+
+
+def check_idefics2_step(case):
+    """The Idefics2 path end to end on the HIP kernels vs the Idefics2 oracle on the golden inputs: NaViT tower with
+    patch mask, perceiver resampler forward + backward, merger, Mistral decoder, CE with ignore_index = image_token_id."""
+    z = Hh.load_case(case)
+    model = Hh.build_idefics2_product(DEV)
+    oracle = Hh.build_idefics2_oracle_bf16()
+    assert model._ensure_grad_arena()
+    rec = {}
+    out = model.engine.step_from_batch(Hh.idefics2_batch(z), compute_grads=True, overwrite_grads=True, need_logits=True, record=rec)
+    torch.cuda.synchronize()
+    rep = Hh.check_idefics2_step_against_oracle(model, oracle, z, out, rec)
+    assert abs(float(out["loss"].cpu()) - float(z["loss"])) < 0.03 * float(z["loss"])
+    return 1.0 - min(c for c, _ in rep.values())
+
+
+def check_idefics2_full_width():
+    """Mantis-8B-Idefics2 layers at full width and reduced depth (SigLIP-so400m NaViT at 448^2 -> 1024 patches, perceiver 16/4 x 96 over
+    1088 keys, Mistral width, V = 32003; 2 images, 1024 tokens): finite loss near ln V, bitwise reproducible, accumulates."""
+    import math
+    from mantis_amd import configuration_idefics2 as C
+    from mantis_amd.modeling_idefics2 import Idefics2ForConditionalGeneration
+    from mantis_amd.trainer import MantisHipTrainer
+    import bench
+    cfg = C.mantis_8b_idefics2()
+    cfg.vision_config.num_hidden_layers = 2
+    cfg.text_config.num_hidden_layers = 2
+    cfg.perceiver_config.resampler_depth = 2
+    model = Idefics2ForConditionalGeneration(cfg, device=DEV, seed=0)
+    batch = bench.synthetic_batch_idefics2(cfg, 1, 1024, 2, 448, 0)
+    tr = MantisHipTrainer(model, gradient_accumulation_steps=1)
+    l1 = tr.training_step(model, batch)
+    g1 = model.grad_arena.clone()
+    for p in model.parameters():
+        p.grad = None
+    l2 = tr.training_step(model, batch)
+    assert torch.equal(l1, l2) and torch.equal(g1, model.grad_arena), "the Idefics2 step is not bitwise reproducible"
+    assert math.isfinite(float(l1)) and 9.0 < float(l1) < 13.0, float(l1)       # ~ln(32003) = 10.37 (+ logit variance) at random init
+    l3 = tr.training_step(model, batch)
+    assert torch.equal(l3, l1)
+    return close(model.grad_arena, 2 * g1.float(), 5e-3, "accumulated gradients = 2x")
+
+
 def check_norm_overlap():
     """The gradient-norm pass taken bucket by bucket on a side stream during the backward (MantisHipTrainer(optimizer=...)) gives the
     same global norm as the separate pass over the whole arena, and the same parameters after the step."""
@@ -934,6 +982,9 @@ def all_checks():
     c["forward_contract_hip"] = check_forward_contract_hip
     c["hf_trainer_on_hip"] = check_hf_trainer_on_hip
     c["optimizer_step_vs_torch"] = check_optimizer_step_vs_torch
+    for case in IDEFICS2_CASES:
+        c["idefics2_step_" + case[9:]] = (lambda case=case: check_idefics2_step(case))
+    c["idefics2_full_width"] = check_idefics2_full_width
     c["pack_segments_random"] = check_pack_segments_random
     c["packed_model_step"] = check_packed_model_step
     c["packed_fullsize_vs_batched"] = check_packed_fullsize_vs_batched
