@@ -149,11 +149,12 @@ def main():
     ap.add_argument("--config", default="mantis_8b_siglip_llama3",
                     choices=["mantis_8b_siglip_llama3", "mantis_8b_clip_llama3", "mantis_tiny", "mantis_8b_idefics2"],
                     help="mantis_8b_siglip_llama3 = the headline (BASELINE.json configs[1]/[2]); mantis_8b_idefics2 = configs[3] "
-                         "(8 interleaved images x 448^2, 2048 tokens, 1 sample per GPU)")
+                         "(8 interleaved images x 448^2 and 2048 tokens per sample, 2 samples per GPU packed into one row)")
     ap.add_argument("--batch-per-gpu", type=int, default=None, help="default: 2 (LLaVA path) / 1 (Idefics2 path)")
     ap.add_argument("--stage", default="finetune", choices=["finetune", "pretrain"],
                     help="finetune: projector + LLM trainable (the headline metric); pretrain: only multi_modal_projector "
                          "(the reference's stage 1, train_mllava.py:177-181)")
+    ap.add_argument("--no-pack", action="store_true", help="Idefics2 config: feed the samples as a batch instead of one packed row")
     ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
@@ -189,7 +190,7 @@ def main():
         from mantis_amd import configuration_idefics2 as C2
         from mantis_amd.modeling_idefics2 import Idefics2ForConditionalGeneration
         cfg = C2.mantis_8b_idefics2()
-        B = args.batch_per_gpu or 1
+        B = args.batch_per_gpu or 2
         T, n_img, img_hw = 2048, 8, 448
         model = Idefics2ForConditionalGeneration(cfg, device=f"cuda:{local_rank}", seed=0)
         flop_per_sample = idefics2_flop_per_sample(cfg, T, n_img, img_hw)
@@ -214,6 +215,14 @@ def main():
     n_batches = args.recycle_batches or (args.warmup + args.steps)
     make = synthetic_batch_idefics2 if idefics else synthetic_batch
     batches = [make(cfg, B, T, n_img, img_hw, rank, s) for s in range(n_batches)]
+    if idefics and not args.no_pack:
+        # BASELINE configs[3] "long-sequence packing": the B samples of a rank travel as ONE row of B*T tokens with segment ids
+        # (block-diagonal attention through O(L) segment bounds, positions restart per sample, data.py:1546-1671)
+        for bt in batches:
+            bt["segment_ids"] = torch.arange(B, dtype=torch.int32).repeat_interleave(T)[None]
+            for k in ("input_ids", "attention_mask", "labels"):
+                bt[k] = bt[k].reshape(1, B * T)
+            bt["pixel_values"] = bt["pixel_values"].reshape(1, B * n_img, *bt["pixel_values"].shape[2:])
     for bt in batches:      # pinned host buffers, as dataloader_pin_memory does in the reference loop
         bt["pixel_values"] = bt["pixel_values"].pin_memory() if idefics else [p.pin_memory() for p in bt["pixel_values"]]
 
@@ -328,7 +337,8 @@ def main():
                                global_batch=world * B, seq_len=T,
                                merged_seq_len=T if idefics else T - n_img + n_img * (cfg.vision_config.image_size // cfg.vision_config.patch_size) ** 2,
                                flop_per_sample=flop_per_sample,
-                               parallelism=f"dp{world}", optimizer=not args.no_optimizer, stage=args.stage),
+                               parallelism=f"dp{world}", optimizer=not args.no_optimizer, stage=args.stage,
+                               packed=bool(idefics and not args.no_pack)),
                    roofline=roof, cpu_baseline=cpu, dp=dp)
         print(json.dumps(out), flush=True)
     if world > 1 or force_dp:

@@ -254,6 +254,8 @@ class Idefics2Engine:
         self._verified = False
 
     def step_from_batch(self, inputs, **kw):
+        if kw.get("segment_ids") is None and inputs.get("segment_ids") is not None:
+            kw["segment_ids"] = inputs["segment_ids"]
         return self.step(inputs["input_ids"], inputs["attention_mask"], inputs.get("labels"), inputs.get("pixel_values"),
                          inputs.get("pixel_attention_mask"), **kw)
 
@@ -398,8 +400,6 @@ class Idefics2Engine:
     # ------------------------------------------------------------------ full step
     def step(self, input_ids, attention_mask, labels, pixel_values, pixel_attention_mask=None, grad_scale=1.0, loss_scale=1.0,
              compute_grads=True, overwrite_grads=True, need_logits=False, record=None, on_bucket_ready=None, segment_ids=None):
-        if segment_ids is not None:
-            raise NotImplementedError("sample packing is wired for the LLaVA path; the Idefics2 path takes batches")
         m, cfg, tc = self.m, self.cfg, self.cfg.text_config
         dev = m.device
         ids_cpu = input_ids.detach().to("cpu") if input_ids.device.type != "cpu" else input_ids
@@ -433,11 +433,20 @@ class Idefics2Engine:
         # order; labels equal to image_token_id are the ignored ones (:1898); positions are Mistral's default arange
         plan = K.pack_plan(ids_d, attn_d, lab_d, 1, n_rows, IMG if img is not None else -(2 ** 62), -1, IMG, T)
         plan.position_ids = torch.arange(T, device=dev, dtype=torch.int64)[None].expand(B, T).contiguous()
+        kstart = qend = None
+        if segment_ids is not None:
+            # long-sequence packing (BASELINE configs[3]; /root/reference/mantis/train/data.py:1546-1671): several samples in one row,
+            # block-diagonal attention through O(L) segment bounds, positions restart per sample (:1641-1648: arange per item),
+            # no prediction across a sample boundary
+            seg_d = segment_ids.to(dev, non_blocking=True).to(torch.int32).contiguous()
+            K.pack_segments(plan, ids_d, seg_d, -(2 ** 62))
+            kstart, qend = plan.kstart, plan.qend
+            plan.position_ids = (torch.arange(T, device=dev, dtype=torch.int64)[None] - kstart.to(torch.int64)).contiguous()
         x = K.pack_rows_fwd(plan, ids_d, m.lm["embed"], img)
         if record is not None and img is not None:
             record["merged_embeds"] = x.view(B, T, -1)
         kmask = plan.kmask
-        x, dctx = D.decoder_forward(K, m.lm, tc, x, B, T, plan.position_ids, kmask, None, compute_grads, record)
+        x, dctx = D.decoder_forward(K, m.lm, tc, x, B, T, plan.position_ids, kmask, kstart, compute_grads, record)
         loss, count, logits_full, hctx = D.head_and_loss(K, m.lm, tc, x, plan, B, T, labels is not None, grad_scale, loss_scale,
                                                          compute_grads, need_logits, record)
         if count is not None and not self._verified:
@@ -449,7 +458,7 @@ class Idefics2Engine:
             return out
         acc = not overwrite_grads
         g = m.grads
-        dx = D.decoder_backward(K, m.lm, g, m.grads_layers, tc, dctx, hctx, plan, B, T, kmask, None, None, acc, on_bucket_ready)
+        dx = D.decoder_backward(K, m.lm, g, m.grads_layers, tc, dctx, hctx, plan, B, T, kmask, kstart, qend, acc, on_bucket_ready)
         if g.get("embed") is not None:
             if overwrite_grads:
                 g["embed"].zero_()

@@ -193,3 +193,29 @@ class Idefics2Ref:
             keep = am[..., 1:] != 0
             loss = F.cross_entropy(logits[..., :-1, :][keep], lab[..., 1:][keep], ignore_index=cfg["image_token_id"])   # :1884-1899
         return loss, logits
+
+    def forward_packed(self, input_ids, pixel_values, pixel_attention_mask, segment_ids, attention_mask, labels):
+        """Long-sequence packing defined through its meaning (cf. LlavaRef.forward_packed): the packed row is unpacked into its samples,
+        each runs through `forward` alone, the loss is the mean over the label positions of all of them.  pixel_values
+        [1, n_images, 3, H, W]: images in order of appearance; a sample owns as many as its <image> tokens / n_latents."""
+        cfg = self.cfg
+        ids, seg, lab, am = (torch.as_tensor(x) for x in (input_ids, segment_ids, labels, attention_mask))
+        pv = None if pixel_values is None else torch.as_tensor(pixel_values)
+        pm = None if pixel_attention_mask is None else torch.as_tensor(pixel_attention_mask)
+        nl = self.pc["resampler_n_latents"]
+        total, count, img0 = 0.0, 0, 0
+        for sid in torch.unique_consecutive(seg[0]).tolist():
+            sel = seg[0] == sid
+            si, sl, sa = ids[0][sel][None], lab[0][sel][None], am[0][sel][None]
+            n_img = int((si == cfg["image_token_id"]).sum()) // nl
+            spv = None if n_img == 0 else pv[:, img0: img0 + n_img]
+            spm = None if (n_img == 0 or pm is None) else pm[:, img0: img0 + n_img]
+            img0 += n_img
+            _, logits = self.forward(si, spv, spm, sa, None)
+            keep = sa[:, 1:] != 0
+            lg, tg = logits[:, :-1][keep], sl[:, 1:][keep]
+            valid = tg != cfg["image_token_id"]
+            if int(valid.sum()):
+                total = total + F.cross_entropy(lg[valid], tg[valid], reduction="sum")
+                count += int(valid.sum())
+        return total / max(count, 1)

@@ -768,6 +768,36 @@ def check_idefics2_step(case):
     return 1.0 - min(c for c, _ in rep.values())
 
 
+def check_idefics2_packed():
+    """Long-sequence packing on the Idefics2 path (BASELINE configs[3]) on the HIP kernels: the two samples of the B=2 golden batch packed
+    into one row give the loss and gradients of the oracle running them one by one."""
+    z = Hh.load_case("idefics2_b2_padimg_rightpad")
+    ids, am, lab = z["input_ids"], z["attention_mask"], z["labels"]
+    keep = [am[b].astype(bool) for b in range(2)]
+    pid = torch.from_numpy(np.concatenate([ids[b][keep[b]] for b in range(2)]))[None]
+    plab = torch.from_numpy(np.concatenate([lab[b][keep[b]] for b in range(2)]))[None]
+    seg = torch.from_numpy(np.concatenate([np.full(int(keep[b].sum()), b, np.int32) for b in range(2)]))[None]
+    pv = torch.from_numpy(np.concatenate([z["pixel_values"][0], z["pixel_values"][1][:1]], 0))[None]
+    pm = torch.from_numpy(np.concatenate([z["pixel_attention_mask"][0], z["pixel_attention_mask"][1][:1]], 0))[None]
+    model = Hh.build_idefics2_product(DEV)
+    oracle = Hh.build_idefics2_oracle_bf16()
+    assert model._ensure_grad_arena()
+    out = model.engine.step(pid, torch.ones_like(pid), plab, pv, pm, compute_grads=True, overwrite_grads=True, segment_ids=seg)
+    oracle.zero_grad()
+    oloss = oracle.forward_packed(pid, pv, pm, seg, torch.ones_like(pid), plab)
+    oloss.backward()
+    loss = float(out["loss"].cpu())
+    assert abs(loss - float(oloss)) <= 5e-3 * float(oloss), (loss, float(oloss))
+    worst = 1.0
+    for name, p in model.named_parameters():
+        if p.requires_grad:
+            g, og = p.grad.float().cpu().numpy(), oracle.w[name].grad.numpy()
+            c = Hh.cosine(g, og)
+            assert c > 0.995 and Hh.rel_l2(g, og) < 6e-2, (name, c, Hh.rel_l2(g, og))
+            worst = min(worst, c)
+    return 1.0 - worst
+
+
 def check_idefics2_full_width():
     """Mantis-8B-Idefics2 layers at full width and reduced depth (SigLIP-so400m NaViT at 448^2 -> 1024 patches, perceiver 16/4 x 96 over
     1088 keys, Mistral width, V = 32003; 2 images, 1024 tokens): finite loss near ln V, bitwise reproducible, accumulates."""
@@ -984,6 +1014,7 @@ def all_checks():
     c["optimizer_step_vs_torch"] = check_optimizer_step_vs_torch
     for case in IDEFICS2_CASES:
         c["idefics2_step_" + case[9:]] = (lambda case=case: check_idefics2_step(case))
+    c["idefics2_packed"] = check_idefics2_packed
     c["idefics2_full_width"] = check_idefics2_full_width
     c["pack_segments_random"] = check_pack_segments_random
     c["packed_model_step"] = check_packed_model_step

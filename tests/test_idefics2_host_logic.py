@@ -60,3 +60,28 @@ def test_state_dict_names_match_reference():
     _, sd = Hh.golden_cfg_and_weights("idefics2")
     assert {n for n, _ in model.named_parameters()} == set(sd)
     assert sum(b.numel() for b in model.grad_buckets().values()) == model.grad_arena.numel()
+
+
+def test_packed_row_equals_the_separate_samples(cpu_backend):
+    """Long-sequence packing on the Idefics2 path (BASELINE configs[3]): the two samples of the B=2 golden batch (unpadded parts)
+    packed into one row -- loss and gradients equal the oracle running them one by one."""
+    z = Hh.load_case("idefics2_b2_padimg_rightpad")
+    ids, am, lab = z["input_ids"], z["attention_mask"], z["labels"]
+    keep = [am[b].astype(bool) for b in range(2)]
+    pid = torch.from_numpy(np.concatenate([ids[b][keep[b]] for b in range(2)]))[None]
+    plab = torch.from_numpy(np.concatenate([lab[b][keep[b]] for b in range(2)]))[None]
+    seg = torch.from_numpy(np.concatenate([np.full(int(keep[b].sum()), b, np.int32) for b in range(2)]))[None]
+    pv = torch.from_numpy(np.concatenate([z["pixel_values"][0], z["pixel_values"][1][:1]], 0))[None]        # 3 real images in order
+    pm = torch.from_numpy(np.concatenate([z["pixel_attention_mask"][0], z["pixel_attention_mask"][1][:1]], 0))[None]
+    model = Hh.build_idefics2_product("cpu")
+    oracle = Hh.build_idefics2_oracle_bf16()
+    assert model._ensure_grad_arena()
+    out = model.engine.step(pid, torch.ones_like(pid), plab, pv, pm, compute_grads=True, overwrite_grads=True, segment_ids=seg)
+    oracle.zero_grad()
+    oloss = oracle.forward_packed(pid, pv, pm, seg, torch.ones_like(pid), plab)
+    oloss.backward()
+    assert abs(float(out["loss"]) - float(oloss)) <= 5e-3 * float(oloss), (float(out["loss"]), float(oloss))
+    for name, p in model.named_parameters():
+        if p.requires_grad:
+            g, og = p.grad.float().numpy(), oracle.w[name].grad.numpy()
+            assert Hh.cosine(g, og) > 0.995 and Hh.rel_l2(g, og) < 6e-2, (name, Hh.cosine(g, og), Hh.rel_l2(g, og))
