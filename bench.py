@@ -83,6 +83,52 @@ def idefics2_flop_per_sample(cfg, T, n_img, img_hw):
     return vit + 3 * (conn + llm)
 
 
+def synthetic_batch_qwen2vl(cfg, B, T, grids, rank, step=0):
+    """BASELINE.json configs[4]: per sample the images of `grids` [(t, h, w) in patches] as the Qwen2-VL processor delivers them
+    (flattened fp32 patches + image_grid_thw), each standing for t*h*w/4 <|image_pad|> tokens between <|vision_start|> / <|vision_end|>
+    inside a T-token sequence; labels ignore (-100) the first half and the image tokens."""
+    import torch
+    g = torch.Generator().manual_seed(9876 + rank + 1000 * step)
+    vc = cfg.vision_config
+    mg2 = vc.spatial_merge_size ** 2
+    IMG, VS, VE = cfg.image_token_id, cfg.vision_start_token_id, cfg.vision_end_token_id
+    ids = torch.randint(3, min(cfg.vocab_size, 151000), (B, T), generator=g)
+    ntok = [t * h * w // mg2 for t, h, w in grids]
+    gap = (T - sum(n + 2 for n in ntok)) // (len(grids) + 1)
+    assert gap >= 1, "sequence too short for the images"
+    for b in range(B):
+        s = gap
+        for n in ntok:
+            ids[b, s] = VS
+            ids[b, s + 1: s + 1 + n] = IMG
+            ids[b, s + 1 + n] = VE
+            s += n + 2 + gap
+    labels = ids.clone()
+    labels[:, : T // 2] = -100
+    labels[ids == IMG] = -100
+    npatch = sum(t * h * w for t, h, w in grids)
+    pix = torch.randn(B * npatch, vc.in_channels * vc.temporal_patch_size * vc.patch_size ** 2, generator=g)
+    return dict(input_ids=ids, attention_mask=torch.ones_like(ids), labels=labels, pixel_values=pix,
+                image_grid_thw=torch.tensor(list(grids) * B, dtype=torch.int64))
+
+
+def qwen2vl_flop_per_sample(cfg, T, grids):
+    """Algorithmic FLOPs of one sample (matmul = 2mnk, causal attention at half, frozen tower + merger forward only, LLM x3)."""
+    vc, tc = cfg.vision_config, cfg.text_config
+    dv, iv = vc.embed_dim, int(vc.embed_dim * vc.mlp_ratio)
+    dm = dv * vc.spatial_merge_size ** 2
+    vit = 0
+    for t, h, w in grids:
+        N = t * h * w
+        vit += N * 2 * vc.in_channels * vc.temporal_patch_size * vc.patch_size ** 2 * dv
+        vit += vc.depth * N * (2 * (4 * dv * dv + 2 * dv * iv) + 4 * N * dv)
+        vit += (N // vc.spatial_merge_size ** 2) * 2 * (dm * dm + dm * tc.hidden_size)
+    d, it, hd = tc.hidden_size, tc.intermediate_size, tc.head_dim
+    per_tok = 2 * ((tc.num_attention_heads + 2 * tc.num_key_value_heads) * hd * d + tc.num_attention_heads * hd * d + 3 * d * it)
+    llm = tc.num_hidden_layers * (T * per_tok + 4 * T * T * tc.num_attention_heads * hd / 2) + T * 2 * d * tc.vocab_size
+    return vit + 3 * llm
+
+
 def _pct(xs, q):
     xs = sorted(xs)
     if not xs:
@@ -147,9 +193,14 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="mantis_8b_siglip_llama3",
-                    choices=["mantis_8b_siglip_llama3", "mantis_8b_clip_llama3", "mantis_tiny", "mantis_8b_idefics2"],
+                    choices=["mantis_8b_siglip_llama3", "mantis_8b_clip_llama3", "mantis_tiny", "mantis_8b_idefics2", "qwen2_vl_7b"],
                     help="mantis_8b_siglip_llama3 = the headline (BASELINE.json configs[1]/[2]); mantis_8b_idefics2 = configs[3] "
-                         "(8 interleaved images x 448^2 and 2048 tokens per sample, 2 samples per GPU packed into one row)")
+                         "(8 interleaved images x 448^2 and 2048 tokens per sample, 2 samples per GPU packed into one row); "
+                         "qwen2_vl_7b = configs[4] (two 1280x960 dynamic-resolution images = 2 x 6256 patches -> 2 x 1564 tokens "
+                         "inside a 4096-token sample)")
+    ap.add_argument("--precision", default=None, choices=["bf16", "fp8"],
+                    help="decoder linears: bf16 MFMA or fp8 (e4m3 / e5m2) MFMA with per-tensor scaling.  Default: fp8 for qwen2_vl_7b "
+                         "(BASELINE configs[4] names fp8 MFMA), bf16 otherwise")
     ap.add_argument("--batch-per-gpu", type=int, default=None, help="default: 2 (LLaVA path) / 1 (Idefics2 path)")
     ap.add_argument("--stage", default="finetune", choices=["finetune", "pretrain"],
                     help="finetune: projector + LLM trainable (the headline metric); pretrain: only multi_modal_projector "
@@ -185,8 +236,21 @@ def main():
     from mantis_amd.optim import FusedAdamW
 
     idefics = args.config == "mantis_8b_idefics2"
+    qwen = args.config == "qwen2_vl_7b"
     tiny = args.config == "mantis_tiny"
-    if idefics:
+    grids = None
+    if qwen:
+        from mantis_amd import configuration_qwen2_vl as C3
+        from mantis_amd.modeling_qwen2_vl import Qwen2VLForConditionalGeneration
+        cfg = C3.qwen2_vl_7b()
+        B = args.batch_per_gpu or 1
+        # 1280 x 960 px -> smart_resize to multiples of 28: 1288 x 952 -> 92 x 68 patches of 14 px (max_pixels raised to hold it,
+        # train_qwen2_vl.py:126-128's default budget would shrink it)
+        T, grids = 4096, [(1, 68, 92), (1, 68, 92)]
+        n_img, img_hw = len(grids), None
+        model = Qwen2VLForConditionalGeneration(cfg, device=f"cuda:{local_rank}", seed=0)
+        flop_per_sample = qwen2vl_flop_per_sample(cfg, T, grids)
+    elif idefics:
         from mantis_amd import configuration_idefics2 as C2
         from mantis_amd.modeling_idefics2 import Idefics2ForConditionalGeneration
         cfg = C2.mantis_8b_idefics2()
@@ -201,6 +265,11 @@ def main():
         img_hw = cfg.vision_config.image_size
         model = LlavaForConditionalGeneration(cfg, device=f"cuda:{local_rank}", seed=0)      # same seed -> identical replicas
         flop_per_sample = FLOP_PER_SAMPLE
+    precision = args.precision or "bf16"
+    if precision == "fp8":
+        if not hasattr(model, "set_precision"):
+            raise SystemExit(f"--precision fp8 is implemented on the Qwen2-VL path only (config {args.config})")
+        model.set_precision("fp8")
     if args.stage == "pretrain":
         for n, p in model.named_parameters():
             if "multi_modal_projector" not in n and "model.connector." not in n:
@@ -214,7 +283,10 @@ def main():
     trainer = MantisHipTrainer(model, gradient_accumulation_steps=1, reducer=reducer, optimizer=opt if overlap else None)
     n_batches = args.recycle_batches or (args.warmup + args.steps)
     make = synthetic_batch_idefics2 if idefics else synthetic_batch
-    batches = [make(cfg, B, T, n_img, img_hw, rank, s) for s in range(n_batches)]
+    if qwen:
+        batches = [synthetic_batch_qwen2vl(cfg, B, T, grids, rank, s) for s in range(n_batches)]
+    else:
+        batches = [make(cfg, B, T, n_img, img_hw, rank, s) for s in range(n_batches)]
     if idefics and not args.no_pack:
         # BASELINE configs[3] "long-sequence packing": the B samples of a rank travel as ONE row of B*T tokens with segment ids
         # (block-diagonal attention through O(L) segment bounds, positions restart per sample, data.py:1546-1671)
@@ -224,7 +296,7 @@ def main():
                 bt[k] = bt[k].reshape(1, B * T)
             bt["pixel_values"] = bt["pixel_values"].reshape(1, B * n_img, *bt["pixel_values"].shape[2:])
     for bt in batches:      # pinned host buffers, as dataloader_pin_memory does in the reference loop
-        bt["pixel_values"] = bt["pixel_values"].pin_memory() if idefics else [p.pin_memory() for p in bt["pixel_values"]]
+        bt["pixel_values"] = bt["pixel_values"].pin_memory() if (idefics or qwen) else [p.pin_memory() for p in bt["pixel_values"]]
 
     split = []          # (start, after training_step, after optimizer) events per timed step
     losses = []
@@ -281,7 +353,7 @@ def main():
         step_ms = [e[0].elapsed_time(e[2]) for e in split]
         ts_ms = [e[0].elapsed_time(e[1]) for e in split]
         pmc = None
-        if not tiny and not idefics and os.path.exists(PMC_JSON):
+        if not tiny and not idefics and not qwen and os.path.exists(PMC_JSON):
             with open(PMC_JSON) as fh:
                 pmc = json.load(fh)
         roof = None
@@ -304,7 +376,7 @@ def main():
                         step_frac_of_peak=round(flop_per_sample * B / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if not tiny else None,
                         training_step_frac_of_peak=round(flop_per_sample * B / (_pct(ts_ms, 0.5) * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if not tiny else None)
         cpu = None
-        if world == 1 and not args.no_cpu_baseline and not idefics:      # the CPU leg times the headline (LLaVA-path) oracle
+        if world == 1 and not args.no_cpu_baseline and not idefics and not qwen:      # the CPU leg times the headline (LLaVA-path) oracle
             cpu = cpu_baseline(args.config)
         dp = None
         if reducer is not None:
@@ -317,6 +389,7 @@ def main():
         names = dict(mantis_8b_siglip_llama3="Mantis-8B-SigLIP-Llama-3", mantis_8b_clip_llama3="Mantis-8B-CLIP-L/14-336-Llama-3")
         metric = ("train samples/sec Mantis-tiny (1 img 224^2 + 128 tok)" if tiny else
                   "train samples/sec (8 img x 448^2, seq 2048) Mantis-8B-Idefics2" if idefics else
+                  "train samples/sec (2 img x 1280x960 dynamic resolution, seq 4096) Qwen2-VL-7B" if qwen else
                   f"train samples/sec (4 img x 336^2 + 512 tok) {names[args.config]}")
         out = dict(metric=metric,
                    value=round(value, 4), unit="samples/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
@@ -335,7 +408,7 @@ def main():
                                         f"{'' if args.no_optimizer else ' + clip + fused AdamW'}; {B} samples/GPU, "
                                         f"{n_img} img + {T} tok per sample; random-init weights",
                                global_batch=world * B, seq_len=T,
-                               merged_seq_len=T if idefics else T - n_img + n_img * (cfg.vision_config.image_size // cfg.vision_config.patch_size) ** 2,
+                               merged_seq_len=T if (idefics or qwen) else T - n_img + n_img * (cfg.vision_config.image_size // cfg.vision_config.patch_size) ** 2,
                                flop_per_sample=flop_per_sample,
                                parallelism=f"dp{world}", optimizer=not args.no_optimizer, stage=args.stage,
                                packed=bool(idefics and not args.no_pack)),

@@ -80,6 +80,10 @@ int mantis_colsum(const void* x, void* grad, int accumulate, float* workspace, i
 /* ---- RoPE: HF:models/llama/modeling_llama.py:113-160 on the position_ids of modeling_llava.py:355 */
 int mantis_rope_table(const int64_t* position_ids, const float* inv_freq, void* cos_out, void* sin_out, int64_t R,
                       int half_dim, void* stream);
+/* Sectioned table (Qwen2-VL): frequency j uses row section_of_freq[j] of position_ids[S, R].  Multimodal RoPE
+ * HF:models/qwen2_vl/modeling_qwen2_vl.py:156-170,207-213 (S = 3) and the vision tower's 2-D rotary embedding :239-248 (S = 2). */
+int mantis_rope_table_sections(const int64_t* position_ids, const float* inv_freq, const int32_t* section_of_freq, void* cos_out,
+                               void* sin_out, int64_t R, int half_dim, void* stream);
 int mantis_rope_apply(void* x, const void* cos_tab, const void* sin_tab, int64_t R, int nheads, int head_dim, int64_t ld,
                       int backward, void* stream);
 /* out[b][h][c][r] = in[b][h][r][c], zero for R <= r < Rpad (operand layouts for dX/dW GEMMs and attention) */
@@ -133,6 +137,8 @@ int mantis_ce_fwd_bwd(void* logits, const int32_t* targets, int R, int V, int64_
 
 /* ---- ViT front end: modeling_llava.py:434-435 + HF Siglip/CLIP VisionEmbeddings; feature select modeling_llava.py:460-461 */
 int mantis_im2col(const float* pixels, void* patches, int I, int C, int H, int W, int P, int Kp, void* stream);
+/* Qwen2-VL PatchEmbed input (HF:models/qwen2_vl/modeling_qwen2_vl.py:268-274): fp32 flattened patches -> bf16 rows zero-padded to Kp */
+int mantis_cast_pad_rows(const float* in, void* out, int64_t rows, int K, int64_t ld_in, int Kp, void* stream);
 int mantis_vit_assemble(const void* patch_out, const void* pos_emb, const void* cls_emb /*nullable*/, void* out, int I, int N,
                         int d, void* stream);
 int mantis_drop_cls(const void* in, void* out, int I, int N, int d, void* stream);

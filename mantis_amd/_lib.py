@@ -33,6 +33,7 @@ SIGNATURES = {
     "mantis_colsum_partials": [L],
     "mantis_colsum": [P, P, I, P, L, I, L, P],
     "mantis_rope_table": [P, P, P, P, L, I, P],
+    "mantis_rope_table_sections": [P, P, P, P, P, L, I, P],
     "mantis_rope_apply": [P, P, P, L, I, I, L, I, P],
     "mantis_transpose": [P, P, I, I, I, L, L, I, I, L, L, L, L, P],
     "mantis_gemm_bf16_nt": [P, L, P, L, P, L, I, I, I, P, P, L, I, P, L, P],
@@ -44,6 +45,7 @@ SIGNATURES = {
     "mantis_attn_bwd_needs_workspace": [I, I, I],
     "mantis_ce_fwd_bwd": [P, P, I, I, L, F, F, I, P, P, P, P, P],
     "mantis_im2col": [P, P, I, I, I, I, I, I, P],
+    "mantis_cast_pad_rows": [P, P, L, I, L, I, P],
     "mantis_vit_assemble": [P, P, P, P, I, I, I, P],
     "mantis_drop_cls": [P, P, I, I, I, P],
     "mantis_adamw": [P, P, P, P, P, L, F, F, F, F, F, F, F, P, P],

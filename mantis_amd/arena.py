@@ -77,7 +77,8 @@ class ArenaModule(nn.Module):
     def _ensure_grad_arena(self):
         """(Re)attach `.grad` views.  Returns True if the gradients are known to be zero-initialised garbage that the
         next backward may OVERWRITE (i.e. every trainable .grad was None, the state after Trainer's model.zero_grad())."""
-        trainable = [(n, p) for n, p in self.named_parameters() if p.requires_grad]
+        # arena order (not module-tree order): fused projections keep their weights -- and their biases -- adjacent in both arenas
+        trainable = sorted(((n, p) for n, p in self.named_parameters() if p.requires_grad), key=lambda np_: self._offs[np_[0]])
         bad = [n for n, _ in trainable if n.startswith(tuple(self.frozen_prefixes))] if self.frozen_prefixes else []
         if bad:
             raise NotImplementedError(f"{bad[0].split('.')[0]}...: frozen on this path (no backward kernels for it); "

@@ -1339,6 +1339,7 @@ int mantis_attn_fwd(const void* Q, const void* K, const void* V, const int32_t* 
         case 16: FWD(16);
         case 64: FWD(64);
         case 72: FWD(72);
+        case 80: FWD(80);
         case 96: FWD(96);
         case 128: FWD(128);
         default: return MANTIS_EUNSUPPORTED;

@@ -19,6 +19,21 @@ __global__ void rope_table_kernel(const long* __restrict__ pos, const float* __r
     }
 }
 
+// Sectioned table: rotary frequency j takes its position from row sec[j] of pos[S][R].  Serves Qwen2-VL's multimodal RoPE
+// (S = 3: temporal / height / width ids, transformers/models/qwen2_vl/modeling_qwen2_vl.py:156-170,207-213) and its vision tower's
+// 2-D rotary embedding (S = 2: patch row / column, :239-248 with inv_freq = [f | f]).
+__global__ void rope_table_sections_kernel(const long* __restrict__ pos, const float* __restrict__ inv_freq, const int* __restrict__ sec,
+                                           bf16_t* __restrict__ cosb, bf16_t* __restrict__ sinb, long R, int half) {
+    const long total = R * half;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / half;
+        const int j = (int)(i - r * half);
+        const float f = (float)pos[(long)sec[j] * R + r] * inv_freq[j];
+        cosb[i] = f2bf(cosf(f));
+        sinb[i] = f2bf(sinf(f));
+    }
+}
+
 // x: [R, ld]; heads 0..nheads-1 start at column h*hd.  DIR = +1 forward (reference's bf16 rounding sequence),
 // -1 backward (transpose of the rotation, single rounding).
 template <int DIR>
@@ -121,6 +136,15 @@ int mantis_rope_table(const int64_t* position_ids, const float* inv_freq, void* 
     if (R == 0) return MANTIS_OK;
     hipLaunchKernelGGL(rope_table_kernel, dim3(ew_grid(R * half_dim)), dim3(256), 0, (hipStream_t)stream,
                        (const long*)position_ids, inv_freq, (bf16_t*)cos_out, (bf16_t*)sin_out, (long)R, half_dim);
+    return mantis_check_launch();
+}
+
+int mantis_rope_table_sections(const int64_t* position_ids /*[S, R]*/, const float* inv_freq /*[half]*/, const int32_t* section_of_freq,
+                               void* cos_out, void* sin_out, int64_t R, int half_dim, void* stream) {
+    if (R == 0) return MANTIS_OK;
+    hipLaunchKernelGGL(rope_table_sections_kernel, dim3(ew_grid(R * half_dim)), dim3(256), 0, (hipStream_t)stream,
+                       (const long*)position_ids, inv_freq, (const int*)section_of_freq, (bf16_t*)cos_out, (bf16_t*)sin_out, (long)R,
+                       half_dim);
     return mantis_check_launch();
 }
 

@@ -70,6 +70,17 @@ __global__ void drop_cls_kernel(const bf16_t* __restrict__ in, bf16_t* __restric
     }
 }
 
+// Qwen2-VL's processor already delivers flattened patches [rows, C*tp*P*P] fp32 (Conv3d with kernel == stride,
+// transformers/models/qwen2_vl/modeling_qwen2_vl.py:251-274): cast to bf16 and zero-pad the row to Kp (GEMM K % 8 == 0).
+__global__ void cast_pad_rows_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long rows, int K, long ld_in, int Kp) {
+    const long total = rows * Kp;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % Kp);
+        const long r = i / Kp;
+        out[i] = k < K ? f2bf(in[r * ld_in + k]) : (bf16_t)0;
+    }
+}
+
 static inline int ew_grid(long n) {
     long g = (n + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -83,6 +94,14 @@ int mantis_im2col(const float* pixels, void* patches, int I, int C, int H, int W
     const long total = (long)I * (H / P) * (W / P) * Kp;
     hipLaunchKernelGGL(im2col_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, pixels, (bf16_t*)patches, I,
                        C, H, W, P, Kp);
+    return mantis_check_launch();
+}
+
+int mantis_cast_pad_rows(const float* in, void* out, int64_t rows, int K, int64_t ld_in, int Kp, void* stream) {
+    if (K <= 0 || Kp < K || Kp % 8 || ld_in < K) return MANTIS_EINVAL;
+    if (rows == 0) return MANTIS_OK;
+    hipLaunchKernelGGL(cast_pad_rows_kernel, dim3(ew_grid(rows * Kp)), dim3(256), 0, (hipStream_t)stream, in, (bf16_t*)out, (long)rows, K,
+                       (long)ld_in, Kp);
     return mantis_check_launch();
 }
 

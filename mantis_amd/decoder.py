@@ -1,5 +1,6 @@
-"""Explicit forward / backward of the decoder-only text model shared by the LLaVA path (Llama-3) and the Idefics2 path (Mistral-7B):
-RMSNorm -> fused q|k|v -> RoPE -> causal GQA attention (+ key mask, + sample-packing segment bounds) -> o_proj -> +res -> RMSNorm ->
+"""Explicit forward / backward of the decoder-only text model shared by the LLaVA path (Llama-3), the Idefics2 path (Mistral-7B) and
+the Qwen2-VL path (Qwen2-7B):
+RMSNorm -> fused q|k|v (+ bias on the Qwen2-VL path) -> RoPE -> causal GQA attention (+ key mask, + sample-packing segment bounds) -> o_proj -> +res -> RMSNorm ->
 SwiGLU MLP -> +res, then final RMSNorm, lm_head on the rows that can carry a label, masked shifted cross-entropy.
 
 Reference control flow: HF LlamaModel / MistralModel.forward (transformers/models/llama/modeling_llama.py:284-325,367-418; Mistral is
@@ -15,17 +16,19 @@ def inv_freq(head_dim, theta):
     return 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
 
 
-def decoder_forward(K, lm, tc, x, B, L, position_ids, kmask, kstart=None, compute_grads=True, record=None):
-    """x [B*L, d] merged input embeddings -> (hidden states before the final norm, ctx for decoder_backward)."""
+def decoder_forward(K, lm, tc, x, B, L, position_ids, kmask, kstart=None, compute_grads=True, record=None, rope=None):
+    """x [B*L, d] merged input embeddings -> (hidden states before the final norm, ctx for decoder_backward).
+    `rope` = (cos, sin) tables [B*L, hd/2] built by the caller (Qwen2-VL's multimodal RoPE); default: 1-D RoPE of position_ids.
+    A layer dict may carry `qkv_b`, the fused q|k|v bias (Qwen2: HF:models/qwen2_vl/modeling_qwen2_vl.py:501-503)."""
     H, Hkv, hd = tc.num_attention_heads, tc.num_key_value_heads, tc.head_dim
     eps = tc.rms_norm_eps
     scale = hd ** -0.5
-    cos, sin = K.rope_table(position_ids.reshape(-1), inv_freq(hd, tc.rope_theta).to(x.device))
+    cos, sin = rope if rope is not None else K.rope_table(position_ids.reshape(-1), inv_freq(hd, tc.rope_theta).to(x.device))
     saved = []
     for i in range(tc.num_hidden_layers):
         lw = lm["layers"][i]
         n1, rstd1 = K.rmsnorm_fwd(x, lw["ln1"], eps)
-        qkv = K.gemm_nt(n1, lw["qkv"])
+        qkv = K.gemm_nt(n1, lw["qkv"], bias=lw.get("qkv_b"))
         K.rope_apply_(qkv, cos, sin, H + Hkv, hd)
         o, lse = K.attn_fwd(qkv, B, L, H, Hkv, hd, kmask, scale, True, kstart=kstart)
         x_mid = K.gemm_nt(o, lw["o"], residual=x)
@@ -109,6 +112,8 @@ def decoder_backward(K, lm, grads, grads_layers, tc, ctx, hctx, plan, B, L, kmas
         K.rope_apply_(dqkv, cos, sin, H + Hkv, hd, backward=True)
         if lg_["qkv"] is not None:
             K.linear_dw(dqkv, n1, lg_["qkv"], acc)
+        if lg_.get("qkv_b") is not None:
+            K.colsum(dqkv, lg_["qkv_b"], acc)
         dn1 = K.linear_dx(dqkv, lw["qkv"])
         del dqkv, n1, qkv
         dx = K.rmsnorm_bwd(dn1, x_in, lw["ln1"], rstd1, dx_mid, lg_["ln1"], acc)

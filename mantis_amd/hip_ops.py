@@ -245,6 +245,17 @@ def rope_table(position_ids, inv_freq):
     return cos, sin
 
 
+def rope_table_sections(position_ids, inv_freq, section_of_freq):
+    """position_ids int64 [S, R]; frequency j of the table takes its position from row section_of_freq[j] (int32 [hd/2])."""
+    S, R = position_ids.shape
+    half = inv_freq.numel()
+    cos = torch.empty((R, half), dtype=BF16, device=position_ids.device)
+    sin = torch.empty_like(cos)
+    _lib.check(_L.mantis_rope_table_sections(_p(position_ids), _p(inv_freq), _p(section_of_freq), _p(cos), _p(sin), R, half, _stream()),
+               "rope_table_sections")
+    return cos, sin
+
+
 def rope_apply_(x, cos, sin, nheads, hd, backward=False):
     _chk2d(x, "x")
     _lib.check(_L.mantis_rope_apply(_p(x), _p(cos), _p(sin), x.shape[0], nheads, hd, x.stride(0), int(backward), _stream()),
@@ -252,14 +263,14 @@ def rope_apply_(x, cos, sin, nheads, hd, backward=False):
     return x
 
 
-def attn_fwd_qkv(q, k, v, B, Lseq, H, Hkv, hd, kmask, scale, causal, want_lse=True, kstart=None):
+def attn_fwd_qkv(q, k, v, B, Lseq, H, Hkv, hd, kmask, scale, causal, want_lse=True, kstart=None, out=None):
     """q [B*L, >=H*hd], k / v [B*L, >=Hkv*hd] bf16 row views (any row stride, heads contiguous inside a row; they may be column
     slices of one fused projection output).  Returns o [B*L, H*hd], lse [B,H,L] fp32."""
     _chk2d(q, "q"), _chk2d(k, "k"), _chk2d(v, "v")
-    o = torch.empty((B * Lseq, H * hd), dtype=BF16, device=q.device)
+    o = torch.empty((B * Lseq, H * hd), dtype=BF16, device=q.device) if out is None else out     # `out`: a row view of a larger buffer
     lse = torch.empty((B, H, Lseq), dtype=torch.float32, device=q.device) if want_lse else None
     rc = _L.mantis_attn_fwd(_p(q), _p(k), _p(v), _p(kmask), _p(kstart), _p(o), _p(lse), B, Lseq, H, Hkv, hd, q.stride(0), k.stride(0),
-                            v.stride(0), H * hd, float(scale), int(causal), _stream())
+                            v.stride(0), o.stride(0), float(scale), int(causal), _stream())
     _lib.check(rc, f"attn_fwd hd={hd}")
     return o, lse
 
@@ -389,6 +400,14 @@ def im2col(pixels, patch, kp):
     n = (H // patch) * (W // patch)
     out = torch.empty((I * n, kp), dtype=BF16, device=pixels.device)
     _lib.check(_L.mantis_im2col(_p(pixels), _p(out), I, C, H, W, patch, kp, _stream()), "im2col")
+    return out
+
+
+def cast_pad_rows(x, kp):
+    """fp32 [R, K] -> bf16 [R, kp], zero tail."""
+    R, Kk = x.shape
+    out = torch.empty((R, kp), dtype=BF16, device=x.device)
+    _lib.check(_L.mantis_cast_pad_rows(_p(x), _p(out), R, Kk, x.stride(0), kp, _stream()), "cast_pad_rows")
     return out
 
 

@@ -147,6 +147,12 @@ def rope_table(position_ids, inv_freq):
     return f.cos().to(torch.bfloat16), f.sin().to(torch.bfloat16)
 
 
+def rope_table_sections(position_ids, inv_freq, section_of_freq):
+    sel = position_ids[section_of_freq.long()].t().float()                 # [R, half]: frequency j reads row section_of_freq[j]
+    f = sel * inv_freq.float()[None]
+    return f.cos().to(torch.bfloat16), f.sin().to(torch.bfloat16)
+
+
 def rope_apply_(x, cos, sin, nheads, hd, backward=False):
     Rr = x.shape[0]
     half = hd // 2
@@ -224,9 +230,13 @@ def attn_bwd(qkv, o, do, lse, B, Lseq, H, Hkv, hd, kmask, scale, causal, kstart=
     return out
 
 
-def attn_fwd_qkv(q, k, v, B, Lseq, H, Hkv, hd, kmask, scale, causal, want_lse=True, kstart=None):
-    return attn_fwd(torch.cat([q[:, : H * hd], k[:, : Hkv * hd], v[:, : Hkv * hd]], dim=1), B, Lseq, H, Hkv, hd, kmask, scale, causal, want_lse,
-                    kstart=kstart)
+def attn_fwd_qkv(q, k, v, B, Lseq, H, Hkv, hd, kmask, scale, causal, want_lse=True, kstart=None, out=None):
+    o, lse = attn_fwd(torch.cat([q[:, : H * hd], k[:, : Hkv * hd], v[:, : Hkv * hd]], dim=1), B, Lseq, H, Hkv, hd, kmask, scale, causal,
+                      want_lse, kstart=kstart)
+    if out is not None:
+        out.copy_(o)
+        o = out
+    return o, lse
 
 
 def attn_bwd_qkv(q, k, v, o, do, lse, dq, dk, dv, B, Lseq, H, Hkv, hd, kmask, scale, causal, kstart=None, qend=None):
@@ -354,6 +364,12 @@ def im2col(pixels, patch, kp):
     cols = F.unfold(pixels.float(), kernel_size=patch, stride=patch)       # [I, C*P*P, N]
     out = torch.zeros((I * cols.shape[2], kp), dtype=torch.bfloat16)
     out[:, : cols.shape[1]] = cols.transpose(1, 2).reshape(-1, cols.shape[1]).to(torch.bfloat16)
+    return out
+
+
+def cast_pad_rows(x, kp):
+    out = torch.zeros((x.shape[0], kp), dtype=torch.bfloat16)
+    out[:, : x.shape[1]] = x.to(torch.bfloat16)
     return out
 
 

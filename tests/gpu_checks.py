@@ -306,14 +306,17 @@ ATTN_FWD_CASES = [(2, 54, 4, 2, 16, True, "right"), (2, 54, 4, 2, 16, True, "lef
                   (1, 700, 8, 2, 128, True, "right"), (1, 128, 4, 1, 128, True, None), (1, 129, 2, 2, 64, True, "left"),
                   (1, 300, 4, 4, 128, False, "right"), (2, 193, 4, 2, 128, False, None),
                   # head dim 96, GQA 16/4, non-causal with a key mask: the Idefics2 perceiver resampler (modeling_idefics2.py:812-912)
-                  (2, 80, 16, 4, 96, False, "right"), (1, 1088, 16, 4, 96, False, "right"), (1, 200, 4, 2, 96, True, None)]
+                  (2, 80, 16, 4, 96, False, "right"), (1, 1088, 16, 4, 96, False, "right"), (1, 200, 4, 2, 96, True, None),
+                  # head dim 80, 16 heads, non-causal, ragged length: the Qwen2-VL vision tower; GQA 7:1: the Qwen2-7B decoder
+                  (2, 391, 16, 16, 80, False, None), (1, 1000, 4, 4, 80, False, "right"), (1, 333, 14, 2, 128, True, "right")]
 ATTN_BWD_CASES = [(2, 54, 4, 2, 16, True, "right"), (2, 54, 4, 2, 16, True, "left"), (1, 323, 12, 12, 64, True, None),
                   (1, 300, 8, 2, 128, True, "right"), (1, 129, 2, 2, 64, True, None), (2, 40, 2, 2, 16, False, None),
                   (1, 200, 4, 2, 128, False, "left"), (2, 130, 4, 4, 128, False, None),
                   # GQA 4:1 at hd 128: the GQA-aware dK/dV kernel (one workgroup per 64-key block and KV head, partials meet in LDS)
                   (2, 200, 4, 1, 128, True, None), (1, 130, 8, 2, 128, False, "left"), (1, 40, 4, 1, 128, True, None),
                   (1, 256, 4, 1, 128, True, "right"), (2, 97, 8, 2, 128, False, None), (1, 33, 4, 1, 128, True, "left"),
-                  (2, 80, 16, 4, 96, False, "right"), (1, 300, 4, 2, 96, True, None), (1, 1088, 16, 4, 96, False, "right")]
+                  (2, 80, 16, 4, 96, False, "right"), (1, 300, 4, 2, 96, True, None), (1, 1088, 16, 4, 96, False, "right"),
+                  (1, 333, 14, 2, 128, True, "right"), (2, 70, 7, 1, 16, True, None)]
 
 
 # ------------------------------------------------------------------------------------------------------------- packing / CE
@@ -825,6 +828,71 @@ def check_idefics2_full_width():
     return close(model.grad_arena, 2 * g1.float(), 5e-3, "accumulated gradients = 2x")
 
 
+QWEN2VL_CASES = ["qwen2vl_b1_img2", "qwen2vl_b1_img1_tall", "qwen2vl_b2_rightpad", "qwen2vl_b1_text_only"]
+
+
+def check_qwen2vl_step(case):
+    """The Qwen2-VL path end to end on the HIP kernels vs the Qwen2-VL oracle on the golden inputs: dynamic-resolution
+    tower with 2-D rotary embedding and per-image attention, patch merger, image-token merge, Qwen2 decoder with q/k/v bias (+ bias
+    gradients), GQA 7:1 and multimodal RoPE, CE."""
+    z = Hh.load_case(case)
+    model = Hh.build_qwen2vl_product(DEV)
+    oracle = Hh.build_qwen2vl_oracle_bf16()
+    assert model._ensure_grad_arena()
+    rec = {}
+    out = model.engine.step_from_batch(Hh.qwen2vl_batch(z), compute_grads=True, overwrite_grads=True, need_logits=True, record=rec)
+    torch.cuda.synchronize()
+    if "position_ids" in z.files:
+        assert np.array_equal(rec["position_ids"].cpu().numpy(), z["position_ids"])
+    rep = Hh.check_qwen2vl_step_against_oracle(model, oracle, z, out, rec)
+    assert abs(float(out["loss"].cpu()) - float(z["loss"])) < 0.03 * float(z["loss"])
+    return 1.0 - min(c for c, _ in rep.values())
+
+
+def check_rope_sections():
+    """Sectioned cos/sin table (multimodal RoPE 16/24/24 and the vision tower's 2-D table) vs the oracle's operator."""
+    k = K()
+    g = torch.Generator().manual_seed(5)
+    worst = 0.0
+    for S, half, secs in [(3, 64, [16, 24, 24]), (2, 40, [20, 20]), (3, 8, [2, 3, 3])]:
+        pos = torch.randint(0, 3000, (S, 777), generator=g)
+        inv = 1.0 / (1e6 ** (torch.arange(0, half, dtype=torch.float32) / half))
+        sec = torch.repeat_interleave(torch.arange(S, dtype=torch.int32), torch.tensor(secs))
+        cr, sr = R.rope_table_sections(pos, inv, sec)
+        c, s_ = k.rope_table_sections(pos.to(DEV), inv.to(DEV), sec.to(DEV))
+        worst = max(worst, close(c, cr, 1e-2, "rope sections cos"), close(s_, sr, 1e-2, "rope sections sin"))
+    x = torch.randn(50, 1176, generator=g)
+    assert torch.equal(k.cast_pad_rows(x.to(DEV), 1184).cpu(), R.cast_pad_rows(x, 1184))
+    return worst
+
+
+def check_qwen2vl_full_width():
+    """Qwen2-VL-7B layers at full width and reduced depth (ViT 1280 wide, 16 heads x 80, two images of 16x24 and 24x16 patches; merger to
+    3584; Qwen2 width 3584, 28/4 heads, intermediate 18944, V = 152064; 1024 tokens): finite loss near ln V, bitwise reproducible,
+    accumulates."""
+    import math
+    from mantis_amd import configuration_qwen2_vl as C
+    from mantis_amd.modeling_qwen2_vl import Qwen2VLForConditionalGeneration
+    from mantis_amd.trainer import MantisHipTrainer
+    import bench
+    cfg = C.qwen2_vl_7b()
+    cfg.vision_config.depth = 2
+    cfg.text_config.num_hidden_layers = 2
+    model = Qwen2VLForConditionalGeneration(cfg, device=DEV, seed=0)
+    batch = bench.synthetic_batch_qwen2vl(cfg, 1, 1024, [(1, 16, 24), (1, 24, 16)], 0)
+    tr = MantisHipTrainer(model, gradient_accumulation_steps=1)
+    l1 = tr.training_step(model, batch)
+    g1 = model.grad_arena.clone()
+    for p in model.parameters():
+        p.grad = None
+    l2 = tr.training_step(model, batch)
+    assert torch.equal(l1, l2) and torch.equal(g1, model.grad_arena), "the Qwen2-VL step is not bitwise reproducible"
+    assert math.isfinite(float(l1)) and 10.5 < float(l1) < 14.5, float(l1)       # ~ln(152064) = 11.93 (+ logit variance) at random init
+    l3 = tr.training_step(model, batch)
+    assert torch.equal(l3, l1)
+    return close(model.grad_arena, 2 * g1.float(), 5e-3, "accumulated gradients = 2x")
+
+
 def check_norm_overlap():
     """The gradient-norm pass taken bucket by bucket on a side stream during the backward (MantisHipTrainer(optimizer=...)) gives the
     same global norm as the separate pass over the whole arena, and the same parameters after the step."""
@@ -1016,6 +1084,10 @@ def all_checks():
         c["idefics2_step_" + case[9:]] = (lambda case=case: check_idefics2_step(case))
     c["idefics2_packed"] = check_idefics2_packed
     c["idefics2_full_width"] = check_idefics2_full_width
+    for case in QWEN2VL_CASES:
+        c["qwen2vl_step_" + case[8:]] = (lambda case=case: check_qwen2vl_step(case))
+    c["rope_sections_cast_pad"] = check_rope_sections
+    c["qwen2vl_full_width"] = check_qwen2vl_full_width
     c["pack_segments_random"] = check_pack_segments_random
     c["packed_model_step"] = check_packed_model_step
     c["packed_fullsize_vs_batched"] = check_packed_fullsize_vs_batched

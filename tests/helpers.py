@@ -170,3 +170,66 @@ def check_idefics2_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-
             continue
         assert c >= grad_cos and r <= grad_rel, (name, c, r)
     return report
+
+
+# ----------------------------------------------------------------------------------------------------------- Qwen2-VL path
+def build_qwen2vl_product(device):
+    from mantis_amd.configuration_qwen2_vl import Qwen2VLConfig
+    from mantis_amd.modeling_qwen2_vl import Qwen2VLForConditionalGeneration
+    meta, sd = golden_cfg_and_weights("qwen2vl")
+    model = Qwen2VLForConditionalGeneration(Qwen2VLConfig.from_oracle_meta(meta), device=device, init=None)
+    model.load_reference_state_dict(sd)
+    return model
+
+
+def build_qwen2vl_oracle_bf16():
+    from oracle.qwen2vl_ref import Qwen2VLRef
+    meta, sd = golden_cfg_and_weights("qwen2vl")
+    return Qwen2VLRef({k: torch.from_numpy(v).to(torch.bfloat16).float() for k, v in sd.items()}, meta)
+
+
+def qwen2vl_batch(z):
+    b = dict(input_ids=torch.from_numpy(z["input_ids"]), attention_mask=torch.from_numpy(z["attention_mask"]),
+             labels=torch.from_numpy(z["labels"]))
+    b["pixel_values"] = torch.from_numpy(z["pixel_values"]) if "pixel_values" in z.files else None
+    b["image_grid_thw"] = torch.from_numpy(z["image_grid_thw"]) if "image_grid_thw" in z.files else None
+    return b
+
+
+def check_qwen2vl_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-3, grad_cos=0.995, grad_rel=6e-2, act_rel=3e-2):
+    """bf16 product path vs the fp32 Qwen2-VL oracle on identical (bf16-rounded) weights."""
+    orec = {}
+    oracle.zero_grad()
+    pv = z["pixel_values"] if "pixel_values" in z.files else None
+    grid = z["image_grid_thw"] if "image_grid_thw" in z.files else None
+    oloss, ologits = oracle.forward(z["input_ids"], pv, grid, z["attention_mask"], z["labels"], record=orec)
+    oloss.backward()
+    loss = float(out["loss"].float().cpu().reshape(-1)[0])
+    assert abs(loss - float(oloss)) <= loss_rtol * abs(float(oloss)), (loss, float(oloss))
+    am = z["attention_mask"].astype(bool)
+    assert np.array_equal(rec["position_ids"].cpu().numpy(), orec["position_ids"].numpy())          # integer work: bit-exact
+    for k in orec:
+        if k == "position_ids":
+            continue
+        a, b = rec[k].float().cpu().numpy(), orec[k].detach().numpy()
+        if k.startswith("llm_layer") or k == "merged_embeds":
+            a, b = a[am], b[am]
+        assert rel_l2(a, b) < act_rel, (k, rel_l2(a, b))
+    lg = out["logits"].float().cpu().numpy()
+    assert rel_l2(lg[am], ologits.detach().numpy()[am]) < act_rel
+    report = {}
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        og = oracle.w[name].grad
+        g = p.grad.float().cpu().numpy()
+        if og is None:
+            assert not g.any(), name
+            continue
+        c, r = cosine(g, og.numpy()), rel_l2(g, og.numpy())
+        report[name] = (c, r)
+        if np.linalg.norm(og.numpy()) < 1e-12:
+            assert np.linalg.norm(g) < 1e-6, name
+            continue
+        assert c >= grad_cos and r <= grad_rel, (name, c, r)
+    return report
