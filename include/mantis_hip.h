@@ -107,6 +107,21 @@ int mantis_gemm_workspace_bytes(int M, int N, int K);
 /* tile variant the auto heuristic (flags bits 8-11 == 0) picks: 12 = 256x256 ring kernel, 1 = 128x128 generic kernel */
 int mantis_gemm_pick_variant(int M, int N, int K);
 
+/* ---- fp8 linears (BASELINE configs[4] "fp8 MFMA"): an accelerated variant of the bf16 nn.Linear of the Qwen2
+ * decoder (HF:models/qwen2_vl/modeling_qwen2_vl.py:453-466,501-504); the reference has no fp8, tolerance is stated against its bf16 /
+ * fp32 path.  OCP e4m3 (fmt 0, max 448) / e5m2 (fmt 1, max 57344), per-tensor just-in-time scaling.  See csrc/gemm_fp8.hip.
+ * quantize: x bf16 [rows, cols] (stride ld elements, cols % 16 == 0) -> q [rows, cols] (stride ldq bytes) and, if qt != NULL, the
+ * transposed copy qt [cols, rows_pad] (stride ldt bytes, rows_pad = rows rounded up to 16, zero tail);
+ * state float[3] <- {amax, FMAX / amax, amax / FMAX}; workspace: mantis_fp8_quantize_ws_floats() floats.
+ * gemm: C[M,N] bf16 = epi(dequant_a * dequant_b * A8[M,K] . B8[N,K]^T), lda / ldb bytes, K % 16 == 0, fmt_a 0|1, B e4m3;
+ * flags 1 bias | 16 residual | 32 accumulate | variant << 8 (0 auto, 1 128x128, 2 256x256). */
+int mantis_fp8_quantize_ws_floats(void);
+int mantis_fp8_quantize(const void* x, int64_t rows, int cols, int64_t ld, int fmt, void* q, int64_t ldq, void* qt, int64_t ldt,
+                        float* state, float* workspace, void* stream);
+int mantis_gemm_fp8_nt(const void* A8, int64_t lda, const void* B8, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
+                       const float* dequant_a, const float* dequant_b, int fmt_a, const void* bias, const void* residual, int64_t ldr,
+                       int flags, void* stream);
+
 /* ---- attention: HF:models/llama/modeling_llama.py:191-214,262-276; HF:models/siglip/modeling_siglip.py:227-247 */
 /* kmask int32 [B,L] (nullable): 1 = key may be attended (key padding).  kstart int32 [B,L] (nullable): packed samples -- query q
  * attends keys >= kstart[b,q] only (the start of its own sample; non-decreasing in q), i.e. the block-diagonal mask of

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libmantis_hip.so")
-SOURCES = ["pack", "norm", "act", "rope", "ce", "vit", "gemm", "attn", "optim"]
+SOURCES = ["pack", "norm", "act", "rope", "ce", "vit", "gemm", "gemm_fp8", "attn", "optim"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"]
 
 

@@ -1,0 +1,389 @@
+// fp8 (OCP e4m3 / e5m2) "NT" GEMM with per-tensor scaling for gfx950, and the quantisers that feed it.
+//      C[M,N] (bf16) = epi( sa * sb * A8[M,K] . B8[N,K]^T ),  fp32 accumulate in the MFMA
+//
+// SURVEY.md section 8 row f3 / BASELINE.json configs[4] ("Qwen2-VL-7B ... fp8 MFMA"): the reference has no fp8 anywhere (its linears
+// are bf16 nn.Linear: transformers/models/qwen2_vl/modeling_qwen2_vl.py:453-466,501-504), so this is an accelerated variant of those
+// linears whose tolerance is stated against the bf16/fp32 oracle (tests/gpu_checks.py: fp8_*), and whose arithmetic is restated
+// exactly (same rounding, same scales) by oracle/ops_ref.py: fp8_quantize / gemm_fp8_nt.
+//
+// Recipe (per-tensor, just-in-time scaling; no history):  q = cvt_fp8( clamp(x * (FMAX / amax(|x|))) ),  dequant factor = amax / FMAX.
+//   forward   Y  = X8 . W8^T          X, W in e4m3
+//   dX        dX = dY8 . (W8T)^T      dY in e5m2 (range), W8T = transposed e4m3 copy of the weight (K-contiguous along N)
+//   dW        dW = dY8T . (X8T)^T     both transposed copies come out of the quantiser for free (one LDS tile transpose)
+// so ONE "NT" kernel (both operands K-contiguous, what the fp8 MFMA wants: 32 consecutive K bytes per lane) serves all three.
+//
+// MFMA: v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (E8M0 127 = 2^0) -- on gfx950 the K = 64 scaled form is the only fp8
+// matrix instruction at 2x the bf16 rate (the non-scaled 32x32x16 fp8 form runs at the bf16 rate, MI355X guide section MFMA).
+// Structure: 256x256 tile per 512-thread workgroup (8 waves of 128x64) or 128x128 (4 waves of 64x64), K step 128 B, A/B tiles
+// HBM -> LDS by LDS-DMA (16 B per lane) into the same [rows][128 B] rotation-swizzled image as the bf16 kernel (conflict-free
+// ds_read_b128), two stages; XCD-aware tile map.  Operands are fed swapped (mfma(a = B rows, b = A rows)) so a lane owns ONE output
+// row m and 4 consecutive n.  Algorithmic FLOPs per launch: 2*M*N*K; algorithmic bytes: M*K + N*K + 2*M*N.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((address_space(3))) void f8_lds_void;
+
+#define F8_EPI_BIAS 1
+#define F8_EPI_RESIDUAL 16
+#define F8_EPI_ACCUM 32
+#define F8_FMT_E4M3 0
+#define F8_FMT_E5M2 1
+
+static __device__ __attribute__((aligned(16))) unsigned int f8_zero_page[16];
+
+// One global_load_lds: 8 rows x 128 B of an operand tile (row block rb) -> LDS; 16-B chunk c of row r lands at slot (c + (r >> 1)) & 7.
+__device__ __forceinline__ void f8_stage_piece(const unsigned char* __restrict__ G, long ld, int row0, int rows_total, int k0, int K,
+                                               char* lds_tile, int rb, int lane) {
+    const int rl = lane >> 3;
+    const int f = (rb * 4 + (rl >> 1)) & 7;
+    const int chunk = ((lane & 7) - f) & 7;
+    const int k = k0 + chunk * 16;
+    int grow = row0 + rb * 8 + rl;
+    grow = grow < rows_total ? grow : rows_total - 1;
+    const void* src = (k < K) ? (const void*)(G + (long)grow * ld + k) : (const void*)f8_zero_page;
+    __builtin_amdgcn_global_load_lds(src, (f8_lds_void*)(lds_tile + rb * 1024), 16, 0, 0);
+}
+
+template <int ROWS, int NW>
+__device__ __forceinline__ void f8_stage_tile(const unsigned char* __restrict__ G, long ld, int row0, int rows_total, int k0, int K,
+                                              char* lds_tile, int wave, int lane) {
+    constexpr int PER = ROWS / 8 / NW;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) f8_stage_piece(G, ld, row0, rows_total, k0, K, lds_tile, wave * PER + j, lane);
+}
+
+// 32 consecutive K bytes of one row = chunks c0, c0 + 1 (c0 even, so both sit in the same 128-B row)
+__device__ __forceinline__ i32x8 f8_read_frag(const char* tile, int row, int c0) {
+    const int f = (row >> 1) & 7;
+    const i32x4 lo = *reinterpret_cast<const i32x4*>(tile + row * 128 + (((c0 + f) & 7) << 4));
+    const i32x4 hi = *reinterpret_cast<const i32x4*>(tile + row * 128 + (((c0 + 1 + f) & 7) << 4));
+    i32x8 r;
+    r[0] = lo[0], r[1] = lo[1], r[2] = lo[2], r[3] = lo[3], r[4] = hi[0], r[5] = hi[1], r[6] = hi[2], r[7] = hi[3];
+    return r;
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void f8_epilogue(f32x16 (&acc)[TN][TM], bf16_t* __restrict__ C, int M, int N, long ldc, float scale,
+                                            const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res, long ldr, int flags,
+                                            int mw0, int nw0, int lane) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int m = mw0 + tm * 32 + (lane & 31);
+        if (m >= M) continue;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int nb = nw0 + tn * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int n = nb + 8 * g4;
+                if (n >= N) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[tn][tm][4 * g4 + e] * scale;
+                const bool full = (n + 3 < N);
+                if (flags & F8_EPI_BIAS) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (full || n + e < N) v[e] += bf2f(bias[n + e]);
+                }
+                bf16_t* cp = C + (long)m * ldc + n;
+                if (full && ((ldc & 3) == 0) && ((ldr & 3) == 0 || !(flags & F8_EPI_RESIDUAL))) {
+                    if (flags & F8_EPI_RESIDUAL) {          // same rounding order as the bf16 kernel: round, then add the residual
+                        const u32x2 rv = *reinterpret_cast<const u32x2*>(res + (long)m * ldr + n);
+                        v[0] = bf2f(f2bf(v[0])) + bf2f_lo(rv[0]);
+                        v[1] = bf2f(f2bf(v[1])) + bf2f_hi(rv[0]);
+                        v[2] = bf2f(f2bf(v[2])) + bf2f_lo(rv[1]);
+                        v[3] = bf2f(f2bf(v[3])) + bf2f_hi(rv[1]);
+                    }
+                    if (flags & F8_EPI_ACCUM) {
+                        const u32x2 cv = *reinterpret_cast<const u32x2*>(cp);
+                        v[0] += bf2f_lo(cv[0]);
+                        v[1] += bf2f_hi(cv[0]);
+                        v[2] += bf2f_lo(cv[1]);
+                        v[3] += bf2f_hi(cv[1]);
+                    }
+                    u32x2 o;
+                    o[0] = pack_bf2(v[0], v[1]);
+                    o[1] = pack_bf2(v[2], v[3]);
+                    *reinterpret_cast<u32x2*>(cp) = o;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (n + e < N) {
+                            float x = v[e];
+                            if (flags & F8_EPI_RESIDUAL) x = bf2f(f2bf(x)) + bf2f(res[(long)m * ldr + n + e]);
+                            if (flags & F8_EPI_ACCUM) x += bf2f(cp[e]);
+                            cp[e] = f2bf(x);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// FA: format of the A matrix (0 e4m3, 1 e5m2); B is always e4m3 (weights / activations).
+template <int BM, int BN, int WM, int WN, int FA>
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_fp8_nt_kernel(
+    const unsigned char* __restrict__ A, const unsigned char* __restrict__ B, bf16_t* __restrict__ C, int M, int N, int K, long lda,
+    long ldb, long ldc, const float* __restrict__ inv_scale_a, const float* __restrict__ inv_scale_b, const bf16_t* __restrict__ bias,
+    const bf16_t* __restrict__ res, long ldr, int flags, int tiles_m, int tiles_n) {
+    constexpr int NWN = BN / WN, NW = (BM / WM) * NWN, TM = WM / 32, TN = WN / 32;
+    constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / NWN, wn = wave % NWN;
+
+    // XCD-aware tile assignment (workgroup b runs on XCD b % 8): every XCD gets a contiguous range of tile ids, 8-row groups
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int GROUP = 8;
+    const int per_group = GROUP * tiles_n;
+    const int g = tile_id / per_group;
+    const int first_m = g * GROUP;
+    const int gsz = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+    const int in_g = tile_id - g * per_group;
+    const int m0 = (first_m + in_g % gsz) * BM, n0 = (in_g / gsz) * BN;
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = (K + 127) / 128;
+    f8_stage_tile<BM, NW>(A, lda, m0, M, 0, K, smem, wave, lane);
+    f8_stage_tile<BN, NW>(B, ldb, n0, N, 0, K, smem + A_BYTES, wave, lane);
+    for (int t = 0; t < nk; ++t) {
+        char* cur = smem + (t & 1) * STAGE;
+        char* nxt = smem + ((t + 1) & 1) * STAGE;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < nk) {
+            f8_stage_tile<BM, NW>(A, lda, m0, M, (t + 1) * 128, K, nxt, wave, lane);
+            f8_stage_tile<BN, NW>(B, ldb, n0, N, (t + 1) * 128, K, nxt + A_BYTES, wave, lane);
+        }
+        const char* At = cur;
+        const char* Bt = cur + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int c0 = ks * 4 + (lane >> 5) * 2;
+            i32x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TN; ++i) fb[i] = f8_read_frag(Bt, wn * WN + i * 32 + (lane & 31), c0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = f8_read_frag(At, wm * WM + i * 32 + (lane & 31), c0);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+                    acc[tn][tm] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[tn], fa[tm], acc[tn][tm], F8_FMT_E4M3, FA, 0,
+                                                                                  0x7f7f7f7f, 0, 0x7f7f7f7f);
+        }
+    }
+    const float scale = inv_scale_a[0] * inv_scale_b[0];
+    f8_epilogue<TM, TN>(acc, C, M, N, ldc, scale, bias, res, ldr, flags, m0 + wm * WM, n0 + wn * WN, lane);
+}
+
+template <int BM, int BN, int WM, int WN, int FA>
+static int launch_fp8(hipStream_t s, const unsigned char* A, const unsigned char* B, bf16_t* C, int M, int N, int K, long lda, long ldb,
+                      long ldc, const float* sa, const float* sb, const bf16_t* bias, const bf16_t* res, long ldr, int flags) {
+    const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
+    hipLaunchKernelGGL((gemm_fp8_nt_kernel<BM, BN, WM, WN, FA>), dim3(tiles_m * tiles_n), dim3((BM / WM) * (BN / WN) * 64), 0, s, A, B, C,
+                       M, N, K, lda, ldb, ldc, sa, sb, bias, res, ldr, flags, tiles_m, tiles_n);
+    return mantis_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------------------- quantisers
+#define Q_PARTS 256
+// pass 1: per-workgroup maxima of |x| (bf16 bit patterns compare like unsigned integers once the sign is cleared)
+__global__ __launch_bounds__(256) void fp8_amax_kernel(const bf16_t* __restrict__ x, long rows, int cols, long ld, float* __restrict__ parts) {
+    const int cpr = cols >> 3;
+    const long total = rows * cpr;
+    unsigned int mx = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / cpr;
+        const int c = (int)(i - r * cpr);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(x + r * ld + c * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned int lo = (v[e] << 16) & 0x7fff0000u, hi = v[e] & 0x7fff0000u;
+            mx = mx > lo ? mx : lo;
+            mx = mx > hi ? mx : hi;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned int y = (unsigned int)__shfl_xor((int)mx, o);
+        mx = mx > y ? mx : y;
+    }
+    __shared__ unsigned int sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) mx = mx > sm[w] ? mx : sm[w];
+        parts[blockIdx.x] = __uint_as_float(mx);
+    }
+}
+
+template <int FMT>
+__device__ __forceinline__ unsigned int cvt4(float a, float b, float c, float d) {
+    int w = 0;
+    if (FMT == F8_FMT_E4M3) {
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    } else {
+        w = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, w, false);
+        w = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, w, true);
+    }
+    return (unsigned int)w;
+}
+
+// pass 2: scale = FMAX / amax; q = cvt(clamp(x * scale)); row-major copy and (optionally) the transposed copy through a 64 x 64 LDS tile.
+// state[0] = amax, state[1] = scale, state[2] = amax / FMAX (the dequant factor the GEMM epilogue reads).
+#define QT_PITCH 68
+template <int FMT>
+__global__ __launch_bounds__(256) void fp8_cast_kernel(const bf16_t* __restrict__ x, long rows, int cols, long ld,
+                                                       const float* __restrict__ parts, unsigned char* __restrict__ q, long ldq,
+                                                       unsigned char* __restrict__ qt, long ldt, long rows_pad, float* __restrict__ state) {
+    __shared__ float s_scale;
+    __shared__ unsigned int sm[4];
+    __shared__ __attribute__((aligned(16))) unsigned char tile[64 * QT_PITCH];
+    const float FMAX = FMT == F8_FMT_E4M3 ? 448.f : 57344.f;
+    {
+        unsigned int mx = __float_as_uint(parts[threadIdx.x]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned int y = (unsigned int)__shfl_xor((int)mx, o);
+            mx = mx > y ? mx : y;
+        }
+        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; ++w) mx = mx > sm[w] ? mx : sm[w];
+            const float amax = __uint_as_float(mx);
+            const float sc = amax > 0.f ? FMAX / amax : 1.f;
+            s_scale = sc;
+            if (blockIdx.x == 0 && blockIdx.y == 0) {
+                state[0] = amax;
+                state[1] = sc;
+                state[2] = amax > 0.f ? amax / FMAX : 1.f;
+            }
+        }
+        __syncthreads();
+    }
+    const float sc = s_scale;
+    const long r0 = (long)blockIdx.y * 64;
+    const int c0 = blockIdx.x * 64;
+    const int t = threadIdx.x;
+    {
+        const int rl = t >> 2, cc = (t & 3) * 16;
+        const long r = r0 + rl;
+        const int c = c0 + cc;
+        unsigned int w[4] = {0u, 0u, 0u, 0u};
+        if (r < rows && c < cols) {           // cols % 16 == 0: a 16-column group is either fully inside or fully outside
+            const u32x4 v0 = *reinterpret_cast<const u32x4*>(x + r * ld + c);
+            const u32x4 v1 = *reinterpret_cast<const u32x4*>(x + r * ld + c + 8);
+            float f[16];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f[2 * e] = bf2f_lo(v0[e]), f[2 * e + 1] = bf2f_hi(v0[e]);
+                f[8 + 2 * e] = bf2f_lo(v1[e]), f[8 + 2 * e + 1] = bf2f_hi(v1[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) f[e] = fminf(fmaxf(f[e] * sc, -FMAX), FMAX);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = cvt4<FMT>(f[4 * e], f[4 * e + 1], f[4 * e + 2], f[4 * e + 3]);
+            u32x4 o;
+            o[0] = w[0], o[1] = w[1], o[2] = w[2], o[3] = w[3];
+            *reinterpret_cast<u32x4*>(q + r * ldq + c) = o;
+        }
+        if (qt != nullptr) {
+            unsigned int* tp = reinterpret_cast<unsigned int*>(tile + rl * QT_PITCH + cc);
+            tp[0] = w[0], tp[1] = w[1], tp[2] = w[2], tp[3] = w[3];
+        }
+    }
+    if (qt == nullptr) return;
+    __syncthreads();
+    {
+        const int cl = t >> 2, rr = (t & 3) * 16;       // output row = source column c0 + cl; 16 source rows r0 + rr ..
+        const int c = c0 + cl;
+        const long r = r0 + rr;
+        if (c < cols && r < rows_pad) {                 // rows_pad % 16 == 0; source rows >= rows were written as zeros above
+            unsigned int w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned int acc = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc |= (unsigned int)tile[(rr + 4 * e + b) * QT_PITCH + cl] << (8 * b);
+                w[e] = acc;
+            }
+            u32x4 o;
+            o[0] = w[0], o[1] = w[1], o[2] = w[2], o[3] = w[3];
+            *reinterpret_cast<u32x4*>(qt + (long)c * ldt + r) = o;
+        }
+    }
+}
+
+extern "C" {
+
+// Workspace floats the quantiser needs (per-workgroup maxima of pass 1).
+int mantis_fp8_quantize_ws_floats(void) { return Q_PARTS; }
+
+// x bf16 [rows, cols] (row stride ld, elements) -> q fp8 [rows, cols] (row stride ldq bytes) and, if qt != NULL, the transposed copy
+// qt [cols, rows_pad] (row stride ldt bytes; rows_pad = rows rounded up to 16, zero tail).  fmt: 0 = e4m3 (max 448), 1 = e5m2 (max
+// 57344).  state float[3] <- {amax, scale = FMAX / amax, dequant = amax / FMAX}.  workspace: mantis_fp8_quantize_ws_floats() floats.
+int mantis_fp8_quantize(const void* x, int64_t rows, int cols, int64_t ld, int fmt, void* q, int64_t ldq, void* qt, int64_t ldt,
+                        float* state, float* workspace, void* stream) {
+    if (rows <= 0 || cols <= 0 || cols % 16 || ld % 8 || ldq % 16 || ldq < cols || (fmt != 0 && fmt != 1) || !state || !workspace)
+        return MANTIS_EINVAL;
+    const long rows_pad = (rows + 15) / 16 * 16;
+    if (qt != nullptr && (ldt % 16 || ldt < rows_pad)) return MANTIS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(fp8_amax_kernel, dim3(Q_PARTS), dim3(256), 0, s, (const bf16_t*)x, (long)rows, cols, (long)ld, workspace);
+    const dim3 grid(cdiv(cols, 64), cdiv(rows_pad, 64));
+    if (grid.y > 65535) return MANTIS_EUNSUPPORTED;
+    if (fmt == 0)
+        hipLaunchKernelGGL(fp8_cast_kernel<F8_FMT_E4M3>, grid, dim3(256), 0, s, (const bf16_t*)x, (long)rows, cols, (long)ld, workspace,
+                           (unsigned char*)q, (long)ldq, (unsigned char*)qt, (long)ldt, rows_pad, state);
+    else
+        hipLaunchKernelGGL(fp8_cast_kernel<F8_FMT_E5M2>, grid, dim3(256), 0, s, (const bf16_t*)x, (long)rows, cols, (long)ld, workspace,
+                           (unsigned char*)q, (long)ldq, (unsigned char*)qt, (long)ldt, rows_pad, state);
+    return mantis_check_launch();
+}
+
+// C[M,N] bf16 (row stride ldc elements) = epi(dequant_a * dequant_b * A8[M,K] . B8[N,K]^T); lda / ldb in bytes, K % 16 == 0.
+// fmt_a: 0 e4m3 | 1 e5m2; B is e4m3.  flags: 1 bias[n] | 16 + residual[m,n] (stride ldr) | 32 accumulate into C | variant << 8
+// (0 auto, 1 = 128x128 tiles, 2 = 256x256 tiles).  dequant_a / dequant_b: device pointers to state[2] of the quantiser.
+int mantis_gemm_fp8_nt(const void* A8, int64_t lda, const void* B8, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
+                       const float* dequant_a, const float* dequant_b, int fmt_a, const void* bias, const void* residual, int64_t ldr,
+                       int flags, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % 16 || lda % 16 || ldb % 16 || lda < K || ldb < K || ldc < N || !dequant_a || !dequant_b)
+        return MANTIS_EINVAL;
+    if ((flags & F8_EPI_BIAS) && !bias) return MANTIS_EINVAL;
+    if ((flags & F8_EPI_RESIDUAL) && !residual) return MANTIS_EINVAL;
+    if (fmt_a != 0 && fmt_a != 1) return MANTIS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    int variant = (flags >> 8) & 15;
+    if (variant == 0) variant = ((long)cdiv(M, 256) * cdiv(N, 256) >= 200) ? 2 : 1;
+    const int f = flags & 0xff;
+#define F8_GO(BM_, BN_, WM_, WN_)                                                                                                        \
+    return fmt_a == 0 ? launch_fp8<BM_, BN_, WM_, WN_, 0>(s, (const unsigned char*)A8, (const unsigned char*)B8, (bf16_t*)C, M, N, K,  \
+                                                          (long)lda, (long)ldb, (long)ldc, dequant_a, dequant_b, (const bf16_t*)bias,     \
+                                                          (const bf16_t*)residual, (long)ldr, f)                                         \
+                      : launch_fp8<BM_, BN_, WM_, WN_, 1>(s, (const unsigned char*)A8, (const unsigned char*)B8, (bf16_t*)C, M, N, K,  \
+                                                          (long)lda, (long)ldb, (long)ldc, dequant_a, dequant_b, (const bf16_t*)bias,     \
+                                                          (const bf16_t*)residual, (long)ldr, f)
+    if (variant == 2) { F8_GO(256, 256, 128, 64); }
+    if (variant == 1) { F8_GO(128, 128, 64, 64); }
+#undef F8_GO
+    return MANTIS_EINVAL;
+}
+
+}  // extern "C"

@@ -69,13 +69,8 @@ def head_and_loss(K, lm, tc, x, plan, B, L, labels_given, grad_scale, loss_scale
     return loss, count, logits_full, ctx
 
 
-def decoder_backward(K, lm, grads, grads_layers, tc, ctx, hctx, plan, B, L, kmask, kstart=None, qend=None, accumulate=False,
-                     on_bucket_ready=None):
-    """Backward of head_and_loss + decoder_forward.  Returns dx [B*L, d], the gradient w.r.t. the merged input embeddings.
-    Fires on_bucket_ready("head") and (("layer", i, "down" | "gu" | "attn")) as each gradient bucket completes."""
-    H, Hkv, hd = tc.num_attention_heads, tc.num_key_value_heads, tc.head_dim
-    acc = accumulate
-    saved, cos, sin, scale = ctx["saved"], ctx["cos"], ctx["sin"], ctx["scale"]
+def head_backward(K, lm, grads, hctx, plan, B, L, acc, on_bucket_ready=None):
+    """Backward of head_and_loss: lm_head dW / dX, final RMSNorm, scatter to the sequence rows.  Returns dx [B*L, d]."""
     dlogits, nf, h_ce, rstdf = hctx["dlogits"], hctx["nf"], hctx["h_ce"], hctx["rstdf"]
     if grads.get("head") is not None:
         K.linear_dw(dlogits, nf, grads["head"], acc)      # pad columns [V, Vp) are zero
@@ -83,9 +78,19 @@ def decoder_backward(K, lm, grads, grads_layers, tc, ctx, hctx, plan, B, L, kmas
     dh_ce = K.rmsnorm_bwd(dnf, h_ce, lm["norm"], rstdf, None, grads.get("norm"), acc)
     dx = K.scatter_rows(dh_ce, plan.ce_row, B * L)
     hctx.clear()
-    del dlogits, dnf, nf, h_ce, dh_ce
     if on_bucket_ready is not None:
         on_bucket_ready("head")
+    return dx
+
+
+def decoder_backward(K, lm, grads, grads_layers, tc, ctx, hctx, plan, B, L, kmask, kstart=None, qend=None, accumulate=False,
+                     on_bucket_ready=None):
+    """Backward of head_and_loss + decoder_forward.  Returns dx [B*L, d], the gradient w.r.t. the merged input embeddings.
+    Fires on_bucket_ready("head") and (("layer", i, "down" | "gu" | "attn")) as each gradient bucket completes."""
+    H, Hkv, hd = tc.num_attention_heads, tc.num_key_value_heads, tc.head_dim
+    acc = accumulate
+    saved, cos, sin, scale = ctx["saved"], ctx["cos"], ctx["sin"], ctx["scale"]
+    dx = head_backward(K, lm, grads, hctx, plan, B, L, acc, on_bucket_ready)
     for i in reversed(range(tc.num_hidden_layers)):
         lw = lm["layers"][i]
         lg_ = grads_layers[i]

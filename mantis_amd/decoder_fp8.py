@@ -1,0 +1,125 @@
+"""fp8 variant of decoder.py's layer loop (BASELINE.json configs[4]: "Qwen2-VL-7B ... fp8 MFMA"): the seven
+linears of every decoder layer (q|k|v, o, gate|up, down: forward, dX and dW) run on the fp8 MFMA GEMM of csrc/gemm_fp8.hip; norms, RoPE,
+attention, SwiGLU, residual stream, lm_head and the loss stay exactly as in decoder.py (bf16 / fp32).
+
+Recipe (per tensor, just-in-time scales, no history): activations and weights in e4m3, output gradients in e5m2; the quantiser hands
+back the transposed copy together with the row-major one, so forward (X8 . W8^T), dX (dY8 . W8T^T) and dW (dY8T . X8T^T) are all the one
+"NT" kernel.  The backward keeps the TRANSPOSED fp8 activations (1 B/element) instead of decoder.py's bf16 n1 / n2 / a.
+
+The reference has no fp8 (its linears are bf16 nn.Linear); parity is therefore stated in two steps (tests/gpu_checks.py fp8_*):
+HIP == the oracle's exact restatement of this arithmetic (oracle/ops_ref.py fp8_quantize / gemm_fp8_nt), and that restatement vs the
+fp32 oracle of the reference within the fp8 tolerance written in the tests."""
+from . import decoder as D
+
+E4M3, E5M2 = 0, 1
+_NAMES = ("qkv", "o", "gu", "down")
+
+
+class Fp8Weights:
+    """e4m3 copies (row-major for the forward, transposed for dX) of the decoder's linear weights.  `refresh()` drops them; they are
+    re-quantised lazily, layer by layer, at first use."""
+
+    def __init__(self, lm):
+        self.lm = lm
+        self.cache = {}
+
+    def refresh(self):
+        self.cache.clear()
+
+    def get(self, K, i, name):
+        key = (i, name)
+        w = self.cache.get(key)
+        if w is None:
+            w = self.cache[key] = K.fp8_quantize(self.lm["layers"][i][name], E4M3, transposed=True)
+        return w
+
+
+def _lin(K, xq, wq, bias=None, residual=None):
+    return K.gemm_fp8_nt(xq.q, xq.dequant, wq.q, wq.dequant, E4M3, bias=bias, residual=residual)
+
+
+def decoder_forward(K, lm, w8, tc, x, B, L, kmask, compute_grads=True, record=None, rope=None):
+    """Same contract as decoder.decoder_forward (rope tables given by the caller)."""
+    H, Hkv, hd = tc.num_attention_heads, tc.num_key_value_heads, tc.head_dim
+    eps = tc.rms_norm_eps
+    scale = hd ** -0.5
+    cos, sin = rope
+    saved = []
+    for i in range(tc.num_hidden_layers):
+        lw = lm["layers"][i]
+        n1, rstd1 = K.rmsnorm_fwd(x, lw["ln1"], eps)
+        n1q = K.fp8_quantize(n1, E4M3, transposed=compute_grads)
+        qkv = _lin(K, n1q, w8.get(K, i, "qkv"), bias=lw.get("qkv_b"))
+        K.rope_apply_(qkv, cos, sin, H + Hkv, hd)
+        o, lse = K.attn_fwd(qkv, B, L, H, Hkv, hd, kmask, scale, True)
+        oq = K.fp8_quantize(o, E4M3, transposed=compute_grads)
+        x_mid = _lin(K, oq, w8.get(K, i, "o"), residual=x)
+        n2, rstd2 = K.rmsnorm_fwd(x_mid, lw["ln2"], eps)
+        n2q = K.fp8_quantize(n2, E4M3, transposed=compute_grads)
+        gu = _lin(K, n2q, w8.get(K, i, "gu"))
+        a = K.swiglu_fwd(gu)
+        aq = K.fp8_quantize(a, E4M3, transposed=compute_grads)
+        x_out = _lin(K, aq, w8.get(K, i, "down"), residual=x_mid)
+        if compute_grads:
+            for t in (n1q, oq, n2q, aq):
+                t.q = None                                  # the backward reads only the transposed copies
+            saved.append((x, rstd1, qkv, o, lse, x_mid, rstd2, gu, n1q, oq, n2q, aq))
+        x = x_out
+        if record is not None:
+            record[f"llm_layer{i}_out"] = x.view(B, L, -1)
+    return x, dict(saved=saved, cos=cos, sin=sin, scale=scale)
+
+
+def _dw(K, dyq, xq, grad, acc):
+    """grad[out, in] (+)= dY^T . X over the (zero-padded) token axis: both operands are the quantiser's transposed copies."""
+    if grad is not None:
+        K.gemm_fp8_nt(dyq.qt, dyq.dequant, xq.qt, xq.dequant, E5M2, out=grad, accumulate=acc)
+
+
+def _dx(K, dyq, wq):
+    return K.gemm_fp8_nt(dyq.q, dyq.dequant, wq.qt, wq.dequant, E5M2)
+
+
+def decoder_backward(K, lm, w8, grads, grads_layers, tc, ctx, hctx, plan, B, L, kmask, accumulate=False, on_bucket_ready=None):
+    """Same contract as decoder.decoder_backward: head + loss backward (bf16, shared), then the fp8 layer loop."""
+    H, Hkv, hd = tc.num_attention_heads, tc.num_key_value_heads, tc.head_dim
+    acc = accumulate
+    saved, cos, sin, scale = ctx["saved"], ctx["cos"], ctx["sin"], ctx["scale"]
+    dx = D.head_backward(K, lm, grads, hctx, plan, B, L, acc, on_bucket_ready)
+    for i in reversed(range(tc.num_hidden_layers)):
+        lw = lm["layers"][i]
+        lg_ = grads_layers[i]
+        x_in, rstd1, qkv, o, lse, x_mid, rstd2, gu, n1q, oq, n2q, aq = saved.pop()
+        dxq = K.fp8_quantize(dx, E5M2, transposed=lg_["down"] is not None)
+        _dw(K, dxq, aq, lg_["down"], acc)
+        if on_bucket_ready is not None:
+            on_bucket_ready(("layer", i, "down"))
+        dgu = K.swiglu_bwd(_dx(K, dxq, w8.get(K, i, "down")), gu)
+        del aq, gu, dxq
+        dguq = K.fp8_quantize(dgu, E5M2, transposed=lg_["gu"] is not None)
+        del dgu
+        _dw(K, dguq, n2q, lg_["gu"], acc)
+        if on_bucket_ready is not None:
+            on_bucket_ready(("layer", i, "gu"))
+        dn2 = _dx(K, dguq, w8.get(K, i, "gu"))
+        del dguq, n2q
+        dx_mid = K.rmsnorm_bwd(dn2, x_mid, lw["ln2"], rstd2, dx, lg_["ln2"], acc)
+        del dn2, dx
+        dmq = K.fp8_quantize(dx_mid, E5M2, transposed=lg_["o"] is not None)
+        _dw(K, dmq, oq, lg_["o"], acc)
+        do = _dx(K, dmq, w8.get(K, i, "o"))
+        del dmq, oq
+        dqkv = K.attn_bwd(qkv, o, do, lse, B, L, H, Hkv, hd, kmask, scale, True)
+        del do, o
+        K.rope_apply_(dqkv, cos, sin, H + Hkv, hd, backward=True)
+        dqq = K.fp8_quantize(dqkv, E5M2, transposed=lg_["qkv"] is not None)
+        _dw(K, dqq, n1q, lg_["qkv"], acc)
+        if lg_.get("qkv_b") is not None:
+            K.colsum(dqkv, lg_["qkv_b"], acc)
+        dn1 = _dx(K, dqq, w8.get(K, i, "qkv"))
+        del dqkv, dqq, n1q, qkv
+        dx = K.rmsnorm_bwd(dn1, x_in, lw["ln1"], rstd1, dx_mid, lg_["ln1"], acc)
+        del dn1, dx_mid, x_in
+        if on_bucket_ready is not None:
+            on_bucket_ready(("layer", i, "attn"))
+    return dx

@@ -96,6 +96,64 @@ def gemm_nt(a, b, bias=None, act=None, residual=None, out=None, accumulate=False
     return out
 
 
+# ----------------------------------------------------------------------------------------------------------- fp8 linears
+FP8_E4M3, FP8_E5M2 = 0, 1
+_Q_WS = {}
+
+
+class Fp8Tensor:
+    """q uint8 [rows, cols] (row-major fp8), qt uint8 [cols, rows_pad] (transposed copy, zero tail) or None, state fp32[3] on the device
+    = {amax, scale, dequant factor}."""
+    __slots__ = ("q", "qt", "state", "fmt", "rows", "cols")
+
+    def __init__(self, q, qt, state, fmt, rows, cols):
+        self.q, self.qt, self.state, self.fmt, self.rows, self.cols = q, qt, state, fmt, rows, cols
+
+    @property
+    def dequant(self):
+        return self.state[2:3]
+
+
+def fp8_quantize(x, fmt=FP8_E4M3, transposed=True, rowmajor=True):
+    """Per-tensor just-in-time quantisation of a bf16 matrix: q = cvt(clamp(x * FMAX / amax)).  Returns Fp8Tensor."""
+    _chk2d(x, "x")
+    rows, cols = x.shape
+    dev = x.device
+    ws = _Q_WS.get(dev)
+    if ws is None:
+        ws = _Q_WS[dev] = torch.zeros(_L.mantis_fp8_quantize_ws_floats(), dtype=torch.float32, device=dev)
+    rp = (rows + 15) // 16 * 16
+    q = torch.empty((rows, cols), dtype=torch.uint8, device=dev)
+    qt = torch.empty((cols, rp), dtype=torch.uint8, device=dev) if transposed else None
+    state = torch.empty(3, dtype=torch.float32, device=dev)
+    _lib.check(_L.mantis_fp8_quantize(_p(x), rows, cols, x.stride(0), fmt, _p(q), cols, _p(qt), rp, _p(state), _p(ws), _stream()),
+               f"fp8_quantize {rows}x{cols}")
+    return Fp8Tensor(q, qt, state, fmt, rows, cols)
+
+
+def gemm_fp8_nt(a8, a_dequant, b8, b_dequant, fmt_a=FP8_E4M3, bias=None, residual=None, out=None, accumulate=False, k=None, variant=0):
+    """out[M,N] bf16 = epi(dequant_a * dequant_b * a8[M,K] . b8[N,K]^T); a8 / b8 uint8 row-major fp8 (b8 e4m3)."""
+    M, K = a8.shape
+    N = b8.shape[0]
+    K = K if k is None else k
+    if out is None:
+        out = torch.empty((M, N), dtype=BF16, device=a8.device)
+    flags = (1 if bias is not None else 0) | (16 if residual is not None else 0) | (32 if accumulate else 0) | (variant << 8)
+    prof = KERNEL_TIMER
+    if prof is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = _L.mantis_gemm_fp8_nt(_p(a8), a8.stride(0), _p(b8), b8.stride(0), _p(out), out.stride(0), M, N, K, _p(a_dequant), _p(b_dequant),
+                               fmt_a, _p(bias), _p(residual), 0 if residual is None else residual.stride(0), flags, _stream())
+    _lib.check(rc, f"gemm_fp8 M={M} N={N} K={K}")
+    if prof is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        prof.append(("gemm_fp8_nt_kernel", 2.0 * M * N * K, 1.0 * (M * K + N * K) + 2.0 * M * N * (1 + (residual is not None) + bool(accumulate)),
+                     e0, e1))
+    return out
+
+
 def transpose(x, rpad=None):
     """[R, C] -> [C, Rpad] (Rpad = R rounded up to 8, zero filled)."""
     _chk2d(x, "x")

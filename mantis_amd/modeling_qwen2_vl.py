@@ -14,6 +14,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import decoder as D
+from . import decoder_fp8 as D8
 from . import hip_ops as K   # tests may monkeypatch `modeling_qwen2_vl.K` with the oracle's operators to test the host logic
 from .arena import ArenaModule
 from .configuration_qwen2_vl import Qwen2VLConfig
@@ -88,6 +89,7 @@ class Qwen2VLForConditionalGeneration(ArenaModule):
         self.config = config
         self.image_token_id = config.image_token_id
         self.vocab_size = config.vocab_size
+        self.precision = "bf16"
         self._init_arena(_param_specs(config), device, dtype)
         self.engine = Qwen2VLEngine(self)
         self._build_views()
@@ -156,6 +158,21 @@ class Qwen2VLForConditionalGeneration(ArenaModule):
                 for a in range(0, flat.numel(), step):
                     b = min(flat.numel(), a + step)
                     flat[a:b] = torch.randn(b - a, generator=gen, device=self.device, dtype=torch.float32).mul_(std)
+
+    def set_precision(self, precision):
+        """"bf16": every linear on the bf16 MFMA GEMM (the reference's arithmetic).  "fp8": the decoder layers' linears (forward, dX,
+        dW) on the fp8 MFMA GEMM with per-tensor e4m3 / e5m2 scaling (BASELINE configs[4]); tower, merger, lm_head stay bf16."""
+        if precision not in ("bf16", "fp8"):
+            raise ValueError(f"precision {precision!r}")
+        tc = self.config.text_config
+        if precision == "fp8":
+            dims = (tc.hidden_size, tc.intermediate_size, tc.num_attention_heads * tc.head_dim,
+                    (tc.num_attention_heads + 2 * tc.num_key_value_heads) * tc.head_dim)
+            if any(v % 16 for v in dims):
+                raise NotImplementedError(f"fp8 linears need every projection width to be a multiple of 16, got {dims}")
+        self.precision = precision
+        self.engine.w8 = D8.Fp8Weights(self.lm) if precision == "fp8" else None
+        return self
 
     def get_input_embeddings(self):
         return self.model.language_model.embed_tokens
@@ -275,6 +292,10 @@ class Qwen2VLEngine:
         self.m = model
         self.cfg = model.config
         self._verified = False
+        self.w8 = None                       # Fp8Weights when model.precision == "fp8"
+        # set by MantisHipTrainer before every micro-batch: True on the 2nd.. micro-batch of an accumulation window (no optimizer step
+        # since the last one), so the fp8 weight copies are reused; any other caller gets a fresh quantisation every step
+        self.weights_unchanged = False
 
     def step_from_batch(self, inputs, **kw):
         return self.step(inputs["input_ids"], inputs["attention_mask"], inputs.get("labels"), inputs.get("pixel_values"),
@@ -381,7 +402,14 @@ class Qwen2VLEngine:
         sec = torch.repeat_interleave(torch.arange(3, dtype=torch.int32), torch.tensor(tc.rope_parameters["mrope_section"])).to(dev)
         rope = K.rope_table_sections(pos3.reshape(3, B * T).to(dev), D.inv_freq(tc.head_dim, tc.rope_theta).to(dev), sec)
         kmask = plan.kmask
-        x, dctx = D.decoder_forward(K, m.lm, tc, x, B, T, None, kmask, None, compute_grads, record, rope=rope)
+        fp8 = self.w8 is not None
+        if fp8:
+            if not self.weights_unchanged:
+                self.w8.refresh()
+            self.weights_unchanged = False
+            x, dctx = D8.decoder_forward(K, m.lm, self.w8, tc, x, B, T, kmask, compute_grads, record, rope=rope)
+        else:
+            x, dctx = D.decoder_forward(K, m.lm, tc, x, B, T, None, kmask, None, compute_grads, record, rope=rope)
         loss, count, logits_full, hctx = D.head_and_loss(K, m.lm, tc, x, plan, B, T, labels is not None, grad_scale, loss_scale,
                                                          compute_grads, need_logits, record)
         if count is not None and not self._verified:
@@ -393,7 +421,10 @@ class Qwen2VLEngine:
             return out
         acc = not overwrite_grads
         g = m.grads
-        dx = D.decoder_backward(K, m.lm, g, m.grads_layers, tc, dctx, hctx, plan, B, T, kmask, None, None, acc, on_bucket_ready)
+        if fp8:
+            dx = D8.decoder_backward(K, m.lm, self.w8, g, m.grads_layers, tc, dctx, hctx, plan, B, T, kmask, acc, on_bucket_ready)
+        else:
+            dx = D.decoder_backward(K, m.lm, g, m.grads_layers, tc, dctx, hctx, plan, B, T, kmask, None, None, acc, on_bucket_ready)
         if g.get("embed") is not None:
             if overwrite_grads:
                 g["embed"].zero_()

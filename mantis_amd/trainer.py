@@ -43,6 +43,9 @@ class MantisHipTrainer:
         inputs = self._prepare_inputs(inputs)
         ga = max(1, int(self.current_gradient_accumulation_steps))
         overwrite = model._ensure_grad_arena()
+        if hasattr(model.engine, "weights_unchanged"):
+            # 2nd.. micro-batch of an accumulation window: no optimizer step since the previous one (fp8 weight copies can be reused)
+            model.engine.weights_unchanged = self._micro > 0
         self._micro += 1
         boundary = (self._micro % ga == 0) if sync is None else bool(sync)
         if boundary:

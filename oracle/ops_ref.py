@@ -51,6 +51,54 @@ def gemm_nt(a, b, bias=None, act=None, residual=None, out=None, accumulate=False
     return out
 
 
+# ---- fp8 linears: exact restatement of csrc/gemm_fp8.hip's arithmetic (same scales, same round-to-nearest-even conversion)
+FP8_E4M3, FP8_E5M2 = 0, 1
+_F8 = {0: (torch.float8_e4m3fn, 448.0), 1: (torch.float8_e5m2, 57344.0)}
+
+
+class Fp8Tensor:
+    def __init__(self, q, qt, state, fmt, rows, cols):
+        self.q, self.qt, self.state, self.fmt, self.rows, self.cols = q, qt, state, fmt, rows, cols
+
+    @property
+    def dequant(self):
+        return self.state[2:3]
+
+
+def fp8_quantize(x, fmt=FP8_E4M3, transposed=True, rowmajor=True):
+    dt, fmax = _F8[fmt]
+    xf = _f(x)
+    amax = xf.abs().max()
+    fm = torch.tensor(fmax, dtype=torch.float32)
+    sc = fm / amax if float(amax) > 0 else torch.tensor(1.0)
+    dq = amax / fm if float(amax) > 0 else torch.tensor(1.0)
+    q = (xf * sc).clamp(-fmax, fmax).to(dt).view(torch.uint8)
+    rows, cols = x.shape
+    qt = None
+    if transposed:
+        rp = (rows + 15) // 16 * 16
+        qt = torch.zeros((cols, rp), dtype=torch.uint8)
+        qt[:, :rows] = q.t()
+    return Fp8Tensor(q, qt, torch.stack([amax, sc, dq]).float(), fmt, rows, cols)
+
+
+def gemm_fp8_nt(a8, a_dequant, b8, b_dequant, fmt_a=FP8_E4M3, bias=None, residual=None, out=None, accumulate=False, k=None, variant=0):
+    K = a8.shape[1] if k is None else k
+    av = a8[:, :K].view(_F8[fmt_a][0]).float()
+    bv = b8[:, :K].view(_F8[0][0]).float()
+    y = (av @ bv.t()) * (a_dequant.float() * b_dequant.float())
+    if bias is not None:
+        y = y + _f(bias)
+    if residual is not None:
+        y = y.to(torch.bfloat16).float() + _f(residual)
+    if out is None:
+        return y.to(torch.bfloat16)
+    if accumulate:
+        y = y + _f(out)
+    out.copy_(y.to(out.dtype))
+    return out
+
+
 def transpose(x, rpad=None):
     Rr, C = x.shape
     Rp = pad8(Rr) if rpad is None else rpad

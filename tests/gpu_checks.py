@@ -893,6 +893,85 @@ def check_qwen2vl_full_width():
     return close(model.grad_arena, 2 * g1.float(), 5e-3, "accumulated gradients = 2x")
 
 
+# ------------------------------------------------------------------------------------------------------------- fp8 linears (row f3)
+def check_fp8_quantize(rows, cols, fmt, scale=1.0):
+    """The quantiser is integer/byte work once the scale is fixed: row-major bytes, transposed bytes (zero tail) and the three state
+    floats must EQUAL the oracle's restatement (torch float8 round-to-nearest-even on the same fp32 products)."""
+    k = K()
+    x = rnd(rows, cols, seed=rows + cols + fmt, scale=scale)
+    x[0, 0] = 0.0
+    ref = R.fp8_quantize(x, fmt)
+    got = k.fp8_quantize(x.to(DEV), fmt)
+    assert torch.equal(got.state.cpu(), ref.state), (got.state.cpu().tolist(), ref.state.tolist())
+    bad = int((got.q.cpu() != ref.q).sum())
+    assert bad == 0, f"fp8 quantize {rows}x{cols} fmt {fmt}: {bad} bytes differ"
+    assert torch.equal(got.qt.cpu(), ref.qt), "transposed copy differs"
+    z = k.fp8_quantize(torch.zeros(16, 32, dtype=BF, device=DEV), fmt)          # all-zero tensor: scale 1, no NaN
+    assert z.state.cpu().tolist() == [0.0, 1.0, 1.0] and not z.q.any()
+    return 0.0
+
+
+def check_fp8_gemm(M, N, K_, fmt_a, epi, variant):
+    """fp8 MFMA GEMM vs the oracle's restatement on IDENTICAL fp8 bytes (only the fp32 accumulation order differs), plus the size of the
+    quantisation error itself against the unquantised product (documented, bounded)."""
+    k = K()
+    a, b = rnd(M, K_, seed=M + K_), rnd(N, K_, seed=N + K_ + 1, scale=0.05)
+    aq, bq = R.fp8_quantize(a, fmt_a, transposed=False), R.fp8_quantize(b, 0, transposed=False)
+    bias = rnd(N, seed=3) if "bias" in epi else None
+    res = rnd(M, N, seed=4) if "res" in epi else None
+    c0 = rnd(M, N, seed=5) if "acc" in epi else None
+    ref = R.gemm_fp8_nt(aq.q, aq.dequant, bq.q, bq.dequant, fmt_a, bias=bias, residual=res, out=None if c0 is None else c0.clone(),
+                        accumulate=c0 is not None)
+    out = k.gemm_fp8_nt(aq.q.to(DEV), aq.dequant.to(DEV), bq.q.to(DEV), bq.dequant.to(DEV), fmt_a, bias=None if bias is None else bias.to(DEV),
+                        residual=None if res is None else res.to(DEV), out=None if c0 is None else c0.to(DEV), accumulate=c0 is not None,
+                        variant=variant)
+    r = close(out, ref, 5e-3, f"gemm_fp8 {M}x{N}x{K_} fmt_a={fmt_a} {epi} v{variant}")
+    if epi == "plain":
+        exact = a.float() @ b.float().t()
+        qerr = rel(out, exact)
+        assert qerr < (0.06 if fmt_a == 0 else 0.10), f"fp8 quantisation error {qerr:.3f} out of the expected range"
+    return r
+
+
+FP8_GEMM_CASES = [(128, 128, 128, 0, "plain", 1), (256, 256, 256, 0, "plain", 2), (300, 200, 80, 0, "plain", 1), (300, 520, 1008, 1, "plain", 2),
+                  (77, 40, 16, 1, "plain", 1), (1000, 777, 2048, 0, "bias", 2), (520, 300, 144, 1, "res", 1), (260, 260, 400, 1, "acc", 2),
+                  (333, 130, 640, 0, "bias+res", 0), (4096, 3584, 3584, 0, "plain", 0), (3584, 4608, 4096, 1, "acc", 0)]
+
+
+def check_qwen2vl_step_fp8(case):
+    """The Qwen2-VL step with the decoder linears on the fp8 MFMA GEMM (BASELINE configs[4]): (1) vs the SAME step run through the
+    oracle's exact restatement of the fp8 arithmetic (tight: only bf16-level differences upstream of a quantiser can flip a rounding);
+    (2) vs the fp32 oracle of the reference within the fp8 tolerance: loss 1e-2, activations 0.15 relative L2, every gradient cosine
+    >= 0.95 (e4m3 activations / weights, e5m2 gradients, per-tensor scales)."""
+    import mantis_amd.modeling_qwen2_vl as mod
+    z = Hh.load_case(case)
+    model = Hh.build_qwen2vl_product(DEV).set_precision("fp8")
+    assert model._ensure_grad_arena()
+    rec = {}
+    out = model.engine.step_from_batch(Hh.qwen2vl_batch(z), compute_grads=True, overwrite_grads=True, need_logits=True, record=rec)
+    torch.cuda.synchronize()
+    # (2) fp32 oracle, fp8 tolerance
+    rep = Hh.check_qwen2vl_step_against_oracle(model, Hh.build_qwen2vl_oracle_bf16(), z, out, rec, loss_rtol=1e-2, grad_cos=0.95,
+                                               grad_rel=0.35, act_rel=0.15)
+    # (1) the emulated fp8 step on the CPU
+    emu = Hh.build_qwen2vl_product("cpu").set_precision("fp8")
+    emu._ensure_grad_arena()
+    saved_k = mod.K
+    mod.K = R
+    try:
+        eout = emu.engine.step_from_batch(Hh.qwen2vl_batch(z), compute_grads=True, overwrite_grads=True, need_logits=True)
+    finally:
+        mod.K = saved_k
+    assert abs(float(out["loss"].cpu()) - float(eout["loss"])) <= 3e-3 * float(eout["loss"])
+    worst = 1.0
+    for (n, p), (_, pe) in zip(model.named_parameters(), emu.named_parameters()):
+        if p.requires_grad:
+            c = Hh.cosine(p.grad.float().cpu().numpy(), pe.grad.float().numpy())
+            assert c > 0.99, (n, c)
+            worst = min(worst, c)
+    return 1.0 - worst
+
+
 def check_norm_overlap():
     """The gradient-norm pass taken bucket by bucket on a side stream during the backward (MantisHipTrainer(optimizer=...)) gives the
     same global norm as the separate pass over the whole arena, and the same parameters after the step."""
@@ -1086,6 +1165,13 @@ def all_checks():
     c["idefics2_full_width"] = check_idefics2_full_width
     for case in QWEN2VL_CASES:
         c["qwen2vl_step_" + case[8:]] = (lambda case=case: check_qwen2vl_step(case))
+    for (r_, c_, f_, sc_) in [(64, 64, 0, 1.0), (300, 208, 0, 3.0), (4096, 3584, 0, 0.02), (1000, 4608, 1, 1e-3), (77, 16, 1, 50.0),
+                              (37888, 3584, 0, 0.02)]:
+        c[f"fp8_quantize_{r_}x{c_}_fmt{f_}"] = (lambda r_=r_, c_=c_, f_=f_, sc_=sc_: check_fp8_quantize(r_, c_, f_, sc_))
+    for a in FP8_GEMM_CASES:
+        c["fp8_gemm_" + "_".join(map(str, a))] = (lambda a=a: check_fp8_gemm(*a))
+    for case in QWEN2VL_CASES:
+        c["qwen2vl_fp8_step_" + case[8:]] = (lambda case=case: check_qwen2vl_step_fp8(case))
     c["rope_sections_cast_pad"] = check_rope_sections
     c["qwen2vl_full_width"] = check_qwen2vl_full_width
     c["pack_segments_random"] = check_pack_segments_random
