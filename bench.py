@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_SAMPLE = 1.351e14      # SURVEY.md section 8d (ViT fwd x1, projector + LLM fwd+bwd x3, causal attention at 1/2)
 PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_FP8_TFLOPS = 5000.0        # MI355X dense fp8 MFMA (MX-scaled K = 64 / 128 forms; MI355X_MICROARCH.md)
 PMC_JSON = os.path.join(ROOT, "profiles", "r02_pmc_step.json")   # tools/pmc_step_report.py output (offline PMC passes, tracked)
 
 
@@ -265,7 +266,7 @@ def main():
         img_hw = cfg.vision_config.image_size
         model = LlavaForConditionalGeneration(cfg, device=f"cuda:{local_rank}", seed=0)      # same seed -> identical replicas
         flop_per_sample = FLOP_PER_SAMPLE
-    precision = args.precision or "bf16"
+    precision = args.precision or ("fp8" if qwen else "bf16")
     if precision == "fp8":
         if not hasattr(model, "set_precision"):
             raise SystemExit(f"--precision fp8 is implemented on the Qwen2-VL path only (config {args.config})")
@@ -363,8 +364,24 @@ def main():
             tot_by = sum(b for _, _, b, _, _ in timer)
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
             gf = (pmc or {}).get("gemm_family") or {}
-            roof = dict(bound="mfma", kernel="gemm_nt_ring_kernel + gemm_nt_kernel (bf16 MFMA GEMM family, csrc/gemm.hip)", achieved=round(ach, 1),
-                        peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4),
+            kname, peak = "gemm_nt_ring_kernel + gemm_nt_kernel (bf16 MFMA GEMM family, csrc/gemm.hip)", PEAK_BF16_TFLOPS
+            bf16_family = None
+            if precision == "fp8":
+                # dominant kernel of this configuration: the fp8 MFMA GEMM (decoder linears); the bf16 family (tower, merger, lm_head)
+                # is reported beside it
+                f8 = [x for x in timer if x[0] == "gemm_fp8_nt_kernel"]
+                b16 = [x for x in timer if x[0] != "gemm_fp8_nt_kernel"]
+                b_ms = sum(e0.elapsed_time(e1) for _, _, _, e0, e1 in b16)
+                bf16_family = dict(achieved=round(sum(x[1] for x in b16) / (b_ms * 1e-3) / 1e12, 1), peak=PEAK_BF16_TFLOPS,
+                                   launches_per_step=len(b16) // args.steps, gemm_ms_per_step=round(b_ms / args.steps, 1))
+                timer = f8
+                tot_ms = sum(e0.elapsed_time(e1) for _, _, _, e0, e1 in timer)
+                tot_fl = sum(f for _, f, _, _, _ in timer)
+                tot_by = sum(b for _, _, b, _, _ in timer)
+                ach = tot_fl / (tot_ms * 1e-3) / 1e12
+                kname, peak = "gemm_fp8_nt_kernel (fp8 e4m3/e5m2 MFMA GEMM, csrc/gemm_fp8.hip)", PEAK_FP8_TFLOPS
+            roof = dict(bound="mfma", kernel=kname, achieved=round(ach, 1),
+                        peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4), bf16_gemm_family=bf16_family,
                         traffic=gf.get("traffic_bytes_per_launch"),
                         traffic_note=None if not gf else "bytes/launch on the L2 memory side (Infinity-Cache hits included), rocprofv3 PMC passes of "
                         "this command summarised in profiles/r02_pmc_step.json by tools/pmc_step_report.py",
@@ -400,7 +417,8 @@ def main():
                    ms_training_step_p10=round(_pct(ts_ms, 0.1), 2), ms_training_step_p90=round(_pct(ts_ms, 0.9), 2),
                    ms_optimizer=round(_pct([e[1].elapsed_time(e[2]) for e in split], 0.5), 2) if opt is not None else None,
                    samples_per_s_training_step_only=round(world * B / (1e-3 * _pct(ts_ms, 0.5)), 4),
-                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="bf16",
+                   higher_is_better=True, scaling="weak", vs_baseline=None,
+                   dtype="bf16" if precision == "bf16" else "fp8 (e4m3 activations/weights, e5m2 gradients in the decoder linears; bf16 elsewhere)",
                    data="synthetic" + ("" if args.recycle_batches else " (fresh batch every step)"),
                    loss=round(loss_vals[-1], 4), loss_first_timed=round(loss_vals[0], 4), loss_after_warmup=first_loss,
                    loss_min=round(min(loss_vals), 4), loss_max=round(max(loss_vals), 4),

@@ -939,10 +939,11 @@ FP8_GEMM_CASES = [(128, 128, 128, 0, "plain", 1), (256, 256, 256, 0, "plain", 2)
 
 
 def check_qwen2vl_step_fp8(case):
-    """The Qwen2-VL step with the decoder linears on the fp8 MFMA GEMM (BASELINE configs[4]): (1) vs the SAME step run through the
-    oracle's exact restatement of the fp8 arithmetic (tight: only bf16-level differences upstream of a quantiser can flip a rounding);
-    (2) vs the fp32 oracle of the reference within the fp8 tolerance: loss 1e-2, activations 0.15 relative L2, every gradient cosine
-    >= 0.95 (e4m3 activations / weights, e5m2 gradients, per-tensor scales)."""
+    """The Qwen2-VL step with the decoder linears on the fp8 MFMA GEMM (BASELINE configs[4]): (1) vs the fp32 oracle of the reference
+    within the fp8 tolerance: loss 1e-2, activations 0.15 relative L2, every gradient cosine >= 0.95 (e4m3 activations / weights, e5m2
+    gradients, per-tensor scales); (2) vs the SAME step run through the oracle's exact restatement of the fp8 arithmetic: loss 3e-3,
+    gradient cosine >= 0.97 (bf16-level differences upstream of a quantiser flip individual fp8 roundings, so deep quantities agree to
+    fp8 noise, not to bf16 noise; the per-kernel checks fp8_quantize_* / fp8_gemm_* are the exact ones)."""
     import mantis_amd.modeling_qwen2_vl as mod
     z = Hh.load_case(case)
     model = Hh.build_qwen2vl_product(DEV).set_precision("fp8")
@@ -950,10 +951,10 @@ def check_qwen2vl_step_fp8(case):
     rec = {}
     out = model.engine.step_from_batch(Hh.qwen2vl_batch(z), compute_grads=True, overwrite_grads=True, need_logits=True, record=rec)
     torch.cuda.synchronize()
-    # (2) fp32 oracle, fp8 tolerance
+    # (1) fp32 oracle, fp8 tolerance
     rep = Hh.check_qwen2vl_step_against_oracle(model, Hh.build_qwen2vl_oracle_bf16(), z, out, rec, loss_rtol=1e-2, grad_cos=0.95,
                                                grad_rel=0.35, act_rel=0.15)
-    # (1) the emulated fp8 step on the CPU
+    # (2) the emulated fp8 step on the CPU
     emu = Hh.build_qwen2vl_product("cpu").set_precision("fp8")
     emu._ensure_grad_arena()
     saved_k = mod.K
