@@ -201,13 +201,33 @@ static int launch_fp8(hipStream_t s, const unsigned char* A, const unsigned char
 }
 
 // ---------------------------------------------------------------------------------------------------------------- quantisers
-#define Q_PARTS 256
+#define Q_PARTS 2048
 // pass 1: per-workgroup maxima of |x| (bf16 bit patterns compare like unsigned integers once the sign is cleared)
 __global__ __launch_bounds__(256) void fp8_amax_kernel(const bf16_t* __restrict__ x, long rows, int cols, long ld, float* __restrict__ parts) {
     const int cpr = cols >> 3;
     const long total = rows * cpr;
     unsigned int mx = 0;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long stride = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    // four independent 16-B loads in flight per lane (HBM-bound: 2048 workgroups x 4 waves x 4 loads cover the latency)
+    for (; i + 3 * stride < total; i += 4 * stride) {
+        u32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long j = i + u * stride;
+            const long r = j / cpr;
+            v[u] = *reinterpret_cast<const u32x4*>(x + r * ld + (j - r * cpr) * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned int lo = (v[u][e] << 16) & 0x7fff0000u, hi = v[u][e] & 0x7fff0000u;
+                mx = mx > lo ? mx : lo;
+                mx = mx > hi ? mx : hi;
+            }
+    }
+    for (; i < total; i += stride) {
         const long r = i / cpr;
         const int c = (int)(i - r * cpr);
         const u32x4 v = *reinterpret_cast<const u32x4*>(x + r * ld + c * 8);
@@ -245,19 +265,26 @@ __device__ __forceinline__ unsigned int cvt4(float a, float b, float c, float d)
     return (unsigned int)w;
 }
 
-// pass 2: scale = FMAX / amax; q = cvt(clamp(x * scale)); row-major copy and (optionally) the transposed copy through a 64 x 64 LDS tile.
-// state[0] = amax, state[1] = scale, state[2] = amax / FMAX (the dequant factor the GEMM epilogue reads).
-#define QT_PITCH 68
+// pass 2: scale = FMAX / amax; q = cvt(clamp(x * scale)); row-major copy and (optionally) the transposed copy through a 128 x 128 LDS
+// tile, so both outputs are written in whole 128-B row segments.  state[0] = amax, state[1] = scale, state[2] = amax / FMAX (the
+// dequant factor the GEMM epilogue reads).
+#define QT_TILE 128
+#define QT_PITCH 132
 template <int FMT>
 __global__ __launch_bounds__(256) void fp8_cast_kernel(const bf16_t* __restrict__ x, long rows, int cols, long ld,
                                                        const float* __restrict__ parts, unsigned char* __restrict__ q, long ldq,
                                                        unsigned char* __restrict__ qt, long ldt, long rows_pad, float* __restrict__ state) {
     __shared__ float s_scale;
     __shared__ unsigned int sm[4];
-    __shared__ __attribute__((aligned(16))) unsigned char tile[64 * QT_PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned char tile[QT_TILE * QT_PITCH];
     const float FMAX = FMT == F8_FMT_E4M3 ? 448.f : 57344.f;
     {
-        unsigned int mx = __float_as_uint(parts[threadIdx.x]);
+        unsigned int mx = 0;
+#pragma unroll
+        for (int u = 0; u < Q_PARTS / 256; ++u) {
+            const unsigned int y = __float_as_uint(parts[threadIdx.x + 256 * u]);
+            mx = mx > y ? mx : y;
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const unsigned int y = (unsigned int)__shfl_xor((int)mx, o);
@@ -279,43 +306,55 @@ __global__ __launch_bounds__(256) void fp8_cast_kernel(const bf16_t* __restrict_
         __syncthreads();
     }
     const float sc = s_scale;
-    const long r0 = (long)blockIdx.y * 64;
-    const int c0 = blockIdx.x * 64;
+    const long r0 = (long)blockIdx.y * QT_TILE;
+    const int c0 = blockIdx.x * QT_TILE;
     const int t = threadIdx.x;
     {
-        const int rl = t >> 2, cc = (t & 3) * 16;
-        const long r = r0 + rl;
+        const int cc = (t & 7) * 16;               // 8 lanes x 16 columns = one 128-B row segment of the fp8 output
         const int c = c0 + cc;
-        unsigned int w[4] = {0u, 0u, 0u, 0u};
-        if (r < rows && c < cols) {           // cols % 16 == 0: a 16-column group is either fully inside or fully outside
-            const u32x4 v0 = *reinterpret_cast<const u32x4*>(x + r * ld + c);
-            const u32x4 v1 = *reinterpret_cast<const u32x4*>(x + r * ld + c + 8);
-            float f[16];
+        u32x4 v0[4], v1[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                f[2 * e] = bf2f_lo(v0[e]), f[2 * e + 1] = bf2f_hi(v0[e]);
-                f[8 + 2 * e] = bf2f_lo(v1[e]), f[8 + 2 * e + 1] = bf2f_hi(v1[e]);
+        for (int u = 0; u < 4; ++u) {
+            const long r = r0 + (t >> 3) + 32 * u;
+            if (r < rows && c < cols) {            // cols % 16 == 0: a 16-column group is either fully inside or fully outside
+                v0[u] = *reinterpret_cast<const u32x4*>(x + r * ld + c);
+                v1[u] = *reinterpret_cast<const u32x4*>(x + r * ld + c + 8);
             }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) f[e] = fminf(fmaxf(f[e] * sc, -FMAX), FMAX);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) w[e] = cvt4<FMT>(f[4 * e], f[4 * e + 1], f[4 * e + 2], f[4 * e + 3]);
-            u32x4 o;
-            o[0] = w[0], o[1] = w[1], o[2] = w[2], o[3] = w[3];
-            *reinterpret_cast<u32x4*>(q + r * ldq + c) = o;
         }
-        if (qt != nullptr) {
-            unsigned int* tp = reinterpret_cast<unsigned int*>(tile + rl * QT_PITCH + cc);
-            tp[0] = w[0], tp[1] = w[1], tp[2] = w[2], tp[3] = w[3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rl = (t >> 3) + 32 * u;
+            const long r = r0 + rl;
+            unsigned int w[4] = {0u, 0u, 0u, 0u};
+            if (r < rows && c < cols) {
+                float f[16];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    f[2 * e] = bf2f_lo(v0[u][e]), f[2 * e + 1] = bf2f_hi(v0[u][e]);
+                    f[8 + 2 * e] = bf2f_lo(v1[u][e]), f[8 + 2 * e + 1] = bf2f_hi(v1[u][e]);
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) f[e] = fminf(fmaxf(f[e] * sc, -FMAX), FMAX);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = cvt4<FMT>(f[4 * e], f[4 * e + 1], f[4 * e + 2], f[4 * e + 3]);
+                u32x4 o;
+                o[0] = w[0], o[1] = w[1], o[2] = w[2], o[3] = w[3];
+                *reinterpret_cast<u32x4*>(q + r * ldq + c) = o;
+            }
+            if (qt != nullptr) {
+                unsigned int* tp = reinterpret_cast<unsigned int*>(tile + rl * QT_PITCH + cc);
+                tp[0] = w[0], tp[1] = w[1], tp[2] = w[2], tp[3] = w[3];
+            }
         }
     }
     if (qt == nullptr) return;
     __syncthreads();
-    {
-        const int cl = t >> 2, rr = (t & 3) * 16;       // output row = source column c0 + cl; 16 source rows r0 + rr ..
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int cl = (t >> 3) + 32 * u, rr = (t & 7) * 16;     // output row = source column c0 + cl; 16 source rows r0 + rr ..
         const int c = c0 + cl;
         const long r = r0 + rr;
-        if (c < cols && r < rows_pad) {                 // rows_pad % 16 == 0; source rows >= rows were written as zeros above
+        if (c < cols && r < rows_pad) {                          // rows_pad % 16 == 0; source rows >= rows were staged as zeros
             unsigned int w[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -347,7 +386,7 @@ int mantis_fp8_quantize(const void* x, int64_t rows, int cols, int64_t ld, int f
     if (qt != nullptr && (ldt % 16 || ldt < rows_pad)) return MANTIS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(fp8_amax_kernel, dim3(Q_PARTS), dim3(256), 0, s, (const bf16_t*)x, (long)rows, cols, (long)ld, workspace);
-    const dim3 grid(cdiv(cols, 64), cdiv(rows_pad, 64));
+    const dim3 grid(cdiv(cols, QT_TILE), cdiv(rows_pad, QT_TILE));
     if (grid.y > 65535) return MANTIS_EUNSUPPORTED;
     if (fmt == 0)
         hipLaunchKernelGGL(fp8_cast_kernel<F8_FMT_E4M3>, grid, dim3(256), 0, s, (const bf16_t*)x, (long)rows, cols, (long)ld, workspace,

@@ -968,7 +968,7 @@ def check_qwen2vl_step_fp8(case):
     for (n, p), (_, pe) in zip(model.named_parameters(), emu.named_parameters()):
         if p.requires_grad:
             c = Hh.cosine(p.grad.float().cpu().numpy(), pe.grad.float().numpy())
-            assert c > 0.99, (n, c)
+            assert c > 0.97, (n, c)
             worst = min(worst, c)
     return 1.0 - worst
 
