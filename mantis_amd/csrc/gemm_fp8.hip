@@ -123,6 +123,84 @@ __device__ __forceinline__ void f8_epilogue(f32x16 (&acc)[TN][TM], bf16_t* __res
     }
 }
 
+// Coalesced epilogue (same scheme as the bf16 ring kernel, csrc/gemm.hip): the MFMA layout gives every lane ONE output row, so storing
+// from registers touches 32 rows x 8 B per instruction.  Instead every wave transposes its tile through a wave-private LDS strip, 64
+// rows x 64 fp32 per pass (row pitch 272 B: conflict-free ds_write_b128), and reads it back as 8 lanes per row x 8 columns per lane:
+// bias / residual / accumulate run on 16-B vectors and every global instruction covers whole 128-B lines.  Arithmetic and rounding
+// order are those of f8_epilogue (bit-identical).
+#define F8_EPI_PITCH 272
+#define F8_EPI_STRIP (64 * F8_EPI_PITCH)
+template <int TM, int TN>
+__device__ __forceinline__ void f8_epilogue_lds(f32x16 (&acc)[TN][TM], char* __restrict__ strip, bf16_t* __restrict__ C, int M, int N,
+                                                long ldc, float scale, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
+                                                long ldr, int flags, int mw0, int nw0, int lane) {
+    static_assert(TN == 2 && (TM % 2) == 0, "strip is 64 columns wide, two 32-row blocks per pass");
+    const bool vec_ok = !(ldc & 7) && !((uintptr_t)C & 15) && (!(flags & F8_EPI_RESIDUAL) || (!(ldr & 7) && !((uintptr_t)res & 15)));
+    const int rr = lane >> 3, cc = lane & 7;
+    const int n = nw0 + cc * 8;
+#pragma unroll
+    for (int pass = 0; pass < TM / 2; ++pass) {
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 v = {acc[tn][pass * 2 + t2][4 * g4] * scale, acc[tn][pass * 2 + t2][4 * g4 + 1] * scale,
+                                     acc[tn][pass * 2 + t2][4 * g4 + 2] * scale, acc[tn][pass * 2 + t2][4 * g4 + 3] * scale};
+                    *reinterpret_cast<f32x4*>(strip + (t2 * 32 + (lane & 31)) * F8_EPI_PITCH + (tn * 32 + 8 * g4 + 4 * (lane >> 5)) * 4) = v;
+                }
+#pragma unroll 2
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 8 + rr;
+            const int m = mw0 + pass * 64 + row;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(strip + row * F8_EPI_PITCH + cc * 32);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(strip + row * F8_EPI_PITCH + cc * 32 + 16);
+            if (m >= M || n >= N) continue;
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            const bool full = vec_ok && (n + 8 <= N);
+            if (flags & F8_EPI_BIAS) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (n + e < N) v[e] += bf2f(bias[n + e]);
+            }
+            bf16_t* cp = C + (long)m * ldc + n;
+            if (full) {
+                if (flags & F8_EPI_RESIDUAL) {
+                    const u32x4 rv = *reinterpret_cast<const u32x4*>(res + (long)m * ldr + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[2 * e] = bf2f(f2bf(v[2 * e])) + bf2f_lo(rv[e]);
+                        v[2 * e + 1] = bf2f(f2bf(v[2 * e + 1])) + bf2f_hi(rv[e]);
+                    }
+                }
+                if (flags & F8_EPI_ACCUM) {
+                    const u32x4 cv = *reinterpret_cast<const u32x4*>(cp);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[2 * e] += bf2f_lo(cv[e]);
+                        v[2 * e + 1] += bf2f_hi(cv[e]);
+                    }
+                }
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+                *reinterpret_cast<u32x4*>(cp) = o;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (n + e < N) {
+                        float x = v[e];
+                        if (flags & F8_EPI_RESIDUAL) x = bf2f(f2bf(x)) + bf2f(res[(long)m * ldr + n + e]);
+                        if (flags & F8_EPI_ACCUM) x += bf2f(cp[e]);
+                        cp[e] = f2bf(x);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // FA: format of the A matrix (0 e4m3, 1 e5m2); B is always e4m3 (weights / activations).
 template <int BM, int BN, int WM, int WN, int FA>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_fp8_nt_kernel(
@@ -131,7 +209,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_fp8_nt_kernel
     const bf16_t* __restrict__ res, long ldr, int flags, int tiles_m, int tiles_n) {
     constexpr int NWN = BN / WN, NW = (BM / WM) * NWN, TM = WM / 32, TN = WN / 32;
     constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    constexpr int SMEM = 2 * STAGE > NW * F8_EPI_STRIP ? 2 * STAGE : NW * F8_EPI_STRIP;
+    __shared__ __attribute__((aligned(16))) char smem[SMEM];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / NWN, wn = wave % NWN;
@@ -188,7 +267,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_fp8_nt_kernel
         }
     }
     const float scale = inv_scale_a[0] * inv_scale_b[0];
-    f8_epilogue<TM, TN>(acc, C, M, N, ldc, scale, bias, res, ldr, flags, m0 + wm * WM, n0 + wn * WN, lane);
+    __syncthreads();                   // every wave is done with the last operand stage: the LDS becomes the epilogue strips
+    f8_epilogue_lds<TM, TN>(acc, smem + wave * F8_EPI_STRIP, C, M, N, ldc, scale, bias, res, ldr, flags, m0 + wm * WM, n0 + wn * WN, lane);
 }
 
 template <int BM, int BN, int WM, int WN, int FA>

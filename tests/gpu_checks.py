@@ -953,7 +953,7 @@ def check_qwen2vl_step_fp8(case):
     torch.cuda.synchronize()
     # (1) fp32 oracle, fp8 tolerance
     rep = Hh.check_qwen2vl_step_against_oracle(model, Hh.build_qwen2vl_oracle_bf16(), z, out, rec, loss_rtol=1e-2, grad_cos=0.95,
-                                               grad_rel=0.35, act_rel=0.15)
+                                               grad_rel=0.35, act_rel=0.15, grad_cos_1d=0.85, grad_rel_1d=0.6)
     # (2) the emulated fp8 step on the CPU
     emu = Hh.build_qwen2vl_product("cpu").set_precision("fp8")
     emu._ensure_grad_arena()

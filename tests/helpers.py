@@ -196,8 +196,11 @@ def qwen2vl_batch(z):
     return b
 
 
-def check_qwen2vl_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-3, grad_cos=0.995, grad_rel=6e-2, act_rel=3e-2):
-    """bf16 product path vs the fp32 Qwen2-VL oracle on identical (bf16-rounded) weights."""
+def check_qwen2vl_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-3, grad_cos=0.995, grad_rel=6e-2, act_rel=3e-2,
+                                      grad_cos_1d=None, grad_rel_1d=None):
+    """bf16 product path vs the fp32 Qwen2-VL oracle on identical (bf16-rounded) weights.  grad_cos_1d / grad_rel_1d: separate bar for
+    the 1-D parameters (biases, norm weights) -- the fp8 variant needs it for the key bias, whose gradient is a near-cancelling sum
+    (a constant added to every key only shifts the scores of a query uniformly, up to RoPE) and therefore mostly quantisation noise."""
     orec = {}
     oracle.zero_grad()
     pv = z["pixel_values"] if "pixel_values" in z.files else None
@@ -231,5 +234,6 @@ def check_qwen2vl_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-3
         if np.linalg.norm(og.numpy()) < 1e-12:
             assert np.linalg.norm(g) < 1e-6, name
             continue
-        assert c >= grad_cos and r <= grad_rel, (name, c, r)
+        one_d = p.dim() == 1 and grad_cos_1d is not None
+        assert c >= (grad_cos_1d if one_d else grad_cos) and r <= (grad_rel_1d if one_d else grad_rel), (name, c, r)
     return report
