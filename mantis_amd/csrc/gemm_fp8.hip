@@ -271,6 +271,183 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_fp8_nt_kernel
     f8_epilogue_lds<TM, TN>(acc, smem + wave * F8_EPI_STRIP, C, M, N, ldc, scale, bias, res, ldr, flags, m0 + wm * WM, n0 + wn * WN, lane);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 256x256 "ring" kernel (the schedule of csrc/gemm.hip's bf16 ring kernel on fp8 operands): the whole 160 KiB LDS is a ring of ten
+// 16-KiB slabs (one slab = 128 rows x 128 K-bytes of A or B), i.e. 2.5 K-steps.  Slab (t, p) -- K-step t, part p in {A rows 0-127,
+// B rows 0-127, A rows 128-255, B rows 128-255} -- lives in slot (4t + p) % 10.  DMA = buffer_load_dwordx4 ... lds with a descriptor,
+// per-lane offsets fixed per tile and a scalar K-step offset (no address arithmetic in the loop, out-of-range lanes read zeros).  A
+// K-step is two clusters of eight 64-cycle MFMAs; every memory instruction sits in the shadow of an MFMA (hand-placed asm reads,
+// sched_barrier pins, counted vmcnt / lgkmcnt); the K-step barrier stands in front of the LAST cluster of a step, so the next step's
+// first fragments and the slab refill ride behind it and the data of a step is requested a full K-step before it is needed.
+template <int OFF>
+__device__ __forceinline__ void f8_lds_read_b128(i32x4& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+
+__device__ __forceinline__ i32x8 f8_cat(const i32x4& a, const i32x4& b) {
+    i32x8 r;
+    r[0] = a[0], r[1] = a[1], r[2] = a[2], r[3] = a[3], r[4] = b[0], r[5] = b[1], r[6] = b[2], r[7] = b[3];
+    return r;
+}
+
+template <int FA>
+__global__ __launch_bounds__(512) void gemm_fp8_ring_kernel(
+    const unsigned char* __restrict__ A, const unsigned char* __restrict__ B, bf16_t* __restrict__ C, int M, int N, int K, long lda,
+    long ldb, long ldc, const float* __restrict__ inv_scale_a, const float* __restrict__ inv_scale_b, const bf16_t* __restrict__ bias,
+    const bf16_t* __restrict__ res, long ldr, int flags, int tiles_m, int tiles_n) {
+    constexpr int TM = 4, TN = 2, SLAB = 16384, PPW = 2;   // 8 waves: 2 (M) x 4 (N), each 128 x 64
+    __shared__ __attribute__((aligned(16))) char smem[10 * SLAB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const int nk = (K + 127) / 128;
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int GROUP = 8;
+    const int per_group = GROUP * tiles_n;
+    const int g = tile_id / per_group;
+    const int first_m = g * GROUP;
+    const int gsz = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+    const int in_g = tile_id - g * per_group;
+    const int m0 = (first_m + in_g % gsz) * 256, n0 = (in_g / gsz) * 256;
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)(unsigned)((long)M * lda), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)(unsigned)((long)N * ldb), 0x00020000);
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    unsigned voA[2][PPW], voB[2][PPW];
+    int kc[PPW];                      // K byte (within a K-step) this lane's 16-B chunk starts at, per piece
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int piece = PPW * wave + j;
+        const int rl = lane >> 3, fz = (piece * 4 + (rl >> 1)) & 7, chunk = (lane & 7) ^ fz;
+        kc[j] = chunk * 16;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            int grow = m0 + half * 128 + piece * 8 + rl;
+            grow = grow < M ? grow : M - 1;
+            voA[half][j] = (unsigned)((long)grow * lda + chunk * 16);
+            grow = n0 + half * 128 + piece * 8 + rl;
+            grow = grow < N ? grow : N - 1;
+            voB[half][j] = (unsigned)((long)grow * ldb + chunk * 16);
+        }
+    }
+    auto issue1 = [&](int t, int p, int j) {
+        char* dst = smem + ((4 * t + p) % 10) * SLAB;
+        const int half = p >> 1;
+        const int krem = K - t * 128;              // K bytes of this K-step inside the range (<= 0: the whole step reads zeros)
+        f8_lds_void* d = (f8_lds_void*)(dst + (PPW * wave + j) * 1024);
+        const unsigned so = (unsigned)t * 128u;
+        if (p & 1) {
+            const unsigned vo = (kc[j] < krem) ? voB[half][j] : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, d, 16, vo, so, 0, 0);
+        } else {
+            const unsigned vo = (kc[j] < krem) ? voA[half][j] : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, d, 16, vo, so, 0, 0);
+        }
+    };
+    auto issue = [&](int t, int p) {
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) issue1(t, p, j);
+    };
+    issue(0, 0); issue(0, 1); issue(0, 2); issue(0, 3);
+    issue(1, 0); issue(1, 1); issue(1, 2); issue(1, 3);
+
+    const unsigned rowoff = (unsigned)(lane & 31) * 128u;
+    const unsigned f = ((unsigned)(lane & 31) >> 1) & 7u;
+    unsigned xo[2][2];                // [cluster][half]: 32 consecutive K bytes = chunks 4*ks + 2*kg + {0, 1}
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) xo[ks][h] = rowoff + ((((unsigned)(ks * 4 + (lane >> 5) * 2 + h)) ^ f) << 4);
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    i32x4 fa[2][TM][2], fb[2][TN][2];
+
+    auto slab_base = [&](int t, unsigned& a_base, unsigned& b_base) {
+        a_base = lds0 + (unsigned)((4 * t + 2 * wm) % 10) * SLAB;                                              // A half wm
+        b_base = lds0 + (unsigned)((4 * t + 1 + 2 * (wn >> 1)) % 10) * SLAB + (unsigned)(wn & 1) * 8192u;     // B half wn >> 1, rows (wn & 1) * 64
+    };
+    // the 12 fragment reads of a cluster (6 fragments x 2 halves); op 0-3: B, op 4-11: A
+    auto frag_op = [&](int op, int ks, int buf, unsigned a_base, unsigned b_base) {
+        const int h = op & 1, i = op >> 1;
+        if (i == 0) f8_lds_read_b128<0>(fb[buf][0][h], b_base + xo[ks][h]);
+        else if (i == 1) f8_lds_read_b128<4096>(fb[buf][1][h], b_base + xo[ks][h]);
+        else if (i == 2) f8_lds_read_b128<0>(fa[buf][0][h], a_base + xo[ks][h]);
+        else if (i == 3) f8_lds_read_b128<4096>(fa[buf][1][h], a_base + xo[ks][h]);
+        else if (i == 4) f8_lds_read_b128<8192>(fa[buf][2][h], a_base + xo[ks][h]);
+        else f8_lds_read_b128<12288>(fa[buf][3][h], a_base + xo[ks][h]);
+    };
+    // 12 ops over the 8 MFMA shadows of a cluster: two per slot in the first four, one per slot afterwards
+    auto slot_ops = [&](int i, int ks, int buf, unsigned a_base, unsigned b_base) {
+        if (i < 4) { frag_op(2 * i, ks, buf, a_base, b_base); frag_op(2 * i + 1, ks, buf, a_base, b_base); }
+        else frag_op(4 + i, ks, buf, a_base, b_base);
+    };
+
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // step 0 landed (this wave's pieces); step 1 may be in flight
+    __builtin_amdgcn_s_barrier();
+    {
+        unsigned a0, b0;
+        slab_base(0, a0, b0);
+#pragma unroll
+        for (int op = 0; op < 12; ++op) frag_op(op, 0, 0, a0, b0);
+    }
+    for (int t = 0; t < nk; ++t) {
+        unsigned a_base, b_base, a_next, b_next;
+        slab_base(t, a_base, b_base);
+        slab_base(t + 1, a_next, b_next);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int cb = ks, nb = ks ^ 1;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // fragments of cluster ks (requested a cluster ago)
+            if (ks == 1) {
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // all but step t+2's parts 0,1 (this wave's 4 newest pieces) landed
+                __builtin_amdgcn_s_barrier();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < TN * TM; ++i) {
+                const int tn = i / TM, tm = i % TM;
+                acc[tn][tm] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(f8_cat(fb[cb][tn][0], fb[cb][tn][1]),
+                                                                              f8_cat(fa[cb][tm][0], fa[cb][tm][1]), acc[tn][tm], F8_FMT_E4M3,
+                                                                              FA, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                if (ks == 0) slot_ops(i, 1, nb, a_base, b_base);
+                else slot_ops(i, 0, nb, a_next, b_next);                 // first fragments of step t + 1, behind the barrier
+                // refill: (t+2: 0,1) go to the slabs released one barrier earlier (cluster 0); (t+2: 2,3) right behind the barrier
+                // that released the slabs of step t (needed one step later: a full K-step of lead)
+                if (i >= 4) { const int qq = i - 4; issue1(t + 2, (ks == 0 ? 0 : 2) + (qq >> 1), qq & 1); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // retire the trailing DMA pieces and the last cluster's fragment reads ...
+    __syncthreads();                                   // ... and every wave's fragment reads: the LDS becomes epilogue scratch
+    const float scale = inv_scale_a[0] * inv_scale_b[0];
+    f8_epilogue_lds<TM, TN>(acc, smem + wave * F8_EPI_STRIP, C, M, N, ldc, scale, bias, res, ldr, flags, m0 + wm * 128, n0 + wn * 64, lane);
+}
+
+template <int FA>
+static int launch_fp8_ring(hipStream_t s, const unsigned char* A, const unsigned char* B, bf16_t* C, int M, int N, int K, long lda,
+                           long ldb, long ldc, const float* sa, const float* sb, const bf16_t* bias, const bf16_t* res, long ldr,
+                           int flags) {
+    const int tiles_m = cdiv(M, 256), tiles_n = cdiv(N, 256);
+    hipLaunchKernelGGL((gemm_fp8_ring_kernel<FA>), dim3(tiles_m * tiles_n), dim3(512), 0, s, A, B, C, M, N, K, lda, ldb, ldc, sa, sb, bias,
+                       res, ldr, flags, tiles_m, tiles_n);
+    return mantis_check_launch();
+}
+
 template <int BM, int BN, int WM, int WN, int FA>
 static int launch_fp8(hipStream_t s, const unsigned char* A, const unsigned char* B, bf16_t* C, int M, int N, int K, long lda, long ldb,
                       long ldc, const float* sa, const float* sb, const bf16_t* bias, const bf16_t* res, long ldr, int flags) {
@@ -479,7 +656,7 @@ int mantis_fp8_quantize(const void* x, int64_t rows, int cols, int64_t ld, int f
 
 // C[M,N] bf16 (row stride ldc elements) = epi(dequant_a * dequant_b * A8[M,K] . B8[N,K]^T); lda / ldb in bytes, K % 16 == 0.
 // fmt_a: 0 e4m3 | 1 e5m2; B is e4m3.  flags: 1 bias[n] | 16 + residual[m,n] (stride ldr) | 32 accumulate into C | variant << 8
-// (0 auto, 1 = 128x128 tiles, 2 = 256x256 tiles).  dequant_a / dequant_b: device pointers to state[2] of the quantiser.
+// (0 auto, 1 = 128x128 tiles, 2 = 256x256 tiles, 3 = 256x256 ring kernel).  dequant_a / dequant_b: device pointers to state[2] of the quantiser.
 int mantis_gemm_fp8_nt(const void* A8, int64_t lda, const void* B8, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
                        const float* dequant_a, const float* dequant_b, int fmt_a, const void* bias, const void* residual, int64_t ldr,
                        int flags, void* stream) {
@@ -505,6 +682,13 @@ int mantis_gemm_fp8_nt(const void* A8, int64_t lda, const void* B8, int64_t ldb,
                       : launch_fp8<BM_, BN_, WM_, WN_, 1>(s, (const unsigned char*)A8, (const unsigned char*)B8, (bf16_t*)C, M, N, K,  \
                                                           (long)lda, (long)ldb, (long)ldc, dequant_a, dequant_b, (const bf16_t*)bias,     \
                                                           (const bf16_t*)residual, (long)ldr, f)
+    if (variant == 3) {
+        if ((long)M * lda >= (1L << 32) || (long)N * ldb >= (1L << 32)) return MANTIS_EUNSUPPORTED;     // 32-bit buffer offsets
+        return fmt_a == 0 ? launch_fp8_ring<0>(s, (const unsigned char*)A8, (const unsigned char*)B8, (bf16_t*)C, M, N, K, (long)lda, (long)ldb,
+                                               (long)ldc, dequant_a, dequant_b, (const bf16_t*)bias, (const bf16_t*)residual, (long)ldr, f)
+                          : launch_fp8_ring<1>(s, (const unsigned char*)A8, (const unsigned char*)B8, (bf16_t*)C, M, N, K, (long)lda, (long)ldb,
+                                               (long)ldc, dequant_a, dequant_b, (const bf16_t*)bias, (const bf16_t*)residual, (long)ldr, f);
+    }
     if (variant == 2) { F8_GO(256, 256, 128, 64); }
     if (variant == 1) { F8_GO(128, 128, 64, 64); }
 #undef F8_GO
