@@ -117,10 +117,16 @@ int mantis_gemm_pick_variant(int M, int N, int K);
  * flags 1 bias | 16 residual | 32 accumulate | variant << 8 (0 auto, 1 128x128, 2 256x256). */
 int mantis_fp8_quantize_ws_floats(void);
 int mantis_fp8_quantize(const void* x, int64_t rows, int cols, int64_t ld, int fmt, void* q, int64_t ldq, void* qt, int64_t ldt,
-                        float* state, float* workspace, void* stream);
+                        float* state, float* workspace, const float* amax_in /*nullable: max|x| already taken by x's producer*/,
+                        void* stream);
 int mantis_gemm_fp8_nt(const void* A8, int64_t lda, const void* B8, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
                        const float* dequant_a, const float* dequant_b, int fmt_a, const void* bias, const void* residual, int64_t ldr,
                        int flags, void* stream);
+/* dgu[M, 2N] = swiglu_backward(dequant * A8[M,K] . B8[N,K]^T, gate_up[M, 2N]): dX of down_proj with the SwiGLU backward (autograd of
+ * HF:models/qwen2_vl/modeling_qwen2_vl.py:453-466) in the epilogue; amax_out (nullable) float[1] <- max |dgu| for the next quantiser. */
+int mantis_gemm_fp8_dx_swiglu(const void* A8, int64_t lda, const void* B8, int64_t ldb, void* dgu, int64_t ld_dgu, int M, int N, int K,
+                              const float* dequant_a, const float* dequant_b, int fmt_a, const void* gate_up, int64_t ld_gu,
+                              float* amax_out, void* stream);
 
 /* ---- attention: HF:models/llama/modeling_llama.py:191-214,262-276; HF:models/siglip/modeling_siglip.py:227-247 */
 /* kmask int32 [B,L] (nullable): 1 = key may be attended (key padding).  kstart int32 [B,L] (nullable): packed samples -- query q

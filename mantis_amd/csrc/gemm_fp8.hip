@@ -130,12 +130,17 @@ __device__ __forceinline__ void f8_epilogue(f32x16 (&acc)[TN][TM], bf16_t* __res
 // order are those of f8_epilogue (bit-identical).
 #define F8_EPI_PITCH 272
 #define F8_EPI_STRIP (64 * F8_EPI_PITCH)
-template <int TM, int TN>
+// SWIGLU: C = [dgate | dup][M, 2N] from dact = scale * A.B^T (rounded to bf16 first, as the unfused path stores it) and res = [gate | up]
+// [M, 2N] (SwiGLU backward behind dX = dY . W_down, HF:models/qwen2_vl/modeling_qwen2_vl.py:453-466 autograd); amax_out (nullable): the
+// maximum |value| of everything written (bf16 bit pattern << 16, atomicMax), i.e. exactly what the quantiser's first pass would find.
+template <int TM, int TN, bool SWIGLU = false>
 __device__ __forceinline__ void f8_epilogue_lds(f32x16 (&acc)[TN][TM], char* __restrict__ strip, bf16_t* __restrict__ C, int M, int N,
                                                 long ldc, float scale, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
-                                                long ldr, int flags, int mw0, int nw0, int lane) {
+                                                long ldr, int flags, int mw0, int nw0, int lane, unsigned int* __restrict__ amax_out = nullptr) {
     static_assert(TN == 2 && (TM % 2) == 0, "strip is 64 columns wide, two 32-row blocks per pass");
-    const bool vec_ok = !(ldc & 7) && !((uintptr_t)C & 15) && (!(flags & F8_EPI_RESIDUAL) || (!(ldr & 7) && !((uintptr_t)res & 15)));
+    const bool vec_ok = !(ldc & 7) && !((uintptr_t)C & 15) && (!((flags & F8_EPI_RESIDUAL) || SWIGLU) || (!(ldr & 7) && !((uintptr_t)res & 15)))
+                        && (!SWIGLU || !(N & 7));
+    unsigned int amax = 0;
     const int rr = lane >> 3, cc = lane & 7;
     const int n = nw0 + cc * 8;
 #pragma unroll
@@ -165,6 +170,55 @@ __device__ __forceinline__ void f8_epilogue_lds(f32x16 (&acc)[TN][TM], char* __r
                     if (n + e < N) v[e] += bf2f(bias[n + e]);
             }
             bf16_t* cp = C + (long)m * ldc + n;
+            if constexpr (SWIGLU) {
+                if (full) {
+                    const u32x4 g = *reinterpret_cast<const u32x4*>(res + (long)m * ldr + n);
+                    const u32x4 u = *reinterpret_cast<const u32x4*>(res + (long)m * ldr + N + n);
+                    u32x4 og, ou;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float gv[2] = {bf2f_lo(g[e]), bf2f_hi(g[e])};
+                        const float uv[2] = {bf2f_lo(u[e]), bf2f_hi(u[e])};
+                        float rg[2], ru[2];
+#pragma unroll
+                        for (int h2 = 0; h2 < 2; ++h2) {
+                            const float dv = bf2f(f2bf(v[2 * e + h2]));
+                            const float sg = 1.f / (1.f + __expf(-gv[h2]));
+                            const float silu = gv[h2] * sg;
+                            rg[h2] = dv * uv[h2] * (sg + silu * (1.f - sg));
+                            ru[h2] = dv * silu;
+                        }
+                        og[e] = pack_bf2(rg[0], rg[1]);
+                        ou[e] = pack_bf2(ru[0], ru[1]);
+                        const unsigned int a0 = (og[e] << 16) & 0x7fff0000u, a1 = og[e] & 0x7fff0000u;
+                        const unsigned int a2 = (ou[e] << 16) & 0x7fff0000u, a3 = ou[e] & 0x7fff0000u;
+                        amax = amax > a0 ? amax : a0;
+                        amax = amax > a1 ? amax : a1;
+                        amax = amax > a2 ? amax : a2;
+                        amax = amax > a3 ? amax : a3;
+                    }
+                    *reinterpret_cast<u32x4*>(cp) = og;
+                    *reinterpret_cast<u32x4*>(cp + N) = ou;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        if (n + e < N) {
+                            const float gv = bf2f(res[(long)m * ldr + n + e]), uv = bf2f(res[(long)m * ldr + N + n + e]);
+                            const float dv = bf2f(f2bf(v[e]));
+                            const float sg = 1.f / (1.f + __expf(-gv));
+                            const float silu = gv * sg;
+                            const bf16_t o0 = f2bf(dv * uv * (sg + silu * (1.f - sg))), o1 = f2bf(dv * silu);
+                            cp[e] = o0;
+                            cp[N + e] = o1;
+                            const unsigned int a0 = ((unsigned int)o0 << 16) & 0x7fff0000u, a1 = ((unsigned int)o1 << 16) & 0x7fff0000u;
+                            amax = amax > a0 ? amax : a0;
+                            amax = amax > a1 ? amax : a1;
+                        }
+                    }
+                }
+                continue;
+            }
+            if (SWIGLU) continue;
             if (full) {
                 if (flags & F8_EPI_RESIDUAL) {
                     const u32x4 rv = *reinterpret_cast<const u32x4*>(res + (long)m * ldr + n);
@@ -197,6 +251,16 @@ __device__ __forceinline__ void f8_epilogue_lds(f32x16 (&acc)[TN][TM], char* __r
                     }
                 }
             }
+        }
+    }
+    if constexpr (SWIGLU) {
+        if (amax_out != nullptr) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned int y = (unsigned int)__shfl_xor((int)amax, o);
+                amax = amax > y ? amax : y;
+            }
+            if (lane == 0 && amax != 0) atomicMax(amax_out, amax);
         }
     }
 }
@@ -290,11 +354,11 @@ __device__ __forceinline__ i32x8 f8_cat(const i32x4& a, const i32x4& b) {
     return r;
 }
 
-template <int FA>
+template <int FA, bool SWIGLU = false>
 __global__ __launch_bounds__(512) void gemm_fp8_ring_kernel(
     const unsigned char* __restrict__ A, const unsigned char* __restrict__ B, bf16_t* __restrict__ C, int M, int N, int K, long lda,
     long ldb, long ldc, const float* __restrict__ inv_scale_a, const float* __restrict__ inv_scale_b, const bf16_t* __restrict__ bias,
-    const bf16_t* __restrict__ res, long ldr, int flags, int tiles_m, int tiles_n) {
+    const bf16_t* __restrict__ res, long ldr, int flags, int tiles_m, int tiles_n, unsigned int* __restrict__ amax_out) {
     constexpr int TM = 4, TN = 2, SLAB = 16384, PPW = 2;   // 8 waves: 2 (M) x 4 (N), each 128 x 64
     __shared__ __attribute__((aligned(16))) char smem[10 * SLAB];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -435,16 +499,17 @@ __global__ __launch_bounds__(512) void gemm_fp8_ring_kernel(
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // retire the trailing DMA pieces and the last cluster's fragment reads ...
     __syncthreads();                                   // ... and every wave's fragment reads: the LDS becomes epilogue scratch
     const float scale = inv_scale_a[0] * inv_scale_b[0];
-    f8_epilogue_lds<TM, TN>(acc, smem + wave * F8_EPI_STRIP, C, M, N, ldc, scale, bias, res, ldr, flags, m0 + wm * 128, n0 + wn * 64, lane);
+    f8_epilogue_lds<TM, TN, SWIGLU>(acc, smem + wave * F8_EPI_STRIP, C, M, N, ldc, scale, bias, res, ldr, flags, m0 + wm * 128, n0 + wn * 64,
+                                    lane, amax_out);
 }
 
-template <int FA>
+template <int FA, bool SWIGLU = false>
 static int launch_fp8_ring(hipStream_t s, const unsigned char* A, const unsigned char* B, bf16_t* C, int M, int N, int K, long lda,
                            long ldb, long ldc, const float* sa, const float* sb, const bf16_t* bias, const bf16_t* res, long ldr,
-                           int flags) {
+                           int flags, unsigned int* amax_out = nullptr) {
     const int tiles_m = cdiv(M, 256), tiles_n = cdiv(N, 256);
-    hipLaunchKernelGGL((gemm_fp8_ring_kernel<FA>), dim3(tiles_m * tiles_n), dim3(512), 0, s, A, B, C, M, N, K, lda, ldb, ldc, sa, sb, bias,
-                       res, ldr, flags, tiles_m, tiles_n);
+    hipLaunchKernelGGL((gemm_fp8_ring_kernel<FA, SWIGLU>), dim3(tiles_m * tiles_n), dim3(512), 0, s, A, B, C, M, N, K, lda, ldb, ldc, sa, sb,
+                       bias, res, ldr, flags, tiles_m, tiles_n, amax_out);
     return mantis_check_launch();
 }
 
@@ -529,17 +594,16 @@ __device__ __forceinline__ unsigned int cvt4(float a, float b, float c, float d)
 #define QT_PITCH 132
 template <int FMT>
 __global__ __launch_bounds__(256) void fp8_cast_kernel(const bf16_t* __restrict__ x, long rows, int cols, long ld,
-                                                       const float* __restrict__ parts, unsigned char* __restrict__ q, long ldq,
+                                                       const float* __restrict__ parts, int nparts, unsigned char* __restrict__ q, long ldq,
                                                        unsigned char* __restrict__ qt, long ldt, long rows_pad, float* __restrict__ state) {
     __shared__ float s_scale;
     __shared__ unsigned int sm[4];
     __shared__ __attribute__((aligned(16))) unsigned char tile[QT_TILE * QT_PITCH];
     const float FMAX = FMT == F8_FMT_E4M3 ? 448.f : 57344.f;
     {
-        unsigned int mx = 0;
-#pragma unroll
-        for (int u = 0; u < Q_PARTS / 256; ++u) {
-            const unsigned int y = __float_as_uint(parts[threadIdx.x + 256 * u]);
+        unsigned int mx = 0;       // nparts = Q_PARTS per-workgroup maxima of pass 1, or 1 = an amax a producer kernel already took
+        for (int u = threadIdx.x; u < nparts; u += 256) {
+            const unsigned int y = __float_as_uint(parts[u]);
             mx = mx > y ? mx : y;
         }
 #pragma unroll
@@ -635,23 +699,49 @@ int mantis_fp8_quantize_ws_floats(void) { return Q_PARTS; }
 // x bf16 [rows, cols] (row stride ld, elements) -> q fp8 [rows, cols] (row stride ldq bytes) and, if qt != NULL, the transposed copy
 // qt [cols, rows_pad] (row stride ldt bytes; rows_pad = rows rounded up to 16, zero tail).  fmt: 0 = e4m3 (max 448), 1 = e5m2 (max
 // 57344).  state float[3] <- {amax, scale = FMAX / amax, dequant = amax / FMAX}.  workspace: mantis_fp8_quantize_ws_floats() floats.
+// amax_in (nullable): device float holding max |x| already taken by x's producer; the amax pass is then skipped.
 int mantis_fp8_quantize(const void* x, int64_t rows, int cols, int64_t ld, int fmt, void* q, int64_t ldq, void* qt, int64_t ldt,
-                        float* state, float* workspace, void* stream) {
-    if (rows <= 0 || cols <= 0 || cols % 16 || ld % 8 || ldq % 16 || ldq < cols || (fmt != 0 && fmt != 1) || !state || !workspace)
+                        float* state, float* workspace, const float* amax_in, void* stream) {
+    if (rows <= 0 || cols <= 0 || cols % 16 || ld % 8 || ldq % 16 || ldq < cols || (fmt != 0 && fmt != 1) || !state || (!workspace && !amax_in))
         return MANTIS_EINVAL;
     const long rows_pad = (rows + 15) / 16 * 16;
     if (qt != nullptr && (ldt % 16 || ldt < rows_pad)) return MANTIS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(fp8_amax_kernel, dim3(Q_PARTS), dim3(256), 0, s, (const bf16_t*)x, (long)rows, cols, (long)ld, workspace);
     const dim3 grid(cdiv(cols, QT_TILE), cdiv(rows_pad, QT_TILE));
     if (grid.y > 65535) return MANTIS_EUNSUPPORTED;
+    // amax_in: the maximum |x| was already taken by the kernel that produced x (mantis_gemm_fp8_dx_swiglu) -- pass 1 is skipped
+    if (amax_in == nullptr)
+        hipLaunchKernelGGL(fp8_amax_kernel, dim3(Q_PARTS), dim3(256), 0, s, (const bf16_t*)x, (long)rows, cols, (long)ld, workspace);
+    const float* parts = amax_in ? amax_in : workspace;
+    const int nparts = amax_in ? 1 : Q_PARTS;
     if (fmt == 0)
-        hipLaunchKernelGGL(fp8_cast_kernel<F8_FMT_E4M3>, grid, dim3(256), 0, s, (const bf16_t*)x, (long)rows, cols, (long)ld, workspace,
+        hipLaunchKernelGGL(fp8_cast_kernel<F8_FMT_E4M3>, grid, dim3(256), 0, s, (const bf16_t*)x, (long)rows, cols, (long)ld, parts, nparts,
                            (unsigned char*)q, (long)ldq, (unsigned char*)qt, (long)ldt, rows_pad, state);
     else
-        hipLaunchKernelGGL(fp8_cast_kernel<F8_FMT_E5M2>, grid, dim3(256), 0, s, (const bf16_t*)x, (long)rows, cols, (long)ld, workspace,
+        hipLaunchKernelGGL(fp8_cast_kernel<F8_FMT_E5M2>, grid, dim3(256), 0, s, (const bf16_t*)x, (long)rows, cols, (long)ld, parts, nparts,
                            (unsigned char*)q, (long)ldq, (unsigned char*)qt, (long)ldt, rows_pad, state);
     return mantis_check_launch();
+}
+
+// dgu[M, 2N] = swiglu_backward(dequant * A8[M,K] . B8[N,K]^T, gate_up[M, 2N]) in one launch (ring kernel; the [M, N] activation gradient
+// never goes to HBM), A8 = dY in e5m2 (fmt_a 1) or e4m3, B8 = the transposed e4m3 copy of W_down.  amax_out (nullable): float[1] <- max
+// |dgu| (set to 0 here first), ready to be handed to mantis_fp8_quantize as amax_in.
+int mantis_gemm_fp8_dx_swiglu(const void* A8, int64_t lda, const void* B8, int64_t ldb, void* dgu, int64_t ld_dgu, int M, int N, int K,
+                              const float* dequant_a, const float* dequant_b, int fmt_a, const void* gate_up, int64_t ld_gu, float* amax_out,
+                              void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % 16 || lda % 16 || ldb % 16 || lda < K || ldb < K || ld_dgu < 2 * (long)N || ld_gu < 2 * (long)N ||
+        !dequant_a || !dequant_b || !gate_up || !dgu)
+        return MANTIS_EINVAL;
+    if (fmt_a != 0 && fmt_a != 1) return MANTIS_EINVAL;
+    if ((long)M * lda >= (1L << 32) || (long)N * ldb >= (1L << 32)) return MANTIS_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    if (amax_out != nullptr && hipMemsetAsync(amax_out, 0, sizeof(float), s) != hipSuccess) return MANTIS_ELAUNCH;
+    return fmt_a == 0 ? launch_fp8_ring<0, true>(s, (const unsigned char*)A8, (const unsigned char*)B8, (bf16_t*)dgu, M, N, K, (long)lda, (long)ldb,
+                                                 (long)ld_dgu, dequant_a, dequant_b, nullptr, (const bf16_t*)gate_up, (long)ld_gu, 0,
+                                                 (unsigned int*)amax_out)
+                      : launch_fp8_ring<1, true>(s, (const unsigned char*)A8, (const unsigned char*)B8, (bf16_t*)dgu, M, N, K, (long)lda, (long)ldb,
+                                                 (long)ld_dgu, dequant_a, dequant_b, nullptr, (const bf16_t*)gate_up, (long)ld_gu, 0,
+                                                 (unsigned int*)amax_out);
 }
 
 // C[M,N] bf16 (row stride ldc elements) = epi(dequant_a * dequant_b * A8[M,K] . B8[N,K]^T); lda / ldb in bytes, K % 16 == 0.

@@ -94,9 +94,12 @@ def decoder_backward(K, lm, w8, grads, grads_layers, tc, ctx, hctx, plan, B, L, 
         _dw(K, dxq, aq, lg_["down"], acc)
         if on_bucket_ready is not None:
             on_bucket_ready(("layer", i, "down"))
-        dgu = K.swiglu_bwd(_dx(K, dxq, w8.get(K, i, "down")), gu)
+        wd = w8.get(K, i, "down")
+        # dact = dx . W_down, the SwiGLU backward and max |dgu| in ONE launch (the [M, I] activation gradient never goes to HBM, the
+        # quantiser's amax pass over the 2I-wide gradient is skipped)
+        dgu, dgu_amax = K.gemm_fp8_dx_swiglu(dxq.q, dxq.dequant, wd.qt, wd.dequant, gu, E5M2)
         del aq, gu, dxq
-        dguq = K.fp8_quantize(dgu, E5M2, transposed=lg_["gu"] is not None)
+        dguq = K.fp8_quantize(dgu, E5M2, transposed=lg_["gu"] is not None, amax=dgu_amax)
         del dgu
         _dw(K, dguq, n2q, lg_["gu"], acc)
         if on_bucket_ready is not None:

@@ -114,8 +114,9 @@ class Fp8Tensor:
         return self.state[2:3]
 
 
-def fp8_quantize(x, fmt=FP8_E4M3, transposed=True, rowmajor=True):
-    """Per-tensor just-in-time quantisation of a bf16 matrix: q = cvt(clamp(x * FMAX / amax)).  Returns Fp8Tensor."""
+def fp8_quantize(x, fmt=FP8_E4M3, transposed=True, rowmajor=True, amax=None):
+    """Per-tensor just-in-time quantisation of a bf16 matrix: q = cvt(clamp(x * FMAX / amax)).  Returns Fp8Tensor.
+    amax: device fp32[1] holding max |x| when x's producer already took it (gemm_fp8_dx_swiglu) -- the amax pass is skipped."""
     _chk2d(x, "x")
     rows, cols = x.shape
     dev = x.device
@@ -126,7 +127,7 @@ def fp8_quantize(x, fmt=FP8_E4M3, transposed=True, rowmajor=True):
     q = torch.empty((rows, cols), dtype=torch.uint8, device=dev)
     qt = torch.empty((cols, rp), dtype=torch.uint8, device=dev) if transposed else None
     state = torch.empty(3, dtype=torch.float32, device=dev)
-    _lib.check(_L.mantis_fp8_quantize(_p(x), rows, cols, x.stride(0), fmt, _p(q), cols, _p(qt), rp, _p(state), _p(ws), _stream()),
+    _lib.check(_L.mantis_fp8_quantize(_p(x), rows, cols, x.stride(0), fmt, _p(q), cols, _p(qt), rp, _p(state), _p(ws), _p(amax), _stream()),
                f"fp8_quantize {rows}x{cols}")
     return Fp8Tensor(q, qt, state, fmt, rows, cols)
 
@@ -152,6 +153,29 @@ def gemm_fp8_nt(a8, a_dequant, b8, b_dequant, fmt_a=FP8_E4M3, bias=None, residua
         prof.append(("gemm_fp8_nt_kernel", 2.0 * M * N * K, 1.0 * (M * K + N * K) + 2.0 * M * N * (1 + (residual is not None) + bool(accumulate)),
                      e0, e1))
     return out
+
+
+def gemm_fp8_dx_swiglu(dy8, dy_dequant, wt8, w_dequant, gu, fmt_a=FP8_E5M2):
+    """(dgu[M, 2I], amax fp32[1]) with dgu = swiglu_bwd(dequant * dy8[M, d] . wt8[I, d]^T, gu[M, 2I]) in one launch (the [M, I] activation
+    gradient never goes to HBM) and amax = max |dgu|, taken by the same epilogue for the quantiser that follows."""
+    M, d = dy8.shape
+    I = wt8.shape[0]
+    if gu.shape != (M, 2 * I):
+        raise ValueError(f"gemm_fp8_dx_swiglu: dy8 {tuple(dy8.shape)} wt8 {tuple(wt8.shape)} gu {tuple(gu.shape)}")
+    dgu = torch.empty_like(gu)
+    amax = torch.empty(1, dtype=torch.float32, device=gu.device)
+    prof = KERNEL_TIMER
+    if prof is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = _L.mantis_gemm_fp8_dx_swiglu(_p(dy8), dy8.stride(0), _p(wt8), wt8.stride(0), _p(dgu), dgu.stride(0), M, I, d, _p(dy_dequant),
+                                      _p(w_dequant), fmt_a, _p(gu), gu.stride(0), _p(amax), _stream())
+    _lib.check(rc, f"gemm_fp8+swiglu_bwd M={M} I={I} d={d}")
+    if prof is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        prof.append(("gemm_fp8_nt_kernel", 2.0 * M * I * d, 1.0 * (M * d + I * d) + 2.0 * 4 * M * I, e0, e1))
+    return dgu, amax
 
 
 def transpose(x, rpad=None):

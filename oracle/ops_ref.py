@@ -65,9 +65,11 @@ class Fp8Tensor:
         return self.state[2:3]
 
 
-def fp8_quantize(x, fmt=FP8_E4M3, transposed=True, rowmajor=True):
+def fp8_quantize(x, fmt=FP8_E4M3, transposed=True, rowmajor=True, amax=None):
     dt, fmax = _F8[fmt]
     xf = _f(x)
+    if amax is not None:
+        assert float(amax) == float(xf.abs().max()), "a producer-side amax must equal the tensor's own"
     amax = xf.abs().max()
     fm = torch.tensor(fmax, dtype=torch.float32)
     sc = fm / amax if float(amax) > 0 else torch.tensor(1.0)
@@ -97,6 +99,11 @@ def gemm_fp8_nt(a8, a_dequant, b8, b_dequant, fmt_a=FP8_E4M3, bias=None, residua
         y = y + _f(out)
     out.copy_(y.to(out.dtype))
     return out
+
+
+def gemm_fp8_dx_swiglu(dy8, dy_dequant, wt8, w_dequant, gu, fmt_a=FP8_E5M2):
+    dgu = swiglu_bwd(gemm_fp8_nt(dy8, dy_dequant, wt8, w_dequant, fmt_a), gu)
+    return dgu, dgu.float().abs().max().reshape(1)
 
 
 def transpose(x, rpad=None):

@@ -933,6 +933,22 @@ def check_fp8_gemm(M, N, K_, fmt_a, epi, variant):
     return r
 
 
+def check_fp8_dx_swiglu(M, d, I, fmt_a):
+    """dX of down_proj with the SwiGLU backward and the amax of the result in the GEMM epilogue vs the oracle's unfused restatement
+    (same fp8 bytes); the amax must EQUAL the maximum of what was written (it replaces the quantiser's first pass)."""
+    k = K()
+    dy, wt = rnd(M, d, seed=M + d, scale=0.01), rnd(I, d, seed=I + d, scale=0.05)
+    gu = rnd(M, 2 * I, seed=7)
+    dq, wq = R.fp8_quantize(dy, fmt_a, transposed=False), R.fp8_quantize(wt, 0, transposed=False)
+    ref, ref_amax = R.gemm_fp8_dx_swiglu(dq.q, dq.dequant, wq.q, wq.dequant, gu, fmt_a)
+    out, amax = k.gemm_fp8_dx_swiglu(dq.q.to(DEV), dq.dequant.to(DEV), wq.q.to(DEV), wq.dequant.to(DEV), gu.to(DEV), fmt_a)
+    assert float(amax.cpu()) == float(out.float().abs().max().cpu()), (float(amax.cpu()), float(out.float().abs().max().cpu()))
+    t = k.fp8_quantize(out, 1, amax=amax)
+    t2 = k.fp8_quantize(out, 1)
+    assert torch.equal(t.q, t2.q) and torch.equal(t.qt, t2.qt) and torch.equal(t.state, t2.state), "amax_in path differs from the two-pass quantiser"
+    return close(out, ref, 1e-2, f"gemm_fp8_dx_swiglu {M}x{d}x{I} fmt_a={fmt_a}")
+
+
 FP8_GEMM_CASES = [(128, 128, 128, 0, "plain", 1), (256, 256, 256, 0, "plain", 2), (300, 200, 80, 0, "plain", 1), (300, 520, 1008, 1, "plain", 2),
                   (77, 40, 16, 1, "plain", 1), (1000, 777, 2048, 0, "bias", 2), (520, 300, 144, 1, "res", 1), (260, 260, 400, 1, "acc", 2),
                   (333, 130, 640, 0, "bias+res", 0), (4096, 3584, 3584, 0, "plain", 0), (3584, 4608, 4096, 1, "acc", 0),
@@ -1175,6 +1191,8 @@ def all_checks():
         c[f"fp8_quantize_{r_}x{c_}_fmt{f_}"] = (lambda r_=r_, c_=c_, f_=f_, sc_=sc_: check_fp8_quantize(r_, c_, f_, sc_))
     for a in FP8_GEMM_CASES:
         c["fp8_gemm_" + "_".join(map(str, a))] = (lambda a=a: check_fp8_gemm(*a))
+    for (m_, d_, i_, f_) in [(300, 112, 256, 1), (1000, 512, 1504, 1), (257, 64, 176, 0), (4096, 3584, 18944, 1)]:
+        c[f"fp8_dx_swiglu_{m_}x{d_}x{i_}_fmt{f_}"] = (lambda m_=m_, d_=d_, i_=i_, f_=f_: check_fp8_dx_swiglu(m_, d_, i_, f_))
     for case in QWEN2VL_CASES:
         c["qwen2vl_fp8_step_" + case[8:]] = (lambda case=case: check_qwen2vl_step_fp8(case))
     c["rope_sections_cast_pad"] = check_rope_sections
