@@ -691,6 +691,24 @@ __global__ __launch_bounds__(256) void fp8_cast_kernel(const bf16_t* __restrict_
     }
 }
 
+// one launch of the chosen kernel on a (sub-)problem; f = epilogue flag bits
+static int fp8_dispatch(hipStream_t s, int variant, const void* A8, long lda, const void* B8, long ldb, void* C, long ldc, int M, int N, int K,
+                        const float* dequant_a, const float* dequant_b, int fmt_a, const void* bias, const void* residual, long ldr, int f) {
+    const unsigned char* A = (const unsigned char*)A8;
+    const unsigned char* B = (const unsigned char*)B8;
+    bf16_t* Cc = (bf16_t*)C;
+    const bf16_t* bi = (const bf16_t*)bias;
+    const bf16_t* re = (const bf16_t*)residual;
+    if (variant == 3)
+        return fmt_a == 0 ? launch_fp8_ring<0>(s, A, B, Cc, M, N, K, lda, ldb, ldc, dequant_a, dequant_b, bi, re, ldr, f)
+                          : launch_fp8_ring<1>(s, A, B, Cc, M, N, K, lda, ldb, ldc, dequant_a, dequant_b, bi, re, ldr, f);
+    if (variant == 2)
+        return fmt_a == 0 ? launch_fp8<256, 256, 128, 64, 0>(s, A, B, Cc, M, N, K, lda, ldb, ldc, dequant_a, dequant_b, bi, re, ldr, f)
+                          : launch_fp8<256, 256, 128, 64, 1>(s, A, B, Cc, M, N, K, lda, ldb, ldc, dequant_a, dequant_b, bi, re, ldr, f);
+    return fmt_a == 0 ? launch_fp8<128, 128, 64, 64, 0>(s, A, B, Cc, M, N, K, lda, ldb, ldc, dequant_a, dequant_b, bi, re, ldr, f)
+                      : launch_fp8<128, 128, 64, 64, 1>(s, A, B, Cc, M, N, K, lda, ldb, ldc, dequant_a, dequant_b, bi, re, ldr, f);
+}
+
 extern "C" {
 
 // Workspace floats the quantiser needs (per-workgroup maxima of pass 1).
@@ -757,33 +775,45 @@ int mantis_gemm_fp8_nt(const void* A8, int64_t lda, const void* B8, int64_t ldb,
     if (fmt_a != 0 && fmt_a != 1) return MANTIS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     int variant = (flags >> 8) & 15;
-    if (variant == 0) {
-        // wave quantisation: 256x256 tiles run one per CU (256 slots), 128x128 tiles two per CU (512 slots); the big tile is ~8 % faster
-        // per flop when both fill their rounds equally (measured, tools/gemm_fp8_bench.py)
-        const long t2 = (long)cdiv(M, 256) * cdiv(N, 256), t1 = (long)cdiv(M, 128) * cdiv(N, 128);
-        const double e2 = (double)t2 / (double)(((t2 + 255) / 256) * 256), e1 = (double)t1 / (double)(((t1 + 511) / 512) * 512);
-        variant = (e2 * 1.20 >= e1) ? 3 : 1;      // the ring kernel is ~20 % faster per flop than the 128x128 kernel at equal fill
-        if (variant == 3 && ((long)M * lda >= (1L << 32) || (long)N * ldb >= (1L << 32))) variant = 2;
-    }
     const int f = flags & 0xff;
-#define F8_GO(BM_, BN_, WM_, WN_)                                                                                                        \
-    return fmt_a == 0 ? launch_fp8<BM_, BN_, WM_, WN_, 0>(s, (const unsigned char*)A8, (const unsigned char*)B8, (bf16_t*)C, M, N, K,  \
-                                                          (long)lda, (long)ldb, (long)ldc, dequant_a, dequant_b, (const bf16_t*)bias,     \
-                                                          (const bf16_t*)residual, (long)ldr, f)                                         \
-                      : launch_fp8<BM_, BN_, WM_, WN_, 1>(s, (const unsigned char*)A8, (const unsigned char*)B8, (bf16_t*)C, M, N, K,  \
-                                                          (long)lda, (long)ldb, (long)ldc, dequant_a, dequant_b, (const bf16_t*)bias,     \
-                                                          (const bf16_t*)residual, (long)ldr, f)
-    if (variant == 3) {
-        if ((long)M * lda >= (1L << 32) || (long)N * ldb >= (1L << 32)) return MANTIS_EUNSUPPORTED;     // 32-bit buffer offsets
-        return fmt_a == 0 ? launch_fp8_ring<0>(s, (const unsigned char*)A8, (const unsigned char*)B8, (bf16_t*)C, M, N, K, (long)lda, (long)ldb,
-                                               (long)ldc, dequant_a, dequant_b, (const bf16_t*)bias, (const bf16_t*)residual, (long)ldr, f)
-                          : launch_fp8_ring<1>(s, (const unsigned char*)A8, (const unsigned char*)B8, (bf16_t*)C, M, N, K, (long)lda, (long)ldb,
-                                               (long)ldc, dequant_a, dequant_b, (const bf16_t*)bias, (const bf16_t*)residual, (long)ldr, f);
+    if (variant == 0) {
+        // Wave quantisation.  256x256 tiles run one per CU (256 slots per round), 128x128 tiles two per CU.  When the big tiles leave an
+        // incomplete last round (q|k|v forward: 288 tiles = 1.125 rounds), the strip of tile columns (or rows) beyond the last FULL round
+        // goes to the 128x128 kernel instead: 2 rounds become 1 + a quarter-length one.  Both launches write disjoint parts of C.
+        const int tm = cdiv(M, 256), tn = cdiv(N, 256);
+        const long t2 = (long)tm * tn;
+        const bool ring_ok = (long)M * lda < (1L << 32) && (long)N * ldb < (1L << 32);
+        if (ring_ok && t2 > 256 && t2 % 256 != 0) {
+            const long full = t2 / 256;
+            if (tn >= tm) {
+                const int cols_ring = (int)(full * 256 / tm);
+                if (cols_ring > 0 && cols_ring < tn) {
+                    const int ns = cols_ring * 256;
+                    int rc = fp8_dispatch(s, 3, A8, lda, B8, ldb, C, ldc, M, ns, K, dequant_a, dequant_b, fmt_a, bias, residual, ldr, f);
+                    if (rc != MANTIS_OK) return rc;
+                    return fp8_dispatch(s, 1, A8, lda, (const unsigned char*)B8 + (long)ns * ldb, ldb, (bf16_t*)C + ns, ldc, M, N - ns, K, dequant_a,
+                                        dequant_b, fmt_a, bias ? (const bf16_t*)bias + ns : nullptr,
+                                        residual ? (const bf16_t*)residual + ns : nullptr, ldr, f);
+                }
+            } else {
+                const int rows_ring = (int)(full * 256 / tn);
+                if (rows_ring > 0 && rows_ring < tm) {
+                    const int ms = rows_ring * 256;
+                    int rc = fp8_dispatch(s, 3, A8, lda, B8, ldb, C, ldc, ms, N, K, dequant_a, dequant_b, fmt_a, bias, residual, ldr, f);
+                    if (rc != MANTIS_OK) return rc;
+                    return fp8_dispatch(s, 1, (const unsigned char*)A8 + (long)ms * lda, lda, B8, ldb, (bf16_t*)C + (long)ms * ldc, ldc, M - ms, N, K,
+                                        dequant_a, dequant_b, fmt_a, bias, residual ? (const bf16_t*)residual + (long)ms * ldr : nullptr, ldr, f);
+                }
+            }
+        }
+        // otherwise: the ring kernel unless the 128x128 kernel fills its rounds much better (the ring is ~20 % faster per flop at equal fill)
+        const long t1 = (long)cdiv(M, 128) * cdiv(N, 128);
+        const double e2 = (double)t2 / (double)(((t2 + 255) / 256) * 256), e1 = (double)t1 / (double)(((t1 + 511) / 512) * 512);
+        variant = (e2 * 1.20 >= e1) ? (ring_ok ? 3 : 2) : 1;
     }
-    if (variant == 2) { F8_GO(256, 256, 128, 64); }
-    if (variant == 1) { F8_GO(128, 128, 64, 64); }
-#undef F8_GO
-    return MANTIS_EINVAL;
+    if (variant == 3 && ((long)M * lda >= (1L << 32) || (long)N * ldb >= (1L << 32))) return MANTIS_EUNSUPPORTED;     // 32-bit buffer offsets
+    if (variant < 1 || variant > 3) return MANTIS_EINVAL;
+    return fp8_dispatch(s, variant, A8, lda, B8, ldb, C, ldc, M, N, K, dequant_a, dequant_b, fmt_a, bias, residual, ldr, f);
 }
 
 }  // extern "C"

@@ -9,7 +9,12 @@ back the transposed copy together with the row-major one, so forward (X8 . W8^T)
 The reference has no fp8 (its linears are bf16 nn.Linear); parity is therefore stated in two steps (tests/gpu_checks.py fp8_*):
 HIP == the oracle's exact restatement of this arithmetic (oracle/ops_ref.py fp8_quantize / gemm_fp8_nt), and that restatement vs the
 fp32 oracle of the reference within the fp8 tolerance written in the tests."""
+import os
+
 from . import decoder as D
+
+# A/B switch (measurements only): 0 = dX(down_proj), SwiGLU backward and the amax pass as three launches
+FUSE_SWIGLU_BWD = os.environ.get("MANTIS_FP8_FUSE_SWIGLU", "1") == "1"
 
 E4M3, E5M2 = 0, 1
 _NAMES = ("qkv", "o", "gu", "down")
@@ -97,7 +102,10 @@ def decoder_backward(K, lm, w8, grads, grads_layers, tc, ctx, hctx, plan, B, L, 
         wd = w8.get(K, i, "down")
         # dact = dx . W_down, the SwiGLU backward and max |dgu| in ONE launch (the [M, I] activation gradient never goes to HBM, the
         # quantiser's amax pass over the 2I-wide gradient is skipped)
-        dgu, dgu_amax = K.gemm_fp8_dx_swiglu(dxq.q, dxq.dequant, wd.qt, wd.dequant, gu, E5M2)
+        if FUSE_SWIGLU_BWD:
+            dgu, dgu_amax = K.gemm_fp8_dx_swiglu(dxq.q, dxq.dequant, wd.qt, wd.dequant, gu, E5M2)
+        else:
+            dgu, dgu_amax = K.swiglu_bwd(_dx(K, dxq, wd), gu), None
         del aq, gu, dxq
         dguq = K.fp8_quantize(dgu, E5M2, transposed=lg_["gu"] is not None, amax=dgu_amax)
         del dgu

@@ -955,7 +955,10 @@ FP8_GEMM_CASES = [(128, 128, 128, 0, "plain", 1), (256, 256, 256, 0, "plain", 2)
                   # variant 3 = the hand-pipelined 256x256 ring kernel: K tails, ragged M / N, every epilogue, short K (1-2 steps)
                   (256, 256, 128, 0, "plain", 3), (256, 256, 256, 1, "plain", 3), (300, 520, 1008, 1, "plain", 3), (77, 40, 16, 0, "plain", 3),
                   (1000, 777, 2048, 0, "bias", 3), (520, 300, 144, 1, "res", 3), (260, 260, 400, 1, "acc", 3), (333, 130, 640, 0, "bias+res", 3),
-                  (4096, 3584, 3584, 0, "plain", 3), (3584, 4608, 4096, 1, "acc", 3), (1024, 768, 18944, 0, "res", 3)]
+                  (4096, 3584, 3584, 0, "plain", 3), (3584, 4608, 4096, 1, "acc", 3), (1024, 768, 18944, 0, "res", 3),
+                  # auto dispatch with an incomplete last round of 256x256 tiles: ring kernel on the full rounds + 128x128 kernel on the
+                  # remaining strip of tile columns (N split) / tile rows (M split), every epilogue across the seam
+                  (4096, 4608, 256, 0, "bias+res", 0), (4608, 4000, 144, 1, "acc", 0), (4100, 4700, 128, 0, "bias", 0)]
 
 
 def check_qwen2vl_step_fp8(case):
