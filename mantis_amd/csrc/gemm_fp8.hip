@@ -787,7 +787,7 @@ int mantis_gemm_fp8_nt(const void* A8, int64_t lda, const void* B8, int64_t ldb,
             const long full = t2 / 256;
             if (tn >= tm) {
                 const int cols_ring = (int)(full * 256 / tm);
-                if (cols_ring > 0 && cols_ring < tn) {
+                if (cols_ring > 0 && cols_ring < tn && (long)(tn - cols_ring) * tm <= 128) {      // the strip fits one round of small tiles
                     const int ns = cols_ring * 256;
                     int rc = fp8_dispatch(s, 3, A8, lda, B8, ldb, C, ldc, M, ns, K, dequant_a, dequant_b, fmt_a, bias, residual, ldr, f);
                     if (rc != MANTIS_OK) return rc;
@@ -797,7 +797,7 @@ int mantis_gemm_fp8_nt(const void* A8, int64_t lda, const void* B8, int64_t ldb,
                 }
             } else {
                 const int rows_ring = (int)(full * 256 / tn);
-                if (rows_ring > 0 && rows_ring < tm) {
+                if (rows_ring > 0 && rows_ring < tm && (long)(tm - rows_ring) * tn <= 128) {
                     const int ms = rows_ring * 256;
                     int rc = fp8_dispatch(s, 3, A8, lda, B8, ldb, C, ldc, ms, N, K, dequant_a, dequant_b, fmt_a, bias, residual, ldr, f);
                     if (rc != MANTIS_OK) return rc;
