@@ -207,6 +207,8 @@ def main():
                     help="finetune: projector + LLM trainable (the headline metric); pretrain: only multi_modal_projector "
                          "(the reference's stage 1, train_mllava.py:177-181)")
     ap.add_argument("--no-pack", action="store_true", help="Idefics2 config: feed the samples as a batch instead of one packed row")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="do not hand the next batch to training_step (no software pipelining of the frozen vision tower beside the optimizer)")
     ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
@@ -306,7 +308,8 @@ def main():
         if timed:
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
             ev[0].record()
-        loss = trainer.training_step(model, batches[i % len(batches)])
+        nxt = None if args.no_prefetch else batches[(i + 1) % len(batches)]
+        loss = trainer.training_step(model, batches[i % len(batches)], next_inputs=nxt)
         if timed:
             ev[1].record()
             losses.append(loss)
@@ -429,7 +432,8 @@ def main():
                                merged_seq_len=T if (idefics or qwen) else T - n_img + n_img * (cfg.vision_config.image_size // cfg.vision_config.patch_size) ** 2,
                                flop_per_sample=flop_per_sample,
                                parallelism=f"dp{world}", optimizer=not args.no_optimizer, stage=args.stage,
-                               packed=bool(idefics and not args.no_pack)),
+                               packed=bool(idefics and not args.no_pack),
+                               vision_prefetch=bool(not args.no_prefetch and hasattr(model.engine, "prefetch_vision"))),
                    roofline=roof, cpu_baseline=cpu, dp=dp)
         print(json.dumps(out), flush=True)
     if world > 1 or force_dp:

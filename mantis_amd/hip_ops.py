@@ -120,9 +120,10 @@ def fp8_quantize(x, fmt=FP8_E4M3, transposed=True, rowmajor=True, amax=None):
     _chk2d(x, "x")
     rows, cols = x.shape
     dev = x.device
-    ws = _Q_WS.get(dev)
+    key = (dev, _stream())          # one scratch buffer per (device, stream): launches on a stream are ordered
+    ws = _Q_WS.get(key)
     if ws is None:
-        ws = _Q_WS[dev] = torch.zeros(_L.mantis_fp8_quantize_ws_floats(), dtype=torch.float32, device=dev)
+        ws = _Q_WS[key] = torch.zeros(_L.mantis_fp8_quantize_ws_floats(), dtype=torch.float32, device=dev)
     rp = (rows + 15) // 16 * 16
     q = torch.empty((rows, cols), dtype=torch.uint8, device=dev)
     qt = torch.empty((cols, rp), dtype=torch.uint8, device=dev) if transposed else None

@@ -296,6 +296,30 @@ class Qwen2VLEngine:
         # set by MantisHipTrainer before every micro-batch: True on the 2nd.. micro-batch of an accumulation window (no optimizer step
         # since the last one), so the fp8 weight copies are reused; any other caller gets a fresh quantisation every step
         self.weights_unchanged = False
+        self._side = None                    # side stream of prefetch_vision
+        self._prefetched = None              # (pixel_values object, image rows, done event)
+
+    # ------------------------------------------------------------------ software pipelining of the frozen tower
+    def prefetch_vision(self, inputs, after_event=None):
+        """Enqueue the tower + merger forward of a FUTURE batch on a side stream (behind `after_event` of the compute stream).  `visual`
+        is frozen, so its output does not depend on the optimizer step in between: MantisHipTrainer calls this at the end of an
+        accumulation window so the MFMA-bound tower of batch i+1 runs beside the HBM-bound clip + AdamW of step i.  The result is
+        consumed by the step that is handed the SAME pixel_values object; any other batch is computed in line as before."""
+        pv = inputs.get("pixel_values")
+        if pv is None or inputs.get("image_grid_thw") is None or not torch.cuda.is_available():
+            return
+        dev = self.m.device
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
+        grids = [tuple(int(v) for v in g) for g in torch.as_tensor(inputs["image_grid_thw"]).tolist()]
+        if after_event is not None:
+            self._side.wait_event(after_event)
+        with torch.cuda.stream(self._side):
+            pix = torch.as_tensor(pv).to(dev, non_blocking=True).to(torch.float32).contiguous()
+            img = self.vision_forward(pix, grids)
+            done = torch.cuda.Event()
+            done.record(self._side)
+        self._prefetched = (pv, img, done)
 
     def step_from_batch(self, inputs, **kw):
         return self.step(inputs["input_ids"], inputs["attention_mask"], inputs.get("labels"), inputs.get("pixel_values"),
@@ -378,8 +402,14 @@ class Qwen2VLEngine:
             if image_grid_thw is None:
                 raise ValueError("pixel_values without image_grid_thw")
             grids = [tuple(int(v) for v in g) for g in torch.as_tensor(image_grid_thw).tolist()]
-            pix = torch.as_tensor(pixel_values).to(dev, non_blocking=True).to(torch.float32).contiguous()
-            img = self.vision_forward(pix, grids, record)
+            pre, self._prefetched = self._prefetched, None
+            if pre is not None and pre[0] is pixel_values and record is None:
+                img = pre[1]                                   # computed ahead on the side stream (prefetch_vision)
+                torch.cuda.current_stream().wait_event(pre[2])
+                img.record_stream(torch.cuda.current_stream())
+            else:
+                pix = torch.as_tensor(pixel_values).to(dev, non_blocking=True).to(torch.float32).contiguous()
+                img = self.vision_forward(pix, grids, record)
             if record is not None:
                 record["vision_merged"] = img
             n_rows = img.shape[0]

@@ -31,14 +31,19 @@ class MantisHipTrainer:
                              "(input_ids, attention_mask, labels, pixel_values)")
         return inputs
 
-    def training_step(self, model, inputs, num_items_in_batch=None, sync=None):
+    def training_step(self, model, inputs, num_items_in_batch=None, sync=None, next_inputs=None):
         """-> 0-dim detached loss tensor on the model's device, already divided by the accumulation steps.
 
         sync: is this micro-batch the accumulation boundary (gradients are all-reduced across ranks during its backward)?
         None = count micro-batches (`micro % GA == 0`), which is right for loops that always run whole GA windows; loops that
         can close a window early (HF closes one on the last batch of an epoch, trainer.py `do_sync_step`) must pass it --
         `as_hf_trainer()` passes `accelerator.sync_gradients`, the flag torch DDP's `no_sync` follows in the reference
-        (HF:trainer.py:1744-1757)."""
+        (HF:trainer.py:1744-1757).
+
+        next_inputs: the batch the NEXT training_step will receive (what a DataLoader with prefetch_factor already holds).  On the
+        accumulation boundary the frozen vision tower of that batch is enqueued on a side stream behind this micro-batch's backward, so
+        it runs beside the HBM-bound clip + optimizer step that follows; the next training_step picks the result up (same arithmetic,
+        same result -- the tower is frozen -- only earlier).  Engines without `prefetch_vision` ignore it."""
         model.train()
         inputs = self._prepare_inputs(inputs)
         ga = max(1, int(self.current_gradient_accumulation_steps))
@@ -73,6 +78,10 @@ class MantisHipTrainer:
             self.reducer.finish()
         if norm_now:
             self.optimizer.end_norm()
+        if next_inputs is not None and boundary and hasattr(model.engine, "prefetch_vision"):
+            ev = torch.cuda.Event()
+            ev.record()                       # end of this window's backward (and gradient reduction) on the compute stream
+            model.engine.prefetch_vision(next_inputs, after_event=ev)
         return out["loss"].reshape(()).detach()
 
 
