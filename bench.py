@@ -207,8 +207,11 @@ def main():
                     help="finetune: projector + LLM trainable (the headline metric); pretrain: only multi_modal_projector "
                          "(the reference's stage 1, train_mllava.py:177-181)")
     ap.add_argument("--no-pack", action="store_true", help="Idefics2 config: feed the samples as a batch instead of one packed row")
-    ap.add_argument("--no-prefetch", action="store_true",
-                    help="do not hand the next batch to training_step (no software pipelining of the frozen vision tower beside the optimizer)")
+    ap.add_argument("--prefetch", action="store_true",
+                    help="hand the next batch to training_step: the frozen vision tower of batch i+1 is enqueued on a side stream beside clip "
+                         "+ AdamW of step i.  Off by default: measured no gain (234.2 vs 235.4 ms on the Qwen2-VL config) -- the grid-stride "
+                         "AdamW keeps every CU partly occupied, and the tower's kernels need whole register files, so the hardware runs "
+                         "the two streams one after the other (profiles/r02_experiments.md)")
     ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
@@ -308,7 +311,7 @@ def main():
         if timed:
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
             ev[0].record()
-        nxt = None if args.no_prefetch else batches[(i + 1) % len(batches)]
+        nxt = batches[(i + 1) % len(batches)] if args.prefetch else None
         loss = trainer.training_step(model, batches[i % len(batches)], next_inputs=nxt)
         if timed:
             ev[1].record()
@@ -433,7 +436,7 @@ def main():
                                flop_per_sample=flop_per_sample,
                                parallelism=f"dp{world}", optimizer=not args.no_optimizer, stage=args.stage,
                                packed=bool(idefics and not args.no_pack),
-                               vision_prefetch=bool(not args.no_prefetch and hasattr(model.engine, "prefetch_vision"))),
+                               vision_prefetch=bool(args.prefetch and hasattr(model.engine, "prefetch_vision"))),
                    roofline=roof, cpu_baseline=cpu, dp=dp)
         print(json.dumps(out), flush=True)
     if world > 1 or force_dp:
