@@ -849,6 +849,33 @@ def check_qwen2vl_step(case):
     return 1.0 - min(c for c, _ in rep.values())
 
 
+def check_qwen2vl_prefetch():
+    """The frozen tower computed ahead on the side stream (engine.prefetch_vision, driven by training_step(next_inputs=)) gives bit-identical
+    loss and gradients to computing it in line; a prefetch for a different batch object is ignored."""
+    from mantis_amd.trainer import MantisHipTrainer
+    z = Hh.load_case("qwen2vl_b2_rightpad")
+    model = Hh.build_qwen2vl_product(DEV)
+    tr = MantisHipTrainer(model, gradient_accumulation_steps=1)
+    b1, b2 = Hh.qwen2vl_batch(z), Hh.qwen2vl_batch(z)
+    l_ref = tr.training_step(model, b1)
+    g_ref = model.grad_arena.clone()
+    for p in model.parameters():
+        p.grad = None
+    tr.training_step(model, b1, next_inputs=b2)              # enqueues the tower of b2 behind this step's backward
+    assert model.engine._prefetched is not None and model.engine._prefetched[0] is b2["pixel_values"]
+    for p in model.parameters():
+        p.grad = None
+    l2 = tr.training_step(model, b2)
+    assert model.engine._prefetched is None
+    assert torch.equal(l2, l_ref) and torch.equal(model.grad_arena, g_ref), "prefetched tower changed the result"
+    model.engine.prefetch_vision(b1)
+    for p in model.parameters():
+        p.grad = None
+    l3 = tr.training_step(model, b2)                         # not the prefetched object: computed in line
+    assert torch.equal(l3, l_ref) and torch.equal(model.grad_arena, g_ref)
+    return 0.0
+
+
 def check_rope_sections():
     """Sectioned cos/sin table (multimodal RoPE 16/24/24 and the vision tower's 2-D table) vs the oracle's operator."""
     k = K()
@@ -1198,6 +1225,7 @@ def all_checks():
         c[f"fp8_dx_swiglu_{m_}x{d_}x{i_}_fmt{f_}"] = (lambda m_=m_, d_=d_, i_=i_, f_=f_: check_fp8_dx_swiglu(m_, d_, i_, f_))
     for case in QWEN2VL_CASES:
         c["qwen2vl_fp8_step_" + case[8:]] = (lambda case=case: check_qwen2vl_step_fp8(case))
+    c["qwen2vl_prefetch_bit_identical"] = check_qwen2vl_prefetch
     c["rope_sections_cast_pad"] = check_rope_sections
     c["qwen2vl_full_width"] = check_qwen2vl_full_width
     c["pack_segments_random"] = check_pack_segments_random
