@@ -188,6 +188,46 @@ def cpu_baseline(cfg_name):
     return out
 
 
+def cpu_baseline_qwen2vl(cfg, T, grids):
+    """Qwen2-VL configuration: the oracle (oracle/qwen2vl_ref.py, "port") on the host cores, fp32, one sample, depth extrapolated."""
+    import torch
+    from oracle.qwen2vl_ref import Qwen2VLRef
+    from mantis_amd.modeling_qwen2_vl import _param_specs
+    full_v, full_l = cfg.vision_config.depth, cfg.text_config.num_hidden_layers
+    meta = dict(vision=cfg.vision_config.to_dict(), text=cfg.text_config.to_dict(), image_token_id=cfg.image_token_id)
+    g = torch.Generator().manual_seed(0)
+    w = {}
+    for name, shape in _param_specs(cfg):
+        if ".blocks." in name and int(name.split(".blocks.")[1].split(".")[0]) >= 2:
+            continue
+        if ".layers." in name and int(name.split(".layers.")[1].split(".")[0]) >= 2:
+            continue
+        if len(shape) == 1:
+            w[name] = torch.ones(shape) if (("norm" in name or "ln_q" in name) and name.endswith("weight")) else torch.zeros(shape)
+        else:
+            w[name] = torch.randn(shape, generator=g).mul_(0.02)
+    model = Qwen2VLRef(w, meta)
+    del w
+    batch = synthetic_batch_qwen2vl(cfg, 1, T, grids, 0)
+
+    def run(nv, nl):
+        model.zero_grad()
+        t0 = time.perf_counter()
+        loss, _ = model.forward(batch["input_ids"], batch["pixel_values"], batch["image_grid_thw"], batch["attention_mask"], batch["labels"],
+                                n_vit_layers=nv, n_llm_layers=nl)
+        loss.backward()
+        return time.perf_counter() - t0
+    t11 = run(1, 1)
+    t21 = run(2, 1)
+    t12 = run(1, 2)
+    per_vit, per_llm = max(t21 - t11, 1e-9), max(t12 - t11, 1e-9)
+    total = t11 + (full_v - 1) * per_vit + (full_l - 1) * per_llm
+    return dict(value=1.0 / total, unit="samples/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"oracle/qwen2vl_ref.py forward + backward, fp32, 1 sample ({len(grids)} images of {grids[0][1]}x{grids[0][2]} patches + "
+                       f"{T} tokens), measured 1 tower block + 1 decoder layer + merger + lm_head {t11:.1f}s, +1 tower block {per_vit:.1f}s, "
+                       f"+1 decoder layer {per_llm:.1f}s, extrapolated linearly to {full_v} blocks / {full_l} layers = {total:.0f}s per sample")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -399,7 +439,9 @@ def main():
                         step_frac_of_peak=round(flop_per_sample * B / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if not tiny else None,
                         training_step_frac_of_peak=round(flop_per_sample * B / (_pct(ts_ms, 0.5) * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if not tiny else None)
         cpu = None
-        if world == 1 and not args.no_cpu_baseline and not idefics and not qwen:      # the CPU leg times the headline (LLaVA-path) oracle
+        if world == 1 and not args.no_cpu_baseline and qwen:
+            cpu = cpu_baseline_qwen2vl(cfg, T, grids)
+        elif world == 1 and not args.no_cpu_baseline and not idefics:      # the CPU leg times the LLaVA-path oracle
             cpu = cpu_baseline(args.config)
         dp = None
         if reducer is not None:

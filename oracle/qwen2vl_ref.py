@@ -116,7 +116,7 @@ class Qwen2VLRef:
             t.grad = None
 
     # ---- vision tower + merger (frozen)
-    def vision(self, pixel_values, grid_thw, record=None):
+    def vision(self, pixel_values, grid_thw, record=None, n_layers=None):
         w, vc = self.w, self.vc
         pre = "model.visual."
         dv, nh = vc["embed_dim"], vc["num_heads"]
@@ -132,7 +132,7 @@ class Qwen2VLRef:
         cos, sin = emb.cos()[:, None], emb.sin()[:, None]
         lens = [t * h * ww for t, h, ww in np.asarray(grid_thw).tolist()]
         act = ACT[vc["hidden_act"]]
-        for i in range(vc["depth"]):
+        for i in range(vc["depth"] if n_layers is None else n_layers):
             p = f"{pre}blocks.{i}."
             y = layernorm(x, w[p + "norm1.weight"], w[p + "norm1.bias"], 1e-6)
             qkv = F.linear(y, w[p + "attn.qkv.weight"], w[p + "attn.qkv.bias"]).view(-1, 3, nh, hd)
@@ -158,7 +158,7 @@ class Qwen2VLRef:
         return F.linear(y, w[m + "mlp.2.weight"], w[m + "mlp.2.bias"])
 
     # ---- Qwen2 decoder
-    def text(self, x, attention_mask, position_ids, record=None):
+    def text(self, x, attention_mask, position_ids, record=None, n_layers=None):
         w, tc = self.w, self.tc
         d, nh, nkv = tc["hidden_size"], tc["num_attention_heads"], tc["num_key_value_heads"]
         hd = d // nh
@@ -168,7 +168,7 @@ class Qwen2VLRef:
         cos, sin = mrope_cos_sin(position_ids, hd, rp["rope_theta"], rp["mrope_section"])
         cos, sin = cos[:, None], sin[:, None]
         pre = "model.language_model."
-        for i in range(tc["num_hidden_layers"]):
+        for i in range(tc["num_hidden_layers"] if n_layers is None else n_layers):
             p = f"{pre}layers.{i}."
             y = rmsnorm(x, w[p + "input_layernorm.weight"], eps)
             q = F.linear(y, w[p + "self_attn.q_proj.weight"], w[p + "self_attn.q_proj.bias"]).view(B, L, nh, hd).transpose(1, 2)
@@ -186,15 +186,16 @@ class Qwen2VLRef:
                 record[f"llm_layer{i}_out"] = x
         return rmsnorm(x, w[pre + "norm.weight"], eps)
 
-    def forward(self, input_ids, pixel_values, image_grid_thw, attention_mask, labels, record=None):
-        """pixel_values fp32 [sum t*h*w, C*tp*p*p] (the processor's flattened patches) or None.  Returns (loss, logits)."""
+    def forward(self, input_ids, pixel_values, image_grid_thw, attention_mask, labels, record=None, n_vit_layers=None, n_llm_layers=None):
+        """pixel_values fp32 [sum t*h*w, C*tp*p*p] (the processor's flattened patches) or None.  Returns (loss, logits).
+        n_vit_layers / n_llm_layers: run only the first n blocks (bench.py's bounded CPU-baseline sample)."""
         cfg, w = self.cfg, self.w
         ids = torch.as_tensor(input_ids)
         am = torch.ones_like(ids) if attention_mask is None else torch.as_tensor(attention_mask)
         emb = F.embedding(ids, w["model.language_model.embed_tokens.weight"])
         B, T = ids.shape
         if pixel_values is not None:
-            img = self.vision(torch.as_tensor(pixel_values).float(), image_grid_thw, record)
+            img = self.vision(torch.as_tensor(pixel_values).float(), image_grid_thw, record, n_vit_layers)
             if record is not None:
                 record["vision_merged"] = img
             sel = ids == cfg["image_token_id"]
@@ -208,7 +209,7 @@ class Qwen2VLRef:
         if record is not None:
             record["merged_embeds"] = emb
             record["position_ids"] = pos
-        h = self.text(emb, am, pos, record)
+        h = self.text(emb, am, pos, record, n_llm_layers)
         logits = F.linear(h, w["lm_head.weight"]).float()
         loss = None
         if labels is not None:
