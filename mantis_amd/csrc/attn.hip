@@ -881,6 +881,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_g4_kernel(
     const int lane = threadIdx.x & 63, hh = lane >> 5, lk = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int kb = wave & 1, hp = wave >> 1;
+    // GQA group of G query heads per KV head, walked as two head streams (hp = 0, 1) of NH = ceil(G / 2) heads each.  Odd G: the last
+    // head slot of stream 1 is a dummy (it re-reads the group's last head with lse = +inf, i.e. p = 0 and dS = 0: it adds exact zeros,
+    // and keeps the two streams' barrier counts equal).  G = 4: Llama-3 / Mistral; G = 7: Qwen2-7B.
+    const int G = H / Hkv, NH = (G + 1) >> 1;
     int bx, hk, b;
     xcd_tile_map((L + 63) >> 6, Hkv, bx, hk, b);
     const int kblk0 = bx * 64, k0 = kblk0 + kb * 32, key = k0 + lk;
@@ -954,7 +958,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_g4_kernel(
     }
     auto stage = [&](int gi, int qt, int slot, float& vl, float& vs, int& ksv) {
         const int q0 = qt * QT;
-        const int h = hk * 4 + hp * 2 + gi;
+        const int hl = hp * NH + gi;                                  // head slot inside the group (hl >= G: the dummy slot)
+        const int h = hk * G + (hl < G ? hl : G - 1);
         char* base = smem + slot * STAGE + hp * STREAM;
         // NB the hardware range check of a raw buffer covers the VECTOR offset only (the scalar offset is added after it), so the
         // tile offset is added into the vector offset: one v_add per access buys "rows beyond L read zeros" for the last tile
@@ -971,8 +976,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_g4_kernel(
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (lds_void_t*)(base + TILE + piece * 1024), 16, voD[j] + soD, 0, 0, 0);
         }
     };
-    auto stage_finish = [&](int qt, int slot, float vl, float vs, int ksv) {
-        const int qq = qt * QT + lk;
+    auto stage_finish = [&](int gi, int qt, int slot, float vl, float vs, int ksv) {
+        const int qq = (hp * NH + gi < G) ? qt * QT + lk : 0x7fffffff;      // dummy head slot: every row is "beyond the last query"
         float* fp = reinterpret_cast<float*>(smem + slot * STAGE + hp * STREAM + 2 * TILE);
         const float val = hh == 0 ? vl * LOG2E : vs;
         // +inf beyond the last query that can see this key block -> p = 0: beyond L, and (packed samples) beyond the end of the
@@ -1042,30 +1047,33 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_g4_kernel(
 
     // ---- masked tiles: plain double-buffered walk (slots 0 / 1), tile j -> (gi = j / nm, qt = qstart + j % nm)
     {
-        const int ntot = 2 * nm;
-        auto tile_m = [&](int j, int& gi, int& qt) { gi = j >= nm ? 1 : 0; qt = qstart + j - gi * nm; };
+        const int ntot = NH * nm;
         if (ntot > 0) {
-            int gi, qt;
+            int gi = 0, qt = qstart;           // tile j = (head slot j / nm, query tile qstart + j % nm), carried instead of divided
             float vl, vs;
             int ksv = 0;
-            tile_m(0, gi, qt);
             stage(gi, qt, 0, vl, vs, ksv);
-            stage_finish(qt, 0, vl, vs, ksv);
+            stage_finish(gi, qt, 0, vl, vs, ksv);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             for (int j = 0; j < ntot; ++j) {
                 const int slot = j & 1;
-                int gn, qn;
-                tile_m(j + 1 < ntot ? j + 1 : j, gn, qn);
+                int gn = gi, qn = qt;
+                if (j + 1 < ntot) {
+                    const bool wrap = (qn + 1 == qstart + nm);
+                    qn = wrap ? qstart : qn + 1;
+                    gn += wrap ? 1 : 0;
+                }
                 stage(gn, qn, slot ^ 1, vl, vs, ksv);
-                stage_finish(qn, slot ^ 1, vl, vs, ksv);
-                tile_m(j, gi, qt);
+                stage_finish(gn, qn, slot ^ 1, vl, vs, ksv);
                 f32x16 s, dp;
                 scores(slot, s, dp);
                 softmax_bwd(std::true_type{}, qt * QT, slot, s, dp);
                 accumulate(slot, s, dp);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
+                gi = gn;
+                qt = qn;
             }
         }
     }
@@ -1079,8 +1087,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_g4_kernel(
     // inline asm with VGPR destinations and the K / V fragments as AGPR operands: S and dP then need no v_accvgpr_read per
     // element (the accumulators proper -- dK, dV -- stay in AGPRs under the compiler's builtin).
     {
-        const int n = 2 * nu1;
-        auto tile_u = [&](int j, int& gi, int& qt) { gi = j >= nu1 ? 1 : 0; qt = qstart + nm + j - gi * nu1; };
+        const int n = NH * nu1;
+        // tile j = (head slot j / nu1, query tile qstart + nm + j % nu1); the staging cursor (pg, pq) walks the tiles one by one and
+        // stays on the last tile once it is reached (re-staging it is harmless), so the loop carries no division
+        int pg = 0, pq = qstart + nm, pj = 0;
+        auto cursor_next = [&]() {
+            if (pj + 1 < n) {
+                const bool wrap = (pq + 1 == qstart + nm + nu1);
+                pq = wrap ? qstart + nm : pq + 1;
+                pg += wrap ? 1 : 0;
+                ++pj;
+            }
+        };
         if (n > 0) {
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) { asm volatile("" : "+a"(kf[ks])); asm volatile("" : "+a"(vf[ks])); }
@@ -1088,9 +1106,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_g4_kernel(
                 float v[3], w[3];
                 int zz[3] = {0, 0, 0}, g[3], q[3];
 #pragma unroll
-                for (int t = 0; t < 3; ++t) { tile_u(t < n ? t : n - 1, g[t], q[t]); stage(g[t], q[t], t, v[t], w[t], zz[t]); }
+                for (int t = 0; t < 3; ++t) { g[t] = pg; q[t] = pq; stage(g[t], q[t], t, v[t], w[t], zz[t]); cursor_next(); }
 #pragma unroll
-                for (int t = 0; t < 3; ++t) stage_finish(q[t], t, v[t], w[t], zz[t]);
+                for (int t = 0; t < 3; ++t) stage_finish(g[t], q[t], t, v[t], w[t], zz[t]);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -1164,8 +1182,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_g4_kernel(
                 constexpr int PF = 4;
                 const char* tq0 = smem + slot0 * STAGE + hp * STREAM;    // tile j: transposed fragments
                 const char* tq2 = smem + slot2 * STAGE + hp * STREAM;    // tile j + 2: row fragments
-                int gi3, qt3;
-                tile_u(j + 3 < n ? j + 3 : n - 1, gi3, qt3);
+                const int gi3 = pg, qt3 = pq;                 // tile j + 3 (or the last tile again)
+                cursor_next();
                 float vl, vs;
                 int ksv = 0;
                 stage(gi3, qt3, slot3, vl, vs, ksv);       // slot3 held tile j-1: released by the barrier that ended step j-1
@@ -1209,7 +1227,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_g4_kernel(
                     }
                 });
                 __builtin_amdgcn_sched_barrier(0);
-                stage_finish(qt3, slot3, vl, vs, ksv);
+                stage_finish(gi3, qt3, slot3, vl, vs, ksv);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile j+3 landed (this wave's pieces)
                 __syncthreads();
             };
@@ -1258,6 +1276,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_g4_kernel(
     }
 }
 
+// group sizes served by attn_bwd_dkv_g4_kernel: every even G, odd G from 5 on (one dummy head slot in G + 1: at most 1/6 wasted)
+static inline bool attn_dkv_group_kernel_ok(int G) { return G >= 2 && (G % 2 == 0 || G >= 5); }
+
 template <int HD>
 static int launch_fwd(bool causal, dim3 grid, hipStream_t s, const bf16_t* Q, const bf16_t* K, const bf16_t* V, const int* kmask,
                       bf16_t* O, float* LSE, int L, int H, int Hkv, long ldq, long ldk, long ldv, long ldo, float scale,
@@ -1279,7 +1300,7 @@ static int launch_bwd(bool causal, hipStream_t s, const bf16_t* Q, const bf16_t*
     const dim3 gq(cdiv(L, 128) * H * B), gk(cdiv(L, DkvCfg<HD>::KEYS) * H * B);
     const int G = H / Hkv;
     if constexpr (HD == 128) {
-        if (G == 4) {      // Llama-3 geometry: GQA-aware dK/dV (no HBM partials, no group reduce); dQ as before (it also publishes Dsum)
+        if (attn_dkv_group_kernel_ok(G)) {      // GQA-aware dK/dV (no HBM partials, no group reduce); dQ as before (it also publishes Dsum)
             if (causal)
                 hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, true>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, L, H, Hkv,
                                    ldq, ldk, ldv, ldo, lddq, scale, Ofwd, ldout, kstart);
@@ -1348,7 +1369,9 @@ int mantis_attn_fwd(const void* Q, const void* K, const void* V, const int32_t* 
 }
 
 // 1 if mantis_attn_bwd needs the 2 * B*L*H*hd bf16 workspace for this geometry (per-query-head dK/dV partials), 0 if not
-int mantis_attn_bwd_needs_workspace(int H, int Hkv, int hd) { return (H == Hkv || (hd == 128 && H == 4 * Hkv)) ? 0 : 1; }
+int mantis_attn_bwd_needs_workspace(int H, int Hkv, int hd) {
+    return (H == Hkv || (hd == 128 && Hkv > 0 && H % Hkv == 0 && attn_dkv_group_kernel_ok(H / Hkv))) ? 0 : 1;
+}
 
 // Dsum [B,H,L] = rowsum(dO * O)
 int mantis_attn_dsum(const void* dO, const void* O, float* Dsum, int B, int L, int H, int hd, int64_t ldo, void* stream) {

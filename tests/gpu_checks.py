@@ -299,7 +299,8 @@ def check_attn_segments(B, L, H, Hkv, hd, cuts, causal=True, mask=None):
 
 ATTN_SEG_CASES = [(1, 300, 8, 2, 128, [[70, 71, 200]], True, None), (2, 200, 4, 2, 16, [[64], [33, 150]], True, None),
                   (1, 257, 4, 4, 64, [[100, 228]], True, "right"), (1, 450, 4, 1, 128, [[128, 320]], True, None),
-                  (1, 190, 8, 2, 128, [[95]], True, "right"), (2, 130, 4, 2, 16, [[], [65]], True, "left")]
+                  (1, 190, 8, 2, 128, [[95]], True, "right"), (2, 130, 4, 2, 16, [[], [65]], True, "left"),
+                  (1, 300, 7, 1, 128, [[70, 71, 200]], True, None), (1, 257, 14, 2, 128, [[100, 228]], True, "right")]
 
 ATTN_FWD_CASES = [(2, 54, 4, 2, 16, True, "right"), (2, 54, 4, 2, 16, True, "left"), (3, 17, 4, 4, 16, False, None),
                   (2, 197, 12, 12, 64, False, None), (2, 577, 16, 16, 72, False, None), (1, 323, 12, 12, 64, True, None),
@@ -316,7 +317,10 @@ ATTN_BWD_CASES = [(2, 54, 4, 2, 16, True, "right"), (2, 54, 4, 2, 16, True, "lef
                   (2, 200, 4, 1, 128, True, None), (1, 130, 8, 2, 128, False, "left"), (1, 40, 4, 1, 128, True, None),
                   (1, 256, 4, 1, 128, True, "right"), (2, 97, 8, 2, 128, False, None), (1, 33, 4, 1, 128, True, "left"),
                   (2, 80, 16, 4, 96, False, "right"), (1, 300, 4, 2, 96, True, None), (1, 1088, 16, 4, 96, False, "right"),
-                  (1, 333, 14, 2, 128, True, "right"), (2, 70, 7, 1, 16, True, None)]
+                  (1, 333, 14, 2, 128, True, "right"), (2, 70, 7, 1, 16, True, None),
+                  # the GQA-aware dK/dV kernel at other group sizes: G = 7 (Qwen2-7B; odd: one dummy head slot), 2, 5, 6, 8
+                  (2, 200, 7, 1, 128, True, None), (1, 130, 14, 2, 128, False, "left"), (1, 97, 2, 1, 128, True, None),
+                  (1, 260, 10, 2, 128, True, "right"), (1, 190, 6, 1, 128, False, None), (1, 160, 8, 1, 128, True, "left")]
 
 
 # ------------------------------------------------------------------------------------------------------------- packing / CE
