@@ -137,8 +137,10 @@ int mantis_attn_fwd(const void* Q, const void* K, const void* V, const int32_t* 
                     void* stream);
 int mantis_attn_dsum(const void* dO, const void* O, float* Dsum, int B, int L, int H, int hd, int64_t ldo, void* stream);
 /* workspace: 2*B*L*H*hd bf16 (per-query-head dK/dV partials, reduced over the GQA group) when
- * mantis_attn_bwd_needs_workspace(H, Hkv, hd) says so, else unused/NULL: not for H == Hkv, and not for the GQA-aware dK/dV kernel
- * (hd 128, H = 4 Hkv -- Llama-3: one workgroup per (64-key block, KV head) walks all four query heads, partials meet in LDS).
+ * mantis_attn_bwd_needs_workspace(H, Hkv, hd) says so, else unused/NULL: not for H == Hkv, and not for hd 128 with H = 4 Hkv
+ * (Llama-3), which always runs the GQA-aware dK/dV kernel (one workgroup per (64-key block, KV head) walks the group's query heads
+ * as two streams, partials meet in LDS).  Other group sizes (even, or odd >= 5; Qwen2-7B's 7:1) run that kernel when the grid is
+ * tiny or at least two rounds deep, and the per-query-head path otherwise -- they are handed the workspace either way.
  * O (forward output, row stride ld_out) optional: if given, Dsum = rowsum(dO * O) is computed inside the dQ kernel and written to
  * Dsum ([B,H,L] fp32); if NULL, Dsum must already hold it (mantis_attn_dsum).
  * kstart / qend (int32 [B,L], both or neither, nullable): segment bounds for packed samples (data.py:1609-1671 block-diagonal mask):

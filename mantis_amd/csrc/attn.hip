@@ -1276,6 +1276,17 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_g4_kernel(
     }
 }
 
+static int attn_num_cus() {
+    static int cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
+        int n = 0;
+        cached[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cached[dev];
+}
+
 // group sizes served by attn_bwd_dkv_g4_kernel: every even G, odd G from 5 on (one dummy head slot in G + 1: at most 1/6 wasted)
 static inline bool attn_dkv_group_kernel_ok(int G) { return G >= 2 && (G % 2 == 0 || G >= 5); }
 
@@ -1300,7 +1311,13 @@ static int launch_bwd(bool causal, hipStream_t s, const bf16_t* Q, const bf16_t*
     const dim3 gq(cdiv(L, 128) * H * B), gk(cdiv(L, DkvCfg<HD>::KEYS) * H * B);
     const int G = H / Hkv;
     if constexpr (HD == 128) {
-        if (attn_dkv_group_kernel_ok(G)) {      // GQA-aware dK/dV (no HBM partials, no group reduce); dQ as before (it also publishes Dsum)
+        // GQA-aware dK/dV (no HBM partials, no group reduce); dQ as before (it also publishes Dsum).  Its grid is one workgroup per
+        // (64-key block, KV head) with causal work that varies 64x across key blocks: below about two workgroups per CU the heaviest
+        // block sets the time (Qwen2-7B at B = 1, L = 4096: 256 workgroups, 553 us vs 490 us for the per-query-head path, measured), so
+        // other group sizes than Llama's take it only when the grid is either tiny or at least two rounds deep
+        const long nwg = (long)cdiv(L, 64) * Hkv * B;
+        const int cus = attn_num_cus();
+        if (attn_dkv_group_kernel_ok(G) && (G == 4 || nwg >= 2L * cus || nwg <= cus / 2 || ws == nullptr)) {
             if (causal)
                 hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, true>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, L, H, Hkv,
                                    ldq, ldk, ldv, ldo, lddq, scale, Ofwd, ldout, kstart);
@@ -1369,9 +1386,9 @@ int mantis_attn_fwd(const void* Q, const void* K, const void* V, const int32_t* 
 }
 
 // 1 if mantis_attn_bwd needs the 2 * B*L*H*hd bf16 workspace for this geometry (per-query-head dK/dV partials), 0 if not
-int mantis_attn_bwd_needs_workspace(int H, int Hkv, int hd) {
-    return (H == Hkv || (hd == 128 && Hkv > 0 && H % Hkv == 0 && attn_dkv_group_kernel_ok(H / Hkv))) ? 0 : 1;
-}
+// 0: never needed (MHA; GQA 4:1 at hd 128 always runs the group kernel).  1: pass a workspace (other group sizes choose between the
+// group kernel and the per-query-head path by grid size; without a workspace they are held to the group kernel where it exists).
+int mantis_attn_bwd_needs_workspace(int H, int Hkv, int hd) { return (H == Hkv || (hd == 128 && H == 4 * Hkv)) ? 0 : 1; }
 
 // Dsum [B,H,L] = rowsum(dO * O)
 int mantis_attn_dsum(const void* dO, const void* O, float* Dsum, int B, int L, int H, int hd, int64_t ldo, void* stream) {
