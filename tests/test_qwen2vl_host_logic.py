@@ -99,3 +99,68 @@ def test_forward_contract(cpu_backend):
     assert out["loss"] is out.loss and out[0] is out.loss
     with pytest.raises(NotImplementedError):
         model(**b, pixel_values_videos=torch.zeros(1, 1))
+
+
+# ----------------------------------------------------------------------------------------------------------- data parallel (gloo, 2 ranks)
+def test_grad_buckets_tile_the_arena_and_every_bucket_is_signalled(cpu_backend):
+    z = Hh.load_case("qwen2vl_b1_img2")
+    for precision in ("bf16", "fp8"):
+        model = Hh.build_qwen2vl_product("cpu").set_precision(precision)
+        b = model.grad_buckets()
+        spans = sorted((v.data_ptr(), v.numel()) for v in b.values())
+        assert spans[0][0] == model.grad_arena.data_ptr() and sum(n for _, n in spans) == model.grad_arena.numel()
+        for (p0, n0), (p1, _) in zip(spans, spans[1:]):
+            assert p0 + 2 * n0 == p1, "buckets overlap or leave a gap"
+        seen = []
+        model.engine.step_from_batch(Hh.qwen2vl_batch(z), compute_grads=True, overwrite_grads=True, on_bucket_ready=seen.append)
+        assert seen[0] == "head" and seen[-1] == "front" and set(seen) == set(b) and len(seen) == len(b), precision
+        nl = model.config.text_config.num_hidden_layers
+        assert seen[1:4] == [("layer", nl - 1, "down"), ("layer", nl - 1, "gu"), ("layer", nl - 1, "attn")]
+
+
+def _dp_worker(rank, world, port, q, precision):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import mantis_amd.modeling_qwen2_vl as mod
+        from oracle import ops_ref
+        mod.K = ops_ref
+        from mantis_amd.trainer import MantisHipTrainer
+        from mantis_amd.dp import GradReducer
+        model = Hh.build_qwen2vl_product("cpu").set_precision(precision)
+        z = Hh.load_case(["qwen2vl_b1_img2", "qwen2vl_b1_img1_tall"][rank])          # different samples (and lengths) per rank
+        tr = MantisHipTrainer(model, gradient_accumulation_steps=1, reducer=GradReducer(model))
+        loss = tr.training_step(model, Hh.qwen2vl_batch(z))
+        q.put((rank, float(loss), model.grad_arena.float().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp8"])
+def test_dp2_gradients_are_the_mean_of_the_per_rank_gradients(cpu_backend, precision):
+    import multiprocessing as mp
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, precision)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert np.array_equal(res[0][2], res[1][2]), "ranks disagree after the bucketed all-reduce"
+    acc = None
+    for case in ("qwen2vl_b1_img2", "qwen2vl_b1_img1_tall"):
+        model = Hh.build_qwen2vl_product("cpu").set_precision(precision)
+        model._ensure_grad_arena()
+        model.engine.step_from_batch(Hh.qwen2vl_batch(Hh.load_case(case)), compute_grads=True, overwrite_grads=True)
+        g = model.grad_arena.float().numpy().copy()
+        acc = g if acc is None else acc + g
+    assert Hh.rel_l2(res[0][2], acc / 2) < 1e-2                                        # bf16 rounding of the averaged buckets
