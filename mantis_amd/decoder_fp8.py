@@ -43,7 +43,7 @@ def _lin(K, xq, wq, bias=None, residual=None):
     return K.gemm_fp8_nt(xq.q, xq.dequant, wq.q, wq.dequant, E4M3, bias=bias, residual=residual)
 
 
-def decoder_forward(K, lm, w8, tc, x, B, L, kmask, compute_grads=True, record=None, rope=None):
+def decoder_forward(K, lm, w8, tc, x, B, L, kmask, compute_grads=True, record=None, rope=None, kstart=None):
     """Same contract as decoder.decoder_forward (rope tables given by the caller)."""
     H, Hkv, hd = tc.num_attention_heads, tc.num_key_value_heads, tc.head_dim
     eps = tc.rms_norm_eps
@@ -56,7 +56,7 @@ def decoder_forward(K, lm, w8, tc, x, B, L, kmask, compute_grads=True, record=No
         n1q = K.fp8_quantize(n1, E4M3, transposed=compute_grads)
         qkv = _lin(K, n1q, w8.get(K, i, "qkv"), bias=lw.get("qkv_b"))
         K.rope_apply_(qkv, cos, sin, H + Hkv, hd)
-        o, lse = K.attn_fwd(qkv, B, L, H, Hkv, hd, kmask, scale, True)
+        o, lse = K.attn_fwd(qkv, B, L, H, Hkv, hd, kmask, scale, True, kstart=kstart)
         oq = K.fp8_quantize(o, E4M3, transposed=compute_grads)
         x_mid = _lin(K, oq, w8.get(K, i, "o"), residual=x)
         n2, rstd2 = K.rmsnorm_fwd(x_mid, lw["ln2"], eps)
@@ -85,7 +85,8 @@ def _dx(K, dyq, wq):
     return K.gemm_fp8_nt(dyq.q, dyq.dequant, wq.qt, wq.dequant, E5M2)
 
 
-def decoder_backward(K, lm, w8, grads, grads_layers, tc, ctx, hctx, plan, B, L, kmask, accumulate=False, on_bucket_ready=None):
+def decoder_backward(K, lm, w8, grads, grads_layers, tc, ctx, hctx, plan, B, L, kmask, accumulate=False, on_bucket_ready=None,
+                     kstart=None, qend=None):
     """Same contract as decoder.decoder_backward: head + loss backward (bf16, shared), then the fp8 layer loop."""
     H, Hkv, hd = tc.num_attention_heads, tc.num_key_value_heads, tc.head_dim
     acc = accumulate
@@ -120,7 +121,7 @@ def decoder_backward(K, lm, w8, grads, grads_layers, tc, ctx, hctx, plan, B, L, 
         _dw(K, dmq, oq, lg_["o"], acc)
         do = _dx(K, dmq, w8.get(K, i, "o"))
         del dmq, oq
-        dqkv = K.attn_bwd(qkv, o, do, lse, B, L, H, Hkv, hd, kmask, scale, True)
+        dqkv = K.attn_bwd(qkv, o, do, lse, B, L, H, Hkv, hd, kmask, scale, True, kstart=kstart, qend=qend)
         del do, o
         K.rope_apply_(dqkv, cos, sin, H + Hkv, hd, backward=True)
         dqq = K.fp8_quantize(dqkv, E5M2, transposed=lg_["qkv"] is not None)

@@ -6,7 +6,9 @@ the hand-written gfx950 kernels (no autograd graph): dynamic-resolution ViT with
 patch merger (`visual`, frozen as the reference's training script keeps it), `<|image_pad|>` merge, Qwen2 decoder with q/k/v bias and
 multimodal RoPE, fp32 cross-entropy.
 
-Documented divergences: video inputs, generation / KV-cache and `rope_deltas` bookkeeping are out of scope (SURVEY.md section 2);
+Sample packing (several samples in one row, `segment_ids`): block-diagonal attention through segment bounds, the 3-D rope index
+restarting per sample.  Documented divergences: video inputs, generation / KV-cache and `rope_deltas` bookkeeping are out of scope
+(SURVEY.md section 2);
 labels at positions with attention_mask == 0 must be -100 (what the reference's collator produces) -- checked on the first step."""
 from dataclasses import dataclass
 from typing import Optional, Tuple
@@ -245,10 +247,11 @@ def vision_hw_ids(grids, merge):
     return torch.stack([torch.cat(hs), torch.cat(ws)])
 
 
-def mrope_position_ids(ids, am, grids, image_token_id, merge):
+def mrope_position_ids(ids, am, grids, image_token_id, merge, segment_ids=None):
     """Qwen2VLModel.get_rope_index (:914-1018), images only -> int64 [3, B, T].  Runs of text count on; an image (t, h, w) puts
     (frame, row, column) of its merged grid on top of the running position and advances it by max(h, w) / merge; positions where
-    attention_mask == 0 stay 0 and do not advance the counter."""
+    attention_mask == 0 stay 0 and do not advance the counter.  segment_ids [B, T] (packed samples): the counter restarts at every
+    sample, i.e. each sample gets the index it would get alone (images are consumed in order of appearance)."""
     B, T = ids.shape
     pos = torch.zeros((3, B, T), dtype=torch.int64)
     gi = 0
@@ -259,12 +262,21 @@ def mrope_position_ids(ids, am, grids, image_token_id, merge):
         if n == 0:
             continue
         img = row == image_token_id
-        edge = torch.nonzero(img[1:] != img[:-1]).reshape(-1) + 1
+        cut = img[1:] != img[:-1]
+        restart = torch.zeros(n, dtype=torch.bool)
+        if segment_ids is not None:
+            seg = segment_ids[b][keep]
+            sb = seg[1:] != seg[:-1]
+            restart[1:] = sb
+            cut = cut | sb                     # a sample boundary also ends a run (two images of two samples may touch)
+        edge = torch.nonzero(cut).reshape(-1) + 1
         starts = [0] + edge.tolist()
         ends = edge.tolist() + [n]
         cur = 0
         out = torch.empty((3, n), dtype=torch.int64)
         for s, e in zip(starts, ends):
+            if bool(restart[s]):
+                cur = 0
             if not bool(img[s]):
                 out[:, s:e] = torch.arange(cur, cur + e - s, dtype=torch.int64)[None]
                 cur += e - s
@@ -322,6 +334,8 @@ class Qwen2VLEngine:
         self._prefetched = (pv, img, done)
 
     def step_from_batch(self, inputs, **kw):
+        if kw.get("segment_ids") is None and inputs.get("segment_ids") is not None:
+            kw["segment_ids"] = inputs["segment_ids"]
         return self.step(inputs["input_ids"], inputs["attention_mask"], inputs.get("labels"), inputs.get("pixel_values"),
                          inputs.get("image_grid_thw"), **kw)
 
@@ -378,9 +392,6 @@ class Qwen2VLEngine:
     # ------------------------------------------------------------------ full step
     def step(self, input_ids, attention_mask, labels, pixel_values, image_grid_thw=None, grad_scale=1.0, loss_scale=1.0,
              compute_grads=True, overwrite_grads=True, need_logits=False, record=None, on_bucket_ready=None, segment_ids=None):
-        if segment_ids is not None:
-            raise NotImplementedError("sample packing is implemented for the LLaVA and Idefics2 paths (BASELINE configs[4] is one 4096-token "
-                                      "sample per row)")
         m, cfg, tc = self.m, self.cfg, self.cfg.text_config
         dev = m.device
         ids_cpu = input_ids.detach().to("cpu") if input_ids.device.type != "cpu" else input_ids
@@ -418,12 +429,23 @@ class Qwen2VLEngine:
                 raise ValueError(f"Image features and image tokens do not match, tokens: {n_tok}, features: {n_rows}")
             if bool((am_cpu[ids_cpu == IMG] == 0).any()):
                 raise NotImplementedError("attention_mask == 0 on an <|image_pad|> token")
-            pos3 = mrope_position_ids(ids_cpu, am_cpu, grids, IMG, mg)
-        else:
+            seg_cpu = None if segment_ids is None else (segment_ids.detach().to("cpu") if segment_ids.device.type != "cpu" else segment_ids)
+            pos3 = mrope_position_ids(ids_cpu, am_cpu, grids, IMG, mg, seg_cpu)
+        elif segment_ids is None:
             pos3 = torch.arange(T, dtype=torch.int64)[None, None].expand(3, B, T).contiguous()   # text only: HF counts 0..T-1 itself
+        else:
+            seg_cpu = segment_ids.detach().to("cpu") if segment_ids.device.type != "cpu" else segment_ids
+            pos3 = mrope_position_ids(ids_cpu, torch.ones_like(ids_cpu), [], IMG, mg, seg_cpu)   # arange restarting at every sample
         # masked_scatter (:1160-1166) = the packing plan with ONE slot per <|image_pad|> token, rows taken in order
         plan = K.pack_plan(ids_d, attn_d, lab_d, 1, n_rows, IMG if img is not None else -(2 ** 62), -1, -100, T)
         plan.position_ids = pos3
+        kstart = qend = None
+        if segment_ids is not None:
+            # sample packing (/root/reference/mantis/train/data.py:1546-1671): several samples in one row, block-diagonal attention
+            # through O(L) segment bounds, rope index restarting per sample (above), no prediction across a sample boundary
+            seg_d = segment_ids.to(dev, non_blocking=True).to(torch.int32).contiguous()
+            K.pack_segments(plan, ids_d, seg_d, -(2 ** 62))
+            kstart, qend = plan.kstart, plan.qend
         x = K.pack_rows_fwd(plan, ids_d, m.lm["embed"], img)
         if record is not None:
             record["merged_embeds"] = x.view(B, T, -1)
@@ -437,9 +459,9 @@ class Qwen2VLEngine:
             if not self.weights_unchanged:
                 self.w8.refresh()
             self.weights_unchanged = False
-            x, dctx = D8.decoder_forward(K, m.lm, self.w8, tc, x, B, T, kmask, compute_grads, record, rope=rope)
+            x, dctx = D8.decoder_forward(K, m.lm, self.w8, tc, x, B, T, kmask, compute_grads, record, rope=rope, kstart=kstart)
         else:
-            x, dctx = D.decoder_forward(K, m.lm, tc, x, B, T, None, kmask, None, compute_grads, record, rope=rope)
+            x, dctx = D.decoder_forward(K, m.lm, tc, x, B, T, None, kmask, kstart, compute_grads, record, rope=rope)
         loss, count, logits_full, hctx = D.head_and_loss(K, m.lm, tc, x, plan, B, T, labels is not None, grad_scale, loss_scale,
                                                          compute_grads, need_logits, record)
         if count is not None and not self._verified:
@@ -452,9 +474,10 @@ class Qwen2VLEngine:
         acc = not overwrite_grads
         g = m.grads
         if fp8:
-            dx = D8.decoder_backward(K, m.lm, self.w8, g, m.grads_layers, tc, dctx, hctx, plan, B, T, kmask, acc, on_bucket_ready)
+            dx = D8.decoder_backward(K, m.lm, self.w8, g, m.grads_layers, tc, dctx, hctx, plan, B, T, kmask, acc, on_bucket_ready,
+                                     kstart=kstart, qend=qend)
         else:
-            dx = D.decoder_backward(K, m.lm, g, m.grads_layers, tc, dctx, hctx, plan, B, T, kmask, None, None, acc, on_bucket_ready)
+            dx = D.decoder_backward(K, m.lm, g, m.grads_layers, tc, dctx, hctx, plan, B, T, kmask, kstart, qend, acc, on_bucket_ready)
         if g.get("embed") is not None:
             if overwrite_grads:
                 g["embed"].zero_()

@@ -216,3 +216,33 @@ class Qwen2VLRef:
             lab = torch.as_tensor(labels)
             loss = F.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]), lab[:, 1:].reshape(-1), ignore_index=-100)
         return loss, logits
+
+    def forward_packed(self, input_ids, pixel_values, image_grid_thw, segment_ids, labels):
+        """Sample packing defined through its meaning (cf. LlavaRef.forward_packed): the packed row is unpacked into its samples, each
+        runs through `forward` alone (its own rope index, its own attention), the loss is the mean over the label positions of all of
+        them.  Images are consumed in order of appearance; a sample owns the grids whose merged sizes fill its <|image_pad|> runs."""
+        cfg = self.cfg
+        ids, seg, lab = (torch.as_tensor(x) for x in (input_ids, segment_ids, labels))
+        grids = [] if image_grid_thw is None else np.asarray(image_grid_thw).tolist()
+        pv = None if pixel_values is None else torch.as_tensor(pixel_values)
+        m2 = self.vc["spatial_merge_size"] ** 2
+        total, count, gi, p0 = 0.0, 0, 0, 0
+        for sid in torch.unique_consecutive(seg[0]).tolist():
+            sel = seg[0] == sid
+            si, sl = ids[0][sel][None], lab[0][sel][None]
+            need = int((si == cfg["image_token_id"]).sum())
+            g0, got, npatch = gi, 0, 0
+            while got < need:
+                t, h, w = grids[gi]
+                got += t * h * w // m2
+                npatch += t * h * w
+                gi += 1
+            spv = None if need == 0 else pv[p0: p0 + npatch]
+            p0 += npatch
+            _, logits = self.forward(si, spv, None if need == 0 else np.asarray(grids[g0:gi]), None, None)
+            lg, tg = logits[0, :-1], sl[0, 1:]
+            valid = tg != -100
+            if int(valid.sum()):
+                total = total + F.cross_entropy(lg[valid], tg[valid], reduction="sum")
+                count += int(valid.sum())
+        return total / max(count, 1)

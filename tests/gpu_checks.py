@@ -853,6 +853,36 @@ def check_qwen2vl_step(case):
     return 1.0 - min(c for c, _ in rep.values())
 
 
+def check_qwen2vl_packed(precision):
+    """Sample packing on the Qwen2-VL path on the HIP kernels: the two samples of the B=2 golden batch packed into one row (segment-bounded
+    attention, rope index restarting per sample) give the loss and gradients of the oracle running them one by one."""
+    z = Hh.load_case("qwen2vl_b2_rightpad")
+    ids, am, lab = z["input_ids"], z["attention_mask"], z["labels"]
+    keep = [am[b].astype(bool) for b in range(2)]
+    pid = torch.from_numpy(np.concatenate([ids[b][keep[b]] for b in range(2)]))[None]
+    plab = torch.from_numpy(np.concatenate([lab[b][keep[b]] for b in range(2)]))[None]
+    seg = torch.from_numpy(np.concatenate([np.full(int(keep[b].sum()), b, np.int32) for b in range(2)]))[None]
+    pv, grid = torch.from_numpy(z["pixel_values"]), torch.from_numpy(z["image_grid_thw"])
+    model = Hh.build_qwen2vl_product(DEV).set_precision(precision)
+    oracle = Hh.build_qwen2vl_oracle_bf16()
+    assert model._ensure_grad_arena()
+    out = model.engine.step(pid, torch.ones_like(pid), plab, pv, grid, compute_grads=True, overwrite_grads=True, segment_ids=seg)
+    oracle.zero_grad()
+    oloss = oracle.forward_packed(pid, pv, grid, seg, plab)
+    oloss.backward()
+    fp8 = precision == "fp8"
+    loss = float(out["loss"].cpu())
+    assert abs(loss - float(oloss)) <= (1e-2 if fp8 else 5e-3) * float(oloss), (loss, float(oloss))
+    worst = 1.0
+    for name, p in model.named_parameters():
+        if p.requires_grad:
+            g, og = p.grad.float().cpu().numpy(), oracle.w[name].grad.numpy()
+            c = Hh.cosine(g, og)
+            assert c > ((0.85 if p.dim() == 1 else 0.95) if fp8 else 0.995), (name, c)
+            worst = min(worst, c)
+    return 1.0 - worst
+
+
 def check_qwen2vl_prefetch():
     """The frozen tower computed ahead on the side stream (engine.prefetch_vision, driven by training_step(next_inputs=)) gives bit-identical
     loss and gradients to computing it in line; a prefetch for a different batch object is ignored."""
@@ -1229,6 +1259,8 @@ def all_checks():
         c[f"fp8_dx_swiglu_{m_}x{d_}x{i_}_fmt{f_}"] = (lambda m_=m_, d_=d_, i_=i_, f_=f_: check_fp8_dx_swiglu(m_, d_, i_, f_))
     for case in QWEN2VL_CASES:
         c["qwen2vl_fp8_step_" + case[8:]] = (lambda case=case: check_qwen2vl_step_fp8(case))
+    c["qwen2vl_packed_bf16"] = lambda: check_qwen2vl_packed("bf16")
+    c["qwen2vl_packed_fp8"] = lambda: check_qwen2vl_packed("fp8")
     c["qwen2vl_prefetch_bit_identical"] = check_qwen2vl_prefetch
     c["rope_sections_cast_pad"] = check_rope_sections
     c["qwen2vl_full_width"] = check_qwen2vl_full_width

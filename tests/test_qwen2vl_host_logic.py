@@ -164,3 +164,41 @@ def test_dp2_gradients_are_the_mean_of_the_per_rank_gradients(cpu_backend, preci
         g = model.grad_arena.float().numpy().copy()
         acc = g if acc is None else acc + g
     assert Hh.rel_l2(res[0][2], acc / 2) < 1e-2                                        # bf16 rounding of the averaged buckets
+
+
+# ----------------------------------------------------------------------------------------------------------- sample packing
+def _packed_from_b2(z):
+    """The two samples of the B=2 golden batch (right padding dropped) as ONE packed row + segment ids; images in order of appearance."""
+    ids, am, lab = z["input_ids"], z["attention_mask"], z["labels"]
+    keep = [am[b].astype(bool) for b in range(2)]
+    pid = torch.from_numpy(np.concatenate([ids[b][keep[b]] for b in range(2)]))[None]
+    plab = torch.from_numpy(np.concatenate([lab[b][keep[b]] for b in range(2)]))[None]
+    seg = torch.from_numpy(np.concatenate([np.full(int(keep[b].sum()), b, np.int32) for b in range(2)]))[None]
+    return pid, plab, seg, torch.from_numpy(z["pixel_values"]), torch.from_numpy(z["image_grid_thw"])
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp8"])
+def test_packed_row_equals_the_separate_samples(cpu_backend, precision):
+    from oracle.qwen2vl_ref import rope_index
+    z = Hh.load_case("qwen2vl_b2_rightpad")
+    pid, plab, seg, pv, grid = _packed_from_b2(z)
+    model = Hh.build_qwen2vl_product("cpu").set_precision(precision)
+    oracle = Hh.build_qwen2vl_oracle_bf16()
+    assert model._ensure_grad_arena()
+    rec = {}
+    out = model.engine.step(pid, torch.ones_like(pid), plab, pv, grid, compute_grads=True, overwrite_grads=True, segment_ids=seg, record=rec)
+    # the 3-D rope index of the packed row = each sample's own index (the reference's get_rope_index on the sample alone), side by side
+    n0 = int((seg[0] == 0).sum())
+    p0 = rope_index(pid[:, :n0], None, grid[:2], model.config.image_token_id, 2)
+    p1 = rope_index(pid[:, n0:], None, grid[2:], model.config.image_token_id, 2)
+    assert torch.equal(rec["position_ids"], torch.cat([p0, p1], dim=2))
+    oracle.zero_grad()
+    oloss = oracle.forward_packed(pid, pv, grid, seg, plab)
+    oloss.backward()
+    fp8 = precision == "fp8"
+    assert abs(float(out["loss"]) - float(oloss)) <= (1e-2 if fp8 else 5e-3) * float(oloss)
+    for name, p in model.named_parameters():
+        if p.requires_grad:
+            g, og = p.grad.float().numpy(), oracle.w[name].grad.numpy()
+            c = Hh.cosine(g, og)
+            assert c > ((0.85 if p.dim() == 1 else 0.95) if fp8 else 0.995), (name, c)
