@@ -438,14 +438,15 @@ class Qwen2VLEngine:
             pos3 = mrope_position_ids(ids_cpu, torch.ones_like(ids_cpu), [], IMG, mg, seg_cpu)   # arange restarting at every sample
         # masked_scatter (:1160-1166) = the packing plan with ONE slot per <|image_pad|> token, rows taken in order
         plan = K.pack_plan(ids_d, attn_d, lab_d, 1, n_rows, IMG if img is not None else -(2 ** 62), -1, -100, T)
-        plan.position_ids = pos3
         kstart = qend = None
         if segment_ids is not None:
             # sample packing (/root/reference/mantis/train/data.py:1546-1671): several samples in one row, block-diagonal attention
             # through O(L) segment bounds, rope index restarting per sample (above), no prediction across a sample boundary
+            # (the kernel also rewrites the plan's own 1-D position buffer, which this path replaces by the 3-D index right after)
             seg_d = segment_ids.to(dev, non_blocking=True).to(torch.int32).contiguous()
             K.pack_segments(plan, ids_d, seg_d, -(2 ** 62))
             kstart, qend = plan.kstart, plan.qend
+        plan.position_ids = pos3
         x = K.pack_rows_fwd(plan, ids_d, m.lm["embed"], img)
         if record is not None:
             record["merged_embeds"] = x.view(B, T, -1)
