@@ -28,7 +28,13 @@ def _stream():
 
 
 def _p(t):
-    return None if t is None else t.data_ptr()
+    """Device address of a tensor argument (None -> NULL).  A host tensor handed to a kernel is a memory fault that takes the process
+    down at the next synchronisation, far from its cause: refuse it here."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise ValueError(f"a {tuple(t.shape)} {t.dtype} tensor on {t.device} was passed to a gfx950 kernel (device tensors only)")
+    return t.data_ptr()
 
 
 def _chk2d(t, name):

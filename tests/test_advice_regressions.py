@@ -168,3 +168,16 @@ def test_adamw_and_clip_oracle_match_torch():
             ref = torch.cat([p.detach().reshape(-1) for p in tp])
             assert torch.allclose(master, ref, rtol=2e-6, atol=1e-7), (wd, step, float((master - ref).abs().max()))
             assert torch.equal(pbf, master.to(torch.bfloat16))
+
+
+def test_host_tensor_is_refused_before_it_reaches_a_kernel():
+    """hip_ops._p: a CPU tensor in a kernel argument list raises at the call (it used to be a GPU memory fault at the next sync)."""
+    import pytest
+    import torch
+    try:
+        from mantis_amd import hip_ops
+    except (ImportError, OSError):
+        pytest.skip("libmantis_hip.so not built")
+    with pytest.raises(ValueError):
+        hip_ops._p(torch.zeros(4))
+    assert hip_ops._p(None) is None
