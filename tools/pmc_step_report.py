@@ -67,7 +67,10 @@ def main():
     ap.add_argument("--sq")
     ap.add_argument("--out", required=True)
     ap.add_argument("--note", default="")
+    ap.add_argument("--gemm-family", default=",".join(GEMM_FAMILY),
+                    help="comma-separated kernel-name prefixes summarised as `gemm_family` (Qwen2-VL fp8 run: gemm_fp8_ring_kernel,gemm_fp8_nt_kernel)")
     a = ap.parse_args()
+    gemm_family = tuple(x for x in a.gemm_family.split(",") if x)
     f, w = read_pass(a.fetch), read_pass(a.write)
     out = dict(source=dict(fetch=a.fetch, write=a.write, sq=a.sq, note=a.note,
                            corrections="FETCH_SIZE KiB x1024 x2 (gfx950 64-B tally of 128-B requests); WRITE_SIZE KiB x1024; "
@@ -81,7 +84,7 @@ def main():
         wb = w[k]["WRITE_SIZE"] * 1024 / n if k in w else None
         out["per_kernel"][k] = dict(launches=n, fetch_bytes_per_launch=fb, write_bytes_per_launch=wb,
                                     avg_us=(f[k]["_us"] / f[k]["_n"]) if f[k]["_n"] else None)
-    for fam, pre in (("gemm_family", GEMM_FAMILY), ("attn_family", ATTN_FAMILY)):
+    for fam, pre in (("gemm_family", gemm_family), ("attn_family", ATTN_FAMILY)):
         n, fb = family(f, pre, "FETCH_SIZE")
         n2, wb = family(w, pre, "WRITE_SIZE")
         if n and n2:
