@@ -451,10 +451,10 @@ __global__ __launch_bounds__(512) void gemm_fp8_ring_kernel(
         else if (i == 4) f8_lds_read_b128<8192>(fa[buf][2][h], a_base + xo[ks][h]);
         else f8_lds_read_b128<12288>(fa[buf][3][h], a_base + xo[ks][h]);
     };
-    // 12 ops over the 8 MFMA shadows of a cluster: two per slot in the first four, one per slot afterwards
+    // 12 ops over the 8 MFMA shadows of a cluster: two per slot in the first six, so the last request is two MFMAs (128+ cycles) old
+    // when the next cluster asks for it (spreading them 2,2,2,2,1,1,1,1 measured the same: LDS latency is not what bounds the loop)
     auto slot_ops = [&](int i, int ks, int buf, unsigned a_base, unsigned b_base) {
-        if (i < 4) { frag_op(2 * i, ks, buf, a_base, b_base); frag_op(2 * i + 1, ks, buf, a_base, b_base); }
-        else frag_op(4 + i, ks, buf, a_base, b_base);
+        if (i < 6) { frag_op(2 * i, ks, buf, a_base, b_base); frag_op(2 * i + 1, ks, buf, a_base, b_base); }
     };
 
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // step 0 landed (this wave's pieces); step 1 may be in flight
