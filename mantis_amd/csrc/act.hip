@@ -169,7 +169,7 @@ extern "C" {
 int mantis_swiglu_fwd(const void* gate_up, void* out, int64_t M, int I, int64_t ld_gate_up, void* stream) {
     if (I % 8 || ld_gate_up % 8) return MANTIS_EUNSUPPORTED;
     if (M == 0) return MANTIS_OK;
-    hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(ew_grid(M * (I / 8))), dim3(256), 0, (hipStream_t)stream,
+    MANTIS_LAUNCH(swiglu_fwd_kernel, dim3(ew_grid(M * (I / 8))), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)gate_up, (bf16_t*)out, (long)M, I, (long)ld_gate_up);
     return mantis_check_launch();
 }
@@ -178,7 +178,7 @@ int mantis_swiglu_bwd(const void* dact, const void* gate_up, void* dgate_up, int
                       void* stream) {
     if (I % 8 || ld_gate_up % 8) return MANTIS_EUNSUPPORTED;
     if (M == 0) return MANTIS_OK;
-    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(ew_grid(M * (I / 8))), dim3(256), 0, (hipStream_t)stream,
+    MANTIS_LAUNCH(swiglu_bwd_kernel, dim3(ew_grid(M * (I / 8))), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)dact, (const bf16_t*)gate_up, (bf16_t*)dgate_up, (long)M, I, (long)ld_gate_up);
     return mantis_check_launch();
 }
@@ -186,7 +186,7 @@ int mantis_swiglu_bwd(const void* dact, const void* gate_up, void* dgate_up, int
 int mantis_act_fwd(const void* x, void* y, int64_t n, int kind, void* stream) {
     if (n % 8 || kind < 0 || kind > 3) return MANTIS_EUNSUPPORTED;
     if (n == 0) return MANTIS_OK;
-    hipLaunchKernelGGL(act_fwd_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+    MANTIS_LAUNCH(act_fwd_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                        (bf16_t*)y, (long)(n / 8), kind);
     return mantis_check_launch();
 }
@@ -194,7 +194,7 @@ int mantis_act_fwd(const void* x, void* y, int64_t n, int kind, void* stream) {
 int mantis_act_bwd(const void* dy, const void* x, void* dx, int64_t n, int kind, void* stream) {
     if (n % 8 || kind < 0 || kind > 3) return MANTIS_EUNSUPPORTED;
     if (n == 0) return MANTIS_OK;
-    hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
+    MANTIS_LAUNCH(act_bwd_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy,
                        (const bf16_t*)x, (bf16_t*)dx, (long)(n / 8), kind);
     return mantis_check_launch();
 }
@@ -202,7 +202,7 @@ int mantis_act_bwd(const void* dy, const void* x, void* dx, int64_t n, int kind,
 int mantis_add(const void* a, const void* b, void* y, int64_t n, void* stream) {
     if (n % 8) return MANTIS_EUNSUPPORTED;
     if (n == 0) return MANTIS_OK;
-    hipLaunchKernelGGL(add_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a,
+    MANTIS_LAUNCH(add_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a,
                        (const bf16_t*)b, (bf16_t*)y, (long)(n / 8));
     return mantis_check_launch();
 }
@@ -217,9 +217,9 @@ int mantis_colsum(const void* x, void* grad, int accumulate, float* workspace, i
     if (M <= 0 || N <= 0) return MANTIS_EINVAL;
     const int P = mantis_colsum_partials(M);
     const int rpb = (int)((M + P - 1) / P);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(N, 64), P), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+    MANTIS_LAUNCH(colsum_partial_kernel, dim3(cdiv(N, 64), P), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                        workspace, (long)M, N, (long)ld, rpb);
-    hipLaunchKernelGGL(reduce_partials_kernel2, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, workspace, P, N,
+    MANTIS_LAUNCH(reduce_partials_kernel2, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, workspace, P, N,
                        (bf16_t*)grad, accumulate);
     return mantis_check_launch();
 }

@@ -1295,10 +1295,10 @@ static int launch_fwd(bool causal, dim3 grid, hipStream_t s, const bf16_t* Q, co
                       bf16_t* O, float* LSE, int L, int H, int Hkv, long ldq, long ldk, long ldv, long ldo, float scale,
                       const int* kstart) {
     if (causal)
-        hipLaunchKernelGGL((attn_fwd_kernel<HD, true>), grid, dim3(256), 0, s, Q, K, V, kmask, O, LSE, L, H, Hkv, ldq, ldk, ldv,
+        MANTIS_LAUNCH((attn_fwd_kernel<HD, true>), grid, dim3(256), 0, s, Q, K, V, kmask, O, LSE, L, H, Hkv, ldq, ldk, ldv,
                            ldo, scale, kstart);
     else
-        hipLaunchKernelGGL((attn_fwd_kernel<HD, false>), grid, dim3(256), 0, s, Q, K, V, kmask, O, LSE, L, H, Hkv, ldq, ldk, ldv,
+        MANTIS_LAUNCH((attn_fwd_kernel<HD, false>), grid, dim3(256), 0, s, Q, K, V, kmask, O, LSE, L, H, Hkv, ldq, ldk, ldv,
                            ldo, scale, kstart);
     return mantis_check_launch();
 }
@@ -1319,13 +1319,13 @@ static int launch_bwd(bool causal, hipStream_t s, const bf16_t* Q, const bf16_t*
         const int cus = attn_num_cus();
         if (attn_dkv_group_kernel_ok(G) && (G == 4 || nwg >= 2L * cus || nwg <= cus / 2 || ws == nullptr)) {
             if (causal)
-                hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, true>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, L, H, Hkv,
+                MANTIS_LAUNCH((attn_bwd_dq_kernel<HD, true>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, L, H, Hkv,
                                    ldq, ldk, ldv, ldo, lddq, scale, Ofwd, ldout, kstart);
             else
-                hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, false>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, L, H, Hkv,
+                MANTIS_LAUNCH((attn_bwd_dq_kernel<HD, false>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, L, H, Hkv,
                                    ldq, ldk, ldv, ldo, lddq, scale, Ofwd, ldout, kstart);
             const dim3 g4(cdiv(L, 64) * Hkv * B);
-#define DKV_G4(C_, S_) hipLaunchKernelGGL((attn_bwd_dkv_g4_kernel<C_, S_>), g4, dim3(256), 0, s, Q, K, V, dO, kmask, kstart, qend, LSE, \
+#define DKV_G4(C_, S_) MANTIS_LAUNCH((attn_bwd_dkv_g4_kernel<C_, S_>), g4, dim3(256), 0, s, Q, K, V, dO, kmask, kstart, qend, LSE, \
                                           Dsum, dK, dV, L, H, Hkv, ldq, ldk, ldv, ldo, lddk, lddv, scale)
             if (causal) { if (kstart) DKV_G4(true, true); else DKV_G4(true, false); }
             else { if (kstart) DKV_G4(false, true); else DKV_G4(false, false); }
@@ -1339,21 +1339,21 @@ static int launch_bwd(bool causal, hipStream_t s, const bf16_t* Q, const bf16_t*
     bf16_t* pv = G == 1 ? dV : ws + rows * H * HD;
     const long ldpk = G == 1 ? lddk : (long)H * HD, ldpv = G == 1 ? lddv : (long)H * HD;
     if (causal) {
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, true>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, L, H, Hkv, ldq,
+        MANTIS_LAUNCH((attn_bwd_dq_kernel<HD, true>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, L, H, Hkv, ldq,
                            ldk, ldv, ldo, lddq, scale, Ofwd, ldout, kstart);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, true>), gk, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, pk, pv, L, H, Hkv,
+        MANTIS_LAUNCH((attn_bwd_dkv_kernel<HD, true>), gk, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, pk, pv, L, H, Hkv,
                            ldq, ldk, ldv, ldo, ldpk, ldpv, scale, kstart, qend);
     } else {
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, false>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, L, H, Hkv, ldq,
+        MANTIS_LAUNCH((attn_bwd_dq_kernel<HD, false>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, L, H, Hkv, ldq,
                            ldk, ldv, ldo, lddq, scale, Ofwd, ldout, kstart);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, false>), gk, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, pk, pv, L, H, Hkv,
+        MANTIS_LAUNCH((attn_bwd_dkv_kernel<HD, false>), gk, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, pk, pv, L, H, Hkv,
                            ldq, ldk, ldv, ldo, ldpk, ldpv, scale, kstart, qend);
     }
     if (G > 1) {
         const long total = rows * Hkv * (HD / 8);
         long g = (total + 255) / 256;
         g = g > 2048 ? 2048 : g;
-        hipLaunchKernelGGL(attn_group_reduce_kernel, dim3((int)g), dim3(256), 0, s, pk, pv, dK, dV, rows, Hkv, G, HD, (long)H * HD,
+        MANTIS_LAUNCH(attn_group_reduce_kernel, dim3((int)g), dim3(256), 0, s, pk, pv, dK, dV, rows, Hkv, G, HD, (long)H * HD,
                            lddk, lddv);
     }
     return mantis_check_launch();
@@ -1394,7 +1394,7 @@ int mantis_attn_bwd_needs_workspace(int H, int Hkv, int hd) { return (H == Hkv |
 int mantis_attn_dsum(const void* dO, const void* O, float* Dsum, int B, int L, int H, int hd, int64_t ldo, void* stream) {
     if (hd % 8 || ldo % 8) return MANTIS_EUNSUPPORTED;
     const long rows = (long)B * L;
-    hipLaunchKernelGGL(attn_dsum_kernel, dim3(cdiv(rows * H, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dO,
+    MANTIS_LAUNCH(attn_dsum_kernel, dim3(cdiv(rows * H, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dO,
                        (const bf16_t*)O, Dsum, rows, H, hd, L, (long)ldo);
     return mantis_check_launch();
 }

@@ -111,10 +111,10 @@ int mantis_ce_fwd_bwd(void* logits, const int32_t* targets, int R, int V, int64_
                       void* stream) {
     if (R <= 0 || V <= 0 || ld % 8 || ld < V) return MANTIS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(ce_count_kernel, dim3(1), dim3(1024), 0, s, targets, R, V, count_out);
-    hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(R), dim3(CE_THREADS), 0, s, (bf16_t*)logits, targets, count_out, row_loss_ws,
+    MANTIS_LAUNCH(ce_count_kernel, dim3(1), dim3(1024), 0, s, targets, R, V, count_out);
+    MANTIS_LAUNCH(ce_fwd_bwd_kernel, dim3(R), dim3(CE_THREADS), 0, s, (bf16_t*)logits, targets, count_out, row_loss_ws,
                        row_lse_out, V, (long)ld, grad_scale, write_grad);
-    hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(1024), 0, s, row_loss_ws, count_out, R, loss_out, loss_scale);
+    MANTIS_LAUNCH(ce_finish_kernel, dim3(1), dim3(1024), 0, s, row_loss_ws, count_out, R, loss_out, loss_scale);
     return mantis_check_launch();
 }
 

@@ -66,6 +66,16 @@ __device__ __forceinline__ float block_max(float v, float* red) {
     return t;
 }
 
+// hipGetLastError() reports the last error of ANY runtime call of this thread, including the host process' own probing calls (PyTorch asks
+// hipPointerGetAttributes about pageable host pointers, which fails by design and is not always cleared): a stale error would be
+// reported as a failed launch of a kernel that ran.  So every launch clears the thread's error state first (MANTIS_LAUNCH) and
+// mantis_check_launch() then sees only what the launches of this entry point produced.
+#define MANTIS_LAUNCH(...)            \
+    do {                              \
+        (void)hipGetLastError();      \
+        hipLaunchKernelGGL(__VA_ARGS__); \
+    } while (0)
+
 static inline int mantis_check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MANTIS_OK : MANTIS_ELAUNCH;

@@ -418,7 +418,7 @@ template <int BM, int BN, int WM, int WN, bool AKM = false, bool BKM = false>
 static int launch_gemm(hipStream_t s, const bf16_t* A, const bf16_t* B, bf16_t* C, int M, int N, int K, long lda, long ldb,
                        long ldc, const bf16_t* bias, const bf16_t* res, long ldr, int flags) {
     const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, AKM, BKM>), dim3(tiles_m * tiles_n), dim3((BM / WM) * (BN / WN) * 64), 0, s, A,
+    MANTIS_LAUNCH((gemm_nt_kernel<BM, BN, WM, WN, AKM, BKM>), dim3(tiles_m * tiles_n), dim3((BM / WM) * (BN / WN) * 64), 0, s, A,
                        B, C, M, N, K, lda, ldb, ldc, bias, res, ldr, flags, tiles_m, tiles_n);
     return mantis_check_launch();
 }
@@ -830,7 +830,7 @@ static int launch_gemm_ring(hipStream_t s, const bf16_t* A, const bf16_t* B, bf1
         cnt = (unsigned int*)ws;
         slabs = (float*)((char*)ws + sk_cnt_bytes(cus));
     }
-    hipLaunchKernelGGL((gemm_nt_ring_kernel<AKM, BKM, SWIGLU>), dim3(grid), dim3(512), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias, res, ldr, flags,
+    MANTIS_LAUNCH((gemm_nt_ring_kernel<AKM, BKM, SWIGLU>), dim3(grid), dim3(512), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias, res, ldr, flags,
                        tiles_m, tiles_n, full, S, slabs, cnt);
     return mantis_check_launch();
 }

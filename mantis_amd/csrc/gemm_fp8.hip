@@ -508,7 +508,7 @@ static int launch_fp8_ring(hipStream_t s, const unsigned char* A, const unsigned
                            long ldb, long ldc, const float* sa, const float* sb, const bf16_t* bias, const bf16_t* res, long ldr,
                            int flags, unsigned int* amax_out = nullptr) {
     const int tiles_m = cdiv(M, 256), tiles_n = cdiv(N, 256);
-    hipLaunchKernelGGL((gemm_fp8_ring_kernel<FA, SWIGLU>), dim3(tiles_m * tiles_n), dim3(512), 0, s, A, B, C, M, N, K, lda, ldb, ldc, sa, sb,
+    MANTIS_LAUNCH((gemm_fp8_ring_kernel<FA, SWIGLU>), dim3(tiles_m * tiles_n), dim3(512), 0, s, A, B, C, M, N, K, lda, ldb, ldc, sa, sb,
                        bias, res, ldr, flags, tiles_m, tiles_n, amax_out);
     return mantis_check_launch();
 }
@@ -517,7 +517,7 @@ template <int BM, int BN, int WM, int WN, int FA>
 static int launch_fp8(hipStream_t s, const unsigned char* A, const unsigned char* B, bf16_t* C, int M, int N, int K, long lda, long ldb,
                       long ldc, const float* sa, const float* sb, const bf16_t* bias, const bf16_t* res, long ldr, int flags) {
     const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
-    hipLaunchKernelGGL((gemm_fp8_nt_kernel<BM, BN, WM, WN, FA>), dim3(tiles_m * tiles_n), dim3((BM / WM) * (BN / WN) * 64), 0, s, A, B, C,
+    MANTIS_LAUNCH((gemm_fp8_nt_kernel<BM, BN, WM, WN, FA>), dim3(tiles_m * tiles_n), dim3((BM / WM) * (BN / WN) * 64), 0, s, A, B, C,
                        M, N, K, lda, ldb, ldc, sa, sb, bias, res, ldr, flags, tiles_m, tiles_n);
     return mantis_check_launch();
 }
@@ -729,14 +729,14 @@ int mantis_fp8_quantize(const void* x, int64_t rows, int cols, int64_t ld, int f
     if (grid.y > 65535) return MANTIS_EUNSUPPORTED;
     // amax_in: the maximum |x| was already taken by the kernel that produced x (mantis_gemm_fp8_dx_swiglu) -- pass 1 is skipped
     if (amax_in == nullptr)
-        hipLaunchKernelGGL(fp8_amax_kernel, dim3(Q_PARTS), dim3(256), 0, s, (const bf16_t*)x, (long)rows, cols, (long)ld, workspace);
+        MANTIS_LAUNCH(fp8_amax_kernel, dim3(Q_PARTS), dim3(256), 0, s, (const bf16_t*)x, (long)rows, cols, (long)ld, workspace);
     const float* parts = amax_in ? amax_in : workspace;
     const int nparts = amax_in ? 1 : Q_PARTS;
     if (fmt == 0)
-        hipLaunchKernelGGL(fp8_cast_kernel<F8_FMT_E4M3>, grid, dim3(256), 0, s, (const bf16_t*)x, (long)rows, cols, (long)ld, parts, nparts,
+        MANTIS_LAUNCH(fp8_cast_kernel<F8_FMT_E4M3>, grid, dim3(256), 0, s, (const bf16_t*)x, (long)rows, cols, (long)ld, parts, nparts,
                            (unsigned char*)q, (long)ldq, (unsigned char*)qt, (long)ldt, rows_pad, state);
     else
-        hipLaunchKernelGGL(fp8_cast_kernel<F8_FMT_E5M2>, grid, dim3(256), 0, s, (const bf16_t*)x, (long)rows, cols, (long)ld, parts, nparts,
+        MANTIS_LAUNCH(fp8_cast_kernel<F8_FMT_E5M2>, grid, dim3(256), 0, s, (const bf16_t*)x, (long)rows, cols, (long)ld, parts, nparts,
                            (unsigned char*)q, (long)ldq, (unsigned char*)qt, (long)ldt, rows_pad, state);
     return mantis_check_launch();
 }

@@ -209,7 +209,7 @@ int mantis_rmsnorm_fwd(const void* x, const void* weight, void* y, float* rstd, 
                        void* stream) {
     if (d % 8 || d <= 0) return MANTIS_EUNSUPPORTED;
     if (rows == 0) return MANTIS_OK;
-    hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(norm_grid(rows)), dim3(64 * NORM_WAVES), 0, (hipStream_t)stream,
+    MANTIS_LAUNCH(rmsnorm_fwd_kernel, dim3(norm_grid(rows)), dim3(64 * NORM_WAVES), 0, (hipStream_t)stream,
                        (const bf16_t*)x, (const bf16_t*)weight, (bf16_t*)y, rstd, (long)rows, d, eps);
     return mantis_check_launch();
 }
@@ -225,7 +225,7 @@ int mantis_rmsnorm_bwd(const void* dy, const void* x, const void* weight, const 
     if (d % 8 || d <= 0 || d > 64 * 8 * NORM_MAXC) return MANTIS_EUNSUPPORTED;
     if (rows == 0) return MANTIS_OK;
     const int P = mantis_rmsnorm_bwd_partials(rows);
-#define RMSB_LAUNCH(MAXC) hipLaunchKernelGGL(rmsnorm_bwd_kernel<MAXC>, dim3(P), dim3(64 * RMSB_WAVES), 0, (hipStream_t)stream, \
+#define RMSB_LAUNCH(MAXC) MANTIS_LAUNCH(rmsnorm_bwd_kernel<MAXC>, dim3(P), dim3(64 * RMSB_WAVES), 0, (hipStream_t)stream, \
                        (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)weight, rstd, (const bf16_t*)dres, (bf16_t*)dx, \
                        grad_weight ? workspace : nullptr, (long)rows, d)
     if (d <= 64 * 8 * 2) RMSB_LAUNCH(2);
@@ -233,7 +233,7 @@ int mantis_rmsnorm_bwd(const void* dy, const void* x, const void* weight, const 
     else RMSB_LAUNCH(NORM_MAXC);
 #undef RMSB_LAUNCH
     if (grad_weight)
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(d, 64)), dim3(1024), 0, (hipStream_t)stream, workspace, P, d,
+        MANTIS_LAUNCH(reduce_partials_kernel, dim3(cdiv(d, 64)), dim3(1024), 0, (hipStream_t)stream, workspace, P, d,
                            (bf16_t*)grad_weight, accumulate);
     return mantis_check_launch();
 }
@@ -242,7 +242,7 @@ int mantis_layernorm_fwd(const void* x, const void* weight, const void* bias, vo
                          void* stream) {
     if (d % 8 || d <= 0) return MANTIS_EUNSUPPORTED;
     if (rows == 0) return MANTIS_OK;
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(norm_grid(rows)), dim3(64 * NORM_WAVES), 0, (hipStream_t)stream,
+    MANTIS_LAUNCH(layernorm_fwd_kernel, dim3(norm_grid(rows)), dim3(64 * NORM_WAVES), 0, (hipStream_t)stream,
                        (const bf16_t*)x, (const bf16_t*)weight, (const bf16_t*)bias, (bf16_t*)y, (long)rows, d, eps);
     return mantis_check_launch();
 }

@@ -79,7 +79,7 @@ int mantis_adamw(void* param_bf16, const void* grad_bf16, float* master, float* 
     if (n == 0) return MANTIS_OK;
     long g = (n / 8 + 255) / 256;
     g = g > 131072 ? 131072 : g;      // measured: 4096 blocks 5.6-5.8 TB/s, 65536-262144 blocks 6.0 TB/s (grid-stride loop, 28 B/element)
-    hipLaunchKernelGGL(adamw_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (bf16_t*)param_bf16,
+    MANTIS_LAUNCH(adamw_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (bf16_t*)param_bf16,
                        (const bf16_t*)grad_bf16, master, exp_avg, exp_avg_sq, (long)(n / 8), lr, beta1, beta2, eps,
                        weight_decay, bias_corr1, bias_corr2, grad_scale_dev);
     return mantis_check_launch();
@@ -89,15 +89,15 @@ int mantis_sumsq_partials(int64_t n) { return SUMSQ_BLOCKS; }
 
 int mantis_sumsq(const void* x_bf16, int64_t n, float* partials_ws, float* out, int accumulate, void* stream) {
     if (n % 8) return MANTIS_EUNSUPPORTED;
-    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x_bf16,
+    MANTIS_LAUNCH(sumsq_partial_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x_bf16,
                        (long)(n / 8), partials_ws);
-    hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, partials_ws, SUMSQ_BLOCKS, out,
+    MANTIS_LAUNCH(sumsq_finish_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, partials_ws, SUMSQ_BLOCKS, out,
                        accumulate);
     return mantis_check_launch();
 }
 
 int mantis_clip_scale(const float* sumsq, float max_norm, float* scale_out, float* norm_out, void* stream) {
-    hipLaunchKernelGGL(clip_scale_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, max_norm, scale_out, norm_out);
+    MANTIS_LAUNCH(clip_scale_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, max_norm, scale_out, norm_out);
     return mantis_check_launch();
 }
 

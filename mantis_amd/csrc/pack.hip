@@ -411,7 +411,7 @@ int mantis_pack_plan(const int64_t* input_ids, const int64_t* attention_mask, co
                      int32_t* ce_tgt, int32_t* status, void* stream) {
     if (B <= 0 || T <= 0 || L < T || num_patches <= 0 || num_images < 0) return MANTIS_EINVAL;
     if ((long)num_images * num_patches >= IMGBIT) return MANTIS_EUNSUPPORTED;
-    hipLaunchKernelGGL(pack_plan_kernel, dim3(1), dim3(PLAN_THREADS), 0, (hipStream_t)stream, (const long*)input_ids,
+    MANTIS_LAUNCH(pack_plan_kernel, dim3(1), dim3(PLAN_THREADS), 0, (hipStream_t)stream, (const long*)input_ids,
                        (const long*)attention_mask, (const long*)labels, B, T, num_patches, num_images,
                        (long)image_token_index, (long)pad_token_id, (long)ignore_index, L, src, (long*)out_mask,
                        (long*)out_labels, (long*)out_pos, kmask, text_pos, img_slot, ce_row, ce_tgt, status);
@@ -422,7 +422,7 @@ int mantis_pack_segments(const int64_t* input_ids, const int32_t* segment_ids, c
                          int num_patches, int64_t image_token_index, int L, int64_t* out_pos, int32_t* ce_row, int32_t* ce_tgt,
                          int32_t* kstart, int32_t* qend, int32_t* workspace, void* stream) {
     if (B <= 0 || T <= 0 || L < T || num_patches <= 0) return MANTIS_EINVAL;
-    hipLaunchKernelGGL(pack_segments_kernel, dim3(B), dim3(PLAN_THREADS), 0, (hipStream_t)stream, (const long*)input_ids,
+    MANTIS_LAUNCH(pack_segments_kernel, dim3(B), dim3(PLAN_THREADS), 0, (hipStream_t)stream, (const long*)input_ids,
                        segment_ids, (const long*)merged_mask, B, T, num_patches, (long)image_token_index, L, (long*)out_pos, ce_row,
                        ce_tgt, kstart, qend, workspace);
     return mantis_check_launch();
@@ -432,7 +432,7 @@ int mantis_pack_rows_fwd(const int32_t* src, const int64_t* input_ids, const voi
                          void* out, int B, int T, int L, int d, int64_t vocab, void* stream) {
     if (d % 8) return MANTIS_EUNSUPPORTED;
     const long chunks = (long)B * L * (d / 8);
-    hipLaunchKernelGGL(pack_rows_fwd_kernel, dim3(row_grid(chunks)), dim3(256), 0, (hipStream_t)stream, src,
+    MANTIS_LAUNCH(pack_rows_fwd_kernel, dim3(row_grid(chunks)), dim3(256), 0, (hipStream_t)stream, src,
                        (const long*)input_ids, (const bf16_t*)embed_weight, (const bf16_t*)image_features, (bf16_t*)out,
                        B, T, L, d, (long)vocab);
     return mantis_check_launch();
@@ -441,7 +441,7 @@ int mantis_pack_rows_fwd(const int32_t* src, const int64_t* input_ids, const voi
 int mantis_gather_rows(const void* in, const int32_t* idx, void* out, int64_t nrows, int d, void* stream) {
     if (d % 8) return MANTIS_EUNSUPPORTED;
     if (nrows == 0) return MANTIS_OK;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(row_grid(nrows * (d / 8))), dim3(256), 0, (hipStream_t)stream,
+    MANTIS_LAUNCH(gather_rows_kernel, dim3(row_grid(nrows * (d / 8))), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)in, idx, (bf16_t*)out, (long)nrows, d);
     return mantis_check_launch();
 }
@@ -449,7 +449,7 @@ int mantis_gather_rows(const void* in, const int32_t* idx, void* out, int64_t nr
 int mantis_scatter_rows(const void* in, const int32_t* idx, void* out, int64_t nrows, int d, void* stream) {
     if (d % 8) return MANTIS_EUNSUPPORTED;
     if (nrows == 0) return MANTIS_OK;
-    hipLaunchKernelGGL(scatter_rows_kernel, dim3(row_grid(nrows * (d / 8))), dim3(256), 0, (hipStream_t)stream,
+    MANTIS_LAUNCH(scatter_rows_kernel, dim3(row_grid(nrows * (d / 8))), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)in, idx, (bf16_t*)out, (long)nrows, d);
     return mantis_check_launch();
 }
@@ -460,9 +460,9 @@ int mantis_embed_grad(const void* dmerged, const int64_t* input_ids, const int32
                       void* stream) {
     if (d % 8) return MANTIS_EUNSUPPORTED;
     const int n = B * T;
-    hipLaunchKernelGGL(embed_chain_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, (const long*)input_ids,
+    MANTIS_LAUNCH(embed_chain_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, (const long*)input_ids,
                        text_pos, n, leader_ws, next_ws);
-    hipLaunchKernelGGL(embed_grad_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dmerged,
+    MANTIS_LAUNCH(embed_grad_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dmerged,
                        (const long*)input_ids, text_pos, leader_ws, next_ws, (bf16_t*)grad_weight, T, L, d, (long)vocab,
                        accumulate);
     return mantis_check_launch();

@@ -134,7 +134,7 @@ extern "C" {
 int mantis_rope_table(const int64_t* position_ids, const float* inv_freq, void* cos_out, void* sin_out, int64_t R,
                       int half_dim, void* stream) {
     if (R == 0) return MANTIS_OK;
-    hipLaunchKernelGGL(rope_table_kernel, dim3(ew_grid(R * half_dim)), dim3(256), 0, (hipStream_t)stream,
+    MANTIS_LAUNCH(rope_table_kernel, dim3(ew_grid(R * half_dim)), dim3(256), 0, (hipStream_t)stream,
                        (const long*)position_ids, inv_freq, (bf16_t*)cos_out, (bf16_t*)sin_out, (long)R, half_dim);
     return mantis_check_launch();
 }
@@ -142,7 +142,7 @@ int mantis_rope_table(const int64_t* position_ids, const float* inv_freq, void* 
 int mantis_rope_table_sections(const int64_t* position_ids /*[S, R]*/, const float* inv_freq /*[half]*/, const int32_t* section_of_freq,
                                void* cos_out, void* sin_out, int64_t R, int half_dim, void* stream) {
     if (R == 0) return MANTIS_OK;
-    hipLaunchKernelGGL(rope_table_sections_kernel, dim3(ew_grid(R * half_dim)), dim3(256), 0, (hipStream_t)stream,
+    MANTIS_LAUNCH(rope_table_sections_kernel, dim3(ew_grid(R * half_dim)), dim3(256), 0, (hipStream_t)stream,
                        (const long*)position_ids, inv_freq, (const int*)section_of_freq, (bf16_t*)cos_out, (bf16_t*)sin_out, (long)R,
                        half_dim);
     return mantis_check_launch();
@@ -154,10 +154,10 @@ int mantis_rope_apply(void* x, const void* cos_tab, const void* sin_tab, int64_t
     if (R == 0 || nheads == 0) return MANTIS_OK;
     const long total = R * nheads * (head_dim / 16);
     if (backward)
-        hipLaunchKernelGGL(rope_apply_kernel<-1>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x,
+        MANTIS_LAUNCH(rope_apply_kernel<-1>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x,
                            (const bf16_t*)cos_tab, (const bf16_t*)sin_tab, (long)R, nheads, head_dim, (long)ld);
     else
-        hipLaunchKernelGGL(rope_apply_kernel<1>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x,
+        MANTIS_LAUNCH(rope_apply_kernel<1>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x,
                            (const bf16_t*)cos_tab, (const bf16_t*)sin_tab, (long)R, nheads, head_dim, (long)ld);
     return mantis_check_launch();
 }
@@ -170,7 +170,7 @@ int mantis_transpose(const void* in, void* out, int R, int C, int Rpad, int64_t 
     if (in_stride_b % 8 || in_stride_h % 8 || out_stride_b % 8 || out_stride_h % 8) return MANTIS_EUNSUPPORTED;
     if (R == 0 || C == 0) return MANTIS_OK;
     if ((long)nb * nh > 65535) return MANTIS_EUNSUPPORTED;
-    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(Rpad, 64), cdiv(C, 64), nb * nh), dim3(256), 0, (hipStream_t)stream,
+    MANTIS_LAUNCH(transpose_kernel, dim3(cdiv(Rpad, 64), cdiv(C, 64), nb * nh), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)in, (bf16_t*)out, R, C, Rpad, (long)ld_in, (long)ld_out, nh, (long)in_stride_b,
                        (long)in_stride_h, (long)out_stride_b, (long)out_stride_h);
     return mantis_check_launch();

@@ -92,7 +92,7 @@ int mantis_im2col(const float* pixels, void* patches, int I, int C, int H, int W
     if (P <= 0 || H % P || W % P || Kp < C * P * P || Kp % 8) return MANTIS_EINVAL;
     if (I == 0) return MANTIS_OK;
     const long total = (long)I * (H / P) * (W / P) * Kp;
-    hipLaunchKernelGGL(im2col_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, pixels, (bf16_t*)patches, I,
+    MANTIS_LAUNCH(im2col_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, pixels, (bf16_t*)patches, I,
                        C, H, W, P, Kp);
     return mantis_check_launch();
 }
@@ -100,7 +100,7 @@ int mantis_im2col(const float* pixels, void* patches, int I, int C, int H, int W
 int mantis_cast_pad_rows(const float* in, void* out, int64_t rows, int K, int64_t ld_in, int Kp, void* stream) {
     if (K <= 0 || Kp < K || Kp % 8 || ld_in < K) return MANTIS_EINVAL;
     if (rows == 0) return MANTIS_OK;
-    hipLaunchKernelGGL(cast_pad_rows_kernel, dim3(ew_grid(rows * Kp)), dim3(256), 0, (hipStream_t)stream, in, (bf16_t*)out, (long)rows, K,
+    MANTIS_LAUNCH(cast_pad_rows_kernel, dim3(ew_grid(rows * Kp)), dim3(256), 0, (hipStream_t)stream, in, (bf16_t*)out, (long)rows, K,
                        (long)ld_in, Kp);
     return mantis_check_launch();
 }
@@ -111,7 +111,7 @@ int mantis_vit_assemble(const void* patch_out, const void* pos_emb, const void* 
     if (I == 0) return MANTIS_OK;
     const int has_cls = cls_emb != nullptr;
     const long total = (long)I * (N + has_cls) * (d / 8);
-    hipLaunchKernelGGL(vit_assemble_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+    MANTIS_LAUNCH(vit_assemble_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)patch_out, (const bf16_t*)pos_emb, (const bf16_t*)cls_emb, (bf16_t*)out, I, N, d,
                        has_cls);
     return mantis_check_launch();
@@ -120,7 +120,7 @@ int mantis_vit_assemble(const void* patch_out, const void* pos_emb, const void* 
 int mantis_drop_cls(const void* in, void* out, int I, int N, int d, void* stream) {
     if (d % 8) return MANTIS_EUNSUPPORTED;
     if (I == 0) return MANTIS_OK;
-    hipLaunchKernelGGL(drop_cls_kernel, dim3(ew_grid((long)I * N * (d / 8))), dim3(256), 0, (hipStream_t)stream,
+    MANTIS_LAUNCH(drop_cls_kernel, dim3(ew_grid((long)I * N * (d / 8))), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)in, (bf16_t*)out, I, N, d);
     return mantis_check_launch();
 }
