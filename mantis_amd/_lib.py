@@ -70,6 +70,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: the MI355X path has no fallback. Build it with `python -m mantis_amd.build`.")
+    # PyTorch first: it brings its own HIP runtime (torch/lib/libamdhip64.so), and this library must bind to THAT instance.  Loaded the
+    # other way round, libmantis_hip.so pulls in /opt/rocm's runtime before torch initialises its own and the first kernel launch fails
+    # ("HIP launch failed" in smoke() when build() -- which loads the library -- ran first in the same process).
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so is stale
