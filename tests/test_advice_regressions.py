@@ -181,3 +181,28 @@ def test_host_tensor_is_refused_before_it_reaches_a_kernel():
     with pytest.raises(ValueError):
         hip_ops._p(torch.zeros(4))
     assert hip_ops._p(None) is None
+
+
+def test_library_load_brings_torch_in_first():
+    """_lib.load() in a process that has not imported torch yet (what __graft_entry__.build() does) must import torch BEFORE dlopen: the
+    library has to bind to torch's own HIP runtime (on the GPU box the other order made the first kernel launch of smoke() fail)."""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys, ctypes\n"
+            "seen = {}\n"
+            "orig = ctypes.CDLL\n"
+            "def spy(path, *a, **k):\n"
+            "    if 'libmantis_hip' in str(path): seen['torch_loaded'] = 'torch' in sys.modules\n"
+            "    return orig(path, *a, **k)\n"
+            "ctypes.CDLL = spy\n"
+            "assert 'torch' not in sys.modules\n"
+            "from mantis_amd import _lib\n"
+            "assert 'torch' not in sys.modules\n"
+            "_lib.load()\n"
+            "assert seen == {'torch_loaded': True}, seen\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    if "not found" in r.stderr and "libmantis_hip" in r.stderr:
+        import pytest
+        pytest.skip("libmantis_hip.so not built")
+    assert r.returncode == 0, r.stderr[-800:]
