@@ -189,6 +189,8 @@ __device__ __forceinline__ void xcd_tile_map(int gx, int gy, int& x, int& y, int
 
 // ------------------------------------------------------------------------------------------------ forward
 // grid (ceil(L/128), H, B); 4 waves x 32 query rows; KV tiles of 64 keys, double buffered.
+// (Three workgroups per CU for the small head dims -- their 53.8 KB of LDS would allow it -- was measured: the 170-VGPR budget spills
+// ~19 registers and the kernel gets SLOWER: hd 80 864 -> 1367 us, hd 72 162 -> 243 us, hd 96 206 -> 324 us; hd 64, no spills: equal.)
 template <int HD, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                        const bf16_t* __restrict__ V, const int* __restrict__ kmask,
