@@ -876,12 +876,15 @@ int mantis_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, 
     int variant = (flags & EPI_VARIANT_MASK) >> EPI_VARIANT_SHIFT;
     if (variant == 0) variant = (flags & EPI_SWIGLU_BWD) ? 12 : gemm_pick_variant(M, N, K);
     if ((flags & EPI_SWIGLU_BWD) && (variant != 12 || akm || !bkm)) return MANTIS_EUNSUPPORTED;
-    // the ring kernel addresses its operands through buffer descriptors: 32-bit num_records, 32-bit lane offset + 32-bit scalar
-    // K-step offset.  An operand of 2 GiB or more would wrap silently -> such shapes go to the generic kernel (64-bit addresses)
-    // when the choice is ours, and are refused when the ring kernel was asked for explicitly.
+    // the ring kernel addresses its operands through buffer descriptors: unsigned 32-bit num_records, unsigned 32-bit lane offset and
+    // unsigned 32-bit scalar K-step offset (the hardware adds them to the 48-bit base without wrapping).  An operand of 4 GiB or more
+    // would wrap silently -> such shapes go to the generic kernel (64-bit addresses) when the choice is ours, and are refused when the
+    // ring kernel was asked for explicitly.  (The first guard stood at 2 GiB; the lm_head logits of 8192 rows x 152064 columns, 2.5 GB,
+    // then fell to the generic kernel at 0.34 PFLOP/s.  `gemm_operand_over_2gib` checks the 2-4 GiB range against the generic kernel.)
     if (variant == 12) {
         const long a_bytes = (long)(akm ? K : M) * (long)lda * 2, b_bytes = (long)(bkm ? K : N) * (long)ldb * 2;
-        if (a_bytes >= (1L << 31) || b_bytes >= (1L << 31)) {
+        const long lim = (1L << 32) - (1L << 16);
+        if (a_bytes >= lim || b_bytes >= lim) {
             if ((flags & EPI_VARIANT_MASK) || (flags & EPI_SWIGLU_BWD)) return MANTIS_EUNSUPPORTED;
             variant = 1;
         }

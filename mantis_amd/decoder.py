@@ -46,6 +46,28 @@ def decoder_forward(K, lm, tc, x, B, L, position_ids, kmask, kstart=None, comput
     return x, dict(saved=saved, cos=cos, sin=sin, scale=scale)
 
 
+def compact_ce_rows(plan, input_ids_cpu, attention_mask_cpu, labels, image_token, ignore_index, dev):
+    """Shrink the plan's cross-entropy lists (one entry per (b, t) token) to the entries that can actually carry a label, so the final
+    norm, lm_head forward / dX / dW and the loss kernel run on the labelled rows only.  Exact: an ignored target contributes neither loss
+    nor gradient (its dlogits row is zero).  The selection is taken on the HOST copy of the batch (no device sync, the GEMM row count must
+    be known at launch) and is a superset of the device-side validity -- the kernel's own -100 entries inside it stay ignored.  The list
+    is padded to a multiple of 8 rows with (row -1, target -100) entries.  Call it after pack_plan / pack_segments."""
+    import torch
+    if labels is None:
+        return
+    lab = labels.detach().to("cpu") if labels.device.type != "cpu" else labels
+    valid = (attention_mask_cpu != 0) & (lab != ignore_index) & (input_ids_cpu != image_token)
+    sel = torch.nonzero(valid.reshape(-1)).reshape(-1)
+    n = int(sel.numel())
+    pad = 8 if n == 0 else (-n) % 8
+    sel_d = sel.to(dev, non_blocking=True)
+    row, tgt = plan.ce_row.index_select(0, sel_d), plan.ce_tgt.index_select(0, sel_d)
+    if pad:
+        row = torch.cat([row, torch.full((pad,), -1, dtype=row.dtype, device=row.device)])
+        tgt = torch.cat([tgt, torch.full((pad,), -100, dtype=tgt.dtype, device=tgt.device)])
+    plan.ce_row, plan.ce_tgt = row.contiguous(), tgt.contiguous()
+
+
 def head_and_loss(K, lm, tc, x, plan, B, L, labels_given, grad_scale, loss_scale, compute_grads, need_logits, record=None):
     """Final norm + lm_head + masked shifted CE.  Only the rows that can carry a label (plan.ce_row) reach lm_head for the loss; the
     full [B, L, V] logits are produced only on request.  Returns (loss, count, logits_full, ctx)."""
@@ -61,7 +83,7 @@ def head_and_loss(K, lm, tc, x, plan, B, L, labels_given, grad_scale, loss_scale
         logits_full = lg.view(B, L, Vp)[:, :, :V]
     loss = count = ctx = None
     if labels_given or compute_grads:
-        h_ce = K.gather_rows(x, plan.ce_row)                       # [B*T, d] rows that can carry a label
+        h_ce = K.gather_rows(x, plan.ce_row)                       # [n, d] rows that carry a label (compact_ce_rows), else all B*T
         nf, rstdf = K.rmsnorm_fwd(h_ce, lm["norm"], eps)
         logits = K.gemm_nt(nf, lm["head"], ldc=Vp)                # [B*T, Vp]
         loss, count = K.ce_fwd_bwd(logits, plan.ce_tgt, V, grad_scale, loss_scale, write_grad=compute_grads)

@@ -447,6 +447,7 @@ class Qwen2VLEngine:
             K.pack_segments(plan, ids_d, seg_d, -(2 ** 62))
             kstart, qend = plan.kstart, plan.qend
         plan.position_ids = pos3
+        D.compact_ce_rows(plan, ids_cpu, am_cpu, labels, IMG, -100, dev)
         x = K.pack_rows_fwd(plan, ids_d, m.lm["embed"], img)
         if record is not None:
             record["merged_embeds"] = x.view(B, T, -1)

@@ -66,6 +66,27 @@ def check_gemm_accumulate_padded():
     return close(c[:, :N], ref[:, :N], 1e-2, "gemm accumulate, ldc > N, N % 4 != 0")
 
 
+def check_gemm_operand_over_2gib():
+    """Ring kernel with an operand between 2 and 4 GiB (32-bit unsigned buffer offsets): row-major A of 2.2 GB, and the same data read
+    K-major, against the generic kernel's 64-bit addressing -- in particular the rows / k-rows that lie beyond the 2 GiB mark."""
+    k = K()
+    g = torch.Generator(device=DEV).manual_seed(11)
+    M, Kk, N = 8448, 131072, 256
+    a = torch.randn(M, Kk, device=DEV, generator=g, dtype=torch.float32).to(BF)
+    assert a.numel() * 2 > (1 << 31)
+    b = (torch.randn(N, Kk, device=DEV, generator=g, dtype=torch.float32) * 0.05).to(BF)
+    ref = k.gemm_nt(a, b, variant=1)
+    out = k.gemm_nt(a, b, variant=12)
+    r1 = close(out, ref, 5e-3, "ring vs generic, A row-major > 2 GiB")
+    close(out[-300:], ref[-300:], 5e-3, "rows beyond the 2 GiB mark")
+    # the same buffer as a K-major operand: C2[Kk-part, N2] = a^T-view . w ; take A = a as [K'=M, M'=Kk] K-major with a narrow M' window
+    a2 = a[:, :1024]                                     # [K' = 8448, M' = 1024], row stride 131072: the window's last rows lie > 2 GiB in
+    w = (torch.randn(N, M, device=DEV, generator=g, dtype=torch.float32) * 0.05).to(BF)      # [N, K']
+    ref2 = k.gemm_nt(a2, w, a_kmajor=True, variant=1)
+    out2 = k.gemm_nt(a2, w, a_kmajor=True, variant=12)
+    return max(r1, close(out2, ref2, 5e-3, "ring vs generic, A K-major spanning > 2 GiB"))
+
+
 def check_transpose():
     k = K()
     worst = 0
@@ -1210,6 +1231,7 @@ def all_checks():
                                     (600, 520, 1000, True, False, 12), (520, 600, 54, True, True, 2), (640, 768, 512, False, True, 2)]:
         c[f"gemm_kmajor_{M}x{N}x{K_}_{int(akm)}{int(bkm)}_v{v}"] = (lambda M=M, N=N, K_=K_, akm=akm, bkm=bkm, v=v: check_gemm_kmajor(M, N, K_, akm, bkm, v))
     c["gemm_ksplit_deterministic"] = check_gemm_ksplit_deterministic
+    c["gemm_operand_over_2gib"] = check_gemm_operand_over_2gib
     c["linear_dx_dw"] = check_linear_dx_dw
     c["linear_dx_swiglu_333x64x176"] = lambda: check_linear_dx_swiglu(333, 64, 176)
     c["linear_dx_swiglu_700x768x3072"] = lambda: check_linear_dx_swiglu(700, 768, 3072)
