@@ -437,6 +437,9 @@ def main():
                         mfma_busy_pct=((pmc or {}).get("step") or {}).get("mfma_busy_pct"),
                         launches_per_step=len(timer) // args.steps,
                         avg_launch_us=round(1e3 * tot_ms / len(timer), 1), gemm_ms_per_step=round(tot_ms / args.steps, 1),
+                        step_model_flops_note="step_model_tflops / *_frac_of_peak divide the REFERENCE's algorithmic FLOPs per sample (SURVEY 8d: "
+                                               "lm_head and loss on every sequence row) by the measured time; this path runs lm_head on the labelled "
+                                               "rows only, so its launched FLOPs are lower -- `achieved` counts launched GEMM work only",
                         step_model_tflops=round(flop_per_sample * B / (ms * 1e-3) / 1e12, 1) if not tiny else None,
                         step_frac_of_peak=round(flop_per_sample * B / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if not tiny else None,
                         training_step_frac_of_peak=round(flop_per_sample * B / (_pct(ts_ms, 0.5) * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if not tiny else None)
