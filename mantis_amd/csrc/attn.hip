@@ -268,6 +268,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
             if (threadIdx.x == 0) bp[64] = (okm == ~0ull) ? 0.f : 1.f;
         }
     };
+    // register-staged layouts (hd != 128): the next tile's global loads are issued BEFORE this tile's MFMA / softmax work and written to
+    // LDS AFTER it, so the HBM / L2 latency rides behind the compute instead of stalling the wave in front of it (24 VGPRs at hd 72 /
+    // 80 / 96); the key bias words of the next tile go to its (free) LDS buffer right away
+    auto stage_bias = [&](int t) {
+        if (threadIdx.x < 64) {
+            const int key = t * 64 + threadIdx.x;
+            const bool ok = key < L && (kmask == nullptr || kmask[(long)b * L + key] != 0);
+            float* bp = reinterpret_cast<float*>(smem + (t & 1) * BUF + 2 * TILE);
+            bp[threadIdx.x] = ok ? 0.f : -INFINITY;
+            const unsigned long long okm = __ballot(ok);
+            if (threadIdx.x == 0) bp[64] = (okm == ~0ull) ? 0.f : 1.f;
+        }
+    };
     stage(t_first);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -278,7 +291,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
         const char* sV = sK + TILE;
         const float* sBias = reinterpret_cast<const float*>(sK + 2 * TILE);
         const bool more = t + 1 < ntiles;
-        if (more) stage(t + 1);
+        TileRegs<64, C::NCH> nk_regs, nv_regs;          // (unused on the one-go paths)
+        // hd <= 64 keeps the one-go copy: it runs 3 waves per SIMD at 168 VGPRs, which the 24 staging registers would cost
+        // (measured: CLIP hd 64 29.3 -> 36.8 us with the split; hd 72 / 80 / 96, at 2 waves either way: -9 ... -16 %)
+        constexpr bool SPLIT_STAGE = !Y::DMA && HD > 64;
+        if constexpr (!SPLIT_STAGE) {
+            if (more) stage(t + 1);
+        } else {
+            if (more) {
+                const int kn = (t + 1) * 64;
+                nk_regs.load(Kb + (long)kn * ldk, ldk, L - kn, HD);
+                nv_regs.load(Vb + (long)kn * ldv, ldv, L - kn, HD);
+                stage_bias(t + 1);
+            }
+        }
         if (!(CAUSAL && key0 > q0 + 31)) {   // wave-uniform: skip tiles entirely in this wave's future (tiles wholly before the
                                              // wave's samples are harmless: fully masked, p = 0, running max stays -inf)
             f32x16 s[2];
@@ -408,6 +434,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
                             oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[d], 0, 0, 0);
                         }
                     }
+            }
+        }
+        if constexpr (SPLIT_STAGE) {
+            if (more) {
+                char* nb = smem + ((t + 1) & 1) * BUF;      // released by the barrier that ended iteration t - 1
+                nk_regs.store(nb, C::PITCH);
+                nv_regs.store(nb + TILE, C::PITCH);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile's DMA landed (this wave's pieces)
