@@ -57,18 +57,20 @@ int mantis_embed_grad(const void* dmerged, const int64_t* input_ids, const int32
                       void* stream);
 
 /* ---- norms: HF:models/llama/modeling_llama.py:53-67 (LlamaRMSNorm) + autograd; HF:models/siglip/modeling_siglip.py:325-358 */
+/* amax_parts (nullable; rmsnorm_fwd, rmsnorm_bwd, swiglu_fwd): mantis_fp8_quantize_ws_floats() floats <- per-workgroup maxima of
+ * |output|, for the fp8 quantiser that consumes the output next (it then skips its own amax pass) */
 int mantis_rmsnorm_fwd(const void* x, const void* weight, void* y, float* rstd /*[rows], nullable*/, int64_t rows, int d,
-                       float eps, void* stream);
+                       float eps, float* amax_parts, void* stream);
 int mantis_rmsnorm_bwd_partials(int64_t rows); /* workspace rows: floats needed = partials * d */
 int mantis_rmsnorm_bwd(const void* dy, const void* x, const void* weight, const float* rstd, const void* dres /*nullable*/,
                        void* dx, void* grad_weight /*nullable*/, int accumulate, float* workspace, int64_t rows, int d,
-                       void* stream);
+                       float* amax_parts, void* stream);
 int mantis_layernorm_fwd(const void* x, const void* weight, const void* bias, void* y, int64_t rows, int d, float eps,
                          void* stream);
 
 /* ---- activations: HF:models/llama/modeling_llama.py:163-176 (SwiGLU), modeling_llava.py:106-118 (GELU), siglip MLP acts.
  * kind: 0 gelu(erf) 1 gelu(tanh) 2 quick_gelu 3 silu.  gate_up is [M, 2I] = (gate | up). */
-int mantis_swiglu_fwd(const void* gate_up, void* out, int64_t M, int I, int64_t ld_gate_up, void* stream);
+int mantis_swiglu_fwd(const void* gate_up, void* out, int64_t M, int I, int64_t ld_gate_up, float* amax_parts, void* stream);
 int mantis_swiglu_bwd(const void* dact, const void* gate_up, void* dgate_up, int64_t M, int I, int64_t ld_gate_up,
                       void* stream);
 int mantis_act_fwd(const void* x, void* y, int64_t n, int kind, void* stream);
@@ -118,6 +120,7 @@ int mantis_gemm_pick_variant(int M, int N, int K);
 int mantis_fp8_quantize_ws_floats(void);
 int mantis_fp8_quantize(const void* x, int64_t rows, int cols, int64_t ld, int fmt, void* q, int64_t ldq, void* qt, int64_t ldt,
                         float* state, float* workspace, const float* amax_in /*nullable: max|x| already taken by x's producer*/,
+                        int amax_in_count /*1 (mantis_gemm_fp8_dx_swiglu) or mantis_fp8_quantize_ws_floats() per-workgroup maxima*/,
                         void* stream);
 int mantis_gemm_fp8_nt(const void* A8, int64_t lda, const void* B8, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
                        const float* dequant_a, const float* dequant_b, int fmt_a, const void* bias, const void* residual, int64_t ldr,

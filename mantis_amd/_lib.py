@@ -21,11 +21,11 @@ SIGNATURES = {
     "mantis_gather_rows": [P, P, P, L, I, P],
     "mantis_scatter_rows": [P, P, P, L, I, P],
     "mantis_embed_grad": [P, P, P, P, P, P, I, I, I, I, L, I, P],
-    "mantis_rmsnorm_fwd": [P, P, P, P, L, I, F, P],
+    "mantis_rmsnorm_fwd": [P, P, P, P, L, I, F, P, P],
     "mantis_rmsnorm_bwd_partials": [L],
-    "mantis_rmsnorm_bwd": [P, P, P, P, P, P, P, I, P, L, I, P],
+    "mantis_rmsnorm_bwd": [P, P, P, P, P, P, P, I, P, L, I, P, P],
     "mantis_layernorm_fwd": [P, P, P, P, L, I, F, P],
-    "mantis_swiglu_fwd": [P, P, L, I, L, P],
+    "mantis_swiglu_fwd": [P, P, L, I, L, P, P],
     "mantis_swiglu_bwd": [P, P, P, L, I, L, P],
     "mantis_act_fwd": [P, P, L, I, P],
     "mantis_act_bwd": [P, P, P, L, I, P],
@@ -40,7 +40,7 @@ SIGNATURES = {
     "mantis_gemm_workspace_bytes": [I, I, I],
     "mantis_gemm_pick_variant": [I, I, I],
     "mantis_fp8_quantize_ws_floats": [],
-    "mantis_fp8_quantize": [P, L, I, L, I, P, L, P, L, P, P, P, P],
+    "mantis_fp8_quantize": [P, L, I, L, I, P, L, P, L, P, P, P, I, P],
     "mantis_gemm_fp8_dx_swiglu": [P, L, P, L, P, L, I, I, I, P, P, I, P, L, P, P],
     "mantis_gemm_fp8_nt": [P, L, P, L, P, L, I, I, I, P, P, I, P, P, L, I, P],
     "mantis_attn_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, L, L, L, L, F, I, P],

@@ -9,9 +9,11 @@
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
 // gate_up: [M, 2I] (gate | up), out: [M, I].  silu(gate) rounded to bf16 before the multiply, as the reference's bf16 graph does.
-__global__ void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ out, long M, int I, long ld_gu) {
+__global__ void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ out, long M, int I, long ld_gu,
+                                  float* __restrict__ amax_parts) {
     const int cpr = I >> 3;
     const long total = M * cpr;
+    unsigned int umax = 0;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long r = i / cpr;
         const int c = (int)(i - r * cpr);
@@ -23,9 +25,11 @@ __global__ void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restr
             const float g0 = bf2f_lo(g[e]), g1 = bf2f_hi(g[e]);
             const float s0 = bf2f(f2bf(g0 * sigmoidf_(g0))), s1 = bf2f(f2bf(g1 * sigmoidf_(g1)));
             o[e] = pack_bf2(s0 * bf2f_lo(u[e]), s1 * bf2f_hi(u[e]));
+            umax = mantis_umax_bf2(umax, o[e]);
         }
         *reinterpret_cast<u32x4*>(out + r * I + c * 8) = o;
     }
+    if (amax_parts) mantis_store_amax_part(umax, amax_parts);
 }
 
 // dgu[:, :I] = dact * up * silu'(gate);  dgu[:, I:] = dact * silu(gate)
@@ -166,11 +170,12 @@ static inline int ew_grid(long n) {
 
 extern "C" {
 
-int mantis_swiglu_fwd(const void* gate_up, void* out, int64_t M, int I, int64_t ld_gate_up, void* stream) {
+// amax_parts (nullable): MANTIS_AMAX_PARTS floats <- per-workgroup maxima of |out| for the fp8 quantiser that consumes it next
+int mantis_swiglu_fwd(const void* gate_up, void* out, int64_t M, int I, int64_t ld_gate_up, float* amax_parts, void* stream) {
     if (I % 8 || ld_gate_up % 8) return MANTIS_EUNSUPPORTED;
     if (M == 0) return MANTIS_OK;
     MANTIS_LAUNCH(swiglu_fwd_kernel, dim3(ew_grid(M * (I / 8))), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)gate_up, (bf16_t*)out, (long)M, I, (long)ld_gate_up);
+                       (const bf16_t*)gate_up, (bf16_t*)out, (long)M, I, (long)ld_gate_up, amax_parts);
     return mantis_check_launch();
 }
 

@@ -76,6 +76,36 @@ __device__ __forceinline__ float block_max(float v, float* red) {
         hipLaunchKernelGGL(__VA_ARGS__); \
     } while (0)
 
+// fp8 quantiser protocol (csrc/gemm_fp8.hip): a kernel that PRODUCES a tensor which is quantised next can take the maximum |value| of what
+// it writes on the way: every workgroup stores its maximum (bf16 bit pattern << 16, as a float) at amax_parts[blockIdx.x], workgroup 0
+// clears the entries from gridDim.x to MANTIS_AMAX_PARTS.  The quantiser then skips its own pass over the tensor.
+#define MANTIS_AMAX_PARTS 2048
+#ifdef __HIPCC__
+// umax: this thread's running maximum of (bits & 0x7fff) << 16 over the bf16 values it stored; 256- or 512-thread workgroups
+__device__ __forceinline__ void mantis_store_amax_part(unsigned int umax, float* __restrict__ amax_parts) {
+    __shared__ unsigned int s_amax[16];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned int y = (unsigned int)__shfl_xor((int)umax, o);
+        umax = umax > y ? umax : y;
+    }
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) s_amax[w] = umax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < nw; ++i) umax = umax > s_amax[i] ? umax : s_amax[i];
+        amax_parts[blockIdx.x] = __uint_as_float(umax);
+    }
+    if (blockIdx.x == 0)
+        for (int i = gridDim.x + threadIdx.x; i < MANTIS_AMAX_PARTS; i += blockDim.x) amax_parts[i] = 0.f;
+}
+__device__ __forceinline__ unsigned int mantis_umax_bf2(unsigned int umax, unsigned int packed) {
+    const unsigned int lo = (packed << 16) & 0x7fff0000u, hi = packed & 0x7fff0000u;
+    umax = umax > lo ? umax : lo;
+    return umax > hi ? umax : hi;
+}
+#endif
+
 static inline int mantis_check_launch() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MANTIS_OK : MANTIS_ELAUNCH;

@@ -523,7 +523,7 @@ static int launch_fp8(hipStream_t s, const unsigned char* A, const unsigned char
 }
 
 // ---------------------------------------------------------------------------------------------------------------- quantisers
-#define Q_PARTS 2048
+#define Q_PARTS MANTIS_AMAX_PARTS
 // pass 1: per-workgroup maxima of |x| (bf16 bit patterns compare like unsigned integers once the sign is cleared)
 __global__ __launch_bounds__(256) void fp8_amax_kernel(const bf16_t* __restrict__ x, long rows, int cols, long ld, float* __restrict__ parts) {
     const int cpr = cols >> 3;
@@ -717,11 +717,13 @@ int mantis_fp8_quantize_ws_floats(void) { return Q_PARTS; }
 // x bf16 [rows, cols] (row stride ld, elements) -> q fp8 [rows, cols] (row stride ldq bytes) and, if qt != NULL, the transposed copy
 // qt [cols, rows_pad] (row stride ldt bytes; rows_pad = rows rounded up to 16, zero tail).  fmt: 0 = e4m3 (max 448), 1 = e5m2 (max
 // 57344).  state float[3] <- {amax, scale = FMAX / amax, dequant = amax / FMAX}.  workspace: mantis_fp8_quantize_ws_floats() floats.
-// amax_in (nullable): device float holding max |x| already taken by x's producer; the amax pass is then skipped.
+// amax_in (nullable): max |x| already taken by x's producer -- amax_in_count = 1: one float (mantis_gemm_fp8_dx_swiglu);
+// = mantis_fp8_quantize_ws_floats(): per-workgroup maxima (mantis_rmsnorm_fwd / _bwd, mantis_swiglu_fwd) -- the amax pass is then skipped.
 int mantis_fp8_quantize(const void* x, int64_t rows, int cols, int64_t ld, int fmt, void* q, int64_t ldq, void* qt, int64_t ldt,
-                        float* state, float* workspace, const float* amax_in, void* stream) {
+                        float* state, float* workspace, const float* amax_in, int amax_in_count, void* stream) {
     if (rows <= 0 || cols <= 0 || cols % 16 || ld % 8 || ldq % 16 || ldq < cols || (fmt != 0 && fmt != 1) || !state || (!workspace && !amax_in))
         return MANTIS_EINVAL;
+    if (amax_in && amax_in_count != 1 && amax_in_count != Q_PARTS) return MANTIS_EINVAL;
     const long rows_pad = (rows + 15) / 16 * 16;
     if (qt != nullptr && (ldt % 16 || ldt < rows_pad)) return MANTIS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -731,7 +733,7 @@ int mantis_fp8_quantize(const void* x, int64_t rows, int cols, int64_t ld, int f
     if (amax_in == nullptr)
         MANTIS_LAUNCH(fp8_amax_kernel, dim3(Q_PARTS), dim3(256), 0, s, (const bf16_t*)x, (long)rows, cols, (long)ld, workspace);
     const float* parts = amax_in ? amax_in : workspace;
-    const int nparts = amax_in ? 1 : Q_PARTS;
+    const int nparts = amax_in ? amax_in_count : Q_PARTS;
     if (fmt == 0)
         MANTIS_LAUNCH(fp8_cast_kernel<F8_FMT_E4M3>, grid, dim3(256), 0, s, (const bf16_t*)x, (long)rows, cols, (long)ld, parts, nparts,
                            (unsigned char*)q, (long)ldq, (unsigned char*)qt, (long)ldt, rows_pad, state);

@@ -15,8 +15,9 @@
 __global__ __launch_bounds__(64 * NORM_WAVES) void rmsnorm_fwd_kernel(const bf16_t* __restrict__ x,
                                                                       const bf16_t* __restrict__ w,
                                                                       bf16_t* __restrict__ y, float* __restrict__ rstd_out,
-                                                                      long rows, int d, float eps) {
+                                                                      long rows, int d, float eps, float* __restrict__ amax_parts) {
     const int lane = threadIdx.x & 63;
+    unsigned int umax = 0;
     const long wave = (long)blockIdx.x * NORM_WAVES + (threadIdx.x >> 6);
     const long nwaves = (long)gridDim.x * NORM_WAVES;
     const int cpr = d >> 3;
@@ -43,10 +44,12 @@ __global__ __launch_bounds__(64 * NORM_WAVES) void rmsnorm_fwd_kernel(const bf16
                 const float a = bf2f(f2bf(bf2f_lo(v[e]) * rstd)) * bf2f_lo(g[e]);
                 const float b = bf2f(f2bf(bf2f_hi(v[e]) * rstd)) * bf2f_hi(g[e]);
                 o[e] = pack_bf2(a, b);
+                umax = mantis_umax_bf2(umax, o[e]);
             }
             *reinterpret_cast<u32x4*>(y + r * d + c * 8) = o;
         }
     }
+    if (amax_parts) mantis_store_amax_part(umax, amax_parts);
 }
 
 // dx = rstd * (g - xhat * mean(g * xhat)) [+ dres],  g = dy * w, xhat = x * rstd;   dW partial[workgroup] += dy * xhat
@@ -58,7 +61,8 @@ template <int MAXC>
 __global__ __launch_bounds__(64 * RMSB_WAVES, MAXC <= 8 ? 4 : 2) void rmsnorm_bwd_kernel(
     const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
     const float* __restrict__ rstd_in, const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx,
-    float* __restrict__ dw_partial, long rows, int d) {
+    float* __restrict__ dw_partial, long rows, int d, float* __restrict__ amax_parts) {
+    unsigned int umax = 0;
     __shared__ float fold[MAXC * 64 * 8];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long wave = (long)blockIdx.x * RMSB_WAVES + wv;
@@ -106,6 +110,7 @@ __global__ __launch_bounds__(64 * RMSB_WAVES, MAXC <= 8 ? 4 : 2) void rmsnorm_bw
                     const float a = rstd * (bf2f_lo(vd[e]) * bf2f_lo(vw[e]) - x0 * dot) + bf2f_lo(vr[e]);
                     const float b = rstd * (bf2f_hi(vd[e]) * bf2f_hi(vw[e]) - x1 * dot) + bf2f_hi(vr[e]);
                     o[e] = pack_bf2(a, b);
+                    umax = mantis_umax_bf2(umax, o[e]);
                 }
                 *reinterpret_cast<u32x4*>(dx + r * d + c * 8) = o;
             }
@@ -131,6 +136,7 @@ __global__ __launch_bounds__(64 * RMSB_WAVES, MAXC <= 8 ? 4 : 2) void rmsnorm_bw
             out[j] = fold[((c >> 6) * 8 + e) * 64 + (c & 63)];
         }
     }
+    if (amax_parts) mantis_store_amax_part(umax, amax_parts);
 }
 
 // grad[j] (+)= sum_p partial[p][j]   (fixed summation order -> deterministic).  64 columns x 16 row groups per workgroup.
@@ -205,12 +211,14 @@ static inline int norm_grid(long rows) {
 
 extern "C" {
 
-int mantis_rmsnorm_fwd(const void* x, const void* weight, void* y, float* rstd, int64_t rows, int d, float eps,
+// amax_parts (nullable, here and in mantis_rmsnorm_bwd): MANTIS_AMAX_PARTS floats <- per-workgroup maxima of |y| (see common.h), for
+// the fp8 quantiser that consumes y next
+int mantis_rmsnorm_fwd(const void* x, const void* weight, void* y, float* rstd, int64_t rows, int d, float eps, float* amax_parts,
                        void* stream) {
     if (d % 8 || d <= 0) return MANTIS_EUNSUPPORTED;
     if (rows == 0) return MANTIS_OK;
     MANTIS_LAUNCH(rmsnorm_fwd_kernel, dim3(norm_grid(rows)), dim3(64 * NORM_WAVES), 0, (hipStream_t)stream,
-                       (const bf16_t*)x, (const bf16_t*)weight, (bf16_t*)y, rstd, (long)rows, d, eps);
+                       (const bf16_t*)x, (const bf16_t*)weight, (bf16_t*)y, rstd, (long)rows, d, eps, amax_parts);
     return mantis_check_launch();
 }
 
@@ -221,13 +229,13 @@ int mantis_rmsnorm_bwd_partials(int64_t rows) {
 }
 
 int mantis_rmsnorm_bwd(const void* dy, const void* x, const void* weight, const float* rstd, const void* dres, void* dx,
-                       void* grad_weight, int accumulate, float* workspace, int64_t rows, int d, void* stream) {
+                       void* grad_weight, int accumulate, float* workspace, int64_t rows, int d, float* amax_parts, void* stream) {
     if (d % 8 || d <= 0 || d > 64 * 8 * NORM_MAXC) return MANTIS_EUNSUPPORTED;
     if (rows == 0) return MANTIS_OK;
     const int P = mantis_rmsnorm_bwd_partials(rows);
 #define RMSB_LAUNCH(MAXC) MANTIS_LAUNCH(rmsnorm_bwd_kernel<MAXC>, dim3(P), dim3(64 * RMSB_WAVES), 0, (hipStream_t)stream, \
                        (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)weight, rstd, (const bf16_t*)dres, (bf16_t*)dx, \
-                       grad_weight ? workspace : nullptr, (long)rows, d)
+                       grad_weight ? workspace : nullptr, (long)rows, d, amax_parts)
     if (d <= 64 * 8 * 2) RMSB_LAUNCH(2);
     else if (d <= 64 * 8 * 8) RMSB_LAUNCH(8);
     else RMSB_LAUNCH(NORM_MAXC);

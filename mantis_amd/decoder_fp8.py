@@ -15,6 +15,7 @@ from . import decoder as D
 
 # A/B switch (measurements only): 0 = dX(down_proj), SwiGLU backward and the amax pass as three launches
 FUSE_SWIGLU_BWD = os.environ.get("MANTIS_FP8_FUSE_SWIGLU", "1") == "1"
+PRODUCER_AMAX = os.environ.get("MANTIS_FP8_PRODUCER_AMAX", "1") == "1"      # 0 = every quantiser runs its own amax pass
 
 E4M3, E5M2 = 0, 1
 _NAMES = ("qkv", "o", "gu", "down")
@@ -50,20 +51,23 @@ def decoder_forward(K, lm, w8, tc, x, B, L, kmask, compute_grads=True, record=No
     scale = hd ** -0.5
     cos, sin = rope
     saved = []
+    # producer-side amax: RMSNorm and SwiGLU take the maximum |value| of what they write, so the quantiser that follows skips its own
+    # pass over the tensor (one scratch buffer, reused: producer and consumer are adjacent on the stream)
+    parts = K.amax_parts_buffer(x.device) if PRODUCER_AMAX else None
     for i in range(tc.num_hidden_layers):
         lw = lm["layers"][i]
-        n1, rstd1 = K.rmsnorm_fwd(x, lw["ln1"], eps)
-        n1q = K.fp8_quantize(n1, E4M3, transposed=compute_grads)
+        n1, rstd1 = K.rmsnorm_fwd(x, lw["ln1"], eps, amax_parts=parts)
+        n1q = K.fp8_quantize(n1, E4M3, transposed=compute_grads, amax=parts)
         qkv = _lin(K, n1q, w8.get(K, i, "qkv"), bias=lw.get("qkv_b"))
         K.rope_apply_(qkv, cos, sin, H + Hkv, hd)
         o, lse = K.attn_fwd(qkv, B, L, H, Hkv, hd, kmask, scale, True, kstart=kstart)
         oq = K.fp8_quantize(o, E4M3, transposed=compute_grads)
         x_mid = _lin(K, oq, w8.get(K, i, "o"), residual=x)
-        n2, rstd2 = K.rmsnorm_fwd(x_mid, lw["ln2"], eps)
-        n2q = K.fp8_quantize(n2, E4M3, transposed=compute_grads)
+        n2, rstd2 = K.rmsnorm_fwd(x_mid, lw["ln2"], eps, amax_parts=parts)
+        n2q = K.fp8_quantize(n2, E4M3, transposed=compute_grads, amax=parts)
         gu = _lin(K, n2q, w8.get(K, i, "gu"))
-        a = K.swiglu_fwd(gu)
-        aq = K.fp8_quantize(a, E4M3, transposed=compute_grads)
+        a = K.swiglu_fwd(gu, amax_parts=parts)
+        aq = K.fp8_quantize(a, E4M3, transposed=compute_grads, amax=parts)
         x_out = _lin(K, aq, w8.get(K, i, "down"), residual=x_mid)
         if compute_grads:
             for t in (n1q, oq, n2q, aq):
@@ -92,11 +96,14 @@ def decoder_backward(K, lm, w8, grads, grads_layers, tc, ctx, hctx, plan, B, L, 
     acc = accumulate
     saved, cos, sin, scale = ctx["saved"], ctx["cos"], ctx["sin"], ctx["scale"]
     dx = D.head_backward(K, lm, grads, hctx, plan, B, L, acc, on_bucket_ready)
+    parts_dx = K.amax_parts_buffer(dx.device) if PRODUCER_AMAX else None
+    parts_mid = K.amax_parts_buffer(dx.device) if PRODUCER_AMAX else None
+    dx_amax = None                     # the top layer's dx comes from the loss head (no producer-side amax); below: rmsnorm_bwd's
     for i in reversed(range(tc.num_hidden_layers)):
         lw = lm["layers"][i]
         lg_ = grads_layers[i]
         x_in, rstd1, qkv, o, lse, x_mid, rstd2, gu, n1q, oq, n2q, aq = saved.pop()
-        dxq = K.fp8_quantize(dx, E5M2, transposed=lg_["down"] is not None)
+        dxq = K.fp8_quantize(dx, E5M2, transposed=lg_["down"] is not None, amax=dx_amax)
         _dw(K, dxq, aq, lg_["down"], acc)
         if on_bucket_ready is not None:
             on_bucket_ready(("layer", i, "down"))
@@ -115,9 +122,9 @@ def decoder_backward(K, lm, w8, grads, grads_layers, tc, ctx, hctx, plan, B, L, 
             on_bucket_ready(("layer", i, "gu"))
         dn2 = _dx(K, dguq, w8.get(K, i, "gu"))
         del dguq, n2q
-        dx_mid = K.rmsnorm_bwd(dn2, x_mid, lw["ln2"], rstd2, dx, lg_["ln2"], acc)
+        dx_mid = K.rmsnorm_bwd(dn2, x_mid, lw["ln2"], rstd2, dx, lg_["ln2"], acc, amax_parts=parts_mid)
         del dn2, dx
-        dmq = K.fp8_quantize(dx_mid, E5M2, transposed=lg_["o"] is not None)
+        dmq = K.fp8_quantize(dx_mid, E5M2, transposed=lg_["o"] is not None, amax=parts_mid)
         _dw(K, dmq, oq, lg_["o"], acc)
         do = _dx(K, dmq, w8.get(K, i, "o"))
         del dmq, oq
@@ -130,7 +137,8 @@ def decoder_backward(K, lm, w8, grads, grads_layers, tc, ctx, hctx, plan, B, L, 
             K.colsum(dqkv, lg_["qkv_b"], acc)
         dn1 = _dx(K, dqq, w8.get(K, i, "qkv"))
         del dqkv, dqq, n1q, qkv
-        dx = K.rmsnorm_bwd(dn1, x_in, lw["ln1"], rstd1, dx_mid, lg_["ln1"], acc)
+        dx = K.rmsnorm_bwd(dn1, x_in, lw["ln1"], rstd1, dx_mid, lg_["ln1"], acc, amax_parts=parts_dx)
+        dx_amax = parts_dx
         del dn1, dx_mid, x_in
         if on_bucket_ready is not None:
             on_bucket_ready(("layer", i, "attn"))

@@ -122,7 +122,8 @@ class Fp8Tensor:
 
 def fp8_quantize(x, fmt=FP8_E4M3, transposed=True, rowmajor=True, amax=None):
     """Per-tensor just-in-time quantisation of a bf16 matrix: q = cvt(clamp(x * FMAX / amax)).  Returns Fp8Tensor.
-    amax: device fp32[1] holding max |x| when x's producer already took it (gemm_fp8_dx_swiglu) -- the amax pass is skipped."""
+    amax: max |x| already taken by x's producer -- fp32[1] (gemm_fp8_dx_swiglu) or an amax_parts_buffer() filled by rmsnorm_fwd /
+    rmsnorm_bwd / swiglu_fwd -- the amax pass is skipped."""
     _chk2d(x, "x")
     rows, cols = x.shape
     dev = x.device
@@ -134,8 +135,8 @@ def fp8_quantize(x, fmt=FP8_E4M3, transposed=True, rowmajor=True, amax=None):
     q = torch.empty((rows, cols), dtype=torch.uint8, device=dev)
     qt = torch.empty((cols, rp), dtype=torch.uint8, device=dev) if transposed else None
     state = torch.empty(3, dtype=torch.float32, device=dev)
-    _lib.check(_L.mantis_fp8_quantize(_p(x), rows, cols, x.stride(0), fmt, _p(q), cols, _p(qt), rp, _p(state), _p(ws), _p(amax), _stream()),
-               f"fp8_quantize {rows}x{cols}")
+    _lib.check(_L.mantis_fp8_quantize(_p(x), rows, cols, x.stride(0), fmt, _p(q), cols, _p(qt), rp, _p(state), _p(ws), _p(amax),
+                                      0 if amax is None else amax.numel(), _stream()), f"fp8_quantize {rows}x{cols}")
     return Fp8Tensor(q, qt, state, fmt, rows, cols)
 
 
@@ -265,23 +266,29 @@ def colsum(x, grad, accumulate):
 
 
 # ----------------------------------------------------------------------------------------------------------- norms / acts
-def rmsnorm_fwd(x, w, eps, want_rstd=True):
+def amax_parts_buffer(device):
+    """Scratch for the producer-side amax protocol (rmsnorm_fwd / rmsnorm_bwd / swiglu_fwd -> fp8_quantize(amax=...))."""
+    return torch.empty(_L.mantis_fp8_quantize_ws_floats(), dtype=torch.float32, device=device)
+
+
+def rmsnorm_fwd(x, w, eps, want_rstd=True, amax_parts=None):
+    """amax_parts: buffer from amax_parts_buffer(); receives the per-workgroup maxima of |y| for the fp8 quantiser that follows."""
     _chk2d(x, "x")
     rows, d = x.shape
     y = torch.empty_like(x)
     rstd = torch.empty((rows,), dtype=torch.float32, device=x.device) if want_rstd else None
-    _lib.check(_L.mantis_rmsnorm_fwd(_p(x), _p(w), _p(y), _p(rstd), rows, d, float(eps), _stream()), "rmsnorm_fwd")
+    _lib.check(_L.mantis_rmsnorm_fwd(_p(x), _p(w), _p(y), _p(rstd), rows, d, float(eps), _p(amax_parts), _stream()), "rmsnorm_fwd")
     return y, rstd
 
 
-def rmsnorm_bwd(dy, x, w, rstd, dres, grad_w, accumulate):
+def rmsnorm_bwd(dy, x, w, rstd, dres, grad_w, accumulate, amax_parts=None):
     rows, d = x.shape
     dx = torch.empty_like(x)
     ws = None
     if grad_w is not None:
         ws = torch.empty((_L.mantis_rmsnorm_bwd_partials(rows), d), dtype=torch.float32, device=x.device)
     _lib.check(_L.mantis_rmsnorm_bwd(_p(dy), _p(x), _p(w), _p(rstd), _p(dres), _p(dx), _p(grad_w), int(accumulate), _p(ws),
-                                     rows, d, _stream()), "rmsnorm_bwd")
+                                     rows, d, _p(amax_parts), _stream()), "rmsnorm_bwd")
     return dx
 
 
@@ -292,10 +299,10 @@ def layernorm_fwd(x, w, b, eps):
     return y
 
 
-def swiglu_fwd(gu):
+def swiglu_fwd(gu, amax_parts=None):
     M, I2 = gu.shape
     out = torch.empty((M, I2 // 2), dtype=BF16, device=gu.device)
-    _lib.check(_L.mantis_swiglu_fwd(_p(gu), _p(out), M, I2 // 2, gu.stride(0), _stream()), "swiglu_fwd")
+    _lib.check(_L.mantis_swiglu_fwd(_p(gu), _p(out), M, I2 // 2, gu.stride(0), _p(amax_parts), _stream()), "swiglu_fwd")
     return out
 
 

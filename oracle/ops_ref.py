@@ -69,7 +69,7 @@ def fp8_quantize(x, fmt=FP8_E4M3, transposed=True, rowmajor=True, amax=None):
     dt, fmax = _F8[fmt]
     xf = _f(x)
     if amax is not None:
-        assert float(amax) == float(xf.abs().max()), "a producer-side amax must equal the tensor's own"
+        assert float(amax.max()) == float(xf.abs().max()), "a producer-side amax must equal the tensor's own"
     amax = xf.abs().max()
     fm = torch.tensor(fmax, dtype=torch.float32)
     sc = fm / amax if float(amax) > 0 else torch.tensor(1.0)
@@ -142,14 +142,25 @@ def colsum(x, grad, accumulate):
     grad.copy_(g.to(grad.dtype))
 
 
-def rmsnorm_fwd(x, w, eps, want_rstd=True):
+def amax_parts_buffer(device):
+    return torch.zeros(2048, dtype=torch.float32)
+
+
+def _put_amax(parts, y):
+    if parts is not None:
+        parts.zero_()
+        parts[0] = y.float().abs().max()
+
+
+def rmsnorm_fwd(x, w, eps, want_rstd=True, amax_parts=None):
     xf = _f(x)
     rstd = torch.rsqrt(xf.pow(2).mean(-1) + eps)
     y = (_f((xf * rstd[:, None]).to(x.dtype)) * _f(w)).to(x.dtype)      # two roundings, as LlamaRMSNorm does in bf16
+    _put_amax(amax_parts, y)
     return y, (rstd if want_rstd else None)
 
 
-def rmsnorm_bwd(dy, x, w, rstd, dres, grad_w, accumulate):
+def rmsnorm_bwd(dy, x, w, rstd, dres, grad_w, accumulate, amax_parts=None):
     xf, g = _f(x), _f(dy) * _f(w)
     xhat = xf * rstd[:, None]
     dx = rstd[:, None] * (g - xhat * (g * xhat).mean(-1, keepdim=True))
@@ -160,6 +171,7 @@ def rmsnorm_bwd(dy, x, w, rstd, dres, grad_w, accumulate):
         if accumulate:
             gw = gw + _f(grad_w)
         grad_w.copy_(gw.to(grad_w.dtype))
+    _put_amax(amax_parts, dx.to(x.dtype))
     return dx.to(x.dtype)
 
 
@@ -167,10 +179,12 @@ def layernorm_fwd(x, w, b, eps):
     return F.layer_norm(_f(x), (x.shape[-1],), _f(w), _f(b), eps).to(x.dtype)
 
 
-def swiglu_fwd(gu):
+def swiglu_fwd(gu, amax_parts=None):
     I = gu.shape[1] // 2
     g, u = _f(gu[:, :I]), _f(gu[:, I:])
-    return (_f(F.silu(g).to(gu.dtype)) * u).to(gu.dtype)
+    out = (_f(F.silu(g).to(gu.dtype)) * u).to(gu.dtype)
+    _put_amax(amax_parts, out)
+    return out
 
 
 def swiglu_bwd(dact, gu):

@@ -1015,6 +1015,34 @@ def check_fp8_gemm(M, N, K_, fmt_a, epi, variant):
     return r
 
 
+def check_fp8_producer_amax():
+    """rmsnorm_fwd / rmsnorm_bwd / swiglu_fwd take the maximum |value| of what they write (per-workgroup partials): it must EQUAL the
+    maximum of the stored tensor, and the quantiser fed with it must give the bytes and scales of the two-pass quantiser."""
+    k = K()
+    for rows, d in [(300, 112), (4096, 3584), (77, 4096)]:
+        x, w = rnd(rows, d, seed=rows), rnd(d, seed=1) + 1
+        parts = k.amax_parts_buffer(DEV)
+        y, rstd = k.rmsnorm_fwd(x.to(DEV), w.to(DEV), 1e-6, amax_parts=parts)
+        assert float(parts.max().cpu()) == float(y.float().abs().max().cpu()), "rmsnorm_fwd amax"
+        a, b = k.fp8_quantize(y, 0, amax=parts), k.fp8_quantize(y, 0)
+        assert torch.equal(a.q, b.q) and torch.equal(a.qt, b.qt) and torch.equal(a.state, b.state)
+        dy, dres = rnd(rows, d, seed=rows + 1, scale=0.01).to(DEV), rnd(rows, d, seed=rows + 2, scale=0.01).to(DEV)
+        gw = torch.zeros(d, dtype=BF, device=DEV)
+        dx = k.rmsnorm_bwd(dy, x.to(DEV), w.to(DEV), rstd, dres, gw, False, amax_parts=parts)
+        assert float(parts.max().cpu()) == float(dx.float().abs().max().cpu()), "rmsnorm_bwd amax"
+        a, b = k.fp8_quantize(dx, 1, amax=parts), k.fp8_quantize(dx, 1)
+        assert torch.equal(a.q, b.q) and torch.equal(a.state, b.state)
+    for M, I in [(300, 256), (4096, 18944), (50, 1504)]:
+        gu = rnd(M, 2 * I, seed=M + I).to(DEV)
+        parts = k.amax_parts_buffer(DEV)
+        out = k.swiglu_fwd(gu, amax_parts=parts)
+        assert float(parts.max().cpu()) == float(out.float().abs().max().cpu()), "swiglu_fwd amax"
+        assert torch.equal(out, k.swiglu_fwd(gu)), "the amax side output must not change the result"
+        a, b = k.fp8_quantize(out, 0, amax=parts), k.fp8_quantize(out, 0)
+        assert torch.equal(a.q, b.q) and torch.equal(a.qt, b.qt) and torch.equal(a.state, b.state)
+    return 0.0
+
+
 def check_fp8_dx_swiglu(M, d, I, fmt_a):
     """dX of down_proj with the SwiGLU backward and the amax of the result in the GEMM epilogue vs the oracle's unfused restatement
     (same fp8 bytes); the amax must EQUAL the maximum of what was written (it replaces the quantiser's first pass)."""
@@ -1277,6 +1305,7 @@ def all_checks():
         c[f"fp8_quantize_{r_}x{c_}_fmt{f_}"] = (lambda r_=r_, c_=c_, f_=f_, sc_=sc_: check_fp8_quantize(r_, c_, f_, sc_))
     for a in FP8_GEMM_CASES:
         c["fp8_gemm_" + "_".join(map(str, a))] = (lambda a=a: check_fp8_gemm(*a))
+    c["fp8_producer_amax"] = check_fp8_producer_amax
     for (m_, d_, i_, f_) in [(300, 112, 256, 1), (1000, 512, 1504, 1), (257, 64, 176, 0), (4096, 3584, 18944, 1)]:
         c[f"fp8_dx_swiglu_{m_}x{d_}x{i_}_fmt{f_}"] = (lambda m_=m_, d_=d_, i_=i_, f_=f_: check_fp8_dx_swiglu(m_, d_, i_, f_))
     for case in QWEN2VL_CASES:
