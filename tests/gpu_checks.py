@@ -1106,6 +1106,45 @@ def check_qwen2vl_step_fp8(case):
     return 1.0 - worst
 
 
+def check_qwen2vl_full_width_fp8():
+    """Qwen2-VL-7B layers at full width and reduced depth with the decoder linears on the fp8 MFMA GEMM: bitwise reproducible, accumulates,
+    and within the stated fp8 tolerance of the SAME step on the bf16 linears (loss 1e-2, weight-matrix gradient cosine >= 0.95) -- the
+    full-size counterpart of the golden-size qwen2vl_fp8_step_* checks (ring kernel, strip dispatch, fused SwiGLU epilogue, producer-side
+    amax all on their real shapes)."""
+    import math
+    from mantis_amd import configuration_qwen2_vl as C
+    from mantis_amd.modeling_qwen2_vl import Qwen2VLForConditionalGeneration
+    from mantis_amd.trainer import MantisHipTrainer
+    import bench
+    cfg = C.qwen2_vl_7b()
+    cfg.vision_config.depth = 2
+    cfg.text_config.num_hidden_layers = 2
+    batch = bench.synthetic_batch_qwen2vl(cfg, 1, 1024, [(1, 16, 24), (1, 24, 16)], 0)
+    ref = Qwen2VLForConditionalGeneration(cfg, device=DEV, seed=0)
+    lb = MantisHipTrainer(ref, gradient_accumulation_steps=1).training_step(ref, batch)
+    gb = {n: p.grad.float().clone() for n, p in ref.named_parameters() if p.requires_grad}
+    del ref
+    model = Qwen2VLForConditionalGeneration(cfg, device=DEV, seed=0).set_precision("fp8")
+    tr = MantisHipTrainer(model, gradient_accumulation_steps=1)
+    l1 = tr.training_step(model, batch)
+    g1 = model.grad_arena.clone()
+    for p in model.parameters():
+        p.grad = None
+    l2 = tr.training_step(model, batch)
+    assert torch.equal(l1, l2) and torch.equal(g1, model.grad_arena), "the fp8 step is not bitwise reproducible"
+    assert math.isfinite(float(l1)) and abs(float(l1) - float(lb)) <= 1e-2 * float(lb), (float(l1), float(lb))
+    worst = 1.0
+    for n, p in model.named_parameters():
+        if p.requires_grad and p.dim() > 1:
+            c = Hh.cosine(p.grad.float().cpu().numpy(), gb[n].cpu().numpy())
+            assert c >= 0.95, (n, c)
+            worst = min(worst, c)
+    l3 = tr.training_step(model, batch)
+    assert torch.equal(l3, l1)
+    close(model.grad_arena, 2 * g1.float(), 5e-3, "accumulated gradients = 2x")
+    return 1.0 - worst
+
+
 def check_norm_overlap():
     """The gradient-norm pass taken bucket by bucket on a side stream during the backward (MantisHipTrainer(optimizer=...)) gives the
     same global norm as the separate pass over the whole arena, and the same parameters after the step."""
@@ -1315,6 +1354,7 @@ def all_checks():
     c["qwen2vl_prefetch_bit_identical"] = check_qwen2vl_prefetch
     c["rope_sections_cast_pad"] = check_rope_sections
     c["qwen2vl_full_width"] = check_qwen2vl_full_width
+    c["qwen2vl_full_width_fp8_vs_bf16"] = check_qwen2vl_full_width_fp8
     c["pack_segments_random"] = check_pack_segments_random
     c["packed_model_step"] = check_packed_model_step
     c["packed_fullsize_vs_batched"] = check_packed_fullsize_vs_batched
