@@ -253,6 +253,7 @@ def main():
                          "+ AdamW of step i.  Off by default: measured no gain (234.2 vs 235.4 ms on the Qwen2-VL config) -- the grid-stride "
                          "AdamW keeps every CU partly occupied, and the tower's kernels need whole register files, so the hardware runs "
                          "the two streams one after the other (profiles/r02_experiments.md)")
+    ap.add_argument("--adam-cus", type=int, default=192, help="with --prefetch: compute units given to the optimizer pass")
     ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
@@ -328,6 +329,13 @@ def main():
     # (+3.5 ms) than the separate pass they replace (-3.2 ms), so the default stays off.
     overlap = opt is not None and os.environ.get("MANTIS_NORM_OVERLAP", "0") == "1"
     trainer = MantisHipTrainer(model, gradient_accumulation_steps=1, reducer=reducer, optimizer=opt if overlap else None)
+    if args.prefetch and opt is not None and hasattr(model.engine, "prefetch_vision"):
+        # CU partition: clip + AdamW on `--adam-cus` compute units (HBM-bound: 192 CUs stream as fast as 256), the next batch's frozen
+        # tower on the others -- the two masked streams run side by side (tools/cu_mask_probe.hip)
+        total = K.num_cus()
+        n_adam = min(max(args.adam_cus, 1), total - 8)
+        opt.stream = K.cu_masked_stream(0, n_adam)
+        trainer.prefetch_stream = K.cu_masked_stream(n_adam, total - n_adam)
     n_batches = args.recycle_batches or (args.warmup + args.steps)
     make = synthetic_batch_idefics2 if idefics else synthetic_batch
     if qwen:

@@ -178,6 +178,11 @@ int mantis_sumsq(const void* x_bf16, int64_t n, float* partials_ws, float* out /
 int mantis_clip_scale(const float* sumsq, float max_norm, float* scale_out, float* norm_out, void* stream);
 
 /* library / device info */
+/* ---- CU-partitioned streams: the HBM-bound optimizer pass on one share of the compute units, the next batch's frozen vision tower on
+ * the rest (software pipelining across HF:trainer.py's training_step -> optimizer.step boundary; same arithmetic, only earlier) */
+int mantis_stream_create_cu_mask(int first_cu, int n_cus, void** stream_out);
+int mantis_stream_destroy(void* stream);
+
 int mantis_version(void);
 
 #ifdef __cplusplus

@@ -56,6 +56,8 @@ SIGNATURES = {
     "mantis_sumsq_partials": [L],
     "mantis_sumsq": [P, L, P, P, I, P],
     "mantis_clip_scale": [P, F, P, P, P],
+    "mantis_stream_create_cu_mask": [I, I, P],
+    "mantis_stream_destroy": [P],
     "mantis_version": [],
 }
 

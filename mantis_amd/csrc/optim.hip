@@ -85,6 +85,26 @@ int mantis_adamw(void* param_bf16, const void* grad_bf16, float* master, float* 
     return mantis_check_launch();
 }
 
+// A stream whose kernels are confined to n_cus compute units (bits [first_cu, first_cu + n_cus) of the device's CU mask; the driver
+// deals consecutive bits round-robin over the XCDs, so a contiguous range is spread over all eight).  Used to run the HBM-bound
+// clip + AdamW pass on 192 CUs beside the next batch's frozen vision tower on the other 64 (tools/cu_mask_probe.hip: a streaming kernel
+// gets 5.5 TB/s from 192 CUs -- as much as from all 256 -- and the two masked streams run truly side by side).
+int mantis_stream_create_cu_mask(int first_cu, int n_cus, void** stream_out) {
+    int dev = 0, total = 0;
+    if (!stream_out || hipGetDevice(&dev) != hipSuccess) return MANTIS_EINVAL;
+    if (hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || total <= 0) return MANTIS_ELAUNCH;
+    if (first_cu < 0 || n_cus <= 0 || first_cu + n_cus > total) return MANTIS_EINVAL;
+    uint32_t mask[32] = {0};
+    if (total > 32 * 32) return MANTIS_EUNSUPPORTED;
+    for (int i = first_cu; i < first_cu + n_cus; ++i) mask[i / 32] |= 1u << (i % 32);
+    hipStream_t s = nullptr;
+    if (hipExtStreamCreateWithCUMask(&s, (uint32_t)((total + 31) / 32), mask) != hipSuccess) return MANTIS_ELAUNCH;
+    *stream_out = (void*)s;
+    return MANTIS_OK;
+}
+
+int mantis_stream_destroy(void* stream) { return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? MANTIS_OK : MANTIS_ELAUNCH; }
+
 int mantis_sumsq_partials(int64_t n) { return SUMSQ_BLOCKS; }
 
 int mantis_sumsq(const void* x_bf16, int64_t n, float* partials_ws, float* out, int accumulate, void* stream) {

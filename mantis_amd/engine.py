@@ -92,6 +92,37 @@ class LlavaEngine:
             raise ValueError(f"Unexpected select feature strategy: {strat}")
         return x, N
 
+    # ------------------------------------------------------------------------------------------------ software pipelining of the tower
+    def _pixels_to_device(self, pixel_values, dev):
+        if isinstance(pixel_values, (list, tuple)):        # modeling_llava.py:431-432 (torch.cat of the per-sample list)
+            # H2D per sample, concatenation on the device: a host-side torch.cat of a few MB costs ~30 ms on a 128-core host
+            # (thread-pool start-up) -- more than the whole tiny-config step
+            parts = [p.to(dev, non_blocking=True) for p in pixel_values if p is not None]
+            pixel_values = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
+        return pixel_values.to(dev, non_blocking=True).to(torch.float32).contiguous()
+
+    def prefetch_vision(self, inputs, after_event=None, stream=None):
+        """Enqueue the frozen tower's forward of a FUTURE batch on `stream` (default: a plain side stream) behind `after_event` of the
+        compute stream.  The tower is frozen, so its output does not depend on the optimizer step in between: with `stream` confined to
+        a share of the compute units (hip_ops.cu_masked_stream) and the optimizer pass on the complementary share, the MFMA-bound tower of
+        batch i+1 runs beside the HBM-bound clip + AdamW of step i.  The features are consumed by the step that is handed the SAME
+        pixel_values object; any other batch is computed in line."""
+        pv = inputs.get("pixel_values")
+        if pv is None or inputs["input_ids"].shape[1] == 1 or not torch.cuda.is_available():
+            return
+        dev = self.m.device
+        if stream is None:
+            stream = getattr(self, "_side", None)
+            if stream is None:
+                stream = self._side = torch.cuda.Stream(device=dev)
+        if after_event is not None:
+            stream.wait_event(after_event)
+        with torch.cuda.stream(stream):
+            feats, N = self.vision_forward(self._pixels_to_device(pv, dev))
+            done = torch.cuda.Event()
+            done.record(stream)
+        self._prefetched = (pv, feats, N, done)
+
     # ------------------------------------------------------------------------------------------------ full step
     def step(self, input_ids, attention_mask, labels, pixel_values, grad_scale=1.0, loss_scale=1.0, compute_grads=True,
              overwrite_grads=True, need_logits=False, record=None, on_bucket_ready=None, segment_ids=None):
@@ -119,14 +150,16 @@ class LlavaEngine:
         I = 0
         N = 1
         if pixel_values is not None and T != 1:
-            if isinstance(pixel_values, (list, tuple)):        # modeling_llava.py:431-432 (torch.cat of the per-sample list)
-                # H2D per sample, concatenation on the device: a host-side torch.cat of a few MB costs ~30 ms on a 128-core host
-                # (thread-pool start-up) -- more than the whole tiny-config step
-                parts = [p.to(dev, non_blocking=True) for p in pixel_values if p is not None]
-                pixel_values = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
-            pix = pixel_values.to(dev, non_blocking=True).to(torch.float32).contiguous()
-            I = pix.shape[0]
-            feats, N = self.vision_forward(pix, record)
+            pre, self._prefetched = getattr(self, "_prefetched", None), None
+            if pre is not None and pre[0] is pixel_values and record is None:
+                feats, N = pre[1], pre[2]                       # computed ahead on another stream (prefetch_vision)
+                torch.cuda.current_stream().wait_event(pre[3])
+                feats.record_stream(torch.cuda.current_stream())
+                I = feats.shape[0] // N
+            else:
+                pix = self._pixels_to_device(pixel_values, dev)
+                I = pix.shape[0]
+                feats, N = self.vision_forward(pix, record)
             if record is not None:
                 record["projector_in"] = feats.view(I, N, -1)
             pw = m.proj

@@ -543,5 +543,17 @@ def clip_scale(sumsq, max_norm):
     return scale, norm
 
 
+def num_cus():
+    return torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+
+
+def cu_masked_stream(first_cu, n_cus):
+    """torch stream whose kernels run on compute units [first_cu, first_cu + n_cus) only (hipExtStreamCreateWithCUMask)."""
+    import ctypes
+    h = ctypes.c_void_p()
+    _lib.check(_L.mantis_stream_create_cu_mask(int(first_cu), int(n_cus), ctypes.byref(h)), "stream_create_cu_mask")
+    return torch.cuda.ExternalStream(h.value, device=torch.device("cuda", torch.cuda.current_device()))
+
+
 def synchronize():
     torch.cuda.synchronize()

@@ -312,7 +312,7 @@ class Qwen2VLEngine:
         self._prefetched = None              # (pixel_values object, image rows, done event)
 
     # ------------------------------------------------------------------ software pipelining of the frozen tower
-    def prefetch_vision(self, inputs, after_event=None):
+    def prefetch_vision(self, inputs, after_event=None, stream=None):
         """Enqueue the tower + merger forward of a FUTURE batch on a side stream (behind `after_event` of the compute stream).  `visual`
         is frozen, so its output does not depend on the optimizer step in between: MantisHipTrainer calls this at the end of an
         accumulation window so the MFMA-bound tower of batch i+1 runs beside the HBM-bound clip + AdamW of step i.  The result is
@@ -321,16 +321,18 @@ class Qwen2VLEngine:
         if pv is None or inputs.get("image_grid_thw") is None or not torch.cuda.is_available():
             return
         dev = self.m.device
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=dev)
+        if stream is None:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=dev)
+            stream = self._side
         grids = [tuple(int(v) for v in g) for g in torch.as_tensor(inputs["image_grid_thw"]).tolist()]
         if after_event is not None:
-            self._side.wait_event(after_event)
-        with torch.cuda.stream(self._side):
+            stream.wait_event(after_event)
+        with torch.cuda.stream(stream):
             pix = torch.as_tensor(pv).to(dev, non_blocking=True).to(torch.float32).contiguous()
             img = self.vision_forward(pix, grids)
             done = torch.cuda.Event()
-            done.record(self._side)
+            done.record(stream)
         self._prefetched = (pv, img, done)
 
     def step_from_batch(self, inputs, **kw):

@@ -93,6 +93,19 @@ class FusedAdamW:
         self._norm_ready = True
 
     def step(self):
+        """`self.stream` (optional, e.g. hip_ops.cu_masked_stream): run the pass there -- behind everything queued on the current stream,
+        and the current stream resumes behind it -- so that work queued on OTHER streams (the next batch's frozen vision tower on the
+        complementary compute units) runs beside it."""
+        st = getattr(self, "stream", None)
+        if st is None:
+            return self._step()
+        cur = torch.cuda.current_stream()
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            self._step()
+        cur.wait_stream(st)
+
+    def _step(self):
         m = self.model
         if getattr(m, "_param_version", 0) != self._seen_version:
             self.resync_master()

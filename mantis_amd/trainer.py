@@ -81,7 +81,7 @@ class MantisHipTrainer:
         if next_inputs is not None and boundary and hasattr(model.engine, "prefetch_vision"):
             ev = torch.cuda.Event()
             ev.record()                       # end of this window's backward (and gradient reduction) on the compute stream
-            model.engine.prefetch_vision(next_inputs, after_event=ev)
+            model.engine.prefetch_vision(next_inputs, after_event=ev, stream=getattr(self, "prefetch_stream", None))
         return out["loss"].reshape(()).detach()
 
 
