@@ -250,9 +250,8 @@ def main():
     ap.add_argument("--no-pack", action="store_true", help="Idefics2 config: feed the samples as a batch instead of one packed row")
     ap.add_argument("--prefetch", action="store_true",
                     help="hand the next batch to training_step: the frozen vision tower of batch i+1 is enqueued on a side stream beside clip "
-                         "+ AdamW of step i.  Off by default: measured no gain (234.2 vs 235.4 ms on the Qwen2-VL config) -- the grid-stride "
-                         "AdamW keeps every CU partly occupied, and the tower's kernels need whole register files, so the hardware runs "
-                         "the two streams one after the other (profiles/r02_experiments.md)")
+                         "+ AdamW of step i, the optimizer on --adam-cus compute units and the tower on the rest (CU-masked streams).  Off "
+                         "by default: measured slower for every split (headline 297 -> 320-344 ms; profiles/r02_experiments.md)")
     ap.add_argument("--adam-cus", type=int, default=192, help="with --prefetch: compute units given to the optimizer pass")
     ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
