@@ -904,6 +904,41 @@ def check_qwen2vl_packed(precision):
     return 1.0 - worst
 
 
+def check_llava_prefetch_cu_masked():
+    """The LLaVA engine's tower computed ahead on a CU-masked stream (64 compute units), the fused AdamW on the complementary masked
+    stream: loss, gradients and updated parameters are bit-identical to the plain in-line / single-stream run."""
+    from mantis_amd.optim import FusedAdamW
+    from mantis_amd.trainer import MantisHipTrainer
+    k = K()
+    z = Hh.load_case("siglip_b2_equal_rightpad")
+
+    def batch():
+        return dict(input_ids=torch.from_numpy(z["input_ids"]), attention_mask=torch.from_numpy(z["attention_mask"]),
+                    labels=torch.from_numpy(z["labels"]), pixel_values=Hh.pixels_list(z))
+
+    def run(masked):
+        model, _, _ = Hh.build_product_model("siglip", DEV)
+        opt = FusedAdamW(model, lr=1e-3, weight_decay=0.0, max_grad_norm=1.0)
+        tr = MantisHipTrainer(model, gradient_accumulation_steps=1)
+        if masked:
+            total = k.num_cus()
+            opt.stream = k.cu_masked_stream(0, total - 64)
+            tr.prefetch_stream = k.cu_masked_stream(total - 64, 64)
+        b1, b2 = batch(), batch()
+        l1 = tr.training_step(model, b1, next_inputs=b2 if masked else None)
+        if masked:
+            assert model.engine._prefetched is not None and model.engine._prefetched[0] is b2["pixel_values"]
+        opt.step()
+        opt.zero_grad()
+        l2 = tr.training_step(model, b2)
+        torch.cuda.synchronize()
+        return l1.clone(), l2.clone(), model.grad_arena.clone(), model.arena.clone()
+    a, b = run(False), run(True)
+    for x, y, what in zip(a, b, ("loss 1", "loss 2", "gradients", "parameters")):
+        assert torch.equal(x, y), f"{what} differ with the CU-partitioned streams"
+    return 0.0
+
+
 def check_qwen2vl_prefetch():
     """The frozen tower computed ahead on the side stream (engine.prefetch_vision, driven by training_step(next_inputs=)) gives bit-identical
     loss and gradients to computing it in line; a prefetch for a different batch object is ignored."""
@@ -1355,6 +1390,7 @@ def all_checks():
     c["qwen2vl_packed_bf16"] = lambda: check_qwen2vl_packed("bf16")
     c["qwen2vl_packed_fp8"] = lambda: check_qwen2vl_packed("fp8")
     c["qwen2vl_prefetch_bit_identical"] = check_qwen2vl_prefetch
+    c["llava_prefetch_cu_masked_bit_identical"] = check_llava_prefetch_cu_masked
     c["rope_sections_cast_pad"] = check_rope_sections
     c["qwen2vl_full_width"] = check_qwen2vl_full_width
     c["qwen2vl_full_width_fp8_vs_bf16"] = check_qwen2vl_full_width_fp8
