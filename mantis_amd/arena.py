@@ -107,6 +107,16 @@ class ArenaModule(nn.Module):
                 p.grad = self._grad_views[n]
         return all_none
 
+    def _loss_anchor(self):
+        # a tiny differentiable input so autograd calls FusedStep.backward (parameters themselves bypass autograd)
+        if not hasattr(self, "_anchor") or self._anchor.device != self.device:
+            self._anchor = torch.zeros((), device=self.device, dtype=torch.float32, requires_grad=True)
+        return self._anchor
+
+    def _autograd_step(self, run):
+        """loss tensor whose .backward() publishes the gradients of `run()` (see FusedStep); logits, if any, in self._last_logits."""
+        return FusedStep.apply(self, self._loss_anchor(), run)
+
     def _gflat(self, first, last_incl, rows, cols):
         if first not in self._grad_offs:
             return None
@@ -149,3 +159,44 @@ class ArenaModule(nn.Module):
         if strict and missing:
             raise KeyError(f"missing keys: {missing[:5]}...")
         return missing
+
+
+class FusedStep(torch.autograd.Function):
+    """Bridge for callers that drive an ArenaModule through autograd (stock `Trainer.training_step`: `model(**batch).loss.backward()`).
+    forward runs the engine's fused forward+backward into a scratch gradient arena (and clears the live arena when it follows a
+    `zero_grad(set_to_none=True)`); backward adds `grad_output * scratch` to `.grad`.  (MantisHipTrainer bypasses this and accumulates in
+    place with the right scale.)  `run()` = the engine step with compute_grads=True, overwrite_grads=True; it returns the engine's dict."""
+
+    @staticmethod
+    def forward(ctx, model, anchor, run):
+        # True = every trainable .grad was None (the state after Trainer's model.zero_grad()): the arena views that were just
+        # re-attached still hold the PREVIOUS step's gradients and this backward must overwrite them, not add to them.
+        overwrite = model._ensure_grad_arena()
+        live = model.grad_arena
+        if overwrite:
+            live.zero_()
+        scratch = torch.zeros_like(live)
+        # run the step with gradients redirected into `scratch`
+        model.grad_arena = scratch
+        model._grad_views_live = model._grad_views
+        model._grad_views = {n: scratch[o: o + model._param(n).numel()].view(model._param(n).shape)
+                             for n, o in model._grad_offs.items()}
+        model._build_grad_views()
+        try:
+            out = run()
+        finally:
+            model.grad_arena = live
+            model._grad_views = model._grad_views_live
+            model._build_grad_views()
+        model._last_logits = out["logits"]
+        ctx.model, ctx.scratch = model, scratch
+        return out["loss"].reshape(()).clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        model, scratch = ctx.model, ctx.scratch
+        model._ensure_grad_arena()
+        # grad_out stays on the device (0-d fp32; torch multiplies the bf16 arena by it in fp32): no host sync
+        model.grad_arena.add_(scratch.mul_(grad_out.to(torch.float32)))
+        ctx.scratch = None
+        return None, None, None

@@ -230,15 +230,20 @@ class Idefics2ForConditionalGeneration(ArenaModule):
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids)
         want_grads = self.training and labels is not None and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        if want_grads:
-            raise NotImplementedError("drive training through MantisHipTrainer.training_step (the fused forward+backward); "
-                                      "the autograd bridge is implemented for the LLaVA module only")
         if return_logits is None:
-            return_logits = True
-        out = self.engine.step(input_ids, attention_mask, labels, pixel_values, pixel_attention_mask, compute_grads=False,
-                               need_logits=return_logits, record=_record)
-        loss = None if labels is None else out["loss"].reshape(())
-        logits = None if out["logits"] is None else out["logits"].float()          # :1882 logits.float()
+            return_logits = not want_grads        # training: the [B,L,V] logits are never materialised unless asked for
+        if want_grads:
+            # stock `loss.backward()` callers: the fused forward+backward runs now, .backward() publishes the gradients (arena.FusedStep)
+            loss = self._autograd_step(lambda: self.engine.step(
+                input_ids, attention_mask, labels, pixel_values, pixel_attention_mask, grad_scale=1.0, loss_scale=1.0, compute_grads=True,
+                overwrite_grads=True, need_logits=return_logits, record=_record))
+            lg = self._last_logits
+        else:
+            out = self.engine.step(input_ids, attention_mask, labels, pixel_values, pixel_attention_mask, compute_grads=False,
+                                   need_logits=return_logits, record=_record)
+            loss = None if labels is None else out["loss"].reshape(())
+            lg = out["logits"]
+        logits = None if lg is None else lg.float()          # :1882 logits.float()
         if not return_dict:
             return ((loss,) if loss is not None else ()) + ((logits,) if logits is not None else ())
         return Idefics2CausalLMOutputWithPast(loss=loss, logits=logits)

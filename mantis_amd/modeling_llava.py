@@ -251,8 +251,9 @@ class LlavaForConditionalGeneration(ArenaModule):
         if return_logits is None:
             return_logits = not want_grads        # training: the [B,L,V] logits are never materialised unless asked for
         if want_grads:
-            loss = _FusedStep.apply(self, input_ids, attention_mask, labels, pixel_values, return_logits, _record,
-                                    self._loss_anchor(), segment_ids)
+            loss = self._autograd_step(lambda: self.engine.step(
+                input_ids, attention_mask, labels, pixel_values, grad_scale=1.0, loss_scale=1.0, compute_grads=True, overwrite_grads=True,
+                need_logits=return_logits, record=_record, segment_ids=segment_ids))       # arena.FusedStep
             logits = self._last_logits
         else:
             out = self.engine.step(input_ids, attention_mask, labels, pixel_values, compute_grads=False,
@@ -262,52 +263,3 @@ class LlavaForConditionalGeneration(ArenaModule):
         if not return_dict:
             return ((loss,) if loss is not None else ()) + ((logits,) if logits is not None else ())
         return LlavaCausalLMOutputWithPast(loss=loss, logits=logits)
-
-    def _loss_anchor(self):
-        # a tiny differentiable input so autograd calls _FusedStep.backward (parameters themselves bypass autograd)
-        if not hasattr(self, "_anchor") or self._anchor.device != self.device:
-            self._anchor = torch.zeros((), device=self.device, dtype=torch.float32, requires_grad=True)
-        return self._anchor
-
-
-class _FusedStep(torch.autograd.Function):
-    """Bridge for callers that drive the model through autograd (stock `Trainer.training_step`: `loss.backward()`).
-    forward runs the fused forward+backward into a scratch gradient arena (and clears the live arena when it follows a
-    `zero_grad(set_to_none=True)`); backward adds `grad_output * scratch` to `.grad`.  (MantisHipTrainer bypasses this
-    and accumulates in place with the right scale.)"""
-
-    @staticmethod
-    def forward(ctx, model, input_ids, attention_mask, labels, pixel_values, need_logits, record, anchor, segment_ids=None):
-        # True = every trainable .grad was None (the state after Trainer's model.zero_grad()): the arena views that were just
-        # re-attached still hold the PREVIOUS step's gradients and this backward must overwrite them, not add to them.
-        overwrite = model._ensure_grad_arena()
-        live = model.grad_arena
-        if overwrite:
-            live.zero_()
-        scratch = torch.zeros_like(live)
-        # run the step with gradients redirected into `scratch`
-        model.grad_arena = scratch
-        model._grad_views_live = model._grad_views
-        model._grad_views = {n: scratch[o: o + model._param(n).numel()].view(model._param(n).shape)
-                             for n, o in model._grad_offs.items()}
-        model._build_grad_views()
-        try:
-            out = model.engine.step(input_ids, attention_mask, labels, pixel_values, grad_scale=1.0, loss_scale=1.0,
-                                    compute_grads=True, overwrite_grads=True, need_logits=need_logits, record=record,
-                                    segment_ids=segment_ids)
-        finally:
-            model.grad_arena = live
-            model._grad_views = model._grad_views_live
-            model._build_grad_views()
-        model._last_logits = out["logits"]
-        ctx.model, ctx.scratch = model, scratch
-        return out["loss"].reshape(()).clone()
-
-    @staticmethod
-    def backward(ctx, grad_out):
-        model, scratch = ctx.model, ctx.scratch
-        model._ensure_grad_arena()
-        # grad_out stays on the device (0-d fp32; torch multiplies the bf16 arena by it in fp32): no host sync
-        model.grad_arena.add_(scratch.mul_(grad_out.to(torch.float32)))
-        ctx.scratch = None
-        return (None,) * 9

@@ -904,6 +904,26 @@ def check_qwen2vl_packed(precision):
     return 1.0 - worst
 
 
+def check_autograd_bridge_idefics2_qwen2vl():
+    """`model(**batch).loss.backward()` on the Idefics2 and Qwen2-VL modules (arena.FusedStep) on the HIP path: loss and gradients
+    bit-identical to MantisHipTrainer.training_step; the fp8 variant of the Qwen2-VL decoder goes through the same bridge."""
+    from mantis_amd.trainer import MantisHipTrainer
+    for build, batch, case, prec in [(Hh.build_idefics2_product, Hh.idefics2_batch, "idefics2_b2_padimg_rightpad", None),
+                                     (Hh.build_qwen2vl_product, Hh.qwen2vl_batch, "qwen2vl_b2_rightpad", "bf16"),
+                                     (Hh.build_qwen2vl_product, Hh.qwen2vl_batch, "qwen2vl_b2_rightpad", "fp8")]:
+        z = Hh.load_case(case)
+        ref, model = build(DEV), build(DEV)
+        if prec is not None:
+            ref.set_precision(prec), model.set_precision(prec)
+        l_ref = MantisHipTrainer(ref, gradient_accumulation_steps=1).training_step(ref, batch(z))
+        model.train()
+        out = model(**batch(z))
+        out.loss.backward()
+        torch.cuda.synchronize()
+        assert torch.equal(out.loss.detach(), l_ref) and torch.equal(model.grad_arena, ref.grad_arena), (case, prec)
+    return 0.0
+
+
 def check_llava_prefetch_cu_masked():
     """The LLaVA engine's tower computed ahead on a CU-masked stream (64 compute units), the fused AdamW on the complementary masked
     stream: loss, gradients and updated parameters are bit-identical to the plain in-line / single-stream run."""
@@ -1391,6 +1411,7 @@ def all_checks():
     c["qwen2vl_packed_fp8"] = lambda: check_qwen2vl_packed("fp8")
     c["qwen2vl_prefetch_bit_identical"] = check_qwen2vl_prefetch
     c["llava_prefetch_cu_masked_bit_identical"] = check_llava_prefetch_cu_masked
+    c["autograd_bridge_idefics2_qwen2vl"] = check_autograd_bridge_idefics2_qwen2vl
     c["rope_sections_cast_pad"] = check_rope_sections
     c["qwen2vl_full_width"] = check_qwen2vl_full_width
     c["qwen2vl_full_width_fp8_vs_bf16"] = check_qwen2vl_full_width_fp8

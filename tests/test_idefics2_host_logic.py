@@ -85,3 +85,22 @@ def test_packed_row_equals_the_separate_samples(cpu_backend):
         if p.requires_grad:
             g, og = p.grad.float().numpy(), oracle.w[name].grad.numpy()
             assert Hh.cosine(g, og) > 0.995 and Hh.rel_l2(g, og) < 6e-2, (name, Hh.cosine(g, og), Hh.rel_l2(g, og))
+
+
+def test_loss_backward_through_the_autograd_bridge(cpu_backend):
+    """Stock `model(**batch).loss.backward()` callers: same loss and bit-identical gradients as MantisHipTrainer.training_step."""
+    import torch
+    from mantis_amd.trainer import MantisHipTrainer
+    z = Hh.load_case("idefics2_b2_padimg_rightpad")
+    ref = Hh.build_idefics2_product("cpu")
+    l_ref = MantisHipTrainer(ref, gradient_accumulation_steps=1).training_step(ref, Hh.idefics2_batch(z))
+    model = Hh.build_idefics2_product("cpu")
+    model.train()
+    out = model(**Hh.idefics2_batch(z))
+    assert out.logits is None and out.loss.requires_grad
+    out.loss.backward()
+    assert torch.equal(out.loss.detach(), l_ref) and torch.equal(model.grad_arena, ref.grad_arena)
+    for p in model.parameters():
+        p.grad = None
+    model(**Hh.idefics2_batch(z)).loss.backward()
+    assert torch.equal(model.grad_arena, ref.grad_arena)

@@ -202,3 +202,25 @@ def test_packed_row_equals_the_separate_samples(cpu_backend, precision):
             g, og = p.grad.float().numpy(), oracle.w[name].grad.numpy()
             c = Hh.cosine(g, og)
             assert c > ((0.85 if p.dim() == 1 else 0.95) if fp8 else 0.995), (name, c)
+
+
+def test_loss_backward_through_the_autograd_bridge(cpu_backend):
+    """Stock `model(**batch).loss.backward()` callers (HF Trainer.training_step without the subclass): same loss and bit-identical
+    gradients as MantisHipTrainer.training_step; a second backward after zero_grad overwrites, without one accumulates."""
+    from mantis_amd.trainer import MantisHipTrainer
+    z = Hh.load_case("qwen2vl_b2_rightpad")
+    ref = Hh.build_qwen2vl_product("cpu")
+    l_ref = MantisHipTrainer(ref, gradient_accumulation_steps=1).training_step(ref, Hh.qwen2vl_batch(z))
+    model = Hh.build_qwen2vl_product("cpu")
+    model.train()
+    out = model(**Hh.qwen2vl_batch(z))
+    assert out.logits is None and out.loss.requires_grad
+    out.loss.backward()
+    assert torch.equal(out.loss.detach(), l_ref) and torch.equal(model.grad_arena, ref.grad_arena)
+    out2 = model(**Hh.qwen2vl_batch(z))
+    (out2.loss / 2).backward()                                      # no zero_grad in between: accumulates, with the caller's scale
+    assert Hh.rel_l2(model.grad_arena.float().numpy(), 1.5 * ref.grad_arena.float().numpy()) < 1e-2
+    for p in model.parameters():
+        p.grad = None
+    model(**Hh.qwen2vl_batch(z)).loss.backward()
+    assert torch.equal(model.grad_arena, ref.grad_arena)
