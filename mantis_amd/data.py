@@ -40,7 +40,9 @@ def plain_label_mask(input_ids, image_token_id, ignore_index=IGNORE_INDEX):
 
 class Collator:
     """samples: dicts with `input_ids` [T_i] (+ optional `labels` [T_i], `pixel_values` [n_i,3,H,W]).  Returns the batch dict
-    `Trainer.training_step` consumes: input_ids / attention_mask / labels int64 [B, T_max] and pixel_values as a list."""
+    `Trainer.training_step` consumes: input_ids / attention_mask / labels int64 [B, T_max] and pixel_values as a list.
+    Qwen2-VL-style samples (`image_grid_thw` present: `pixel_values` = flattened patches [n_patches_i, C*tp*p*p]) and any other tensor
+    key follow the reference Collator's generic rule (data.py:1521-1522): concatenated along dim 0."""
 
     def __init__(self, pad_token_id, image_token_id=None, max_length=None, pin_memory=False):
         self.pad_token_id, self.image_token_id, self.max_length, self.pin = pad_token_id, image_token_id, max_length, pin_memory
@@ -60,6 +62,21 @@ class Collator:
             if samples[b].get("labels") is not None:
                 lab = np.asarray(samples[b]["labels"], dtype=np.int64).reshape(-1)[: len(x)]
                 labels[b, : len(lab)] = lab
+        known = ("input_ids", "attention_mask", "labels", "pixel_values")
+        extra = {}
+        for k in samples[0]:
+            if k in known or samples[0][k] is None:
+                continue
+            extra[k] = torch.cat([torch.as_tensor(s[k]) for s in samples if s.get(k) is not None], dim=0)
+        if "image_grid_thw" in extra:                # Qwen2-VL: patches of all samples in one [sum n_patches, C*tp*p*p] tensor
+            pvs = [torch.as_tensor(s["pixel_values"], dtype=torch.float32) for s in samples if s.get("pixel_values") is not None]
+            pv = torch.cat(pvs, dim=0) if pvs else None
+            if pv is not None and self.pin and torch.cuda.is_available():
+                pv = pv.pin_memory()
+            batch = dict(input_ids=torch.from_numpy(out_ids), attention_mask=torch.from_numpy(mask), labels=torch.from_numpy(labels),
+                         pixel_values=pv)
+            batch.update(extra)
+            return batch
         pix = []
         for b, s in enumerate(samples):
             pv = s.get("pixel_values")
@@ -73,6 +90,7 @@ class Collator:
             pix.append(pv.pin_memory() if self.pin and torch.cuda.is_available() else pv)
         batch = dict(input_ids=torch.from_numpy(out_ids), attention_mask=torch.from_numpy(mask), labels=torch.from_numpy(labels))
         batch["pixel_values"] = pix if pix else None
+        batch.update(extra)
         return batch
 
 

@@ -4,6 +4,7 @@ RUNNING the reference's own code (/root/reference/mantis/train/data.py) on synth
 
   label_rule.npz      ChatDataset.getitem label masking, data.py:415-466 -- the real method, LLAMA_3 and PLAIN branches
   collate_ref.npz     Collator._right_pad_inputs_with_attention_mask, data.py:1392-1527 -- right-pad ids / mask / labels
+  collate_qwen_ref.npz  the same method on Qwen2-VL-style items (flattened patches + image_grid_thw: concatenated along dim 0)
   pack_batch_ref.npz  PackingDataset.pack_batch, data.py:1609-1671 -- packed ids, block-diagonal 4-D mask, position ids, labels
 
 `mantis.train.data` imports `av` and `decord` (video decoding, absent here and irrelevant to these code paths): empty
@@ -130,6 +131,34 @@ def collate(D):
     print("collate_ref.npz:", {k: tuple(v.shape) for k, v in res.items()})
 
 
+def collate_qwen(D):
+    """The same generic Collator on Qwen2-VL-style items (what Qwen2VLProcessor returns per sample: flattened patches [n_patches, C*tp*p*p]
+    and image_grid_thw [n_images, 3]): every key other than ids / masks / labels / position ids is concatenated along dim 0."""
+    rng = np.random.default_rng(17)
+    col = D.Collator(processor=object())
+    col.tokenizer = _Tok()
+    items = []
+    for T, grids in ((17, [(1, 2, 4), (1, 4, 2)]), (9, [(1, 2, 2)]), (21, [(1, 4, 4), (1, 2, 2), (1, 2, 6)])):
+        ids = rng.integers(1, 280, size=T, dtype=np.int64)
+        lab = ids.copy()
+        lab[: T // 3] = -100
+        npatch = sum(t * h * w for t, h, w in grids)
+        items.append(dict(input_ids=torch.from_numpy(ids)[None], attention_mask=torch.ones(1, T, dtype=torch.int64),
+                          labels=torch.from_numpy(lab)[None],
+                          pixel_values=torch.from_numpy(rng.standard_normal((npatch, 12)).astype(np.float32)),
+                          image_grid_thw=torch.tensor(grids, dtype=torch.int64)))
+    res = col(items)
+    keys = ("input_ids", "attention_mask", "labels", "pixel_values", "image_grid_thw")
+    out = {"n": np.array(len(items)), "pad_token_id": np.array(PAD)}
+    for i, it in enumerate(items):
+        for k in keys:
+            out[f"s{i}.{k}"] = it[k].numpy()
+    for k in keys:
+        out[f"out.{k}"] = res[k].numpy()
+    np.savez_compressed(os.path.join(HERE, "collate_qwen_ref.npz"), **out)
+    print("collate_qwen_ref.npz:", {k: tuple(v.shape) for k, v in res.items()})
+
+
 def pack_batch(D):
     rng = np.random.default_rng(13)
     pk = object.__new__(D.PackingDataset)
@@ -156,6 +185,7 @@ def main():
     D, Style = _import_reference_data()
     label_rule(D, Style)
     collate(D)
+    collate_qwen(D)
     pack_batch(D)
 
 

@@ -47,6 +47,20 @@ def test_collator_matches_the_reference_collator_fixture():
     assert np.array_equal(torch.cat(b["pixel_values"], 0).numpy(), z["out.pixel_values"])
 
 
+def test_collator_matches_the_reference_collator_on_qwen2vl_items():
+    """collate_qwen_ref.npz = the reference's Collator on Qwen2-VL-style items (flattened patches + image_grid_thw): ids / mask / labels
+    right-padded, every other key concatenated along dim 0 -- the batch dict the Qwen2-VL engine consumes."""
+    from mantis_amd.data import Collator
+    z = Hh.load_case("collate_qwen_ref")
+    n = int(z["n"])
+    samples = [dict(input_ids=z[f"s{i}.input_ids"][0], labels=z[f"s{i}.labels"][0], pixel_values=z[f"s{i}.pixel_values"],
+                    image_grid_thw=z[f"s{i}.image_grid_thw"]) for i in range(n)]
+    b = Collator(pad_token_id=int(z["pad_token_id"]))(samples)
+    for k in ("input_ids", "attention_mask", "labels", "pixel_values", "image_grid_thw"):
+        assert np.array_equal(b[k].numpy(), z[f"out.{k}"]), k
+        assert b[k].dtype == torch.from_numpy(z[f"out.{k}"]).dtype, k
+
+
 @pytest.mark.parametrize("case", ["eq", "ragged"])
 def test_pack_samples_matches_the_reference_pack_batch_fixture(case):
     """pack_batch_ref.npz = output of the reference's PackingDataset.pack_batch (data.py:1609-1671)."""

@@ -15,7 +15,7 @@ from oracle.llava_ref import LlavaRef
 
 G = os.path.join(os.path.dirname(__file__), "golden")
 CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(G, "*.npz"))
-               if not os.path.basename(p).startswith(("weights_", "label_rule", "siglip_training_step", "cfg1_", "collate_ref", "pack_batch_ref", "idefics2_", "qwen2vl_")))
+               if not os.path.basename(p).startswith(("weights_", "label_rule", "siglip_training_step", "cfg1_", "collate_ref", "collate_qwen_ref", "pack_batch_ref", "idefics2_", "qwen2vl_")))
 
 
 def _pixels(z):
