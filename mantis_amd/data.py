@@ -68,7 +68,10 @@ class Collator:
             if k in known or samples[0][k] is None:
                 continue
             extra[k] = torch.cat([torch.as_tensor(s[k]) for s in samples if s.get(k) is not None], dim=0)
-        if "image_grid_thw" in extra:                # Qwen2-VL: patches of all samples in one [sum n_patches, C*tp*p*p] tensor
+        first_pv = next((s["pixel_values"] for s in samples if s.get("pixel_values") is not None), None)
+        idefics2_style = first_pv is not None and torch.as_tensor(first_pv).dim() == 5      # [1, n_images, 3, H, W] per sample
+        if "image_grid_thw" in extra or idefics2_style:
+            # Qwen2-VL: patches of all samples in one [sum n_patches, C*tp*p*p] tensor; Idefics2: [B, n_images, 3, H, W]
             pvs = [torch.as_tensor(s["pixel_values"], dtype=torch.float32) for s in samples if s.get("pixel_values") is not None]
             pv = torch.cat(pvs, dim=0) if pvs else None
             if pv is not None and self.pin and torch.cuda.is_available():

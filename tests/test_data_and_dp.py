@@ -61,6 +61,18 @@ def test_collator_matches_the_reference_collator_on_qwen2vl_items():
         assert b[k].dtype == torch.from_numpy(z[f"out.{k}"]).dtype, k
 
 
+def test_collator_idefics2_items_are_concatenated_along_the_batch_axis():
+    """Idefics2Processor items: pixel_values [1, n_images, 3, H, W] and pixel_attention_mask [1, n_images, H, W] -> the reference
+    Collator's generic rule (data.py:1521-1522) concatenates them along dim 0."""
+    from mantis_amd.data import Collator
+    g = torch.Generator().manual_seed(0)
+    samples = [dict(input_ids=np.arange(5 + i), labels=np.arange(5 + i), pixel_values=torch.randn(1, 2, 3, 4, 4, generator=g),
+                    pixel_attention_mask=torch.ones(1, 2, 4, 4, dtype=torch.bool)) for i in range(3)]
+    b = Collator(pad_token_id=0)(samples)
+    assert tuple(b["pixel_values"].shape) == (3, 2, 3, 4, 4) and tuple(b["pixel_attention_mask"].shape) == (3, 2, 4, 4)
+    assert torch.equal(b["pixel_values"][1], samples[1]["pixel_values"][0]) and tuple(b["input_ids"].shape) == (3, 7)
+
+
 @pytest.mark.parametrize("case", ["eq", "ragged"])
 def test_pack_samples_matches_the_reference_pack_batch_fixture(case):
     """pack_batch_ref.npz = output of the reference's PackingDataset.pack_batch (data.py:1609-1671)."""
