@@ -138,6 +138,9 @@ def pack_samples(samples, materialize_mask=True):
         out["pixel_values"] = sum([list(p or []) for p in pv], []) or None
     else:
         out["pixel_values"] = torch.cat([torch.as_tensor(p) for p in pv if p is not None], dim=0)
+    for k in samples[0]:                  # e.g. Qwen2-VL's image_grid_thw: one row per image, images in order of appearance
+        if k not in out and k != "pixel_values" and samples[0][k] is not None:
+            out[k] = torch.cat([torch.as_tensor(s[k]) for s in samples if s.get(k) is not None], dim=0)
     return out
 
 

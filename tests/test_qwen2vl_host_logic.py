@@ -224,3 +224,27 @@ def test_loss_backward_through_the_autograd_bridge(cpu_backend):
         p.grad = None
     model(**Hh.qwen2vl_batch(z)).loss.backward()
     assert torch.equal(model.grad_arena, ref.grad_arena)
+
+
+def test_pack_samples_feeds_the_packed_qwen2vl_step(cpu_backend):
+    """data.pack_samples on two Qwen2-VL samples (patches and image_grid_thw concatenated in order of appearance) + the trainer's
+    packed-batch route (4-D block-diagonal mask or segment ids) = the packed step of test_packed_row_equals_the_separate_samples."""
+    from mantis_amd.data import pack_samples
+    from mantis_amd.trainer import MantisHipTrainer
+    z = Hh.load_case("qwen2vl_b2_rightpad")
+    ids, am, lab = z["input_ids"], z["attention_mask"], z["labels"]
+    grids, pv = z["image_grid_thw"], z["pixel_values"]
+    n0 = int((grids[:2, 0] * grids[:2, 1] * grids[:2, 2]).sum())
+    keep = [am[b].astype(bool) for b in range(2)]
+    samples = [dict(input_ids=ids[0][keep[0]], labels=lab[0][keep[0]], pixel_values=pv[:n0], image_grid_thw=grids[:2]),
+               dict(input_ids=ids[1][keep[1]], labels=lab[1][keep[1]], pixel_values=pv[n0:], image_grid_thw=grids[2:])]
+    packed = pack_samples(samples)
+    assert torch.equal(packed["image_grid_thw"], torch.from_numpy(grids)) and torch.equal(packed["pixel_values"], torch.from_numpy(pv))
+    pid, plab, seg, pv_t, grid_t = _packed_from_b2(z)
+    assert torch.equal(packed["input_ids"], pid) and torch.equal(packed["segment_ids"], seg)
+    ref = Hh.build_qwen2vl_product("cpu")
+    ref._ensure_grad_arena()
+    out = ref.engine.step(pid, torch.ones_like(pid), plab, pv_t, grid_t, compute_grads=True, overwrite_grads=True, segment_ids=seg)
+    model = Hh.build_qwen2vl_product("cpu")
+    loss = MantisHipTrainer(model, gradient_accumulation_steps=1).training_step(model, packed)
+    assert torch.equal(loss, out["loss"].reshape(())) and torch.equal(model.grad_arena, ref.grad_arena)
