@@ -107,6 +107,23 @@ class ArenaModule(nn.Module):
                 p.grad = self._grad_views[n]
         return all_none
 
+    def set_precision(self, precision):
+        """"bf16": every linear on the bf16 MFMA GEMM (the reference's arithmetic; the default).  "fp8": the decoder layers' linears
+        (forward, dX, dW) on the fp8 MFMA GEMM with per-tensor e4m3 / e5m2 scaling (decoder_fp8.py; BASELINE configs[4] names it for
+        the Qwen2-VL path); towers, projector / connector / merger, lm_head, norms, attention and the loss stay bf16 / fp32."""
+        from .decoder_fp8 import Fp8Weights
+        if precision not in ("bf16", "fp8"):
+            raise ValueError(f"precision {precision!r}")
+        tc = self.config.text_config
+        if precision == "fp8":
+            dims = (tc.hidden_size, tc.intermediate_size, tc.num_attention_heads * tc.head_dim,
+                    (tc.num_attention_heads + 2 * tc.num_key_value_heads) * tc.head_dim)
+            if any(v % 16 for v in dims):
+                raise NotImplementedError(f"fp8 linears need every projection width to be a multiple of 16, got {dims}")
+        self.precision = precision
+        self.engine.w8 = Fp8Weights(self.lm) if precision == "fp8" else None
+        return self
+
     def _loss_anchor(self):
         # a tiny differentiable input so autograd calls FusedStep.backward (parameters themselves bypass autograd)
         if not hasattr(self, "_anchor") or self._anchor.device != self.device:

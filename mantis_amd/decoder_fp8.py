@@ -143,3 +143,27 @@ def decoder_backward(K, lm, w8, grads, grads_layers, tc, ctx, hctx, plan, B, L, 
         if on_bucket_ready is not None:
             on_bucket_ready(("layer", i, "attn"))
     return dx
+
+
+# ---------------------------------------------------------------------------------------------------------------- engine-side dispatch
+def forward(K, eng, lm, tc, x, B, L, position_ids, kmask, kstart, compute_grads, record, rope=None):
+    """Decoder forward on the engine's precision: `eng.w8` (Fp8Weights, set by ArenaModule.set_precision("fp8")) selects the fp8
+    layer loop, None the bf16 one of decoder.py.  The e4m3 weight copies are re-made unless the trainer flagged this micro-batch as
+    following another one of the same accumulation window (`eng.weights_unchanged`)."""
+    w8 = getattr(eng, "w8", None)
+    if w8 is None:
+        return D.decoder_forward(K, lm, tc, x, B, L, position_ids, kmask, kstart, compute_grads, record, rope=rope)
+    if not getattr(eng, "weights_unchanged", False):
+        w8.refresh()
+    eng.weights_unchanged = False
+    if rope is None:
+        rope = K.rope_table(position_ids.reshape(-1), D.inv_freq(tc.head_dim, tc.rope_theta).to(x.device))
+    return decoder_forward(K, lm, w8, tc, x, B, L, kmask, compute_grads, record, rope=rope, kstart=kstart)
+
+
+def backward(K, eng, lm, grads, grads_layers, tc, ctx, hctx, plan, B, L, kmask, kstart, qend, accumulate, on_bucket_ready):
+    w8 = getattr(eng, "w8", None)
+    if w8 is None:
+        return D.decoder_backward(K, lm, grads, grads_layers, tc, ctx, hctx, plan, B, L, kmask, kstart, qend, accumulate, on_bucket_ready)
+    return decoder_backward(K, lm, w8, grads, grads_layers, tc, ctx, hctx, plan, B, L, kmask, accumulate, on_bucket_ready, kstart=kstart,
+                            qend=qend)

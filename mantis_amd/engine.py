@@ -17,6 +17,7 @@ import numpy as np
 import torch
 
 from . import decoder as D
+from . import decoder_fp8 as D8
 from . import hip_ops as K   # the ONLY compute backend; tests may monkeypatch `engine.K` with the oracle to test host logic
 
 
@@ -34,6 +35,8 @@ class LlavaEngine:
         # device-side status words (pack plan status, out-of-range CE targets) are read back -- one host sync -- on the first
         # step of an engine and on every step under MANTIS_DEBUG_SYNC=1; the hot loop otherwise never syncs.
         self._verified = False
+        self.w8 = None                       # decoder_fp8.Fp8Weights after model.set_precision("fp8")
+        self.weights_unchanged = False       # set by MantisHipTrainer on the 2nd.. micro-batch of an accumulation window
 
     def _verify_device_status(self, plan, count):
         st = plan.status.cpu().tolist()
@@ -203,7 +206,7 @@ class LlavaEngine:
 
         # ---- rows H, I: Llama decoder, final norm, lm_head, masked shifted CE (decoder.py, shared with the Idefics2 path)
         kmask = plan.kmask
-        x, dctx = D.decoder_forward(K, m.lm, tc, x, B, L, plan.position_ids, kmask, kstart, compute_grads, record)
+        x, dctx = D8.forward(K, self, m.lm, tc, x, B, L, plan.position_ids, kmask, kstart, compute_grads, record)
         loss, count, logits_full, hctx = D.head_and_loss(K, m.lm, tc, x, plan, B, L, labels is not None, grad_scale, loss_scale,
                                                          compute_grads, need_logits, record)
         if count is not None and (not self._verified or _DEBUG_SYNC):
@@ -219,7 +222,7 @@ class LlavaEngine:
         def gw(key):
             return g.get(key)
 
-        dx = D.decoder_backward(K, m.lm, g, m.grads_layers, tc, dctx, hctx, plan, B, L, kmask, kstart, qend, acc, on_bucket_ready)
+        dx = D8.backward(K, self, m.lm, g, m.grads_layers, tc, dctx, hctx, plan, B, L, kmask, kstart, qend, acc, on_bucket_ready)
 
         # ---- rows G, F, E backward: merged-row grads -> embedding rows + image-feature rows -> projector
         if gw("embed") is not None:

@@ -12,6 +12,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import decoder as D
+from . import decoder_fp8 as D8
 from . import hip_ops as K   # tests may monkeypatch `modeling_idefics2.K` with the oracle's operators to test the host logic
 from .arena import ArenaModule
 from .configuration_idefics2 import Idefics2Config
@@ -257,6 +258,8 @@ class Idefics2Engine:
         self.m = model
         self.cfg = model.config
         self._verified = False
+        self.w8 = None                       # decoder_fp8.Fp8Weights after model.set_precision("fp8")
+        self.weights_unchanged = False       # set by MantisHipTrainer on the 2nd.. micro-batch of an accumulation window
 
     def step_from_batch(self, inputs, **kw):
         if kw.get("segment_ids") is None and inputs.get("segment_ids") is not None:
@@ -452,7 +455,7 @@ class Idefics2Engine:
         if record is not None and img is not None:
             record["merged_embeds"] = x.view(B, T, -1)
         kmask = plan.kmask
-        x, dctx = D.decoder_forward(K, m.lm, tc, x, B, T, plan.position_ids, kmask, kstart, compute_grads, record)
+        x, dctx = D8.forward(K, self, m.lm, tc, x, B, T, plan.position_ids, kmask, kstart, compute_grads, record)
         loss, count, logits_full, hctx = D.head_and_loss(K, m.lm, tc, x, plan, B, T, labels is not None, grad_scale, loss_scale,
                                                          compute_grads, need_logits, record)
         if count is not None and not self._verified:
@@ -464,7 +467,7 @@ class Idefics2Engine:
             return out
         acc = not overwrite_grads
         g = m.grads
-        dx = D.decoder_backward(K, m.lm, g, m.grads_layers, tc, dctx, hctx, plan, B, T, kmask, kstart, qend, acc, on_bucket_ready)
+        dx = D8.backward(K, self, m.lm, g, m.grads_layers, tc, dctx, hctx, plan, B, T, kmask, kstart, qend, acc, on_bucket_ready)
         if g.get("embed") is not None:
             if overwrite_grads:
                 g["embed"].zero_()

@@ -161,21 +161,6 @@ class Qwen2VLForConditionalGeneration(ArenaModule):
                     b = min(flat.numel(), a + step)
                     flat[a:b] = torch.randn(b - a, generator=gen, device=self.device, dtype=torch.float32).mul_(std)
 
-    def set_precision(self, precision):
-        """"bf16": every linear on the bf16 MFMA GEMM (the reference's arithmetic).  "fp8": the decoder layers' linears (forward, dX,
-        dW) on the fp8 MFMA GEMM with per-tensor e4m3 / e5m2 scaling (BASELINE configs[4]); tower, merger, lm_head stay bf16."""
-        if precision not in ("bf16", "fp8"):
-            raise ValueError(f"precision {precision!r}")
-        tc = self.config.text_config
-        if precision == "fp8":
-            dims = (tc.hidden_size, tc.intermediate_size, tc.num_attention_heads * tc.head_dim,
-                    (tc.num_attention_heads + 2 * tc.num_key_value_heads) * tc.head_dim)
-            if any(v % 16 for v in dims):
-                raise NotImplementedError(f"fp8 linears need every projection width to be a multiple of 16, got {dims}")
-        self.precision = precision
-        self.engine.w8 = D8.Fp8Weights(self.lm) if precision == "fp8" else None
-        return self
-
     def get_input_embeddings(self):
         return self.model.language_model.embed_tokens
 
@@ -463,14 +448,7 @@ class Qwen2VLEngine:
         sec = torch.repeat_interleave(torch.arange(3, dtype=torch.int32), torch.tensor(tc.rope_parameters["mrope_section"])).to(dev)
         rope = K.rope_table_sections(pos3.reshape(3, B * T).to(dev), D.inv_freq(tc.head_dim, tc.rope_theta).to(dev), sec)
         kmask = plan.kmask
-        fp8 = self.w8 is not None
-        if fp8:
-            if not self.weights_unchanged:
-                self.w8.refresh()
-            self.weights_unchanged = False
-            x, dctx = D8.decoder_forward(K, m.lm, self.w8, tc, x, B, T, kmask, compute_grads, record, rope=rope, kstart=kstart)
-        else:
-            x, dctx = D.decoder_forward(K, m.lm, tc, x, B, T, None, kmask, kstart, compute_grads, record, rope=rope)
+        x, dctx = D8.forward(K, self, m.lm, tc, x, B, T, None, kmask, kstart, compute_grads, record, rope=rope)
         loss, count, logits_full, hctx = D.head_and_loss(K, m.lm, tc, x, plan, B, T, labels is not None, grad_scale, loss_scale,
                                                          compute_grads, need_logits, record)
         if count is not None and not self._verified:
@@ -482,11 +460,7 @@ class Qwen2VLEngine:
             return out
         acc = not overwrite_grads
         g = m.grads
-        if fp8:
-            dx = D8.decoder_backward(K, m.lm, self.w8, g, m.grads_layers, tc, dctx, hctx, plan, B, T, kmask, acc, on_bucket_ready,
-                                     kstart=kstart, qend=qend)
-        else:
-            dx = D.decoder_backward(K, m.lm, g, m.grads_layers, tc, dctx, hctx, plan, B, T, kmask, kstart, qend, acc, on_bucket_ready)
+        dx = D8.backward(K, self, m.lm, g, m.grads_layers, tc, dctx, hctx, plan, B, T, kmask, kstart, qend, acc, on_bucket_ready)
         if g.get("embed") is not None:
             if overwrite_grads:
                 g["embed"].zero_()

@@ -1161,6 +1161,35 @@ def check_qwen2vl_step_fp8(case):
     return 1.0 - worst
 
 
+def check_fp8_other_paths():
+    """set_precision("fp8") on the LLaVA and Idefics2 modules on the HIP path: within the fp8 variant's stated tolerance of the fp32
+    oracles of the reference (loss 1e-2, weight-matrix gradient cosine >= 0.95, 1-D parameters >= 0.85), and bitwise reproducible."""
+    z = Hh.load_case("siglip_b2_equal_rightpad")
+    model, _, _ = Hh.build_product_model("siglip", DEV)
+    model.set_precision("fp8")
+    oracle = Hh.build_oracle_bf16_weights("siglip")
+    assert model._ensure_grad_arena()
+    args = (torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"]), torch.from_numpy(z["labels"]), Hh.pixels_list(z))
+    out = model.engine.step(*args, compute_grads=True, overwrite_grads=True)
+    g1 = model.grad_arena.clone()
+    out2 = model.engine.step(*args, compute_grads=True, overwrite_grads=True)
+    assert torch.equal(out["loss"], out2["loss"]) and torch.equal(g1, model.grad_arena)
+    oracle.zero_grad()
+    oloss, _ = oracle.forward(z["input_ids"], Hh.pixels_list(z), z["attention_mask"], z["labels"])
+    oloss.backward()
+    w1 = Hh.check_fp8_grads_against_oracle(model, oracle, out["loss"].cpu(), oloss)
+    z = Hh.load_case("idefics2_b2_padimg_rightpad")
+    model = Hh.build_idefics2_product(DEV).set_precision("fp8")
+    oracle = Hh.build_idefics2_oracle_bf16()
+    assert model._ensure_grad_arena()
+    out = model.engine.step_from_batch(Hh.idefics2_batch(z), compute_grads=True, overwrite_grads=True)
+    oracle.zero_grad()
+    oloss, _ = oracle.forward(z["input_ids"], z["pixel_values"], z["pixel_attention_mask"], z["attention_mask"], z["labels"])
+    oloss.backward()
+    w2 = Hh.check_fp8_grads_against_oracle(model, oracle, out["loss"].cpu(), oloss)
+    return 1.0 - min(w1, w2)
+
+
 def check_qwen2vl_full_width_fp8():
     """Qwen2-VL-7B layers at full width and reduced depth with the decoder linears on the fp8 MFMA GEMM: bitwise reproducible, accumulates,
     and within the stated fp8 tolerance of the SAME step on the bf16 linears (loss 1e-2, weight-matrix gradient cosine >= 0.95, q / k
@@ -1415,6 +1444,7 @@ def all_checks():
     c["rope_sections_cast_pad"] = check_rope_sections
     c["qwen2vl_full_width"] = check_qwen2vl_full_width
     c["qwen2vl_full_width_fp8_vs_bf16"] = check_qwen2vl_full_width_fp8
+    c["fp8_llava_idefics2_paths"] = check_fp8_other_paths
     c["pack_segments_random"] = check_pack_segments_random
     c["packed_model_step"] = check_packed_model_step
     c["packed_fullsize_vs_batched"] = check_packed_fullsize_vs_batched

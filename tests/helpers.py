@@ -237,3 +237,22 @@ def check_qwen2vl_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-3
         one_d = p.dim() == 1 and grad_cos_1d is not None
         assert c >= (grad_cos_1d if one_d else grad_cos) and r <= (grad_rel_1d if one_d else grad_rel), (name, c, r)
     return report
+
+
+# ----------------------------------------------------------------------------------------------------------- fp8 variant, any path
+def check_fp8_grads_against_oracle(model, oracle, loss, oloss, loss_rtol=1e-2, cos_2d=0.95, cos_1d=0.85):
+    """The stated tolerance of the fp8-linear variant (per-tensor e4m3 activations / weights, e5m2 output gradients) against the fp32
+    oracle of the reference: loss 1e-2 relative, weight-matrix gradient cosine >= 0.95, bias / norm-weight gradient cosine >= 0.85."""
+    assert abs(float(loss) - float(oloss)) <= loss_rtol * abs(float(oloss)), (float(loss), float(oloss))
+    worst = 1.0
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        og = oracle.w[name].grad
+        g = p.grad.float().cpu().numpy()
+        if og is None or np.linalg.norm(og.numpy()) < 1e-12:
+            continue
+        c = cosine(g, og.numpy())
+        assert c >= (cos_2d if p.dim() > 1 else cos_1d), (name, c)
+        worst = min(worst, c)
+    return worst
