@@ -248,3 +248,36 @@ def test_pack_samples_feeds_the_packed_qwen2vl_step(cpu_backend):
     model = Hh.build_qwen2vl_product("cpu")
     loss = MantisHipTrainer(model, gradient_accumulation_steps=1).training_step(model, packed)
     assert torch.equal(loss, out["loss"].reshape(())) and torch.equal(model.grad_arena, ref.grad_arena)
+
+
+def test_rope_index_random_layouts_match_the_oracle():
+    """The product's host-side get_rope_index (modeling_qwen2_vl.mrope_position_ids) against the oracle's restatement (pinned to the HF
+    output on the goldens) on random batches: several images per row, left / right padding, text-only rows; and the tower's 2-D ids."""
+    from mantis_amd.modeling_qwen2_vl import mrope_position_ids, vision_hw_ids
+    from oracle.qwen2vl_ref import rope_index, vision_position_ids
+    rng = np.random.default_rng(5)
+    IMG = 7
+    for trial in range(60):
+        B = int(rng.integers(1, 4))
+        rows, grids = [], []
+        for b in range(B):
+            toks = []
+            for _ in range(int(rng.integers(0, 4))):
+                toks += rng.integers(10, 50, size=int(rng.integers(1, 6))).tolist()      # at least one text token between two images
+                h, w = 2 * int(rng.integers(1, 4)), 2 * int(rng.integers(1, 4))
+                grids.append((1, h, w))
+                toks += [IMG] * (h * w // 4)
+            toks += rng.integers(10, 50, size=int(rng.integers(1, 6))).tolist()
+            rows.append(toks)
+        T = max(len(r) for r in rows)
+        ids = np.zeros((B, T), np.int64)
+        am = np.zeros((B, T), np.int64)
+        for b, r in enumerate(rows):
+            off = (T - len(r)) if (trial % 2) else 0            # left padding on odd trials, right padding on even ones
+            ids[b, off: off + len(r)] = r
+            am[b, off: off + len(r)] = 1
+        want = rope_index(ids, am, np.array(grids, np.int64).reshape(-1, 3), IMG, 2)
+        got = mrope_position_ids(torch.from_numpy(ids), torch.from_numpy(am), grids, IMG, 2)
+        assert torch.equal(got, want), trial
+    g = [(1, 4, 6), (2, 2, 4)]
+    assert torch.equal(vision_hw_ids(g, 2).t(), vision_position_ids(np.array(g), 2))
