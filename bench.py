@@ -240,9 +240,10 @@ def main():
                          "(8 interleaved images x 448^2 and 2048 tokens per sample, 2 samples per GPU packed into one row); "
                          "qwen2_vl_7b = configs[4] (two 1280x960 dynamic-resolution images = 2 x 6256 patches -> 2 x 1564 tokens "
                          "inside a 4096-token sample)")
-    ap.add_argument("--precision", default=None, choices=["bf16", "fp8"],
-                    help="decoder linears: bf16 MFMA or fp8 (e4m3 / e5m2) MFMA with per-tensor scaling.  Default: fp8 for qwen2_vl_7b "
-                         "(BASELINE configs[4] names fp8 MFMA), bf16 otherwise")
+    ap.add_argument("--precision", default=None, choices=["bf16", "fp8", "fp8_rowwise"],
+                    help="decoder linears: bf16 MFMA or fp8 (e4m3 / e5m2) MFMA with per-tensor scaling (fp8_rowwise: the opt-in finer "
+                         "recipe, one scale per token / feature).  Default: fp8 for qwen2_vl_7b (BASELINE configs[4] names fp8 MFMA), "
+                         "bf16 otherwise")
     ap.add_argument("--batch-per-gpu", type=int, default=None, help="samples per GPU and step (default 2 on every configuration)")
     ap.add_argument("--stage", default="finetune", choices=["finetune", "pretrain"],
                     help="finetune: projector + LLM trainable (the headline metric); pretrain: only multi_modal_projector "
@@ -313,10 +314,10 @@ def main():
         model = LlavaForConditionalGeneration(cfg, device=f"cuda:{local_rank}", seed=0)      # same seed -> identical replicas
         flop_per_sample = FLOP_PER_SAMPLE
     precision = args.precision or ("fp8" if qwen else "bf16")
-    if precision == "fp8":
+    if precision != "bf16":
         if not hasattr(model, "set_precision"):
-            raise SystemExit(f"--precision fp8 is implemented on the Qwen2-VL path only (config {args.config})")
-        model.set_precision("fp8")
+            raise SystemExit(f"--precision {precision} needs a module with set_precision (config {args.config})")
+        model.set_precision(precision)
     if args.stage == "pretrain":
         for n, p in model.named_parameters():
             if "multi_modal_projector" not in n and "model.connector." not in n:
@@ -421,7 +422,7 @@ def main():
             gf = (pmc or {}).get("gemm_family") or {}
             kname, peak = "gemm_nt_ring_kernel + gemm_nt_kernel (bf16 MFMA GEMM family, csrc/gemm.hip)", PEAK_BF16_TFLOPS
             bf16_family = None
-            if precision == "fp8":
+            if precision != "bf16":
                 # dominant kernel of this configuration: the fp8 MFMA GEMM (decoder linears); the bf16 family (tower, merger, lm_head)
                 # is reported beside it
                 f8 = [x for x in timer if x[0] == "gemm_fp8_nt_kernel"]
@@ -478,7 +479,8 @@ def main():
                    ms_optimizer=round(_pct([e[1].elapsed_time(e[2]) for e in split], 0.5), 2) if opt is not None else None,
                    samples_per_s_training_step_only=round(world * B / (1e-3 * _pct(ts_ms, 0.5)), 4),
                    higher_is_better=True, scaling="weak", vs_baseline=None,
-                   dtype="bf16" if precision == "bf16" else "fp8 (e4m3 activations/weights, e5m2 gradients in the decoder linears; bf16 elsewhere)",
+                   dtype="bf16" if precision == "bf16" else "fp8 (e4m3 activations/weights, e5m2 gradients in the decoder linears" +
+                         (", per-row / per-column scales" if precision == "fp8_rowwise" else "") + "; bf16 elsewhere)",
                    data="synthetic" + ("" if args.recycle_batches else " (fresh batch every step)"),
                    loss=round(loss_vals[-1], 4), loss_first_timed=round(loss_vals[0], 4), loss_after_warmup=first_loss,
                    loss_min=round(min(loss_vals), 4), loss_max=round(max(loss_vals), 4),

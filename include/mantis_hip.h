@@ -125,6 +125,11 @@ int mantis_fp8_quantize(const void* x, int64_t rows, int cols, int64_t ld, int f
 int mantis_gemm_fp8_nt(const void* A8, int64_t lda, const void* B8, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
                        const float* dequant_a, const float* dequant_b, int fmt_a, const void* bias, const void* residual, int64_t ldr,
                        int flags, void* stream);
+/* Opt-in finer scaling (set_precision("fp8_rowwise")): q (nullable) with one scale per ROW of x, row_dequant float[rows]; qt (nullable)
+ * with one scale per COLUMN of x, col_dequant float[cols]; workspace rows + cols floats.  mantis_gemm_fp8_nt flag 128: dequant_a /
+ * dequant_b are such vectors (float[M] / float[N]) and the epilogue multiplies out[m, n] by dequant_a[m] * dequant_b[n]. */
+int mantis_fp8_quantize_2d(const void* x, int64_t rows, int cols, int64_t ld, int fmt, void* q, int64_t ldq, float* row_dequant, void* qt,
+                           int64_t ldt, float* col_dequant, float* workspace, void* stream);
 /* dgu[M, 2N] = swiglu_backward(dequant * A8[M,K] . B8[N,K]^T, gate_up[M, 2N]): dX of down_proj with the SwiGLU backward (autograd of
  * HF:models/qwen2_vl/modeling_qwen2_vl.py:453-466) in the epilogue; amax_out (nullable) float[1] <- max |dgu| for the next quantiser. */
 int mantis_gemm_fp8_dx_swiglu(const void* A8, int64_t lda, const void* B8, int64_t ldb, void* dgu, int64_t ld_dgu, int M, int N, int K,

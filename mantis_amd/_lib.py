@@ -41,6 +41,7 @@ SIGNATURES = {
     "mantis_gemm_pick_variant": [I, I, I],
     "mantis_fp8_quantize_ws_floats": [],
     "mantis_fp8_quantize": [P, L, I, L, I, P, L, P, L, P, P, P, I, P],
+    "mantis_fp8_quantize_2d": [P, L, I, L, I, P, L, P, P, L, P, P, P],
     "mantis_gemm_fp8_dx_swiglu": [P, L, P, L, P, L, I, I, I, P, P, I, P, L, P, P],
     "mantis_gemm_fp8_nt": [P, L, P, L, P, L, I, I, I, P, P, I, P, P, L, I, P],
     "mantis_attn_fwd": [P, P, P, P, P, P, P, I, I, I, I, I, L, L, L, L, F, I, P],

@@ -110,18 +110,21 @@ class ArenaModule(nn.Module):
     def set_precision(self, precision):
         """"bf16": every linear on the bf16 MFMA GEMM (the reference's arithmetic; the default).  "fp8": the decoder layers' linears
         (forward, dX, dW) on the fp8 MFMA GEMM with per-tensor e4m3 / e5m2 scaling (decoder_fp8.py; BASELINE configs[4] names it for
-        the Qwen2-VL path); towers, projector / connector / merger, lm_head, norms, attention and the loss stay bf16 / fp32."""
+        the Qwen2-VL path); towers, projector / connector / merger, lm_head, norms, attention and the loss stay bf16 / fp32.
+        "fp8_rowwise": the same linears with finer scales -- one per token / per feature instead of one per tensor (every "NT" GEMM
+        operand carries one scale per row, the epilogue multiplies by their outer product); closer to bf16 where a few rows dominate
+        a tensor's range, at the price of a two-pass quantiser with no producer-side amax and an unfused SwiGLU backward."""
         from .decoder_fp8 import Fp8Weights
-        if precision not in ("bf16", "fp8"):
+        if precision not in ("bf16", "fp8", "fp8_rowwise"):
             raise ValueError(f"precision {precision!r}")
         tc = self.config.text_config
-        if precision == "fp8":
+        if precision != "bf16":
             dims = (tc.hidden_size, tc.intermediate_size, tc.num_attention_heads * tc.head_dim,
                     (tc.num_attention_heads + 2 * tc.num_key_value_heads) * tc.head_dim)
             if any(v % 16 for v in dims):
                 raise NotImplementedError(f"fp8 linears need every projection width to be a multiple of 16, got {dims}")
         self.precision = precision
-        self.engine.w8 = Fp8Weights(self.lm) if precision == "fp8" else None
+        self.engine.w8 = Fp8Weights(self.lm, rowwise=precision == "fp8_rowwise") if precision != "bf16" else None
         return self
 
     def _loss_anchor(self):

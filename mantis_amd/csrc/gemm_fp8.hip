@@ -27,6 +27,7 @@ typedef __attribute__((address_space(3))) void f8_lds_void;
 #define F8_EPI_BIAS 1
 #define F8_EPI_RESIDUAL 16
 #define F8_EPI_ACCUM 32
+#define F8_EPI_VECSCALE 128                  // dequant_a / dequant_b are vectors: one factor per row of A (m) and per row of B (n)
 #define F8_FMT_E4M3 0
 #define F8_FMT_E5M2 1
 
@@ -136,7 +137,8 @@ __device__ __forceinline__ void f8_epilogue(f32x16 (&acc)[TN][TM], bf16_t* __res
 template <int TM, int TN, bool SWIGLU = false>
 __device__ __forceinline__ void f8_epilogue_lds(f32x16 (&acc)[TN][TM], char* __restrict__ strip, bf16_t* __restrict__ C, int M, int N,
                                                 long ldc, float scale, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
-                                                long ldr, int flags, int mw0, int nw0, int lane, unsigned int* __restrict__ amax_out = nullptr) {
+                                                long ldr, int flags, int mw0, int nw0, int lane, unsigned int* __restrict__ amax_out = nullptr,
+                                                const float* __restrict__ sa_vec = nullptr, const float* __restrict__ sb_vec = nullptr) {
     static_assert(TN == 2 && (TM % 2) == 0, "strip is 64 columns wide, two 32-row blocks per pass");
     const bool vec_ok = !(ldc & 7) && !((uintptr_t)C & 15) && (!((flags & F8_EPI_RESIDUAL) || SWIGLU) || (!(ldr & 7) && !((uintptr_t)res & 15)))
                         && (!SWIGLU || !(N & 7));
@@ -164,6 +166,12 @@ __device__ __forceinline__ void f8_epilogue_lds(f32x16 (&acc)[TN][TM], char* __r
             if (m >= M || n >= N) continue;
             float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             const bool full = vec_ok && (n + 8 <= N);
+            if (flags & F8_EPI_VECSCALE) {          // per-row scales of both operands (`scale` is 1 then): out[m, n] = acc * (sa[m] * sb[n])
+                const float sm = sa_vec[m];
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (n + e < N) v[e] *= sm * sb_vec[n + e];
+            }
             if (flags & F8_EPI_BIAS) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
@@ -330,9 +338,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void gemm_fp8_nt_kernel
                                                                                   0x7f7f7f7f, 0, 0x7f7f7f7f);
         }
     }
-    const float scale = inv_scale_a[0] * inv_scale_b[0];
+    const float scale = (flags & F8_EPI_VECSCALE) ? 1.f : inv_scale_a[0] * inv_scale_b[0];
     __syncthreads();                   // every wave is done with the last operand stage: the LDS becomes the epilogue strips
-    f8_epilogue_lds<TM, TN>(acc, smem + wave * F8_EPI_STRIP, C, M, N, ldc, scale, bias, res, ldr, flags, m0 + wm * WM, n0 + wn * WN, lane);
+    f8_epilogue_lds<TM, TN>(acc, smem + wave * F8_EPI_STRIP, C, M, N, ldc, scale, bias, res, ldr, flags, m0 + wm * WM, n0 + wn * WN, lane,
+                            nullptr, inv_scale_a, inv_scale_b);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -498,9 +507,9 @@ __global__ __launch_bounds__(512) void gemm_fp8_ring_kernel(
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // retire the trailing DMA pieces and the last cluster's fragment reads ...
     __syncthreads();                                   // ... and every wave's fragment reads: the LDS becomes epilogue scratch
-    const float scale = inv_scale_a[0] * inv_scale_b[0];
+    const float scale = (flags & F8_EPI_VECSCALE) ? 1.f : inv_scale_a[0] * inv_scale_b[0];
     f8_epilogue_lds<TM, TN, SWIGLU>(acc, smem + wave * F8_EPI_STRIP, C, M, N, ldc, scale, bias, res, ldr, flags, m0 + wm * 128, n0 + wn * 64,
-                                    lane, amax_out);
+                                    lane, amax_out, inv_scale_a, inv_scale_b);
 }
 
 template <int FA, bool SWIGLU = false>
@@ -691,6 +700,155 @@ __global__ __launch_bounds__(256) void fp8_cast_kernel(const bf16_t* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------ row / column scaled quantiser ("2-D")
+// One scale per ROW for the row-major copy (tokens of an activation, output features of a weight) and one per COLUMN for the transposed
+// copy, so each of the three GEMMs of a linear sees per-row scales on both of its "NT" operands:
+//   forward  X8.q  (per token)        . W8.q  (per output feature)
+//   dX       dY8.q (per token)        . W8.qt (per input feature = column of W)
+//   dW       dY8.qt (per out feature) . X8.qt (per input feature)
+// pass 1: |x| maxima per row and per column (bf16 magnitudes compare as unsigned integers), atomically into rowmax[rows] / colmax[cols]
+__global__ __launch_bounds__(256) void fp8_amax2d_kernel(const bf16_t* __restrict__ x, long rows, int cols, long ld,
+                                                         unsigned int* __restrict__ rowmax, unsigned int* __restrict__ colmax) {
+    __shared__ unsigned int cm[QT_TILE];
+    const int t = threadIdx.x;
+    if (t < QT_TILE) cm[t] = 0u;
+    __syncthreads();
+    const long r0 = (long)blockIdx.y * QT_TILE;
+    const int c0 = blockIdx.x * QT_TILE;
+    const int cc = (t & 7) * 16;
+    const int c = c0 + cc;
+    unsigned int colm[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) colm[e] = 0u;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long r = r0 + (t >> 3) + 32 * u;
+        unsigned int rm = 0u;
+        if (r < rows && c < cols) {
+            const u32x4 v0 = *reinterpret_cast<const u32x4*>(x + r * ld + c);
+            const u32x4 v1 = *reinterpret_cast<const u32x4*>(x + r * ld + c + 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned int a0 = (v0[e] << 16) & 0x7fff0000u, a1 = v0[e] & 0x7fff0000u;
+                const unsigned int b0 = (v1[e] << 16) & 0x7fff0000u, b1 = v1[e] & 0x7fff0000u;
+                colm[2 * e] = colm[2 * e] > a0 ? colm[2 * e] : a0;
+                colm[2 * e + 1] = colm[2 * e + 1] > a1 ? colm[2 * e + 1] : a1;
+                colm[8 + 2 * e] = colm[8 + 2 * e] > b0 ? colm[8 + 2 * e] : b0;
+                colm[8 + 2 * e + 1] = colm[8 + 2 * e + 1] > b1 ? colm[8 + 2 * e + 1] : b1;
+                const unsigned int m01 = a0 > a1 ? a0 : a1, m23 = b0 > b1 ? b0 : b1;
+                const unsigned int mm = m01 > m23 ? m01 : m23;
+                rm = rm > mm ? rm : mm;
+            }
+        }
+        // the 8 lanes of one row are neighbours in the wave
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            const unsigned int y = (unsigned int)__shfl_xor((int)rm, o);
+            rm = rm > y ? rm : y;
+        }
+        if ((t & 7) == 0 && r < rows && rm != 0u) atomicMax(rowmax + r, rm);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+        if (colm[e] != 0u) atomicMax(&cm[cc + e], colm[e]);
+    __syncthreads();
+    if (t < QT_TILE && c0 + t < cols && cm[t] != 0u) atomicMax(colmax + c0 + t, cm[t]);
+}
+
+// pass 2: q[r, c] = cvt(clamp(x * FMAX / rowmax[r])), qt[c, r] = cvt(clamp(x * FMAX / colmax[c])); row_dequant[r] = rowmax[r] / FMAX and
+// col_dequant[c] = colmax[c] / FMAX (1 where the maximum is 0) are what the GEMM epilogue multiplies by.  q or qt may be NULL.
+template <int FMT>
+__global__ __launch_bounds__(256) void fp8_cast2d_kernel(const bf16_t* __restrict__ x, long rows, int cols, long ld,
+                                                         const unsigned int* __restrict__ rowmax, const unsigned int* __restrict__ colmax,
+                                                         unsigned char* __restrict__ q, long ldq, float* __restrict__ row_dequant,
+                                                         unsigned char* __restrict__ qt, long ldt, long rows_pad,
+                                                         float* __restrict__ col_dequant) {
+    __shared__ __attribute__((aligned(16))) unsigned char tile[QT_TILE * QT_PITCH];
+    const float FMAX = FMT == F8_FMT_E4M3 ? 448.f : 57344.f;
+    const long r0 = (long)blockIdx.y * QT_TILE;
+    const int c0 = blockIdx.x * QT_TILE;
+    const int t = threadIdx.x;
+    const int cc = (t & 7) * 16;
+    const int c = c0 + cc;
+    float csc[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) csc[e] = 1.f;
+    if (qt != nullptr && c < cols) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float am = __uint_as_float(colmax[c + e]);
+            csc[e] = am > 0.f ? FMAX / am : 1.f;
+        }
+        if (blockIdx.y == 0 && t < 8) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float am = __uint_as_float(colmax[c + e]);
+                col_dequant[c + e] = am > 0.f ? am / FMAX : 1.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int rl = (t >> 3) + 32 * u;
+        const long r = r0 + rl;
+        unsigned int w[4] = {0u, 0u, 0u, 0u}, wt[4] = {0u, 0u, 0u, 0u};
+        if (r < rows && c < cols) {
+            const u32x4 v0 = *reinterpret_cast<const u32x4*>(x + r * ld + c);
+            const u32x4 v1 = *reinterpret_cast<const u32x4*>(x + r * ld + c + 8);
+            float f[16];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f[2 * e] = bf2f_lo(v0[e]), f[2 * e + 1] = bf2f_hi(v0[e]);
+                f[8 + 2 * e] = bf2f_lo(v1[e]), f[8 + 2 * e + 1] = bf2f_hi(v1[e]);
+            }
+            if (q != nullptr) {
+                const float am = __uint_as_float(rowmax[r]);
+                const float rsc = am > 0.f ? FMAX / am : 1.f;
+                if (blockIdx.x == 0 && (t & 7) == 0) row_dequant[r] = am > 0.f ? am / FMAX : 1.f;
+                float g[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) g[e] = fminf(fmaxf(f[e] * rsc, -FMAX), FMAX);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = cvt4<FMT>(g[4 * e], g[4 * e + 1], g[4 * e + 2], g[4 * e + 3]);
+                u32x4 o;
+                o[0] = w[0], o[1] = w[1], o[2] = w[2], o[3] = w[3];
+                *reinterpret_cast<u32x4*>(q + r * ldq + c) = o;
+            }
+            if (qt != nullptr) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) f[e] = fminf(fmaxf(f[e] * csc[e], -FMAX), FMAX);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wt[e] = cvt4<FMT>(f[4 * e], f[4 * e + 1], f[4 * e + 2], f[4 * e + 3]);
+            }
+        }
+        if (qt != nullptr) {
+            unsigned int* tp = reinterpret_cast<unsigned int*>(tile + rl * QT_PITCH + cc);
+            tp[0] = wt[0], tp[1] = wt[1], tp[2] = wt[2], tp[3] = wt[3];
+        }
+    }
+    if (qt == nullptr) return;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int cl = (t >> 3) + 32 * u, rr = (t & 7) * 16;
+        const int co = c0 + cl;
+        const long r = r0 + rr;
+        if (co < cols && r < rows_pad) {
+            unsigned int w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned int acc = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc |= (unsigned int)tile[(rr + 4 * e + b) * QT_PITCH + cl] << (8 * b);
+                w[e] = acc;
+            }
+            u32x4 o;
+            o[0] = w[0], o[1] = w[1], o[2] = w[2], o[3] = w[3];
+            *reinterpret_cast<u32x4*>(qt + (long)co * ldt + r) = o;
+        }
+    }
+}
+
 // one launch of the chosen kernel on a (sub-)problem; f = epilogue flag bits
 static int fp8_dispatch(hipStream_t s, int variant, const void* A8, long lda, const void* B8, long ldb, void* C, long ldc, int M, int N, int K,
                         const float* dequant_a, const float* dequant_b, int fmt_a, const void* bias, const void* residual, long ldr, int f) {
@@ -743,6 +901,31 @@ int mantis_fp8_quantize(const void* x, int64_t rows, int cols, int64_t ld, int f
     return mantis_check_launch();
 }
 
+// Row / column scaled variant: q fp8 [rows, cols] (nullable) quantised with ONE SCALE PER ROW, row_dequant float[rows] <- rowmax / FMAX;
+// qt fp8 [cols, rows_pad] (nullable, zero tail) quantised with ONE SCALE PER COLUMN of x, col_dequant float[cols] <- colmax / FMAX.
+// workspace: rows + cols floats (set to 0 here).  The vectors are what mantis_gemm_fp8_nt takes with flag 128.
+int mantis_fp8_quantize_2d(const void* x, int64_t rows, int cols, int64_t ld, int fmt, void* q, int64_t ldq, float* row_dequant, void* qt,
+                           int64_t ldt, float* col_dequant, float* workspace, void* stream) {
+    if (rows <= 0 || cols <= 0 || cols % 16 || ld % 8 || (fmt != 0 && fmt != 1) || !workspace || (!q && !qt)) return MANTIS_EINVAL;
+    if (q != nullptr && (ldq % 16 || ldq < cols || !row_dequant)) return MANTIS_EINVAL;
+    const long rows_pad = (rows + 15) / 16 * 16;
+    if (qt != nullptr && (ldt % 16 || ldt < rows_pad || !col_dequant)) return MANTIS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(cdiv(cols, QT_TILE), cdiv(rows_pad, QT_TILE));
+    if (grid.y > 65535) return MANTIS_EUNSUPPORTED;
+    unsigned int* rowmax = (unsigned int*)workspace;
+    unsigned int* colmax = rowmax + rows;
+    if (hipMemsetAsync(workspace, 0, sizeof(float) * (size_t)(rows + cols), s) != hipSuccess) return MANTIS_ELAUNCH;
+    MANTIS_LAUNCH(fp8_amax2d_kernel, grid, dim3(256), 0, s, (const bf16_t*)x, (long)rows, cols, (long)ld, rowmax, colmax);
+    if (fmt == 0)
+        MANTIS_LAUNCH(fp8_cast2d_kernel<F8_FMT_E4M3>, grid, dim3(256), 0, s, (const bf16_t*)x, (long)rows, cols, (long)ld, rowmax, colmax,
+                      (unsigned char*)q, (long)ldq, row_dequant, (unsigned char*)qt, (long)ldt, rows_pad, col_dequant);
+    else
+        MANTIS_LAUNCH(fp8_cast2d_kernel<F8_FMT_E5M2>, grid, dim3(256), 0, s, (const bf16_t*)x, (long)rows, cols, (long)ld, rowmax, colmax,
+                      (unsigned char*)q, (long)ldq, row_dequant, (unsigned char*)qt, (long)ldt, rows_pad, col_dequant);
+    return mantis_check_launch();
+}
+
 // dgu[M, 2N] = swiglu_backward(dequant * A8[M,K] . B8[N,K]^T, gate_up[M, 2N]) in one launch (ring kernel; the [M, N] activation gradient
 // never goes to HBM), A8 = dY in e5m2 (fmt_a 1) or e4m3, B8 = the transposed e4m3 copy of W_down.  amax_out (nullable): float[1] <- max
 // |dgu| (set to 0 here first), ready to be handed to mantis_fp8_quantize as amax_in.
@@ -765,7 +948,8 @@ int mantis_gemm_fp8_dx_swiglu(const void* A8, int64_t lda, const void* B8, int64
 }
 
 // C[M,N] bf16 (row stride ldc elements) = epi(dequant_a * dequant_b * A8[M,K] . B8[N,K]^T); lda / ldb in bytes, K % 16 == 0.
-// fmt_a: 0 e4m3 | 1 e5m2; B is e4m3.  flags: 1 bias[n] | 16 + residual[m,n] (stride ldr) | 32 accumulate into C | variant << 8
+// fmt_a: 0 e4m3 | 1 e5m2; B is e4m3.  flags: 1 bias[n] | 16 + residual[m,n] (stride ldr) | 32 accumulate into C | 128 dequant_a / dequant_b
+// are vectors float[M] / float[N] (one factor per row of A / of B: mantis_fp8_quantize_2d) instead of one float each | variant << 8
 // (0 auto, 1 = 128x128 tiles, 2 = 256x256 tiles, 3 = 256x256 ring kernel).  dequant_a / dequant_b: device pointers to state[2] of the quantiser.
 int mantis_gemm_fp8_nt(const void* A8, int64_t lda, const void* B8, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
                        const float* dequant_a, const float* dequant_b, int fmt_a, const void* bias, const void* residual, int64_t ldr,
@@ -794,7 +978,7 @@ int mantis_gemm_fp8_nt(const void* A8, int64_t lda, const void* B8, int64_t ldb,
                     int rc = fp8_dispatch(s, 3, A8, lda, B8, ldb, C, ldc, M, ns, K, dequant_a, dequant_b, fmt_a, bias, residual, ldr, f);
                     if (rc != MANTIS_OK) return rc;
                     return fp8_dispatch(s, 1, A8, lda, (const unsigned char*)B8 + (long)ns * ldb, ldb, (bf16_t*)C + ns, ldc, M, N - ns, K, dequant_a,
-                                        dequant_b, fmt_a, bias ? (const bf16_t*)bias + ns : nullptr,
+                                        (f & F8_EPI_VECSCALE) ? dequant_b + ns : dequant_b, fmt_a, bias ? (const bf16_t*)bias + ns : nullptr,
                                         residual ? (const bf16_t*)residual + ns : nullptr, ldr, f);
                 }
             } else {
@@ -804,7 +988,8 @@ int mantis_gemm_fp8_nt(const void* A8, int64_t lda, const void* B8, int64_t ldb,
                     int rc = fp8_dispatch(s, 3, A8, lda, B8, ldb, C, ldc, ms, N, K, dequant_a, dequant_b, fmt_a, bias, residual, ldr, f);
                     if (rc != MANTIS_OK) return rc;
                     return fp8_dispatch(s, 1, (const unsigned char*)A8 + (long)ms * lda, lda, B8, ldb, (bf16_t*)C + (long)ms * ldc, ldc, M - ms, N, K,
-                                        dequant_a, dequant_b, fmt_a, bias, residual ? (const bf16_t*)residual + (long)ms * ldr : nullptr, ldr, f);
+                                        (f & F8_EPI_VECSCALE) ? dequant_a + ms : dequant_a, dequant_b, fmt_a, bias,
+                                        residual ? (const bf16_t*)residual + (long)ms * ldr : nullptr, ldr, f);
                 }
             }
         }

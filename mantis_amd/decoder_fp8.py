@@ -5,6 +5,8 @@ attention, SwiGLU, residual stream, lm_head and the loss stay exactly as in deco
 Recipe (per tensor, just-in-time scales, no history): activations and weights in e4m3, output gradients in e5m2; the quantiser hands
 back the transposed copy together with the row-major one, so forward (X8 . W8^T), dX (dY8 . W8T^T) and dW (dY8T . X8T^T) are all the one
 "NT" kernel.  The backward keeps the TRANSPOSED fp8 activations (1 B/element) instead of decoder.py's bf16 n1 / n2 / a.
+Opt-in `rowwise` recipe (set_precision("fp8_rowwise")): the row-major copy carries one scale per row and the transposed copy one per
+column of the source, so both operands of each of the three GEMMs are scaled per row and the epilogue multiplies by sa[m] * sb[n].
 
 The reference has no fp8 (its linears are bf16 nn.Linear); parity is therefore stated in two steps (tests/gpu_checks.py fp8_*):
 HIP == the oracle's exact restatement of this arithmetic (oracle/ops_ref.py fp8_quantize / gemm_fp8_nt), and that restatement vs the
@@ -25,8 +27,9 @@ class Fp8Weights:
     """e4m3 copies (row-major for the forward, transposed for dX) of the decoder's linear weights.  `refresh()` drops them; they are
     re-quantised lazily, layer by layer, at first use."""
 
-    def __init__(self, lm):
+    def __init__(self, lm, rowwise=False):
         self.lm = lm
+        self.rowwise = rowwise
         self.cache = {}
 
     def refresh(self):
@@ -36,12 +39,18 @@ class Fp8Weights:
         key = (i, name)
         w = self.cache.get(key)
         if w is None:
-            w = self.cache[key] = K.fp8_quantize(self.lm["layers"][i][name], E4M3, transposed=True)
+            w = self.cache[key] = _quant(K, self.lm["layers"][i][name], E4M3, True, None, self.rowwise)
         return w
 
 
+def _quant(K, x, fmt, transposed, amax, rowwise):
+    if rowwise:
+        return K.fp8_quantize(x, fmt, transposed=transposed, rowwise=True)
+    return K.fp8_quantize(x, fmt, transposed=transposed, amax=amax)
+
+
 def _lin(K, xq, wq, bias=None, residual=None):
-    return K.gemm_fp8_nt(xq.q, xq.dequant, wq.q, wq.dequant, E4M3, bias=bias, residual=residual)
+    return K.gemm_fp8_nt(xq.q, xq.dequant, wq.q, wq.dequant, E4M3, bias=bias, residual=residual, rowwise=xq.rowwise)
 
 
 def decoder_forward(K, lm, w8, tc, x, B, L, kmask, compute_grads=True, record=None, rope=None, kstart=None):
@@ -53,21 +62,22 @@ def decoder_forward(K, lm, w8, tc, x, B, L, kmask, compute_grads=True, record=No
     saved = []
     # producer-side amax: RMSNorm and SwiGLU take the maximum |value| of what they write, so the quantiser that follows skips its own
     # pass over the tensor (one scratch buffer, reused: producer and consumer are adjacent on the stream)
-    parts = K.amax_parts_buffer(x.device) if PRODUCER_AMAX else None
+    rw = w8.rowwise
+    parts = K.amax_parts_buffer(x.device) if PRODUCER_AMAX and not rw else None
     for i in range(tc.num_hidden_layers):
         lw = lm["layers"][i]
         n1, rstd1 = K.rmsnorm_fwd(x, lw["ln1"], eps, amax_parts=parts)
-        n1q = K.fp8_quantize(n1, E4M3, transposed=compute_grads, amax=parts)
+        n1q = _quant(K, n1, E4M3, compute_grads, parts, rw)
         qkv = _lin(K, n1q, w8.get(K, i, "qkv"), bias=lw.get("qkv_b"))
         K.rope_apply_(qkv, cos, sin, H + Hkv, hd)
         o, lse = K.attn_fwd(qkv, B, L, H, Hkv, hd, kmask, scale, True, kstart=kstart)
-        oq = K.fp8_quantize(o, E4M3, transposed=compute_grads)
+        oq = _quant(K, o, E4M3, compute_grads, None, rw)
         x_mid = _lin(K, oq, w8.get(K, i, "o"), residual=x)
         n2, rstd2 = K.rmsnorm_fwd(x_mid, lw["ln2"], eps, amax_parts=parts)
-        n2q = K.fp8_quantize(n2, E4M3, transposed=compute_grads, amax=parts)
+        n2q = _quant(K, n2, E4M3, compute_grads, parts, rw)
         gu = _lin(K, n2q, w8.get(K, i, "gu"))
         a = K.swiglu_fwd(gu, amax_parts=parts)
-        aq = K.fp8_quantize(a, E4M3, transposed=compute_grads, amax=parts)
+        aq = _quant(K, a, E4M3, compute_grads, parts, rw)
         x_out = _lin(K, aq, w8.get(K, i, "down"), residual=x_mid)
         if compute_grads:
             for t in (n1q, oq, n2q, aq):
@@ -82,11 +92,11 @@ def decoder_forward(K, lm, w8, tc, x, B, L, kmask, compute_grads=True, record=No
 def _dw(K, dyq, xq, grad, acc):
     """grad[out, in] (+)= dY^T . X over the (zero-padded) token axis: both operands are the quantiser's transposed copies."""
     if grad is not None:
-        K.gemm_fp8_nt(dyq.qt, dyq.dequant, xq.qt, xq.dequant, E5M2, out=grad, accumulate=acc)
+        K.gemm_fp8_nt(dyq.qt, dyq.dequant_t, xq.qt, xq.dequant_t, E5M2, out=grad, accumulate=acc, rowwise=dyq.rowwise)
 
 
 def _dx(K, dyq, wq):
-    return K.gemm_fp8_nt(dyq.q, dyq.dequant, wq.qt, wq.dequant, E5M2)
+    return K.gemm_fp8_nt(dyq.q, dyq.dequant, wq.qt, wq.dequant_t, E5M2, rowwise=dyq.rowwise)
 
 
 def decoder_backward(K, lm, w8, grads, grads_layers, tc, ctx, hctx, plan, B, L, kmask, accumulate=False, on_bucket_ready=None,
@@ -96,26 +106,27 @@ def decoder_backward(K, lm, w8, grads, grads_layers, tc, ctx, hctx, plan, B, L, 
     acc = accumulate
     saved, cos, sin, scale = ctx["saved"], ctx["cos"], ctx["sin"], ctx["scale"]
     dx = D.head_backward(K, lm, grads, hctx, plan, B, L, acc, on_bucket_ready)
-    parts_dx = K.amax_parts_buffer(dx.device) if PRODUCER_AMAX else None
-    parts_mid = K.amax_parts_buffer(dx.device) if PRODUCER_AMAX else None
+    rw = w8.rowwise
+    parts_dx = K.amax_parts_buffer(dx.device) if PRODUCER_AMAX and not rw else None
+    parts_mid = K.amax_parts_buffer(dx.device) if PRODUCER_AMAX and not rw else None
     dx_amax = None                     # the top layer's dx comes from the loss head (no producer-side amax); below: rmsnorm_bwd's
     for i in reversed(range(tc.num_hidden_layers)):
         lw = lm["layers"][i]
         lg_ = grads_layers[i]
         x_in, rstd1, qkv, o, lse, x_mid, rstd2, gu, n1q, oq, n2q, aq = saved.pop()
-        dxq = K.fp8_quantize(dx, E5M2, transposed=lg_["down"] is not None, amax=dx_amax)
+        dxq = _quant(K, dx, E5M2, lg_["down"] is not None, dx_amax, rw)
         _dw(K, dxq, aq, lg_["down"], acc)
         if on_bucket_ready is not None:
             on_bucket_ready(("layer", i, "down"))
         wd = w8.get(K, i, "down")
         # dact = dx . W_down, the SwiGLU backward and max |dgu| in ONE launch (the [M, I] activation gradient never goes to HBM, the
         # quantiser's amax pass over the 2I-wide gradient is skipped)
-        if FUSE_SWIGLU_BWD:
+        if FUSE_SWIGLU_BWD and not rw:
             dgu, dgu_amax = K.gemm_fp8_dx_swiglu(dxq.q, dxq.dequant, wd.qt, wd.dequant, gu, E5M2)
         else:
             dgu, dgu_amax = K.swiglu_bwd(_dx(K, dxq, wd), gu), None
         del aq, gu, dxq
-        dguq = K.fp8_quantize(dgu, E5M2, transposed=lg_["gu"] is not None, amax=dgu_amax)
+        dguq = _quant(K, dgu, E5M2, lg_["gu"] is not None, dgu_amax, rw)
         del dgu
         _dw(K, dguq, n2q, lg_["gu"], acc)
         if on_bucket_ready is not None:
@@ -124,14 +135,14 @@ def decoder_backward(K, lm, w8, grads, grads_layers, tc, ctx, hctx, plan, B, L, 
         del dguq, n2q
         dx_mid = K.rmsnorm_bwd(dn2, x_mid, lw["ln2"], rstd2, dx, lg_["ln2"], acc, amax_parts=parts_mid)
         del dn2, dx
-        dmq = K.fp8_quantize(dx_mid, E5M2, transposed=lg_["o"] is not None, amax=parts_mid)
+        dmq = _quant(K, dx_mid, E5M2, lg_["o"] is not None, parts_mid, rw)
         _dw(K, dmq, oq, lg_["o"], acc)
         do = _dx(K, dmq, w8.get(K, i, "o"))
         del dmq, oq
         dqkv = K.attn_bwd(qkv, o, do, lse, B, L, H, Hkv, hd, kmask, scale, True, kstart=kstart, qend=qend)
         del do, o
         K.rope_apply_(dqkv, cos, sin, H + Hkv, hd, backward=True)
-        dqq = K.fp8_quantize(dqkv, E5M2, transposed=lg_["qkv"] is not None)
+        dqq = _quant(K, dqkv, E5M2, lg_["qkv"] is not None, None, rw)
         _dw(K, dqq, n1q, lg_["qkv"], acc)
         if lg_.get("qkv_b") is not None:
             K.colsum(dqkv, lg_["qkv_b"], acc)

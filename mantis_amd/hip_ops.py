@@ -110,23 +110,47 @@ _Q_WS = {}
 class Fp8Tensor:
     """q uint8 [rows, cols] (row-major fp8), qt uint8 [cols, rows_pad] (transposed copy, zero tail) or None, state fp32[3] on the device
     = {amax, scale, dequant factor}."""
-    __slots__ = ("q", "qt", "state", "fmt", "rows", "cols")
+    __slots__ = ("q", "qt", "state", "fmt", "rows", "cols", "row_dequant", "col_dequant")
 
-    def __init__(self, q, qt, state, fmt, rows, cols):
+    def __init__(self, q, qt, state, fmt, rows, cols, row_dequant=None, col_dequant=None):
         self.q, self.qt, self.state, self.fmt, self.rows, self.cols = q, qt, state, fmt, rows, cols
+        self.row_dequant, self.col_dequant = row_dequant, col_dequant      # fp8_quantize(rowwise=True): fp32 [rows] / [cols]
+
+    @property
+    def rowwise(self):
+        return self.state is None
 
     @property
     def dequant(self):
-        return self.state[2:3]
+        """dequant factor(s) of the row-major copy `q`: fp32[1], or fp32[rows] when quantised rowwise"""
+        return self.row_dequant if self.state is None else self.state[2:3]
+
+    @property
+    def dequant_t(self):
+        """dequant factor(s) of the transposed copy `qt`: the same fp32[1], or fp32[cols] when quantised rowwise"""
+        return self.col_dequant if self.state is None else self.state[2:3]
 
 
-def fp8_quantize(x, fmt=FP8_E4M3, transposed=True, rowmajor=True, amax=None):
+def fp8_quantize(x, fmt=FP8_E4M3, transposed=True, rowmajor=True, amax=None, rowwise=False):
     """Per-tensor just-in-time quantisation of a bf16 matrix: q = cvt(clamp(x * FMAX / amax)).  Returns Fp8Tensor.
     amax: max |x| already taken by x's producer -- fp32[1] (gemm_fp8_dx_swiglu) or an amax_parts_buffer() filled by rmsnorm_fwd /
-    rmsnorm_bwd / swiglu_fwd -- the amax pass is skipped."""
+    rmsnorm_bwd / swiglu_fwd -- the amax pass is skipped.
+    rowwise=True: one scale per row for q and one per column of x for qt (mantis_fp8_quantize_2d); `amax` is not used."""
     _chk2d(x, "x")
     rows, cols = x.shape
     dev = x.device
+    if rowwise:
+        if not (rowmajor or transposed):
+            raise ValueError("fp8_quantize: nothing to produce")
+        rp = (rows + 15) // 16 * 16
+        ws = torch.empty(rows + cols, dtype=torch.float32, device=dev)
+        q = torch.empty((rows, cols), dtype=torch.uint8, device=dev) if rowmajor else None
+        qt = torch.empty((cols, rp), dtype=torch.uint8, device=dev) if transposed else None
+        rd = torch.empty(rows, dtype=torch.float32, device=dev) if rowmajor else None
+        cd = torch.empty(cols, dtype=torch.float32, device=dev) if transposed else None
+        _lib.check(_L.mantis_fp8_quantize_2d(_p(x), rows, cols, x.stride(0), fmt, _p(q), cols, _p(rd), _p(qt), rp, _p(cd), _p(ws), _stream()),
+                   f"fp8_quantize_2d {rows}x{cols}")
+        return Fp8Tensor(q, qt, None, fmt, rows, cols, rd, cd)
     key = (dev, _stream())          # one scratch buffer per (device, stream): launches on a stream are ordered
     ws = _Q_WS.get(key)
     if ws is None:
@@ -140,14 +164,21 @@ def fp8_quantize(x, fmt=FP8_E4M3, transposed=True, rowmajor=True, amax=None):
     return Fp8Tensor(q, qt, state, fmt, rows, cols)
 
 
-def gemm_fp8_nt(a8, a_dequant, b8, b_dequant, fmt_a=FP8_E4M3, bias=None, residual=None, out=None, accumulate=False, k=None, variant=0):
-    """out[M,N] bf16 = epi(dequant_a * dequant_b * a8[M,K] . b8[N,K]^T); a8 / b8 uint8 row-major fp8 (b8 e4m3)."""
+def gemm_fp8_nt(a8, a_dequant, b8, b_dequant, fmt_a=FP8_E4M3, bias=None, residual=None, out=None, accumulate=False, k=None, variant=0,
+                rowwise=False):
+    """out[M,N] bf16 = epi(dequant_a * dequant_b * a8[M,K] . b8[N,K]^T); a8 / b8 uint8 row-major fp8 (b8 e4m3).
+    rowwise=True: a_dequant fp32[M] and b_dequant fp32[N], out[m, n] = epi(a_dequant[m] * b_dequant[n] * ...)."""
     M, K = a8.shape
     N = b8.shape[0]
     K = K if k is None else k
     if out is None:
         out = torch.empty((M, N), dtype=BF16, device=a8.device)
-    flags = (1 if bias is not None else 0) | (16 if residual is not None else 0) | (32 if accumulate else 0) | (variant << 8)
+    if rowwise and (a_dequant.numel() != M or b_dequant.numel() != N):
+        raise ValueError(f"gemm_fp8_nt rowwise: dequant vectors {a_dequant.numel()} / {b_dequant.numel()} for M={M} N={N}")
+    if not rowwise and (a_dequant.numel() != 1 or b_dequant.numel() != 1):
+        raise ValueError("gemm_fp8_nt: per-tensor dequant factors are fp32[1]; pass rowwise=True for vectors")
+    flags = ((1 if bias is not None else 0) | (16 if residual is not None else 0) | (32 if accumulate else 0) | (128 if rowwise else 0) |
+             (variant << 8))
     prof = KERNEL_TIMER
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)

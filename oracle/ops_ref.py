@@ -57,15 +57,49 @@ _F8 = {0: (torch.float8_e4m3fn, 448.0), 1: (torch.float8_e5m2, 57344.0)}
 
 
 class Fp8Tensor:
-    def __init__(self, q, qt, state, fmt, rows, cols):
+    def __init__(self, q, qt, state, fmt, rows, cols, row_dequant=None, col_dequant=None):
         self.q, self.qt, self.state, self.fmt, self.rows, self.cols = q, qt, state, fmt, rows, cols
+        self.row_dequant, self.col_dequant = row_dequant, col_dequant
+
+    @property
+    def rowwise(self):
+        return self.state is None
 
     @property
     def dequant(self):
-        return self.state[2:3]
+        return self.row_dequant if self.state is None else self.state[2:3]
+
+    @property
+    def dequant_t(self):
+        return self.col_dequant if self.state is None else self.state[2:3]
 
 
-def fp8_quantize(x, fmt=FP8_E4M3, transposed=True, rowmajor=True, amax=None):
+def _fp8_quantize_2d(x, fmt, transposed, rowmajor):
+    """csrc/gemm_fp8.hip fp8_amax2d_kernel / fp8_cast2d_kernel: one scale per row for q, one per column of x for qt"""
+    dt, fmax = _F8[fmt]
+    xf = _f(x)
+    rows, cols = x.shape
+    fm = torch.tensor(fmax, dtype=torch.float32)
+    one = torch.tensor(1.0)
+    q = qt = rd = cd = None
+    if rowmajor:
+        am = xf.abs().amax(dim=1)
+        sc = torch.where(am > 0, fm / am, one)
+        rd = torch.where(am > 0, am / fm, one)
+        q = (xf * sc[:, None]).clamp(-fmax, fmax).to(dt).view(torch.uint8)
+    if transposed:
+        am = xf.abs().amax(dim=0)
+        sc = torch.where(am > 0, fm / am, one)
+        cd = torch.where(am > 0, am / fm, one)
+        rp = (rows + 15) // 16 * 16
+        qt = torch.zeros((cols, rp), dtype=torch.uint8)
+        qt[:, :rows] = (xf * sc[None, :]).clamp(-fmax, fmax).to(dt).view(torch.uint8).t()
+    return Fp8Tensor(q, qt, None, fmt, rows, cols, rd, cd)
+
+
+def fp8_quantize(x, fmt=FP8_E4M3, transposed=True, rowmajor=True, amax=None, rowwise=False):
+    if rowwise:
+        return _fp8_quantize_2d(x, fmt, transposed, rowmajor)
     dt, fmax = _F8[fmt]
     xf = _f(x)
     if amax is not None:
@@ -84,11 +118,17 @@ def fp8_quantize(x, fmt=FP8_E4M3, transposed=True, rowmajor=True, amax=None):
     return Fp8Tensor(q, qt, torch.stack([amax, sc, dq]).float(), fmt, rows, cols)
 
 
-def gemm_fp8_nt(a8, a_dequant, b8, b_dequant, fmt_a=FP8_E4M3, bias=None, residual=None, out=None, accumulate=False, k=None, variant=0):
+def gemm_fp8_nt(a8, a_dequant, b8, b_dequant, fmt_a=FP8_E4M3, bias=None, residual=None, out=None, accumulate=False, k=None, variant=0,
+                rowwise=False):
     K = a8.shape[1] if k is None else k
     av = a8[:, :K].view(_F8[fmt_a][0]).float()
     bv = b8[:, :K].view(_F8[0][0]).float()
-    y = (av @ bv.t()) * (a_dequant.float() * b_dequant.float())
+    if rowwise:
+        assert a_dequant.numel() == a8.shape[0] and b_dequant.numel() == b8.shape[0]
+        y = (av @ bv.t()) * (a_dequant.float()[:, None] * b_dequant.float()[None, :])
+    else:
+        assert a_dequant.numel() == 1 and b_dequant.numel() == 1
+        y = (av @ bv.t()) * (a_dequant.float() * b_dequant.float())
     if bias is not None:
         y = y + _f(bias)
     if residual is not None:

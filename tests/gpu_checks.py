@@ -1048,6 +1048,78 @@ def check_fp8_quantize(rows, cols, fmt, scale=1.0):
     return 0.0
 
 
+def _outlier_matrix(rows, cols, seed, scale):
+    """random matrix with one dominant row, one dominant column, an all-zero row and an all-zero column"""
+    x = rnd(rows, cols, seed=seed, scale=scale).float()
+    x[rows // 3] *= 100.0
+    x[:, cols // 5] *= 40.0
+    x[rows // 2] = 0.0
+    x[:, cols - 3] = 0.0
+    return x.to(BF)
+
+
+def check_fp8_quantize_2d(rows, cols, fmt, scale=1.0):
+    """Row / column scaled quantiser (set_precision("fp8_rowwise")): row-major bytes + per-row dequant factors, transposed bytes (zero
+    tail) + per-column dequant factors must EQUAL the oracle's restatement; q-only and qt-only calls give the same bytes."""
+    k = K()
+    x = _outlier_matrix(rows, cols, rows + cols + fmt, scale)
+    ref = R.fp8_quantize(x, fmt, rowwise=True)
+    got = k.fp8_quantize(x.to(DEV), fmt, rowwise=True)
+    assert got.rowwise and torch.equal(got.row_dequant.cpu(), ref.row_dequant), "row dequant factors differ"
+    assert torch.equal(got.col_dequant.cpu(), ref.col_dequant), "column dequant factors differ"
+    assert float(ref.row_dequant[rows // 2]) == 1.0 and float(ref.col_dequant[cols - 3]) == 1.0          # all-zero row / column
+    bad = int((got.q.cpu() != ref.q).sum())
+    assert bad == 0, f"fp8 quantize 2d {rows}x{cols} fmt {fmt}: {bad} row-major bytes differ"
+    bad = int((got.qt.cpu() != ref.qt).sum())
+    assert bad == 0, f"fp8 quantize 2d {rows}x{cols} fmt {fmt}: {bad} transposed bytes differ"
+    a = k.fp8_quantize(x.to(DEV), fmt, transposed=False, rowwise=True)
+    b = k.fp8_quantize(x.to(DEV), fmt, rowmajor=False, rowwise=True)
+    assert a.qt is None and b.q is None and torch.equal(a.q, got.q) and torch.equal(b.qt, got.qt)
+    assert torch.equal(a.row_dequant, got.row_dequant) and torch.equal(b.col_dequant, got.col_dequant)
+    return 0.0
+
+
+def check_fp8_gemm_rowwise(M, N, K_, fmt_a, epi, variant):
+    """fp8 MFMA GEMM with one dequant factor per row of each operand (flag 128) vs the oracle's restatement on IDENTICAL fp8 bytes; with a
+    dominant row in A the per-row scales must beat the per-tensor ones against the unquantised product."""
+    k = K()
+    a, b = _outlier_matrix(M, K_, M + K_, 1.0), _outlier_matrix(N, K_, N + K_ + 1, 0.05)
+    aq, bq = R.fp8_quantize(a, fmt_a, transposed=False, rowwise=True), R.fp8_quantize(b, 0, transposed=False, rowwise=True)
+    bias = rnd(N, seed=3) if "bias" in epi else None
+    res = rnd(M, N, seed=4) if "res" in epi else None
+    c0 = rnd(M, N, seed=5) if "acc" in epi else None
+    ref = R.gemm_fp8_nt(aq.q, aq.dequant, bq.q, bq.dequant, fmt_a, bias=bias, residual=res, out=None if c0 is None else c0.clone(),
+                        accumulate=c0 is not None, rowwise=True)
+    out = k.gemm_fp8_nt(aq.q.to(DEV), aq.dequant.to(DEV), bq.q.to(DEV), bq.dequant.to(DEV), fmt_a, bias=None if bias is None else bias.to(DEV),
+                        residual=None if res is None else res.to(DEV), out=None if c0 is None else c0.to(DEV), accumulate=c0 is not None,
+                        variant=variant, rowwise=True)
+    r = close(out, ref, 5e-3, f"gemm_fp8 rowwise {M}x{N}x{K_} fmt_a={fmt_a} {epi} v{variant}")
+    if epi == "plain":
+        exact = a.float() @ b.float().t()
+        at, bt = R.fp8_quantize(a, fmt_a, transposed=False), R.fp8_quantize(b, 0, transposed=False)
+        tens = R.gemm_fp8_nt(at.q, at.dequant, bt.q, bt.dequant, fmt_a)
+        km, kn = torch.ones(M, dtype=torch.bool), torch.ones(N, dtype=torch.bool)
+        km[M // 3] = kn[N // 3] = False            # away from the two dominant rows, whose products hide every other error
+        e_row, e_tens = rel(out.cpu()[km][:, kn], exact[km][:, kn]), rel(tens[km][:, kn], exact[km][:, kn])
+        # the dominant K column is each row's maximum: with per-row scales it quantises EXACTLY (CPU probe: 0.002 vs 0.04-0.06 per tensor)
+        assert e_row < 0.01 and e_row < 0.25 * e_tens, (e_row, e_tens)
+    with pytest_raises(ValueError):
+        k.gemm_fp8_nt(aq.q.to(DEV), aq.dequant.to(DEV), bq.q.to(DEV), bq.dequant.to(DEV), fmt_a)      # vectors without rowwise=True
+    return r
+
+
+class pytest_raises:
+    def __init__(self, exc):
+        self.exc = exc
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, et, ev, tb):
+        assert et is not None and issubclass(et, self.exc), f"expected {self.exc.__name__}"
+        return True
+
+
 def check_fp8_gemm(M, N, K_, fmt_a, epi, variant):
     """fp8 MFMA GEMM vs the oracle's restatement on IDENTICAL fp8 bytes (only the fp32 accumulation order differs), plus the size of the
     quantisation error itself against the unquantised product (documented, bounded)."""
@@ -1114,6 +1186,11 @@ def check_fp8_dx_swiglu(M, d, I, fmt_a):
     return close(out, ref, 1e-2, f"gemm_fp8_dx_swiglu {M}x{d}x{I} fmt_a={fmt_a}")
 
 
+FP8_GEMM_ROWWISE_CASES = [(300, 200, 80, 0, "plain", 1), (300, 520, 1008, 1, "plain", 2), (77, 40, 16, 1, "plain", 3),
+                          (1000, 777, 2048, 0, "bias+res", 3), (260, 260, 400, 1, "acc", 3), (333, 130, 640, 0, "bias+res", 0),
+                          (4096, 3584, 3584, 0, "plain", 0),
+                          # auto dispatch across the ring / 128x128 seam: the strip launch starts inside the dequant vectors (N and M splits)
+                          (4096, 4608, 256, 0, "bias+res", 0), (4608, 4000, 144, 1, "acc", 0)]
 FP8_GEMM_CASES = [(128, 128, 128, 0, "plain", 1), (256, 256, 256, 0, "plain", 2), (300, 200, 80, 0, "plain", 1), (300, 520, 1008, 1, "plain", 2),
                   (77, 40, 16, 1, "plain", 1), (1000, 777, 2048, 0, "bias", 2), (520, 300, 144, 1, "res", 1), (260, 260, 400, 1, "acc", 2),
                   (333, 130, 640, 0, "bias+res", 0), (4096, 3584, 3584, 0, "plain", 0), (3584, 4608, 4096, 1, "acc", 0),
@@ -1126,15 +1203,16 @@ FP8_GEMM_CASES = [(128, 128, 128, 0, "plain", 1), (256, 256, 256, 0, "plain", 2)
                   (4096, 4608, 256, 0, "bias+res", 0), (4608, 4000, 144, 1, "acc", 0), (4100, 4700, 128, 0, "bias", 0)]
 
 
-def check_qwen2vl_step_fp8(case):
-    """The Qwen2-VL step with the decoder linears on the fp8 MFMA GEMM (BASELINE configs[4]): (1) vs the fp32 oracle of the reference
+def check_qwen2vl_step_fp8(case, precision="fp8"):
+    """precision="fp8_rowwise": the same two comparisons for the opt-in per-row / per-column scaled recipe.
+    The Qwen2-VL step with the decoder linears on the fp8 MFMA GEMM (BASELINE configs[4]): (1) vs the fp32 oracle of the reference
     within the fp8 tolerance: loss 1e-2, activations 0.15 relative L2, every gradient cosine >= 0.95 (e4m3 activations / weights, e5m2
     gradients, per-tensor scales); (2) vs the SAME step run through the oracle's exact restatement of the fp8 arithmetic: loss 3e-3,
     gradient cosine >= 0.97 (1-D parameters 0.90) (bf16-level differences upstream of a quantiser flip individual fp8 roundings, so deep quantities agree to
     fp8 noise, not to bf16 noise; the per-kernel checks fp8_quantize_* / fp8_gemm_* are the exact ones)."""
     import mantis_amd.modeling_qwen2_vl as mod
     z = Hh.load_case(case)
-    model = Hh.build_qwen2vl_product(DEV).set_precision("fp8")
+    model = Hh.build_qwen2vl_product(DEV).set_precision(precision)
     assert model._ensure_grad_arena()
     rec = {}
     out = model.engine.step_from_batch(Hh.qwen2vl_batch(z), compute_grads=True, overwrite_grads=True, need_logits=True, record=rec)
@@ -1143,7 +1221,7 @@ def check_qwen2vl_step_fp8(case):
     rep = Hh.check_qwen2vl_step_against_oracle(model, Hh.build_qwen2vl_oracle_bf16(), z, out, rec, loss_rtol=1e-2, grad_cos=0.95,
                                                grad_rel=0.35, act_rel=0.15, grad_cos_1d=0.85, grad_rel_1d=0.6)
     # (2) the emulated fp8 step on the CPU
-    emu = Hh.build_qwen2vl_product("cpu").set_precision("fp8")
+    emu = Hh.build_qwen2vl_product("cpu").set_precision(precision)
     emu._ensure_grad_arena()
     saved_k = mod.K
     mod.K = R
@@ -1432,6 +1510,12 @@ def all_checks():
     for a in FP8_GEMM_CASES:
         c["fp8_gemm_" + "_".join(map(str, a))] = (lambda a=a: check_fp8_gemm(*a))
     c["fp8_producer_amax"] = check_fp8_producer_amax
+    for (r_, c_, f_, sc_) in [(64, 64, 0, 1.0), (300, 208, 0, 3.0), (77, 16, 1, 50.0), (1000, 4608, 1, 1e-3), (4096, 3584, 0, 0.02)]:
+        c[f"fp8_quantize_2d_{r_}x{c_}_fmt{f_}"] = (lambda r_=r_, c_=c_, f_=f_, sc_=sc_: check_fp8_quantize_2d(r_, c_, f_, sc_))
+    for a in FP8_GEMM_ROWWISE_CASES:
+        c["fp8_gemm_rowwise_" + "_".join(map(str, a))] = (lambda a=a: check_fp8_gemm_rowwise(*a))
+    for case in ("qwen2vl_b1_img2", "qwen2vl_b2_rightpad"):
+        c["qwen2vl_fp8_rowwise_step_" + case[8:]] = (lambda case=case: check_qwen2vl_step_fp8(case, "fp8_rowwise"))
     for (m_, d_, i_, f_) in [(300, 112, 256, 1), (1000, 512, 1504, 1), (257, 64, 176, 0), (4096, 3584, 18944, 1)]:
         c[f"fp8_dx_swiglu_{m_}x{d_}x{i_}_fmt{f_}"] = (lambda m_=m_, d_=d_, i_=i_, f_=f_: check_fp8_dx_swiglu(m_, d_, i_, f_))
     for case in QWEN2VL_CASES:

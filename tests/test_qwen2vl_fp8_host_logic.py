@@ -31,6 +31,54 @@ def test_fp8_step_within_stated_tolerance(cpu_backend, case):
                                          act_rel=0.15, grad_cos_1d=0.85, grad_rel_1d=0.6)
 
 
+@pytest.mark.parametrize("case", ["qwen2vl_b1_img2", "qwen2vl_b2_rightpad"])
+def test_fp8_rowwise_step_within_stated_tolerance(cpu_backend, case):
+    """set_precision("fp8_rowwise"): the same stated tolerance as the per-tensor recipe (it is at least as fine everywhere)."""
+    z = Hh.load_case(case)
+    model = Hh.build_qwen2vl_product("cpu").set_precision("fp8_rowwise")
+    assert model._ensure_grad_arena() and model.engine.w8.rowwise
+    rec = {}
+    out = model.engine.step_from_batch(Hh.qwen2vl_batch(z), compute_grads=True, overwrite_grads=True, need_logits=True, record=rec)
+    Hh.check_qwen2vl_step_against_oracle(model, Hh.build_qwen2vl_oracle_bf16(), z, out, rec, loss_rtol=1e-2, grad_cos=0.95, grad_rel=0.35,
+                                         act_rel=0.15, grad_cos_1d=0.85, grad_rel_1d=0.6)
+
+
+def test_rowwise_quantiser_restatement_properties():
+    from oracle import ops_ref as R
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(37, 48, generator=g) * 3)
+    x[5] *= 1e-6                                    # a row far below the tensor's range: per-tensor e4m3 flushes it to zero
+    x[9] = 0.0
+    x[:, 7] = 0.0
+    x = x.to(torch.bfloat16)
+    for fmt, fmax, dt in ((0, 448.0, torch.float8_e4m3fn), (1, 57344.0, torch.float8_e5m2)):
+        t = R.fp8_quantize(x, fmt, rowwise=True)
+        assert t.rowwise and t.state is None and t.dequant is t.row_dequant and t.dequant_t is t.col_dequant
+        assert t.row_dequant.shape == (37,) and t.col_dequant.shape == (48,) and t.qt.shape == (48, 48) and not t.qt[:, 37:].any()
+        assert float(t.row_dequant[9]) == 1.0 and float(t.col_dequant[7]) == 1.0 and not t.q[9].any() and not t.qt[7].any()
+        deq = t.q.view(dt).float() * t.row_dequant[:, None]
+        deq_t = t.qt[:, :37].view(dt).float() * t.col_dequant[:, None]
+        # every row's (column's) largest element maps to FMAX exactly
+        assert torch.allclose(deq.abs().amax(1)[x.float().abs().amax(1) > 0], x.float().abs().amax(1)[x.float().abs().amax(1) > 0], rtol=1e-6)
+        assert torch.allclose(deq_t.abs().amax(1)[x.float().abs().amax(0) > 0], x.float().abs().amax(0)[x.float().abs().amax(0) > 0], rtol=1e-6)
+        bound = 0.04 if fmt == 0 else 0.08
+        assert Hh.rel_l2(deq.numpy(), x.float().numpy()) < bound
+        assert Hh.rel_l2(deq[5].numpy(), x[5].float().numpy()) < bound            # the tiny row keeps full relative precision ...
+        if fmt == 0:
+            pt = R.fp8_quantize(x, fmt)
+            assert not (pt.q[5] & 0x7f).any()                                     # ... which one scale per tensor cannot give it
+    # GEMM on the quantised bytes = matmul of the dequantised values, scales applied as an outer product
+    a, b = R.fp8_quantize(x, 1, transposed=False, rowwise=True), R.fp8_quantize(x[:20], 0, transposed=False, rowwise=True)
+    y = R.gemm_fp8_nt(a.q, a.dequant, b.q, b.dequant, 1, rowwise=True)
+    ref = (a.q.view(torch.float8_e5m2).float() * a.row_dequant[:, None]) @ (b.q.view(torch.float8_e4m3fn).float() * b.row_dequant[:, None]).t()
+    assert Hh.rel_l2(y.float().numpy(), ref.numpy()) < 5e-3
+    # the three GEMMs of a linear see per-row scales on both operands: dW = dY^T X from the transposed copies
+    dy = (torch.randn(37, 32, generator=g)).to(torch.bfloat16)
+    dq, xq = R.fp8_quantize(dy, 1, rowwise=True), R.fp8_quantize(x, 0, rowwise=True)
+    dw = R.gemm_fp8_nt(dq.qt, dq.dequant_t, xq.qt, xq.dequant_t, 1, rowwise=True)
+    assert dw.shape == (32, 48) and Hh.rel_l2(dw.float().numpy(), (dy.float().t() @ x.float()).numpy()) < 0.08
+
+
 def test_fp8_quantiser_restatement_properties():
     from oracle import ops_ref as R
     g = torch.Generator().manual_seed(0)
@@ -87,3 +135,4 @@ def test_set_precision_validates():
     with pytest.raises(ValueError):
         model.set_precision("int4")
     assert model.set_precision("fp8").engine.w8 is not None and model.set_precision("bf16").engine.w8 is None
+    assert model.set_precision("fp8_rowwise").engine.w8.rowwise and not model.set_precision("fp8").engine.w8.rowwise
