@@ -104,3 +104,67 @@ def test_loss_backward_through_the_autograd_bridge(cpu_backend):
         p.grad = None
     model(**Hh.idefics2_batch(z)).loss.backward()
     assert torch.equal(model.grad_arena, ref.grad_arena)
+
+
+# ----------------------------------------------------------------------------------------------------------- data parallel (gloo, 2 ranks)
+def test_every_grad_bucket_is_signalled_once_in_backward_order(cpu_backend):
+    z = Hh.load_case("idefics2_b1_img2")
+    model = Hh.build_idefics2_product("cpu")
+    b = model.grad_buckets()
+    spans = sorted((v.data_ptr(), v.numel()) for v in b.values())
+    assert spans[0][0] == model.grad_arena.data_ptr() and sum(n for _, n in spans) == model.grad_arena.numel()
+    for (p0, n0), (p1, _) in zip(spans, spans[1:]):
+        assert p0 + 2 * n0 == p1, "buckets overlap or leave a gap"
+    seen = []
+    model.engine.step_from_batch(Hh.idefics2_batch(z), compute_grads=True, overwrite_grads=True, on_bucket_ready=seen.append)
+    assert set(seen) == set(b) and len(seen) == len(b)
+    nl = model.config.text_config.num_hidden_layers
+    layer_order = [s[1] for s in seen if isinstance(s, tuple) and s[0] == "layer" and s[2] == "down"]
+    assert layer_order == list(range(nl - 1, -1, -1))                       # the decoder's buckets leave in backward order
+
+
+def _dp_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import mantis_amd.modeling_idefics2 as mod
+        from oracle import ops_ref
+        mod.K = ops_ref
+        from mantis_amd.trainer import MantisHipTrainer
+        from mantis_amd.dp import GradReducer
+        model = Hh.build_idefics2_product("cpu")
+        z = Hh.load_case(["idefics2_b1_img2", "idefics2_b1_navit"][rank])              # different samples (and image shapes) per rank
+        tr = MantisHipTrainer(model, gradient_accumulation_steps=1, reducer=GradReducer(model))
+        loss = tr.training_step(model, Hh.idefics2_batch(z))
+        q.put((rank, float(loss), model.grad_arena.float().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dp2_gradients_are_the_mean_of_the_per_rank_gradients(cpu_backend):
+    import multiprocessing as mp
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert np.array_equal(res[0][2], res[1][2]), "ranks disagree after the bucketed all-reduce"
+    acc = None
+    for case in ("idefics2_b1_img2", "idefics2_b1_navit"):
+        model = Hh.build_idefics2_product("cpu")
+        model._ensure_grad_arena()
+        model.engine.step_from_batch(Hh.idefics2_batch(Hh.load_case(case)), compute_grads=True, overwrite_grads=True)
+        g = model.grad_arena.float().numpy().copy()
+        acc = g if acc is None else acc + g
+    assert Hh.rel_l2(res[0][2], acc / 2) < 1e-2                                        # bf16 rounding of the averaged buckets
