@@ -151,6 +151,8 @@ def fp8_quantize(x, fmt=FP8_E4M3, transposed=True, rowmajor=True, amax=None, row
         _lib.check(_L.mantis_fp8_quantize_2d(_p(x), rows, cols, x.stride(0), fmt, _p(q), cols, _p(rd), _p(qt), rp, _p(cd), _p(ws), _stream()),
                    f"fp8_quantize_2d {rows}x{cols}")
         return Fp8Tensor(q, qt, None, fmt, rows, cols, rd, cd)
+    if not rowmajor:
+        raise ValueError("fp8_quantize: the per-tensor quantiser always writes the row-major copy (rowmajor=False needs rowwise=True)")
     key = (dev, _stream())          # one scratch buffer per (device, stream): launches on a stream are ordered
     ws = _Q_WS.get(key)
     if ws is None:

@@ -100,6 +100,7 @@ def _fp8_quantize_2d(x, fmt, transposed, rowmajor):
 def fp8_quantize(x, fmt=FP8_E4M3, transposed=True, rowmajor=True, amax=None, rowwise=False):
     if rowwise:
         return _fp8_quantize_2d(x, fmt, transposed, rowmajor)
+    assert rowmajor, "the per-tensor quantiser always writes the row-major copy"
     dt, fmax = _F8[fmt]
     xf = _f(x)
     if amax is not None:
