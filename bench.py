@@ -160,29 +160,40 @@ def cpu_baseline(cfg_name):
         model = LlavaRef(w, meta, dtype=dtype)
         del w
 
-        def run(nv, nl):
-            model.zero_grad()
-            t0 = time.perf_counter()
-            model.training_step(batch, n_vit_layers=nv, n_llm_layers=nl)
-            return time.perf_counter() - t0
         with torch.no_grad():
             pv = torch.cat(batch["pixel_values"], 0).to(dtype)
             t0 = time.perf_counter(); model.vision_tower(pv, 1); tv1 = time.perf_counter() - t0
             t0 = time.perf_counter(); model.vision_tower(pv, 2); tv2 = time.perf_counter() - t0
-        t11 = run(1, 1)
-        t12 = run(1, 2)
-        per_llm, per_vit = max(t12 - t11, 1e-9), max(tv2 - tv1, 1e-9)
+        # the whole step at depth 1 (tower layer, projector, merge, ONE decoder layer, lm_head + loss, backward) ...
+        rec = {}
+        model.zero_grad()
+        t0 = time.perf_counter()
+        model.training_step(batch, n_vit_layers=1, n_llm_layers=1, record=rec)
+        t11 = time.perf_counter() - t0
+        # ... and one more decoder layer on its own (forward + backward on the merged sequence length): ~30 s of host work for both
+        # precisions together instead of ~80 s for timing the step again at depth 2
+        L, d = rec["llm_final_norm"].shape[1], rec["llm_final_norm"].shape[2]
+        del rec
+        model.zero_grad()
+        g = torch.Generator().manual_seed(1)
+        x = torch.randn(1, L, d, generator=g).to(dtype).requires_grad_(True)
+        t0 = time.perf_counter()
+        y = model.decoder(x, torch.ones(1, L, dtype=torch.int64), torch.arange(L)[None], n_layers=1)
+        y.float().sum().backward()
+        per_llm = max(time.perf_counter() - t0, 1e-9)
+        model.zero_grad()
+        per_vit = max(tv2 - tv1, 1e-9)
         total = t11 + (full_l - 1) * per_llm + (full_v - 1) * per_vit
-        return total, t11, t12, per_vit
-    total, t11, t12, per_vit = leg(torch.float32)
+        return total, t11, per_llm, per_vit
+    total, t11, per_llm, per_vit = leg(torch.float32)
     out = dict(value=1.0 / total, unit="samples/s", cores=torch.get_num_threads(), kind="port",
                sample=f"oracle/llava_ref.py training_step, fp32, 1 sample ({'1 img 224^2 + 128' if tiny else '4 img 336^2 + 512'} "
-                      f"tok), measured 1 ViT + 1 and 2 LLM layers + lm_head ({t11:.1f}s, {t12:.1f}s; ViT layer {per_vit:.2f}s), "
-                      f"extrapolated linearly to {full_v} ViT / {full_l} LLM layers = {total:.0f}s per sample")
+                      f"tok), measured: the step with 1 ViT + 1 LLM layer + lm_head {t11:.1f}s, one more LLM layer fwd+bwd {per_llm:.1f}s, "
+                      f"one more ViT layer {per_vit:.2f}s; extrapolated linearly to {full_v} ViT / {full_l} LLM layers = {total:.0f}s per sample")
     try:
-        tb, b11, b12, _ = leg(torch.bfloat16)
+        tb, b11, bl, _ = leg(torch.bfloat16)
         out["value_bf16"] = 1.0 / tb
-        out["sample_bf16"] = f"same sample and extrapolation with bf16 weights/activations on the CPU ({b11:.1f}s, {b12:.1f}s) = {tb:.0f}s per sample"
+        out["sample_bf16"] = f"same sample and extrapolation with bf16 weights/activations on the CPU ({b11:.1f}s, +{bl:.1f}s per LLM layer) = {tb:.0f}s per sample"
     except Exception as e:  # a CPU without usable bf16 kernels must not take the bench line down
         out["value_bf16"] = None
         out["sample_bf16"] = f"bf16 leg failed: {type(e).__name__}: {e}"
