@@ -222,22 +222,32 @@ def cpu_baseline_qwen2vl(cfg, T, grids):
     del w
     batch = synthetic_batch_qwen2vl(cfg, 1, T, grids, 0)
 
-    def run(nv, nl):
-        model.zero_grad()
-        t0 = time.perf_counter()
-        loss, _ = model.forward(batch["input_ids"], batch["pixel_values"], batch["image_grid_thw"], batch["attention_mask"], batch["labels"],
-                                n_vit_layers=nv, n_llm_layers=nl)
-        loss.backward()
-        return time.perf_counter() - t0
-    t11 = run(1, 1)
-    t21 = run(2, 1)
-    t12 = run(1, 2)
-    per_vit, per_llm = max(t21 - t11, 1e-9), max(t12 - t11, 1e-9)
+    # the whole step at depth 1 (patch embedding, ONE tower block, merger, rope index, ONE decoder layer, lm_head + loss, backward) ...
+    model.zero_grad()
+    t0 = time.perf_counter()
+    loss, _ = model.forward(batch["input_ids"], batch["pixel_values"], batch["image_grid_thw"], batch["attention_mask"], batch["labels"],
+                            n_vit_layers=1, n_llm_layers=1)
+    loss.backward()
+    t11 = time.perf_counter() - t0
+    del loss
+    model.zero_grad()
+    # ... one more tower block (frozen: forward only) as the difference of two tower forwards, and one more decoder layer (forward +
+    # backward) on its own
+    with torch.no_grad():
+        t0 = time.perf_counter(); model.vision(batch["pixel_values"].float(), batch["image_grid_thw"], n_layers=1); tv1 = time.perf_counter() - t0
+        t0 = time.perf_counter(); model.vision(batch["pixel_values"].float(), batch["image_grid_thw"], n_layers=2); tv2 = time.perf_counter() - t0
+    x = torch.randn(1, T, cfg.text_config.hidden_size, generator=g).requires_grad_(True)
+    pos3 = torch.arange(T)[None, None].expand(3, 1, T)
+    t0 = time.perf_counter()
+    model.text(x, torch.ones(1, T, dtype=torch.int64), pos3, n_layers=1).sum().backward()
+    per_llm = max(time.perf_counter() - t0, 1e-9)
+    model.zero_grad()
+    per_vit = max(tv2 - tv1, 1e-9)
     total = t11 + (full_v - 1) * per_vit + (full_l - 1) * per_llm
     return dict(value=1.0 / total, unit="samples/s", cores=torch.get_num_threads(), kind="port",
                 sample=f"oracle/qwen2vl_ref.py forward + backward, fp32, 1 sample ({len(grids)} images of {grids[0][1]}x{grids[0][2]} patches + "
-                       f"{T} tokens), measured 1 tower block + 1 decoder layer + merger + lm_head {t11:.1f}s, +1 tower block {per_vit:.1f}s, "
-                       f"+1 decoder layer {per_llm:.1f}s, extrapolated linearly to {full_v} blocks / {full_l} layers = {total:.0f}s per sample")
+                       f"{T} tokens), measured: the step with 1 tower block + 1 decoder layer + merger + lm_head {t11:.1f}s, one more tower block "
+                       f"(frozen, forward) {per_vit:.1f}s, one more decoder layer fwd+bwd {per_llm:.1f}s; extrapolated linearly to {full_v} blocks / {full_l} layers = {total:.0f}s per sample")
 
 
 def main():
