@@ -250,6 +250,57 @@ def cpu_baseline_qwen2vl(cfg, T, grids):
                        f"(frozen, forward) {per_vit:.1f}s, one more decoder layer fwd+bwd {per_llm:.1f}s; extrapolated linearly to {full_v} blocks / {full_l} layers = {total:.0f}s per sample")
 
 
+def cpu_baseline_idefics2(cfg, T, n_img, img_hw):
+    """Idefics2 configuration: the oracle (oracle/idefics2_ref.py, "port") on the host cores, fp32, one sample, depth extrapolated
+    (connector / resampler at full depth: it is 3 blocks)."""
+    import torch
+    from oracle.idefics2_ref import Idefics2Ref
+    from mantis_amd.modeling_idefics2 import _param_specs
+    full_v, full_l = cfg.vision_config.num_hidden_layers, cfg.text_config.num_hidden_layers
+    meta = dict(vision=cfg.vision_config.to_dict(), perceiver=cfg.perceiver_config.to_dict(), text=cfg.text_config.to_dict(),
+                image_token_id=cfg.image_token_id)
+    g = torch.Generator().manual_seed(0)
+    w = {}
+    for name, shape in _param_specs(cfg):
+        if ".layers." in name and "perceiver_resampler" not in name and int(name.split(".layers.")[1].split(".")[0]) >= 2:
+            continue
+        if len(shape) == 1:
+            w[name] = torch.ones(shape) if ("norm" in name and name.endswith("weight")) else torch.zeros(shape)
+        else:
+            w[name] = torch.randn(shape, generator=g).mul_(0.02)
+    model = Idefics2Ref(w, meta)
+    del w
+    batch = synthetic_batch_idefics2(cfg, 1, T, n_img, img_hw, 0)
+    # the whole step at depth 1 (NaViT embeddings, ONE tower layer, connector, merge, ONE decoder layer, lm_head + loss, backward) ...
+    model.vc["num_hidden_layers"] = model.tc["num_hidden_layers"] = 1
+    model.zero_grad()
+    t0 = time.perf_counter()
+    loss, _ = model.forward(batch["input_ids"], batch["pixel_values"], None, batch["attention_mask"], batch["labels"])
+    loss.backward()
+    t11 = time.perf_counter() - t0
+    del loss
+    model.zero_grad()
+    # ... one more tower layer (frozen: forward only) as the difference of two tower forwards, one more decoder layer (fwd + bwd) alone
+    pv = batch["pixel_values"].reshape(-1, *batch["pixel_values"].shape[2:]).float()
+    pm = torch.ones(pv.shape[0], img_hw // cfg.vision_config.patch_size, img_hw // cfg.vision_config.patch_size, dtype=torch.bool)
+    with torch.no_grad():
+        t0 = time.perf_counter(); model.vision(pv, pm); tv1 = time.perf_counter() - t0
+        model.vc["num_hidden_layers"] = 2
+        t0 = time.perf_counter(); model.vision(pv, pm); tv2 = time.perf_counter() - t0
+    x = torch.randn(1, T, cfg.text_config.hidden_size, generator=g).requires_grad_(True)
+    t0 = time.perf_counter()
+    model.text(x, torch.ones(1, T, dtype=torch.int64)).sum().backward()
+    per_llm = max(time.perf_counter() - t0, 1e-9)
+    model.zero_grad()
+    per_vit = max(tv2 - tv1, 1e-9)
+    total = t11 + (full_v - 1) * per_vit + (full_l - 1) * per_llm
+    return dict(value=1.0 / total, unit="samples/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"oracle/idefics2_ref.py forward + backward, fp32, 1 sample ({n_img} images of {img_hw}^2 px + {T} tokens), measured: the "
+                       f"step with 1 tower layer + connector + 1 decoder layer + lm_head {t11:.1f}s, one more tower layer (frozen, forward) "
+                       f"{per_vit:.1f}s, one more decoder layer fwd+bwd {per_llm:.1f}s; extrapolated linearly to {full_v} tower / {full_l} "
+                       f"decoder layers = {total:.0f}s per sample")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -473,10 +524,17 @@ def main():
                         step_frac_of_peak=round(flop_per_sample * B / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if not tiny else None,
                         training_step_frac_of_peak=round(flop_per_sample * B / (_pct(ts_ms, 0.5) * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if not tiny else None)
         cpu = None
-        if world == 1 and not args.no_cpu_baseline and qwen:
-            cpu = cpu_baseline_qwen2vl(cfg, T, grids)
-        elif world == 1 and not args.no_cpu_baseline and not idefics:      # the CPU leg times the LLaVA-path oracle
-            cpu = cpu_baseline(args.config)
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                if qwen:
+                    cpu = cpu_baseline_qwen2vl(cfg, T, grids)
+                elif idefics:
+                    cpu = cpu_baseline_idefics2(cfg, T, n_img, img_hw)
+                else:
+                    cpu = cpu_baseline(args.config)
+            except Exception as e:      # the host-side oracle leg must not take the measured GPU line down with it
+                cpu = dict(value=None, unit="samples/s", cores=torch.get_num_threads(), kind="port",
+                           sample=f"CPU baseline failed: {type(e).__name__}: {e}")
         dp = None
         if reducer is not None:
             ex = reducer.collect_exposed_ms()
