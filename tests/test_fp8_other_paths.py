@@ -8,13 +8,18 @@ import torch
 from tests import helpers as Hh
 
 
-def test_llava_fp8_step(monkeypatch):
+PRECISIONS = ["fp8", "fp8_rowwise"]          # per-tensor scales; one scale per token / per feature (opt-in)
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_llava_fp8_step(monkeypatch, precision):
     import mantis_amd.engine as eng
     from oracle import ops_ref
     monkeypatch.setattr(eng, "K", ops_ref)
     z = Hh.load_case("siglip_b2_equal_rightpad")
     model, _, _ = Hh.build_product_model("siglip", "cpu")
-    model.set_precision("fp8")
+    model.set_precision(precision)
+    assert model.engine.w8.rowwise == (precision == "fp8_rowwise")
     oracle = Hh.build_oracle_bf16_weights("siglip")
     assert model._ensure_grad_arena()
     out = model.engine.step(torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"]), torch.from_numpy(z["labels"]),
@@ -26,12 +31,13 @@ def test_llava_fp8_step(monkeypatch):
     assert model.set_precision("bf16").engine.w8 is None
 
 
-def test_idefics2_fp8_step(monkeypatch):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_idefics2_fp8_step(monkeypatch, precision):
     import mantis_amd.modeling_idefics2 as mod
     from oracle import ops_ref
     monkeypatch.setattr(mod, "K", ops_ref)
     z = Hh.load_case("idefics2_b2_padimg_rightpad")
-    model = Hh.build_idefics2_product("cpu").set_precision("fp8")
+    model = Hh.build_idefics2_product("cpu").set_precision(precision)
     oracle = Hh.build_idefics2_oracle_bf16()
     assert model._ensure_grad_arena()
     out = model.engine.step_from_batch(Hh.idefics2_batch(z), compute_grads=True, overwrite_grads=True)
