@@ -25,7 +25,18 @@
 // GUARD = 0: rows past the end are addressed as they are (loads beyond the tensor, stores beyond the tensor: the scalar offset is not
 //            part of the descriptor's range check) -- the form that PASSED on the GPU (round 2), unsafe as it stands;
 // GUARD = 3: loads clamped to the last row (bit 0), stores under `if (row < rows)` (bit 1) -- the form that FAILED on the GPU (0.1-0.2 %
-//            of dx wrong or never written) for a reason not yet found; GUARD = 1 and 2 are there to bisect.
+//            of dx garbage, dW correct); GUARD = 1 and 2 are there to bisect.
+// GUARD bit 2 (4): dx through plain global stores instead of buffer stores.  Working theory for the failure (from the ISA, not yet
+//            run): in the failing form `buffer_store_dwordx4 v[38:41], v25, s[12:15], s49 offen` is followed IMMEDIATELY by
+//            `v_mov_b32 v38, ...` -- a VALU write of the store's data registers.  gfx940+ needs 2 wait states there for stores wider than
+//            64 bits; the compiler's hazard recogniser skips MUBUF stores whose soffset is an SGPR (an older-generation exemption: the
+//            SGPR offset costs one extra cycle, which covered the 1 wait state those parts needed).  In the passing form the store
+//            happens to be followed by an s_waitcnt.  The register-fence draft's zeros (lanes 12-15 of each row, dword 0 of the store)
+//            fit the same race.  If form 7 passes where form 3 fails, that is it: never use an SGPR soffset on a >64-bit buffer store
+//            on this target (or follow the store with s_nop 1).
+// GUARD bit 3 (8): the store goes through a per-row descriptor (base = the row, 8192 records, 0 for rows past the end) with an immediate
+//            soffset: range-checked by the hardware, no branch, and the compiler pads the data hazard (s_nop 1 in the ISA).  Form 9 =
+//            clamped loads + this store is the product candidate: 126 VGPRs, no scratch.
 #define RMSQ_NQ 4        // waves per row
 #define RMSQ_SLOTS 2     // rows per workgroup iteration
 #define RMSQ_MAXC 2      // chunks per lane: d = 8 * 64 * RMSQ_NQ * RMSQ_MAXC
@@ -141,7 +152,14 @@ __global__ __launch_bounds__(64 * RMSQ_NQ * RMSQ_SLOTS, 4) void rmsnorm_bwd_d409
                     o[e] = pack_bf2(a, b);
                     if (AMAX) umax = mantis_umax_bf2(umax, o[e]);
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(o, rsO, lane_bytes + 1024u * k, soff, 0);
+                if (GUARD & 8) {    // per-row store descriptor, immediate soffset: range-checked (dead rows: 0 records) and hazard-padded
+                    const __amdgpu_buffer_rsrc_t rsRow = __builtin_amdgcn_make_buffer_rsrc(
+                        (void*)(reinterpret_cast<char*>(dx) + (size_t)soff), 0, (r < rows) ? d * 2 : 0, 0x00020000);
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rsRow, lane_bytes + 1024u * k, 0, 0);
+                } else if (GUARD & 4)      // plain global store (SGPR row base + 32-bit lane offset): the compiler pads its data hazard itself
+                    *reinterpret_cast<rmsq_u32x4v*>(reinterpret_cast<char*>(dx) + (size_t)soff + lane_bytes + 1024u * k) = o;
+                else
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rsO, lane_bytes + 1024u * k, soff, 0);
             }
         }
         cur = nxt;
@@ -231,8 +249,8 @@ int main() {
         const bf16_t* rp = res ? dres : (const bf16_t*)nullptr;
         float* wp = dw ? ws : (float*)nullptr;
 #define RUN_Q(G, A) hipLaunchKernelGGL((rmsnorm_bwd_d4096_kernel<G, A>), g, t, 0, 0, dy, x, w, rstd, rp, dx1, wp, rows, parts)
-        if (amax) { if (guard == 0) RUN_Q(0, true); else if (guard == 1) RUN_Q(1, true); else if (guard == 2) RUN_Q(2, true); else RUN_Q(3, true); }
-        else { if (guard == 0) RUN_Q(0, false); else if (guard == 1) RUN_Q(1, false); else if (guard == 2) RUN_Q(2, false); else RUN_Q(3, false); }
+        if (amax) { if (guard == 0) RUN_Q(0, true); else if (guard == 1) RUN_Q(1, true); else if (guard == 2) RUN_Q(2, true); else if (guard == 3) RUN_Q(3, true); else if (guard == 7) RUN_Q(7, true); else RUN_Q(9, true); }
+        else { if (guard == 0) RUN_Q(0, false); else if (guard == 1) RUN_Q(1, false); else if (guard == 2) RUN_Q(2, false); else if (guard == 3) RUN_Q(3, false); else if (guard == 7) RUN_Q(7, false); else RUN_Q(9, false); }
 #undef RUN_Q
         if (dw) hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(d, 64)), dim3(1024), 0, 0, ws, P, d, gw1, 0);
         return hipGetLastError() == hipSuccess ? MANTIS_OK : MANTIS_ELAUNCH;
@@ -241,7 +259,7 @@ int main() {
     std::vector<float> hp(MANTIS_AMAX_PARTS);
     int fails = 0;
     const long row_counts[] = {5624, 4099, 300, 1};
-    for (int guard = 0; guard < 4; ++guard)
+    for (int guard : {0, 1, 2, 3, 7, 9})
     for (long rows : row_counts)
         for (int combo = 0; combo < 4; ++combo) {
             const bool res = combo != 1, dw = combo != 2, amax = combo == 3;
@@ -282,10 +300,10 @@ int main() {
                 for (float f : hp) { unsigned int u; memcpy(&u, &f, 4); got = u > got ? u : got; }
                 amax_ok = got == want_amax;
             }
-            const bool ok = rc == MANTIS_OK && big <= 0.0626 && differ <= 64 + m / 20000 && (beyond == 0 || !(guard & 2)) && gerr < 2e-3 && amax_ok;
+            const bool ok = rc == MANTIS_OK && big <= 0.0626 && differ <= 64 + m / 20000 && (beyond == 0 || !(guard & 10)) && gerr < 2e-3 && amax_ok;
             fails += !ok;
             printf("%s %s rows %5ld res %d dW %d amax %d: rc %d, %zu of %zu values differ (max |diff| %.3g, rel L2 %.2e), dW rel L2 %.2e, amax %s, past the end %zu\n",
-                   ok ? "PASS" : "FAIL", guard == 0 ? "unguarded " : guard == 1 ? "clamp loads" : guard == 2 ? "guard store" : "clamp+guard", rows, res, dw, amax, rc, differ, m, big, den > 0 ? sqrt(num / den) : 0.0, gerr, amax ? (amax_ok ? "equal" : "WRONG") : "-",
+                   ok ? "PASS" : "FAIL", guard == 0 ? "unguarded  " : guard == 1 ? "clamp loads" : guard == 2 ? "guard store" : guard == 3 ? "clamp+guard" : guard == 7 ? "clamp+guard+global store" : "clamp+row descriptor", rows, res, dw, amax, rc, differ, m, big, den > 0 ? sqrt(num / den) : 0.0, gerr, amax ? (amax_ok ? "equal" : "WRONG") : "-",
                    beyond);
         }
     hipEvent_t e0, e1;
