@@ -2,10 +2,15 @@
 // candidate (below: registers kept between the passes, next row prefetched, buffer addressing, DPP wave sum).  Checks both forms of the
 // candidate over row counts (full rounds, ragged, one row), with / without the residual input, with / without dW, with / without the
 // producer-side amax, then times them at the cfg2 shape.
-// Status at the end of round 2 (the round's GPU minutes ran out here):
-//   * measured 61-66 us -> 39 us at 5624 x 4096 (2.8-3.0 -> 4.7 TB/s) = ~1.6 ms per headline step;
-//   * the unguarded form passed (37 of 23 M bf16 values differ from the shipped kernel: the dot is summed in another order);
-//   * the guarded form, which is what a product kernel needs, failed and is NOT in csrc/norm.hip; the shipped kernel is unchanged;
+// Status at the end of round 2 (the round's GPU minutes ran out here; last run: profiles/r02_rmsnorm_bwd_probe.log):
+//   * measured 60-66 us -> 38-39 us at 5624 x 4096 (2.8-3.1 -> 4.7-4.8 TB/s) = ~1.6 ms per headline step;
+//   * forms 0 (unguarded), 7 (global stores) and 9 (per-row store descriptor) PASS every case (33-65 of 23 M bf16 values differ from
+//     the shipped kernel: the dot is summed in another order; amax equal; nothing written past the last row);
+//   * forms 2 and 3 (buffer store with an SGPR soffset under `if (row < rows)`) FAIL with 0.1-0.2 % garbage in dx: CONFIRMED cause = the
+//     store is followed at once by a VALU write of its data registers and gets no hazard padding (see GUARD bit 2 below); form 1 fails
+//     by construction (dead rows store onto the clamped last row);
+//   * NOT yet in csrc/norm.hip (no GPU minutes left to run the test suite on the integrated library): form 9 is the one to integrate --
+//     dispatch at d == 4096 && rows * d * 2 < 2^32, grid = mantis_rmsnorm_bwd_partials(rows), then the full `-m gpu` suite;
 //   * an earlier draft fenced the packed registers with `asm volatile("" : "+v"(reg))` to stop common sub-expressions crossing the
 //     barrier: that MISCOMPILED (lanes 12-15 of every 16-lane row of one register came back as zeros in ~170 wave-iterations per
 //     launch) -- do not reintroduce it; the kernel needs no fence (123-128 VGPRs, no scratch without the amax tracking).
@@ -26,14 +31,14 @@
 //            part of the descriptor's range check) -- the form that PASSED on the GPU (round 2), unsafe as it stands;
 // GUARD = 3: loads clamped to the last row (bit 0), stores under `if (row < rows)` (bit 1) -- the form that FAILED on the GPU (0.1-0.2 %
 //            of dx garbage, dW correct); GUARD = 1 and 2 are there to bisect.
-// GUARD bit 2 (4): dx through plain global stores instead of buffer stores.  Working theory for the failure (from the ISA, not yet
-//            run): in the failing form `buffer_store_dwordx4 v[38:41], v25, s[12:15], s49 offen` is followed IMMEDIATELY by
+// GUARD bit 2 (4): dx through plain global stores instead of buffer stores.  Cause of the failure of forms 2 / 3 (read off the ISA,
+//            then confirmed by forms 7 and 9 passing): in the failing form `buffer_store_dwordx4 v[38:41], v25, s[12:15], s49 offen` is followed IMMEDIATELY by
 //            `v_mov_b32 v38, ...` -- a VALU write of the store's data registers.  gfx940+ needs 2 wait states there for stores wider than
 //            64 bits; the compiler's hazard recogniser skips MUBUF stores whose soffset is an SGPR (an older-generation exemption: the
 //            SGPR offset costs one extra cycle, which covered the 1 wait state those parts needed).  In the passing form the store
 //            happens to be followed by an s_waitcnt.  The register-fence draft's zeros (lanes 12-15 of each row, dword 0 of the store)
-//            fit the same race.  If form 7 passes where form 3 fails, that is it: never use an SGPR soffset on a >64-bit buffer store
-//            on this target (or follow the store with s_nop 1).
+//            fit the same race.  Rule: no SGPR soffset on a >64-bit buffer store on this target (or follow the store with s_nop 1);
+//            no kernel of csrc/ has a buffer store (checked in the ISA of all ten sources).
 // GUARD bit 3 (8): the store goes through a per-row descriptor (base = the row, 8192 records, 0 for rows past the end) with an immediate
 //            soffset: range-checked by the hardware, no branch, and the compiler pads the data hazard (s_nop 1 in the ISA).  Form 9 =
 //            clamped loads + this store is the product candidate: 126 VGPRs, no scratch.
