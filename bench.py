@@ -131,6 +131,36 @@ def qwen2vl_flop_per_sample(cfg, T, grids):
     return vit + 3 * llm
 
 
+class _HostEvent:
+    """Stand-in for torch.cuda.Event on the host-only plumbing run (MANTIS_BENCH_DEVICE=cpu, tests/test_bench_launch.py)."""
+    def __init__(self, enable_timing=True):
+        self.t = None
+
+    def record(self):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return 1e3 * (other.t - self.t)
+
+
+def _self_launch(n):
+    """`python bench.py --gpus N` without a launcher around it (the driver's plain command form): re-exec this very command line under
+    torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1; rank 0 of the child job prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # torch.distributed.run exports OMP_NUM_THREADS=1 when it is unset, which slows every host-side torch op of the step (index
+    # bookkeeping of the packing plan, the CPU baseline): give each rank its share of the cores instead
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(sys.argv[0]), *sys.argv[1:]]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def _pct(xs, q):
     xs = sorted(xs)
     if not xs:
@@ -332,6 +362,8 @@ def main():
     ap.add_argument("--recycle-batches", type=int, default=0, help="0 = a fresh synthetic batch every step (default); n > 0 = cycle n batches")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        _self_launch(args.gpus)
     import torch
     import torch.distributed as dist
     import __graft_entry__
@@ -340,13 +372,25 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    if local_rank == 0:
+    # MANTIS_BENCH_DEVICE=cpu: host-only plumbing run of this script (launcher, rank wiring, gloo reduction, JSON contract) for
+    # tests/test_bench_launch.py, whose harness installs a CPU operator backend first; without such a harness the product operators
+    # refuse host tensors.  Never a measurement.
+    host_only = os.environ.get("MANTIS_BENCH_DEVICE") == "cpu"
+    on_gpu = not host_only
+    if local_rank == 0 and on_gpu:
         __graft_entry__.build()
-    torch.cuda.set_device(local_rank)
+    if on_gpu:
+        torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}" if on_gpu else "cpu"
+    Event = torch.cuda.Event if on_gpu else _HostEvent
+    sync = torch.cuda.synchronize if on_gpu else (lambda: None)
     force_dp = os.environ.get("MANTIS_DP_FORCE") == "1" and "RANK" in os.environ
     if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if on_gpu:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
         dist.barrier()
     from mantis_amd import configuration_llava as C
     from mantis_amd import hip_ops as K
@@ -368,7 +412,7 @@ def main():
         # train_qwen2_vl.py:126-128's default budget would shrink it)
         T, grids = 4096, [(1, 68, 92), (1, 68, 92)]
         n_img, img_hw = len(grids), None
-        model = Qwen2VLForConditionalGeneration(cfg, device=f"cuda:{local_rank}", seed=0)
+        model = Qwen2VLForConditionalGeneration(cfg, device=device, seed=0)
         flop_per_sample = qwen2vl_flop_per_sample(cfg, T, grids)
     elif idefics:
         from mantis_amd import configuration_idefics2 as C2
@@ -376,14 +420,14 @@ def main():
         cfg = C2.mantis_8b_idefics2()
         B = args.batch_per_gpu or 2
         T, n_img, img_hw = 2048, 8, 448
-        model = Idefics2ForConditionalGeneration(cfg, device=f"cuda:{local_rank}", seed=0)
+        model = Idefics2ForConditionalGeneration(cfg, device=device, seed=0)
         flop_per_sample = idefics2_flop_per_sample(cfg, T, n_img, img_hw)
     else:
         cfg = getattr(C, args.config)()
         B = args.batch_per_gpu or 2
         T, n_img = (128, 1) if tiny else (512, 4)
         img_hw = cfg.vision_config.image_size
-        model = LlavaForConditionalGeneration(cfg, device=f"cuda:{local_rank}", seed=0)      # same seed -> identical replicas
+        model = LlavaForConditionalGeneration(cfg, device=device, seed=0)      # same seed -> identical replicas
         flop_per_sample = FLOP_PER_SAMPLE
     precision = args.precision or ("fp8" if qwen else "bf16")
     if precision != "bf16":
@@ -423,14 +467,33 @@ def main():
                 bt[k] = bt[k].reshape(1, B * T)
             bt["pixel_values"] = bt["pixel_values"].reshape(1, B * n_img, *bt["pixel_values"].shape[2:])
     for bt in batches:      # pinned host buffers, as dataloader_pin_memory does in the reference loop
-        bt["pixel_values"] = bt["pixel_values"].pin_memory() if (idefics or qwen) else [p.pin_memory() for p in bt["pixel_values"]]
+        if on_gpu:
+            bt["pixel_values"] = bt["pixel_values"].pin_memory() if (idefics or qwen) else [p.pin_memory() for p in bt["pixel_values"]]
+
+    # lm_head rows the reference computes and this path does not (decoder.compact_ce_rows keeps the rows that can carry a label,
+    # padded to a multiple of 8), averaged over the timed batches: enters the launched-FLOP count of the step-level fractions
+    def _head_rows(bt):
+        ids, lab = bt["input_ids"], bt["labels"]
+        img = getattr(cfg, "image_token_index", None)
+        img = cfg.image_token_id if img is None else img
+        ign = img if idefics else -100
+        n = int(((lab != ign) & (ids != img) & (bt["attention_mask"] != 0)).sum())
+        return ids.numel() + (n_img_tokens_per_row(bt)) - ((n + 7) // 8 * 8 if n else 8)
+
+    def n_img_tokens_per_row(bt):
+        if idefics or qwen:
+            return 0                          # one slot per image token: the merged length equals T
+        N = (cfg.vision_config.image_size // cfg.vision_config.patch_size) ** 2
+        return int((bt["input_ids"] == cfg.image_token_index).sum()) * (N - 1)
+    timed_batches = [batches[(args.warmup + i) % len(batches)] for i in range(args.steps)]
+    skipped_head_rows = sum(_head_rows(bt) for bt in timed_batches) / max(1, len(timed_batches))
 
     split = []          # (start, after training_step, after optimizer) events per timed step
     losses = []
 
     def one_step(i, timed=False):
         if timed:
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            ev = [Event(enable_timing=True) for _ in range(3)]
             ev[0].record()
         nxt = batches[(i + 1) % len(batches)] if args.prefetch else None
         loss = trainer.training_step(model, batches[i % len(batches)], next_inputs=nxt)
@@ -452,26 +515,26 @@ def main():
         loss = one_step(i)
     first_loss = float(loss) if args.warmup else None
     if reducer is not None:
-        torch.cuda.synchronize()
+        sync()
         reducer.collect_exposed_ms()
         reducer.stats.update(buckets=0, bytes=0, exposed_ms=[], steps=0)
-    timer = None if args.no_kernel_timer else []
+    timer = None if (args.no_kernel_timer or host_only) else []
     K.KERNEL_TIMER = timer
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = one_step(args.warmup + i, timed=True)
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
     K.KERNEL_TIMER = None
     if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     loss_vals = [float(x) for x in losses]
@@ -521,8 +584,20 @@ def main():
                                                "lm_head and loss on every sequence row) by the measured time; this path runs lm_head on the labelled "
                                                "rows only, so its launched FLOPs are lower -- `achieved` counts launched GEMM work only",
                         step_model_tflops=round(flop_per_sample * B / (ms * 1e-3) / 1e12, 1) if not tiny else None,
-                        step_frac_of_peak=round(flop_per_sample * B / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if not tiny else None,
-                        training_step_frac_of_peak=round(flop_per_sample * B / (_pct(ts_ms, 0.5) * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if not tiny else None)
+                        step_frac_of_peak=round(flop_per_sample * B / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if (not tiny and precision == "bf16") else None,
+                        training_step_frac_of_peak=round(flop_per_sample * B / (_pct(ts_ms, 0.5) * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if (not tiny and precision == "bf16") else None)
+            if not tiny:
+                # the honest step-level figures: FLOPs actually LAUNCHED (the reference's count minus the lm_head rows this path never
+                # computes: forward + dX + dW of every row without a label), against the roof of the precision each FLOP runs at
+                # (fp8 lines: sum_i flops_i / peak_i -- the fp8 GEMM family at the fp8 peak, everything else at the bf16 peak)
+                tc_ = cfg.text_config
+                launched = flop_per_sample * B - 3.0 * 2.0 * tc_.hidden_size * tc_.vocab_size * skipped_head_rows
+                f8_fl = (sum(x[1] for x in timer) / args.steps) if precision != "bf16" else 0.0
+                t_roof = f8_fl / (PEAK_FP8_TFLOPS * 1e12) + (launched - f8_fl) / (PEAK_BF16_TFLOPS * 1e12)
+                roof.update(step_launched_flops=launched,
+                            step_launched_tflops=round(launched / (ms * 1e-3) / 1e12, 1),
+                            step_frac_of_peak_launched=round(t_roof / (ms * 1e-3), 4),
+                            training_step_frac_of_peak_launched=round(t_roof / (_pct(ts_ms, 0.5) * 1e-3), 4))
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             try:
@@ -560,7 +635,8 @@ def main():
                    higher_is_better=True, scaling="weak", vs_baseline=None,
                    dtype="bf16" if precision == "bf16" else "fp8 (e4m3 activations/weights, e5m2 gradients in the decoder linears" +
                          (", per-row / per-column scales" if precision == "fp8_rowwise" else "") + "; bf16 elsewhere)",
-                   data="synthetic" + ("" if args.recycle_batches else " (fresh batch every step)"),
+                   data="synthetic" + ("" if args.recycle_batches else " (fresh batch every step)") +
+                        (" -- HOST-ONLY PLUMBING RUN, not a measurement" if host_only else ""),
                    loss=round(loss_vals[-1], 4), loss_first_timed=round(loss_vals[0], 4), loss_after_warmup=first_loss,
                    loss_min=round(min(loss_vals), 4), loss_max=round(max(loss_vals), 4),
                    config=dict(workload=f"{args.config}: ViT fwd + projector + packing + Llama fwd/bwd"

@@ -34,15 +34,33 @@ __device__ __forceinline__ unsigned int pack_bf2(float lo, float hi) {
     return c.u;
 }
 
+// Wave-wide reductions on the VALU (DPP): xor 1 and xor 2 inside a quad, mirror inside 8 and inside 16 lanes -- every lane of a 16-lane
+// row then holds the row's result -- and the four rows meet through v_readlane.  No LDS round trips and no lane-index registers (the
+// six dependent ds_bpermute of the __shfl_xor form cost rmsnorm_bwd 4-5 us of 61 and seven spilled VGPRs, tools/rmsnorm_bwd_probe.hip).
+// All 64 lanes must be active.  The result is wave-uniform.
+template <int CTRL>
+__device__ __forceinline__ float mantis_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += mantis_dpp<0xB1>(v);         // quad_perm [1,0,3,2]
+    v += mantis_dpp<0x4E>(v);         // quad_perm [2,3,0,1]
+    v += mantis_dpp<0x141>(v);        // row_half_mirror
+    v += mantis_dpp<0x140>(v);        // row_mirror
+    const int i = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(i, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(i, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(i, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(i, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, mantis_dpp<0xB1>(v));
+    v = fmaxf(v, mantis_dpp<0x4E>(v));
+    v = fmaxf(v, mantis_dpp<0x141>(v));
+    v = fmaxf(v, mantis_dpp<0x140>(v));
+    const int i = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(i, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(i, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(i, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(i, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 // block-wide sum for blockDim.x <= 1024 (<=16 waves); `red` is >=16 floats of LDS; result broadcast to all threads.
 __device__ __forceinline__ float block_sum(float v, float* red) {

@@ -139,6 +139,165 @@ __global__ __launch_bounds__(64 * RMSB_WAVES, MAXC <= 8 ? 4 : 2) void rmsnorm_bw
     if (amax_parts) mantis_store_amax_part(umax, amax_parts);
 }
 
+// ---- d = 4096 (Llama-3 / Mistral hidden size): the same arithmetic with a row split over FOUR waves.  Measured on 5624 x 4096
+// (tools/rmsnorm_bwd_probe.hip, profiles/r02_rmsnorm_bwd_probe.log): 38-39 us against 60-66 us of the kernel above (4.7-4.8 vs 2.8-3.1
+// TB/s).  What changed:
+//   * 2 chunks of 8 per lane instead of 8: dy / x of a row stay in registers between the two passes (no second read), the NEXT row's
+//     dy / x / rstd are requested before the current row is reduced, the current row's residual gradient at the top of the iteration
+//     (it is needed only after the barrier) -- 126 VGPRs, no scratch, 4 waves / SIMD;
+//   * buffer loads: descriptor over the whole tensor, the row's byte offset as the scalar offset, one 32-bit lane offset; rows past the
+//     end load the last row with rstd = 0 (xhat = 0: nothing added to the dot or to dW);
+//   * wave-wide sum by DPP (xor 1, xor 2 in a quad, mirrors inside 8 and 16 lanes, v_readlane across the four rows) instead of six
+//     dependent ds_bpermute; the four partial dots of a row meet in a double-buffered LDS cell, one barrier per row pair.
+// The dot is summed in another order than above (33-65 of 23 M bf16 values of dx round differently).
+#define RMSQ_NQ 4        // waves per row
+#define RMSQ_SLOTS 2     // rows per workgroup iteration
+#define RMSQ_MAXC 2      // chunks per lane: d = 8 * 64 * RMSQ_NQ * RMSQ_MAXC
+#define RMSQ_D (8 * 64 * RMSQ_NQ * RMSQ_MAXC)
+typedef unsigned int rmsq_u32x4v __attribute__((vector_size(16)));
+
+template <int CTRL>
+__device__ __forceinline__ float rmsq_dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {            // result is wave-uniform
+    v = rmsq_dpp_add<0xB1>(v);        // quad_perm [1,0,3,2]
+    v = rmsq_dpp_add<0x4E>(v);        // quad_perm [2,3,0,1]
+    v = rmsq_dpp_add<0x141>(v);       // row_half_mirror
+    v = rmsq_dpp_add<0x140>(v);       // row_mirror
+    const int i = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(i, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(i, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(i, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(i, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+__device__ __forceinline__ u32x4 rmsq_ld(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    const rmsq_u32x4v t = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    u32x4 o;
+    o[0] = t[0], o[1] = t[1], o[2] = t[2], o[3] = t[3];
+    return o;
+}
+struct RmsqRow {
+    u32x4 vd[RMSQ_MAXC], vx[RMSQ_MAXC];
+    float rstd;
+};
+// Rows past the end: the loads are issued for the LAST row instead (the scalar offset is not part of the descriptor's range check) and
+// rstd = 0 makes xhat = 0, so they add nothing to the dot or to dW; their dx is not stored.
+__device__ __forceinline__ void rmsq_load(RmsqRow& t, __amdgpu_buffer_rsrc_t rsD, __amdgpu_buffer_rsrc_t rsX, const float* __restrict__ rstd_in,
+                                          long r, long rows, unsigned lane_bytes) {
+    const long rc = r < rows ? r : rows - 1;
+    const unsigned soff = (unsigned)(rc * (RMSQ_D * 2));
+#pragma unroll
+    for (int k = 0; k < RMSQ_MAXC; ++k) {
+        t.vd[k] = rmsq_ld(rsD, lane_bytes + 1024u * k, soff);
+        t.vx[k] = rmsq_ld(rsX, lane_bytes + 1024u * k, soff);
+    }
+    t.rstd = r < rows ? rstd_in[r < rows ? r : 0] : 0.f;
+}
+
+template <bool AMAX>
+__global__ __launch_bounds__(64 * RMSQ_NQ * RMSQ_SLOTS, 4) void rmsnorm_bwd_d4096_kernel(
+    const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, const float* __restrict__ rstd_in,
+    const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx, float* __restrict__ dw_partial, long rows, float* __restrict__ amax_parts) {
+    constexpr int d = RMSQ_D;
+    __shared__ float dotbuf[2][RMSQ_SLOTS][RMSQ_NQ];
+    __shared__ float fold[d];                                  // one fp32 row
+    unsigned int umax = 0;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform: row index and row offsets live in SGPRs
+    const int slot = wv / RMSQ_NQ, q = wv % RMSQ_NQ;
+    const int c0 = q * (RMSQ_MAXC * 64) + lane;                // chunk index of k = 0; k-th chunk = c0 + 64 k
+    u32x4 vw[RMSQ_MAXC];
+#pragma unroll
+    for (int k = 0; k < RMSQ_MAXC; ++k) vw[k] = *reinterpret_cast<const u32x4*>(w + (long)(c0 + 64 * k) * 8);
+    float dwacc[RMSQ_MAXC][8];
+#pragma unroll
+    for (int k = 0; k < RMSQ_MAXC; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dwacc[k][e] = 0.f;
+    const long stride = (long)gridDim.x * RMSQ_SLOTS;
+    const int niter = (int)((rows + stride - 1) / stride);    // the same for every wave of the grid: the barriers stay uniform
+    long r = (long)blockIdx.x * RMSQ_SLOTS + slot;
+    const unsigned lane_bytes = (unsigned)c0 * 16u;
+    const int nbytes = (int)(unsigned)(rows * d * 2);          // < 4 GiB: checked by the launcher
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, nbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, nbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)dres, 0, dres ? nbytes : 0, 0x00020000);   // none: zeros
+    RmsqRow cur, nxt;
+    rmsq_load(cur, rsD, rsX, rstd_in, r, rows, lane_bytes);
+#pragma unroll 1
+    for (int it = 0; it < niter; ++it) {
+        rmsq_load(nxt, rsD, rsX, rstd_in, r + stride, rows, lane_bytes);
+        const unsigned soff = (unsigned)((r < rows ? r : rows - 1) * (d * 2));
+        u32x4 vr[RMSQ_MAXC];
+#pragma unroll
+        for (int k = 0; k < RMSQ_MAXC; ++k) vr[k] = rmsq_ld(rsR, lane_bytes + 1024u * k, soff);
+        const float rstd = cur.rstd;
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < RMSQ_MAXC; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d0 = bf2f_lo(cur.vd[k][e]), d1 = bf2f_hi(cur.vd[k][e]);
+                const float x0 = bf2f_lo(cur.vx[k][e]) * rstd, x1 = bf2f_hi(cur.vx[k][e]) * rstd;
+                dot += d0 * bf2f_lo(vw[k][e]) * x0 + d1 * bf2f_hi(vw[k][e]) * x1;
+                dwacc[k][2 * e] += d0 * x0;
+                dwacc[k][2 * e + 1] += d1 * x1;
+            }
+        dot = wave_sum_dpp(dot);
+        if (lane == 0) dotbuf[it & 1][slot][q] = dot;
+        __syncthreads();
+        float tot = 0.f;
+#pragma unroll
+        for (int j = 0; j < RMSQ_NQ; ++j) tot += dotbuf[it & 1][slot][j];      // fixed order: deterministic
+        tot /= (float)d;
+        {
+#pragma unroll
+            for (int k = 0; k < RMSQ_MAXC; ++k) {
+                rmsq_u32x4v o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x0 = bf2f_lo(cur.vx[k][e]) * rstd, x1 = bf2f_hi(cur.vx[k][e]) * rstd;
+                    const float a = rstd * (bf2f_lo(cur.vd[k][e]) * bf2f_lo(vw[k][e]) - x0 * tot) + bf2f_lo(vr[k][e]);
+                    const float b = rstd * (bf2f_hi(cur.vd[k][e]) * bf2f_hi(vw[k][e]) - x1 * tot) + bf2f_hi(vr[k][e]);
+                    o[e] = pack_bf2(a, b);
+                    if (AMAX) umax = mantis_umax_bf2(umax, o[e]);
+                }
+                // per-row store descriptor with an IMMEDIATE soffset: range-checked by the hardware (rows past the end: 0 records,
+                // the store is dropped) and hazard-padded by the compiler.  NOT `rsO + SGPR soffset`: a >64-bit MUBUF store whose
+                // soffset is an SGPR gets no padding against a following VALU write of its data registers (0.1-0.2 % garbage on
+                // gfx950, tools/rmsnorm_bwd_probe.hip forms 2 / 3).
+                const __amdgpu_buffer_rsrc_t rsRow = __builtin_amdgcn_make_buffer_rsrc(
+                    (void*)(reinterpret_cast<char*>(dx) + (size_t)soff), 0, (r < rows) ? d * 2 : 0, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b128(o, rsRow, lane_bytes + 1024u * k, 0, 0);
+            }
+        }
+        cur = nxt;
+        r += stride;
+    }
+    if (dw_partial) {
+        // the two row slots own the same columns: slot 0 writes, slot 1 adds (fixed order), then the row goes out coalesced
+        for (int s = 0; s < RMSQ_SLOTS; ++s) {
+            if (slot == s) {
+#pragma unroll
+                for (int k = 0; k < RMSQ_MAXC; ++k)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float* f = fold + ((q * RMSQ_MAXC + k) * 8 + e) * 64 + lane;
+                        *f = (s == 0) ? dwacc[k][e] : *f + dwacc[k][e];
+                    }
+            }
+            __syncthreads();
+        }
+        float* out = dw_partial + (long)blockIdx.x * d;
+        for (int j = threadIdx.x; j < d; j += 64 * RMSQ_NQ * RMSQ_SLOTS) {
+            const int c = j >> 3, e = j & 7;                   // column j = chunk c = (q * MAXC + k) * 64 + lane
+            out[j] = fold[((c >> 6) * 8 + e) * 64 + (c & 63)];
+        }
+    }
+    if (AMAX) mantis_store_amax_part(umax, amax_parts);
+}
+
+
 // grad[j] (+)= sum_p partial[p][j]   (fixed summation order -> deterministic).  64 columns x 16 row groups per workgroup.
 __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ partial, int P, int d,
                                                                bf16_t* __restrict__ grad, int accumulate) {
@@ -233,6 +392,18 @@ int mantis_rmsnorm_bwd(const void* dy, const void* x, const void* weight, const 
     if (d % 8 || d <= 0 || d > 64 * 8 * NORM_MAXC) return MANTIS_EUNSUPPORTED;
     if (rows == 0) return MANTIS_OK;
     const int P = mantis_rmsnorm_bwd_partials(rows);
+    if (d == RMSQ_D && (long)rows * d * 2 < (1L << 32) - (1L << 16)) {
+#define RMSQ_LAUNCH(AMAX) MANTIS_LAUNCH(rmsnorm_bwd_d4096_kernel<AMAX>, dim3(P), dim3(64 * RMSQ_NQ * RMSQ_SLOTS), 0, (hipStream_t)stream, \
+                       (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)weight, rstd, (const bf16_t*)dres, (bf16_t*)dx, \
+                       grad_weight ? workspace : nullptr, (long)rows, amax_parts)
+        if (amax_parts) RMSQ_LAUNCH(true);
+        else RMSQ_LAUNCH(false);
+#undef RMSQ_LAUNCH
+        if (grad_weight)
+            MANTIS_LAUNCH(reduce_partials_kernel, dim3(cdiv(d, 64)), dim3(1024), 0, (hipStream_t)stream, workspace, P, d,
+                          (bf16_t*)grad_weight, accumulate);
+        return mantis_check_launch();
+    }
 #define RMSB_LAUNCH(MAXC) MANTIS_LAUNCH(rmsnorm_bwd_kernel<MAXC>, dim3(P), dim3(64 * RMSB_WAVES), 0, (hipStream_t)stream, \
                        (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)weight, rstd, (const bf16_t*)dres, (bf16_t*)dx, \
                        grad_weight ? workspace : nullptr, (long)rows, d, amax_parts)

@@ -67,7 +67,7 @@ class Collator:
         for k in samples[0]:
             if k in known or samples[0][k] is None:
                 continue
-            extra[k] = torch.cat([torch.as_tensor(s[k]) for s in samples if s.get(k) is not None], dim=0)
+            extra[k] = _pack_extra([s[k] for s in samples if s.get(k) is not None])
         first_pv = next((s["pixel_values"] for s in samples if s.get("pixel_values") is not None), None)
         idefics2_style = first_pv is not None and torch.as_tensor(first_pv).dim() == 5      # [1, n_images, 3, H, W] per sample
         if "image_grid_thw" in extra or idefics2_style:
@@ -140,8 +140,19 @@ def pack_samples(samples, materialize_mask=True):
         out["pixel_values"] = torch.cat([torch.as_tensor(p) for p in pv if p is not None], dim=0)
     for k in samples[0]:                  # e.g. Qwen2-VL's image_grid_thw: one row per image, images in order of appearance
         if k not in out and k != "pixel_values" and samples[0][k] is not None:
-            out[k] = torch.cat([torch.as_tensor(s[k]) for s in samples if s.get(k) is not None], dim=0)
+            out[k] = _pack_extra([s[k] for s in samples if s.get(k) is not None])
     return out
+
+
+def _pack_extra(vals):
+    """The reference's `rest_keys` rule (data.py:1659-1666): tensors (and arrays) concatenated along dim 0, lists concatenated,
+    anything else (strings, ids, dicts) collected into a list."""
+    v0 = vals[0]
+    if isinstance(v0, (torch.Tensor, np.ndarray)):
+        return torch.cat([torch.as_tensor(v) for v in vals], dim=0)
+    if isinstance(v0, list):
+        return sum(vals, [])
+    return list(vals)
 
 
 def segments_from_packed(batch):
@@ -152,8 +163,14 @@ def segments_from_packed(batch):
         return batch["segment_ids"], batch["key_mask"]
     if batch.get("position_ids") is None:
         raise ValueError("a packed batch needs `position_ids` (restarting at 0 per sample) or `segment_ids` + `key_mask`")
-    pos = torch.as_tensor(batch["position_ids"]).reshape(-1)
-    seg = (torch.cumsum((pos == 0).to(torch.int32), 0) - 1).to(torch.int32)[None]
+    ids = torch.as_tensor(batch["input_ids"])
     m = torch.as_tensor(batch["attention_mask"])
+    # the reference's packed batch is ONE row (pack_batch concatenates along the sequence, :1612; its collator never stacks packed rows)
+    if ids.dim() != 2 or ids.shape[0] != 1 or m.dim() != 4 or m.shape[0] != 1:
+        raise ValueError(f"a packed batch is one row: input_ids [1, S] and a [1, 1, S, S] mask; got {tuple(ids.shape)} / {tuple(m.shape)}")
+    pos = torch.as_tensor(batch["position_ids"]).reshape(-1)
+    if pos.numel() != ids.shape[1]:
+        raise ValueError(f"packed position_ids have {pos.numel()} entries for a row of {ids.shape[1]} tokens")
+    seg = (torch.cumsum((pos == 0).to(torch.int32), 0) - 1).to(torch.int32)[None]
     key = torch.diagonal(m[0, 0], 0).to(torch.int64)[None]
     return seg, key

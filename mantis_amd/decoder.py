@@ -46,17 +46,30 @@ def decoder_forward(K, lm, tc, x, B, L, position_ids, kmask, kstart=None, comput
     return x, dict(saved=saved, cos=cos, sin=sin, scale=scale)
 
 
-def compact_ce_rows(plan, input_ids_cpu, attention_mask_cpu, labels, image_token, ignore_index, dev):
+def compact_ce_rows(plan, input_ids_cpu, attention_mask_cpu, labels, image_token, ignore_index, dev, vocab_size=None,
+                    refuse_image_targets=False):
     """Shrink the plan's cross-entropy lists (one entry per (b, t) token) to the entries that can actually carry a label, so the final
     norm, lm_head forward / dX / dW and the loss kernel run on the labelled rows only.  Exact: an ignored target contributes neither loss
     nor gradient (its dlogits row is zero).  The selection is taken on the HOST copy of the batch (no device sync, the GEMM row count must
     be known at launch) and is a superset of the device-side validity -- the kernel's own -100 entries inside it stay ignored.  The list
-    is padded to a multiple of 8 rows with (row -1, target -100) entries.  Call it after pack_plan / pack_segments."""
+    is padded to a multiple of 8 rows with (row -1, target -100) entries.  Call it after pack_plan / pack_segments.
+    vocab_size: raise IndexError for a countable target outside [0, V), as torch does, on every step.  refuse_image_targets: raise
+    where a target sits on an image placeholder (paths with one slot per placeholder, where HF would count it)."""
     import torch
     if labels is None:
         return
     lab = labels.detach().to("cpu") if labels.device.type != "cpu" else labels
+    # host-side label checks, EVERY step (the labels are on the host here anyway; only the device-side status words are read back on
+    # the first step alone): torch's CrossEntropyLoss raises on a target outside [0, V) on every call, and so does this
+    if refuse_image_targets and bool(((lab != ignore_index) & (input_ids_cpu == image_token) & (attention_mask_cpu != 0)).any()):
+        raise NotImplementedError("a label other than the ignore index sits on an image placeholder token: HF's loss would count it, "
+                                  "this path drops targets on image slots (the reference's collators never produce them)")
     valid = (attention_mask_cpu != 0) & (lab != ignore_index) & (input_ids_cpu != image_token)
+    if vocab_size is not None:
+        bad = valid & ((lab < 0) | (lab >= vocab_size))
+        if bool(bad.any()):
+            raise IndexError(f"{int(bad.sum())} label(s) are outside [0, vocab_size = {vocab_size}) "
+                             f"(torch.nn.CrossEntropyLoss: 'Target out of bounds')")
     sel = torch.nonzero(valid.reshape(-1)).reshape(-1)
     n = int(sel.numel())
     pad = 8 if n == 0 else (-n) % 8

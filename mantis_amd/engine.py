@@ -197,7 +197,7 @@ class LlavaEngine:
             kstart, qend = plan.kstart, plan.qend
         am_cpu = attention_mask.detach().to("cpu") if attention_mask.device.type != "cpu" else attention_mask
         D.compact_ce_rows(plan, ids_cpu, am_cpu, labels, cfg.image_token_index if (pixel_values is not None and T != 1) else -(2 ** 62),
-                          ign, dev)
+                          ign, dev, vocab_size=tc.vocab_size)
         emb_w = m.lm["embed"]
         x = K.pack_rows_fwd(plan, ids_d, emb_w, img)        # rows F+G fused: [B*L, d]
         if record is not None:

@@ -92,8 +92,35 @@ def mantis_hip_attention(module, query, key, value, attention_mask, scaling=None
     return out, None
 
 
+def mantis_hip_mask(batch_size, q_length, kv_length, q_offset=0, kv_offset=0, mask_function=None, attention_mask=None, **kwargs):
+    """HF mask-interface function for this implementation (transformers.masking_utils.AttentionMaskInterface): hands the 2-D key-padding
+    mask through untouched -- the kernels take causality as a flag and padding as an O(S) key mask, so no [B,1,S,S] tensor is built
+    and no device sync is needed (HF's flash-attention mask function tests `mask.all()` on the host).  Everything that is not plain
+    causal (+ padding) -- packed-sequence / sliding / chunked mask functions, a KV cache -- is refused instead of being dropped."""
+    from transformers import masking_utils as M
+    if mask_function is not None and mask_function is not M.causal_mask_function:
+        raise NotImplementedError("mantis_hip attention: only the plain causal mask (+ key padding) is implemented; HF composed another "
+                                  "mask function (packed sequences / sliding window / chunked attention)")
+    if q_length != kv_length or q_offset != 0 or kv_offset != 0:
+        raise NotImplementedError("mantis_hip attention: KV-cache decoding (query length != key length) is out of scope")
+    if attention_mask is None:
+        return None
+    return attention_mask[:, -kv_length:]
+
+
 def register(name="mantis_hip"):
-    """Make `--attn_implementation mantis_hip` (config._attn_implementation) resolve to the gfx950 kernels."""
+    """Make `--attn_implementation mantis_hip` (config._attn_implementation) resolve to the gfx950 kernels.
+
+    BOTH registries are needed: `AttentionInterface` for the attention function and `AttentionMaskInterface` for the mask that HF's
+    `create_causal_mask` hands to it -- for a name missing from the mask registry `create_causal_mask` returns None and the hook would
+    run every batch unmasked (a left-padded batch then attends its pad keys: round-2 advisor finding).  If this transformers version has
+    no mask registry to add to, registration fails rather than computing unmasked attention."""
     from transformers import AttentionInterface
+    try:
+        from transformers.masking_utils import AttentionMaskInterface
+    except ImportError as e:
+        raise RuntimeError("mantis_hip attention needs transformers.masking_utils.AttentionMaskInterface to receive the padding mask; "
+                           "this transformers version does not have it") from e
+    AttentionMaskInterface.register(name, mantis_hip_mask)
     AttentionInterface.register(name, mantis_hip_attention)
     return name

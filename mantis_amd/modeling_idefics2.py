@@ -450,7 +450,8 @@ class Idefics2Engine:
             K.pack_segments(plan, ids_d, seg_d, -(2 ** 62))
             kstart, qend = plan.kstart, plan.qend
             plan.position_ids = (torch.arange(T, device=dev, dtype=torch.int64)[None] - kstart.to(torch.int64)).contiguous()
-        D.compact_ce_rows(plan, ids_cpu, am_cpu, labels, IMG, IMG, dev)          # labels equal to image_token_id are the ignored ones
+        D.compact_ce_rows(plan, ids_cpu, am_cpu, labels, IMG, IMG, dev, vocab_size=tc.vocab_size,      # labels equal to image_token_id are
+                          refuse_image_targets=True)                                                  # the ignored ones
         x = K.pack_rows_fwd(plan, ids_d, m.lm["embed"], img)
         if record is not None and img is not None:
             record["merged_embeds"] = x.view(B, T, -1)

@@ -390,8 +390,8 @@ class Qwen2VLEngine:
         B, T = ids_cpu.shape
         IMG = cfg.image_token_id
         am_cpu = attention_mask.detach().to("cpu") if attention_mask.device.type != "cpu" else attention_mask
-        if labels is not None and not self._verified:
-            lab_cpu = labels.detach().to("cpu")
+        if labels is not None:                  # host-only check, every step
+            lab_cpu = labels.detach().to("cpu") if labels.device.type != "cpu" else labels
             if bool((lab_cpu[am_cpu == 0] != -100).any()):
                 raise NotImplementedError("labels != -100 where attention_mask == 0 (HF's loss would count them; the reference's collator "
                                           "never produces them)")
@@ -439,7 +439,7 @@ class Qwen2VLEngine:
             K.pack_segments(plan, ids_d, seg_d, -(2 ** 62))
             kstart, qend = plan.kstart, plan.qend
         plan.position_ids = pos3
-        D.compact_ce_rows(plan, ids_cpu, am_cpu, labels, IMG, -100, dev)
+        D.compact_ce_rows(plan, ids_cpu, am_cpu, labels, IMG, -100, dev, vocab_size=tc.vocab_size, refuse_image_targets=True)
         x = K.pack_rows_fwd(plan, ids_d, m.lm["embed"], img)
         if record is not None:
             record["merged_embeds"] = x.view(B, T, -1)

@@ -56,7 +56,11 @@ class MantisHipTrainer:
         if boundary:
             self._micro = 0                 # the optimizer steps after this micro-batch: the next window starts at 0
         reduce_now = self.reducer is not None and boundary
-        norm_now = boundary and self.optimizer is not None and self.optimizer.begin_norm()
+        # the overlapped gradient norm reads each bucket behind its collective's async handle; only the nccl path hands such handles
+        # out (under gloo the mean lands in finish(), after the hook) -- otherwise the optimizer takes its norm after finish()
+        red = self.reducer
+        red_ok = red is None or not getattr(red, "active", True) or bool(getattr(red, "_is_nccl", lambda: False)())
+        norm_now = boundary and self.optimizer is not None and red_ok and self.optimizer.begin_norm()
         if reduce_now:
             self.reducer.begin()
         hook = None
@@ -72,6 +76,12 @@ class MantisHipTrainer:
             from .data import segments_from_packed
             seg, attn = segments_from_packed(inputs)
         batch = inputs if attn is inputs["attention_mask"] else dict(inputs, attention_mask=attn)
+        if batch is not inputs and batch.get("labels") is not None and tuple(batch["labels"].shape) != tuple(batch["input_ids"].shape):
+            # the reference's pack_batch concatenates the [1, T] label rows of its items along dim 0 (data.py:1651): [n, T] for the
+            # packed row [1, n*T]; row-major that is the row's label vector
+            if batch["labels"].numel() != batch["input_ids"].numel():
+                raise ValueError(f"packed labels {tuple(batch['labels'].shape)} do not cover the packed row {tuple(batch['input_ids'].shape)}")
+            batch["labels"] = batch["labels"].reshape(batch["input_ids"].shape)
         out = model.engine.step_from_batch(batch, grad_scale=1.0 / ga, loss_scale=1.0 / ga, compute_grads=True,
                                            overwrite_grads=overwrite, on_bucket_ready=hook, segment_ids=seg)
         if reduce_now:

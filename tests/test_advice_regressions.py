@@ -206,3 +206,83 @@ def test_library_load_brings_torch_in_first():
         import pytest
         pytest.skip("libmantis_hip.so not built")
     assert r.returncode == 0, r.stderr[-800:]
+
+
+# ------------------------------------------------------------------------------------------------ round-2 advisor findings
+def test_out_of_range_label_raises_on_every_step_not_only_the_first(cpu_backend):
+    """the label checks ran only until `_verified` was set.  torch.nn.CrossEntropyLoss raises 'Target out of bounds' on
+    every call; the host-side check now does too (the device readback stays first-step-only)."""
+    import pytest
+    z = Hh.load_case("siglip_b1_img2_adjacent")
+    model, meta, _ = Hh.build_product_model("siglip", "cpu")
+    model._ensure_grad_arena()
+    batch = _batch(z)
+    model.engine.step_from_batch(batch)                       # first step: fine, engine marks itself verified
+    assert model.engine._verified
+    bad = dict(batch, labels=batch["labels"].clone())
+    pos = int((bad["labels"][0] != -100).nonzero()[0])
+    bad["labels"][0, pos] = meta["text"]["vocab_size"] + 3
+    with pytest.raises(IndexError):
+        model.engine.step_from_batch(bad)
+
+
+def test_packed_reference_batch_labels_n_by_t_and_metadata_keys(cpu_backend):
+    """the reference's pack_batch hands over labels [n, T] (items concatenated along dim 0) for the packed row [1, n*T],
+    and passes list / str metadata through its rest_keys rule; `segments_from_packed` insists on one packed row."""
+    import pytest
+    from mantis_amd.data import pack_samples, segments_from_packed, Collator
+    from mantis_amd.trainer import MantisHipTrainer
+    z = Hh.load_case("siglip_b2_equal_nopad")
+    pv = Hh.pixels_list(z)
+    samples = [dict(input_ids=torch.from_numpy(z["input_ids"][[r]]), attention_mask=torch.from_numpy(z["attention_mask"][[r]]),
+                    labels=torch.from_numpy(z["labels"][[r]]), pixel_values=pv[r], sample_id=f"s{r}", tags=[r, r + 10]) for r in range(2)]
+    packed = pack_samples(samples)
+    assert packed["sample_id"] == ["s0", "s1"] and packed["tags"] == [0, 10, 1, 11]
+    ref_style = {k: packed[k] for k in ("input_ids", "pixel_values", "attention_mask", "position_ids")}
+    ref_style["labels"] = torch.cat([s["labels"] for s in samples], dim=0)          # [n, T], what pack_batch produces (data.py:1651)
+    model, _, _ = Hh.build_product_model("siglip", "cpu")
+    tr = MantisHipTrainer(model)
+    loss_ref_style = float(tr.training_step(model, ref_style))
+    g1 = model.grad_arena.float().clone()
+    model2, _, _ = Hh.build_product_model("siglip", "cpu")
+    loss_own = float(MantisHipTrainer(model2).training_step(model2, {k: v for k, v in packed.items() if k not in ("sample_id", "tags")}))
+    assert loss_ref_style == loss_own and torch.equal(g1, model2.grad_arena.float())
+    two_rows = dict(ref_style, input_ids=torch.cat([packed["input_ids"]] * 2), attention_mask=torch.cat([packed["attention_mask"]] * 2))
+    with pytest.raises(ValueError):
+        segments_from_packed(two_rows)
+    col = Collator(pad_token_id=299)([dict(input_ids=[1, 2, 3], note="a", tags=[1]), dict(input_ids=[4, 5], note="b", tags=[2])])
+    assert col["note"] == ["a", "b"] and col["tags"] == [1, 2]
+
+
+def test_norm_overlap_is_off_when_the_reducer_is_not_nccl(cpu_backend, monkeypatch):
+    """under gloo `bucket_ready` returns no handles and the mean lands in finish(); the overlapped gradient norm would
+    then be taken over UN-reduced gradients.  The trainer enables the overlap only without an active reducer or on nccl."""
+    from mantis_amd.trainer import MantisHipTrainer
+
+    class Red:
+        active = True
+        stats = dict(buckets=0)
+
+        def _is_nccl(self):
+            return False
+
+        def begin(self):
+            pass
+
+        def bucket_ready(self, key):
+            return ()
+
+        def finish(self):
+            pass
+
+    class Opt:
+        began = False
+
+        def begin_norm(self):
+            Opt.began = True
+            return True
+
+    z = Hh.load_case("siglip_b1_img2_adjacent")
+    model, _, _ = Hh.build_product_model("siglip", "cpu")
+    MantisHipTrainer(model, reducer=Red(), optimizer=Opt()).training_step(model, _batch(z))
+    assert not Opt.began
