@@ -364,6 +364,7 @@ def main():
 
     if args.gpus > 1 and "RANK" not in os.environ:
         _self_launch(args.gpus)
+    import mantis_amd  # noqa: F401  (sets GPU_MAX_HW_QUEUES before the HIP runtime initialises: the RCCL stream needs its own hardware queue)
     import torch
     import torch.distributed as dist
     import __graft_entry__

@@ -97,8 +97,11 @@ int mantis_transpose(const void* in, void* out, int R, int C, int Rpad, int64_t 
  *        | 64 SwiGLU backward fused behind dact = A.B^T: residual = [gate | up][M, 2N], C = [dgate | dup][M, 2N]
  *        | bits 8-11 tile variant (0 = auto) | 4096 A is K-major ([K,M], row stride lda) | 8192 B is K-major ([K,N]):
  *        dX = dY.W uses B K-major (the weight as stored), dW = dY^T.X uses both K-major -- no transposed copies.
- * The ring kernel (variant 12) addresses operands through 32-bit buffer descriptors: an operand of >= 2 GiB is routed to the
- * generic kernel when the variant is auto and returns MANTIS_EUNSUPPORTED when variant 12 (or the SwiGLU epilogue) was forced. */
+ * Tile variants: 1 = 128x128 generic kernel, 2 = 256x256 generic kernel, 12 = 256x256 ring kernel with 8 waves of 32x32x16 MFMAs,
+ * 13 = 256x256 ring kernel with 4 waves x (128 x 128) of 16x16x32 MFMAs (the cooler-running shape: the automatic choice's ring kernel
+ * unless the process was started with MANTIS_GEMM_RING=12).  The ring kernels address operands through 32-bit buffer descriptors: an
+ * operand of >= 4 GiB is routed to the generic kernel when the variant is auto and returns MANTIS_EUNSUPPORTED when a ring variant (or
+ * the SwiGLU epilogue) was forced. */
 int mantis_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
                         const void* bias, const void* residual, int64_t ldr, int flags, void* workspace /*nullable*/,
                         int64_t workspace_bytes, void* stream);
@@ -106,7 +109,7 @@ int mantis_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, 
  * ring kernel's deterministic split-K remainder round uses it; every launch leaves it zeroed-for-reuse, so one buffer per stream
  * serves all stream-ordered launches).  M = N = K = 0: the largest requirement of any shape on the current device (~64 MB). */
 int mantis_gemm_workspace_bytes(int M, int N, int K);
-/* tile variant the auto heuristic (flags bits 8-11 == 0) picks: 12 = 256x256 ring kernel, 1 = 128x128 generic kernel */
+/* tile family the auto heuristic (flags bits 8-11 == 0) picks: 12 = a 256x256 ring kernel (12 or 13, see above), 1 = 128x128 generic kernel */
 int mantis_gemm_pick_variant(int M, int N, int K);
 
 /* ---- fp8 linears (BASELINE configs[4] "fp8 MFMA"): an accelerated variant of the bf16 nn.Linear of the Qwen2

@@ -28,6 +28,7 @@
 //     share A/B panels in that XCD's private 4 MiB L2
 // Algorithmic FLOPs per launch: 2*M*N*K.
 #include "common.h"
+#include <type_traits>
 
 #define BK 64
 #define EPI_BIAS 1
@@ -217,16 +218,122 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TN][TM], bf16_t* __r
 // every global instruction covers 8 whole 128-B lines.  Arithmetic and rounding order are those of gemm_epilogue (bit-identical).
 #define EPI_PITCH 272
 #define EPI_STRIP (64 * EPI_PITCH)
+// Read-back half of the LDS-transposed epilogue, shared by both 256x256 kernels: a wave-private strip holds 64 rows x 64 fp32 columns
+// of the result (row pitch 272 B); lane (rr = lane >> 3, cc = lane & 7) takes 8 consecutive columns of row it*8 + rr, applies bias /
+// activation / residual / accumulate / the fused SwiGLU backward on 16-B vectors and stores 16 B: every global instruction covers 8
+// whole 128-B lines.  Arithmetic and rounding order are those of gemm_epilogue (bit-identical).
+template <bool SWIGLU>
+__device__ __forceinline__ void epi_readback64(const char* __restrict__ strip, bf16_t* __restrict__ C, int M, int N, long ldc,
+                                               const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res, long ldr, int flags,
+                                               int m_base, int n0w, int lane) {
+    const int act = (flags & EPI_ACT_MASK) >> EPI_ACT_SHIFT;
+    const bool vec_ok = !(ldc & 7) && !((uintptr_t)C & 15) && (!(flags & (EPI_RESIDUAL | EPI_SWIGLU_BWD)) || (!(ldr & 7) && !((uintptr_t)res & 15)))
+                        && (!(flags & EPI_SWIGLU_BWD) || !(N & 7));
+    const int rr = lane >> 3, cc = lane & 7;
+    const int n = n0w + cc * 8;
+#pragma unroll 2
+    for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + rr;
+        const int m = m_base + row;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(strip + row * EPI_PITCH + cc * 32);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(strip + row * EPI_PITCH + cc * 32 + 16);
+        if (m >= M || n >= N) continue;
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const bool full = vec_ok && (n + 8 <= N);
+        if (flags & EPI_BIAS) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (n + e < N) v[e] += bf2f(bias[n + e]);
+        }
+        if (act) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gemm_act(bf2f(f2bf(v[e])), act);
+        }
+        bf16_t* cp = C + (long)m * ldc + n;
+        if constexpr (SWIGLU) {
+            // SwiGLU backward fused behind dact = dY . W_down (transformers/models/llama/modeling_llama.py:163-176, autograd):
+            // dgate = dact * up * silu'(gate), dup = dact * silu(gate); dact rounded to bf16 first, as the unfused path stores it
+            if (full) {
+                const u32x4 g = *reinterpret_cast<const u32x4*>(res + (long)m * ldr + n);
+                const u32x4 u = *reinterpret_cast<const u32x4*>(res + (long)m * ldr + N + n);
+                u32x4 og, ou;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float gv[2] = {bf2f_lo(g[e]), bf2f_hi(g[e])};
+                    const float uv[2] = {bf2f_lo(u[e]), bf2f_hi(u[e])};
+                    float rg[2], ru[2];
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const float dv = bf2f(f2bf(v[2 * e + h2]));
+                        const float sg = 1.f / (1.f + __expf(-gv[h2]));
+                        const float silu = gv[h2] * sg;
+                        rg[h2] = dv * uv[h2] * (sg + silu * (1.f - sg));
+                        ru[h2] = dv * silu;
+                    }
+                    og[e] = pack_bf2(rg[0], rg[1]);
+                    ou[e] = pack_bf2(ru[0], ru[1]);
+                }
+                *reinterpret_cast<u32x4*>(cp) = og;
+                *reinterpret_cast<u32x4*>(cp + N) = ou;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (n + e < N) {
+                        const float gv = bf2f(res[(long)m * ldr + n + e]), uv = bf2f(res[(long)m * ldr + N + n + e]);
+                        const float dv = bf2f(f2bf(v[e]));
+                        const float sg = 1.f / (1.f + __expf(-gv));
+                        const float silu = gv * sg;
+                        cp[e] = f2bf(dv * uv * (sg + silu * (1.f - sg)));
+                        cp[N + e] = f2bf(dv * silu);
+                    }
+                }
+            }
+            continue;
+        }
+        if (SWIGLU) continue;
+        if (full) {
+            if (flags & EPI_RESIDUAL) {
+                const u32x4 rv = *reinterpret_cast<const u32x4*>(res + (long)m * ldr + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[2 * e] = bf2f(f2bf(v[2 * e])) + bf2f_lo(rv[e]);
+                    v[2 * e + 1] = bf2f(f2bf(v[2 * e + 1])) + bf2f_hi(rv[e]);
+                }
+            }
+            if (flags & EPI_ACCUM) {
+                const u32x4 cv = *reinterpret_cast<const u32x4*>(cp);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[2 * e] += bf2f_lo(cv[e]);
+                    v[2 * e + 1] += bf2f_hi(cv[e]);
+                }
+            }
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+            *reinterpret_cast<u32x4*>(cp) = o;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (n + e < N) {
+                    float x = v[e];
+                    if (flags & EPI_RESIDUAL) x = bf2f(f2bf(x)) + bf2f(res[(long)m * ldr + n + e]);
+                    if (flags & EPI_ACCUM) x += bf2f(cp[e]);
+                    cp[e] = f2bf(x);
+                }
+            }
+        }
+    }
+}
+
+// Epilogue of the 8-wave 256x256 kernel (32x32x16 accumulators): the MFMA layout gives every lane ONE output row, so storing from
+// registers touches 32 rows x 16 B per instruction (measured: 17 us of a 146 us K = 4096 tile, 34 us with a residual).  Instead every
+// wave transposes its 128 x 64 tile through a wave-private LDS strip, 64 rows x 64 fp32 per pass (conflict-free ds_write_b128).
 template <int TM, int TN, bool SWIGLU>
 __device__ __forceinline__ void gemm_epilogue_lds(f32x16 (&acc)[TN][TM], char* __restrict__ strip, bf16_t* __restrict__ C, int M,
                                                   int N, long ldc, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res,
                                                   long ldr, int flags, int mw0, int nw0, int lane) {
     static_assert(TN == 2 && (TM % 2) == 0, "strip is 64 columns wide, two 32-row blocks per pass");
-    const int act = (flags & EPI_ACT_MASK) >> EPI_ACT_SHIFT;
-    const bool vec_ok = !(ldc & 7) && !((uintptr_t)C & 15) && (!(flags & (EPI_RESIDUAL | EPI_SWIGLU_BWD)) || (!(ldr & 7) && !((uintptr_t)res & 15)))
-                        && (!(flags & EPI_SWIGLU_BWD) || !(N & 7));
-    const int rr = lane >> 3, cc = lane & 7;
-    const int n = nw0 + cc * 8;
 #pragma unroll
     for (int pass = 0; pass < TM / 2; ++pass) {
 #pragma unroll
@@ -239,99 +346,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(f32x16 (&acc)[TN][TM], char* _
                                      acc[tn][pass * 2 + t2][4 * g4 + 3]};
                     *reinterpret_cast<f32x4*>(strip + (t2 * 32 + (lane & 31)) * EPI_PITCH + (tn * 32 + 8 * g4 + 4 * (lane >> 5)) * 4) = v;
                 }
-#pragma unroll 2
-        for (int it = 0; it < 8; ++it) {
-            const int row = it * 8 + rr;
-            const int m = mw0 + pass * 64 + row;
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(strip + row * EPI_PITCH + cc * 32);
-            const f32x4 hi = *reinterpret_cast<const f32x4*>(strip + row * EPI_PITCH + cc * 32 + 16);
-            if (m >= M || n >= N) continue;
-            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            const bool full = vec_ok && (n + 8 <= N);
-            if (flags & EPI_BIAS) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (n + e < N) v[e] += bf2f(bias[n + e]);
-            }
-            if (act) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = gemm_act(bf2f(f2bf(v[e])), act);
-            }
-            bf16_t* cp = C + (long)m * ldc + n;
-            if constexpr (SWIGLU) {
-                // SwiGLU backward fused behind dact = dY . W_down (transformers/models/llama/modeling_llama.py:163-176, autograd):
-                // dgate = dact * up * silu'(gate), dup = dact * silu(gate); dact rounded to bf16 first, as the unfused path stores it
-                if (full) {
-                    const u32x4 g = *reinterpret_cast<const u32x4*>(res + (long)m * ldr + n);
-                    const u32x4 u = *reinterpret_cast<const u32x4*>(res + (long)m * ldr + N + n);
-                    u32x4 og, ou;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float gv[2] = {bf2f_lo(g[e]), bf2f_hi(g[e])};
-                        const float uv[2] = {bf2f_lo(u[e]), bf2f_hi(u[e])};
-                        float rg[2], ru[2];
-#pragma unroll
-                        for (int h2 = 0; h2 < 2; ++h2) {
-                            const float dv = bf2f(f2bf(v[2 * e + h2]));
-                            const float sg = 1.f / (1.f + __expf(-gv[h2]));
-                            const float silu = gv[h2] * sg;
-                            rg[h2] = dv * uv[h2] * (sg + silu * (1.f - sg));
-                            ru[h2] = dv * silu;
-                        }
-                        og[e] = pack_bf2(rg[0], rg[1]);
-                        ou[e] = pack_bf2(ru[0], ru[1]);
-                    }
-                    *reinterpret_cast<u32x4*>(cp) = og;
-                    *reinterpret_cast<u32x4*>(cp + N) = ou;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        if (n + e < N) {
-                            const float gv = bf2f(res[(long)m * ldr + n + e]), uv = bf2f(res[(long)m * ldr + N + n + e]);
-                            const float dv = bf2f(f2bf(v[e]));
-                            const float sg = 1.f / (1.f + __expf(-gv));
-                            const float silu = gv * sg;
-                            cp[e] = f2bf(dv * uv * (sg + silu * (1.f - sg)));
-                            cp[N + e] = f2bf(dv * silu);
-                        }
-                    }
-                }
-                continue;
-            }
-            if (SWIGLU) continue;
-            if (full) {
-                if (flags & EPI_RESIDUAL) {
-                    const u32x4 rv = *reinterpret_cast<const u32x4*>(res + (long)m * ldr + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[2 * e] = bf2f(f2bf(v[2 * e])) + bf2f_lo(rv[e]);
-                        v[2 * e + 1] = bf2f(f2bf(v[2 * e + 1])) + bf2f_hi(rv[e]);
-                    }
-                }
-                if (flags & EPI_ACCUM) {
-                    const u32x4 cv = *reinterpret_cast<const u32x4*>(cp);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[2 * e] += bf2f_lo(cv[e]);
-                        v[2 * e + 1] += bf2f_hi(cv[e]);
-                    }
-                }
-                u32x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
-                *reinterpret_cast<u32x4*>(cp) = o;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    if (n + e < N) {
-                        float x = v[e];
-                        if (flags & EPI_RESIDUAL) x = bf2f(f2bf(x)) + bf2f(res[(long)m * ldr + n + e]);
-                        if (flags & EPI_ACCUM) x += bf2f(cp[e]);
-                        cp[e] = f2bf(x);
-                    }
-                }
-            }
-        }
+        epi_readback64<SWIGLU>(strip, C, M, N, ldc, bias, res, ldr, flags, mw0 + pass * 64, nw0, lane);
     }
 }
 
@@ -764,6 +779,347 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(
     gemm_epilogue_lds<TM, TN, SWIGLU>(acc, smem + wave * EPI_STRIP, C, M, N, ldc, bias, res, ldr, flags, m0 + wm * 128, n0 + wn * 64, lane);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 256x256 "ring16" kernel (round 3): the ring kernel's data path -- ten 16-KiB LDS slabs, buffer_load ... lds DMA with counted waits,
+// XCD-grouped tiles, K-split remainder round, LDS-transposed epilogue -- under the MFMA shape and wave layout the matrix pipe runs
+// coolest at: 4 waves x (128 x 128) of v_mfma_f32_16x16x32_bf16, accumulators pinned in 256 AGPRs, ONE wave per SIMD.
+// Why (profiles/r03_mfma_shape_probe.md): on random operands the chip is power limited, and with no global traffic at all the loop of
+// 32x32x16 MFMAs tops out at 1.75 PF in either wave layout while 16x16x32 reaches 1.89 PF fed from LDS at 128 x 128 per wave (2.0 PF
+// from registers): K = 32 per instruction halves the accumulator traffic per FLOP, and the 128 x 128 wave tile needs one third fewer
+// LDS fragment bytes per FLOP than 128 x 64 (which only pays once the MFMA itself is cheaper).  It is also the shape the vendor
+// library's own gfx950 kernels use.
+//
+// Per K-step (64 k) a wave issues 128 MFMAs in two halves (k 0-31, 32-63) of 8 x 8 blocks, 16 fragment reads per half (ds_read_b128
+// from the row-major slab image: lane (r = lane & 15, kg = lane >> 4) owns row r, k = 8 kg .. 8 kg + 7 -- the same XOR swizzle is
+// conflict-free for this access too; K-major operands: two ds_read_b64_tr_b16 per fragment) and 16 DMA pieces, every one of them in the
+// shadow of an MFMA.  Operands swapped as in the 8-wave kernel (a = B rows, b = A rows): a lane owns ONE output row and 4 consecutive
+// columns per 16 x 16 block.  Schedule of step t:
+//   half 0: MFMAs on fragments (t, k-half 0); shadows: read fragments (t, k-half 1), issue DMA (t+2: parts 0,1)
+//   lgkmcnt(0), vmcnt(8), s_barrier: every wave has read all of step t's slabs (free for refill) and step t+1 has landed everywhere
+//   half 1: MFMAs on fragments (t, k-half 1); shadows: read fragments (t+1, k-half 0), issue DMA (t+2: parts 2,3)
+// i.e. one barrier per K-step and a full K-step of lead for every slab, as before.
+template <int V> using ic_ = std::integral_constant<int, V>;
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(ic_<I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read_b128_v(bf16x8& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read_tr64_h(bf16x8& dst, unsigned addr, int h) {
+    // one transposing half read (4 k) into the low (h = 0) or high (h = 1) half of the 8-k fragment
+    if (h == 0) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(reinterpret_cast<gs16x4*>(&dst)[0]) : "v"(addr), "i"(OFF));
+    else asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(reinterpret_cast<gs16x4*>(&dst)[1]) : "v"(addr), "i"(OFF + 1024));
+}
+// accumulators live in AGPRs, updated in place: the compiler neither moves them nor pads hazards around these (the loop has none:
+// consecutive MFMAs never share an accumulator, fragment registers are rewritten only by LDS reads issued >= 16 MFMAs later)
+__device__ __forceinline__ void mfma16(f32x4& c, const bf16x8& a, const bf16x8& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+
+template <int NBN, int NBM, int NT>
+__device__ __forceinline__ void sk_store16(const f32x4 (&acc)[NBN][NBM], float* __restrict__ slab, int tid) {
+#pragma unroll
+    for (int i = 0; i < NBN; ++i)
+#pragma unroll
+        for (int j = 0; j < NBM; ++j) reinterpret_cast<f32x4*>(slab)[(i * NBM + j) * NT + tid] = acc[i][j];
+}
+template <int NBN, int NBM, int NT>
+__device__ __forceinline__ void sk_add16(f32x4 (&acc)[NBN][NBM], const float* __restrict__ slab, int tid) {
+#pragma unroll
+    for (int i = 0; i < NBN; ++i)
+#pragma unroll
+        for (int j = 0; j < NBM; ++j) {
+            const f32x4 v = reinterpret_cast<const f32x4*>(slab)[(i * NBM + j) * NT + tid];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] += v[e];
+        }
+}
+
+// NW = 4: 2 x 2 waves of 128 x 128 (one wave per SIMD, the coolest loop: variant 13); NW = 8: 2 x 4 waves of 128 x 64 (two waves per
+// SIMD: the 8-wave kernel's latency hiding and epilogue width under the 16x16x32 shape: variant 14)
+template <int NW, bool AKM, bool BKM, bool SWIGLU = false>
+__global__ __launch_bounds__(NW * 64) void gemm_nt_ring16_kernel(
+    const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C, int M, int N, int K, long lda, long ldb,
+    long ldc, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res, long ldr, int flags, int tiles_m, int tiles_n,
+    int full, int S, float* __restrict__ sk_slabs, unsigned int* __restrict__ sk_cnt) {
+    static_assert(NW == 4 || NW == 8, "4 waves of 128 x 128 or 8 waves of 128 x 64");
+    constexpr int NBM = 8, NBN = NW == 4 ? 8 : 4;          // 16 x 16 blocks per wave along M / N
+    constexpr int SLAB = 16384, RING = 10 * SLAB, PPW = 16 / NW, NMF = NBN * NBM;
+    __shared__ __attribute__((aligned(16))) char smem[RING];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = NW == 4 ? wave >> 1 : wave >> 2;        // A rows wm*128 .. +127  (slab part 2 wm)
+    const int wn = NW == 4 ? wave & 1 : wave & 3;          // B rows wn*(NBN*16) ..  (slab part 1 + 2 wnh, block offset wno)
+    const int wnh = NW == 4 ? wn : wn >> 1, wno = NW == 4 ? 0 : (wn & 1) * 4;
+
+    // workgroup -> unit, exactly as in the 8-wave kernel (XCD-contiguous tile ranges, K parts of the remainder tiles adjacent)
+    const int nk = (K + BK - 1) / BK;
+    const int bid = blockIdx.x;
+    int tile_id, part = 0;
+    if (bid < full) {
+        const int q = full >> 3, r = full & 7, xcd = bid & 7;
+        tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    } else {
+        const int j = bid - full, nu = gridDim.x - full, rem = nu / S;
+        const int q = nu >> 3, r = nu & 7, xcd = j & 7;
+        const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (j >> 3);
+        part = lin / rem;
+        tile_id = full + lin - part * rem;
+    }
+    const int t0 = (bid < full) ? 0 : (int)((long)nk * part / S);
+    const int t1 = (bid < full) ? nk : (int)((long)nk * (part + 1) / S);
+    const int GROUP = 8;
+    const int per_group = GROUP * tiles_n;
+    const int g = tile_id / per_group;
+    const int first_m = g * GROUP;
+    const int gsz = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+    const int in_g = tile_id - g * per_group;
+    const int m0 = (first_m + in_g % gsz) * 256, n0 = (in_g / gsz) * 256;
+    const int Kseg = (t1 * BK < K) ? t1 * BK : K;
+
+    f32x4 acc[NBN][NBM];       // acc[tn][tm]: block (n block tn, m block tm)
+#pragma unroll
+    for (int i = 0; i < NBN; ++i)
+#pragma unroll
+        for (int j = 0; j < NBM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // DMA pieces: slab (t, p) = 16 pieces of 1 KiB, pieces PPW*w .. PPW*w + PPW - 1 belong to wave w (descriptor + fixed lane offset +
+    // scalar K-step offset)
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)A, 0, (int)(unsigned)(((long)(AKM ? K : M) * lda) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)B, 0, (int)(unsigned)(((long)(BKM ? K : N) * ldb) * 2), 0x00020000);
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    unsigned voA[2][PPW], voB[2][PPW];
+    int kcA[PPW], kcB[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int piece = PPW * wave + j;
+        {   // row-major piece: 8 rows x 128 B, 16-B chunk swizzled with the row pair (slot = chunk ^ ((row >> 1) & 7))
+            const int rl = lane >> 3, fz = (piece * 4 + (rl >> 1)) & 7, chunk = (lane & 7) ^ fz;
+            if constexpr (!AKM) {
+                kcA[j] = chunk * 8;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    int grow = m0 + half * 128 + piece * 8 + rl;
+                    grow = grow < M ? grow : M - 1;
+                    voA[half][j] = (unsigned)(((long)grow * lda + chunk * 8) * 2);
+                }
+            }
+            if constexpr (!BKM) {
+                kcB[j] = chunk * 8;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    int grow = n0 + half * 128 + piece * 8 + rl;
+                    grow = grow < N ? grow : N - 1;
+                    voB[half][j] = (unsigned)(((long)grow * ldb + chunk * 8) * 2);
+                }
+            }
+        }
+        {   // K-major piece: 4 k-rows x 256 B; LDS slot s of k-row kk holds the 16-B chunk s ^ ((kk & 3) << 2) ^ (((kk >> 3) & 1) << 1):
+            // the 64-B segment index is XORed with kk & 3 (the four k-rows of one transposing read land on the four quarters of a
+            // bank row) and the 32-B half with bit 3 of kk (the two k-groups that share an LDS cycle land on different halves)
+            const int kk = piece * 4 + (lane >> 4), slot = lane & 15, cc = slot ^ ((kk & 3) << 2) ^ (((kk >> 3) & 1) << 1);
+            if constexpr (AKM) {
+                kcA[j] = kk;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const long col = (long)m0 + half * 128 + cc * 8;
+                    voA[half][j] = (col + 8 <= lda) ? (unsigned)(((long)kk * lda + col) * 2) : OOB;
+                }
+            }
+            if constexpr (BKM) {
+                kcB[j] = kk;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const long col = (long)n0 + half * 128 + cc * 8;
+                    voB[half][j] = (col + 8 <= ldb) ? (unsigned)(((long)kk * ldb + col) * 2) : OOB;
+                }
+            }
+        }
+    }
+    // ring arithmetic on byte offsets, scalar and incremental (no division in the loop): slab (t, p) lives at wrap(base(t) + p*SLAB),
+    // base(t) = ((4 t) mod 10) * SLAB relative to this unit's first step (any consistent mapping will do: the ring is private)
+    auto wrap = [](unsigned x) {
+        x = x >= (unsigned)RING ? x - RING : x;
+        return x >= (unsigned)RING ? x - RING : x;
+    };
+    const unsigned soA1 = AKM ? (unsigned)(BK * 2) * (unsigned)lda : (unsigned)(BK * 2);      // K-step advance of the scalar offset
+    const unsigned soB1 = BKM ? (unsigned)(BK * 2) * (unsigned)ldb : (unsigned)(BK * 2);
+    const unsigned wave_dst = (unsigned)(PPW * wave) * 1024u;
+    // one DMA piece: part P (compile-time) of the step whose slab offset is `doff`, K-step scalar offsets soa / sob, `krem` k left
+    auto issue1 = [&](auto pc, int j, unsigned doff, unsigned soa, unsigned sob, int krem) {
+        constexpr int p = decltype(pc)::value, half = p >> 1;
+        lds_void* d = (lds_void*)(smem + doff + wave_dst + j * 1024);
+        if constexpr (p & 1) {
+            const unsigned vo = (kcB[j] < krem) ? voB[half][j] : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, d, 16, vo, sob, 0, 0);
+        } else {
+            const unsigned vo = (kcA[j] < krem) ? voA[half][j] : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, d, 16, vo, soa, 0, 0);
+        }
+    };
+    {   // prologue: steps t0 (slabs 0-3) and t0 + 1 (slabs 4-7), all four parts each
+        const unsigned a0 = (unsigned)t0 * soA1, b0 = (unsigned)t0 * soB1;
+        const int kr = Kseg - t0 * BK;
+        static_for<0, 4>([&](auto pc) {
+#pragma unroll
+            for (int j = 0; j < PPW; ++j) issue1(pc, j, decltype(pc)::value * SLAB, a0, b0, kr);
+        });
+        static_for<0, 4>([&](auto pc) {
+#pragma unroll
+            for (int j = 0; j < PPW; ++j) issue1(pc, j, (4 + decltype(pc)::value) * SLAB, a0 + soA1, b0 + soB1, kr - BK);
+        });
+    }
+
+    // fragment addresses.  Row-major image: lane (r, kg) reads 16 B of row blk*16 + r at chunk kh*4 + kg, swizzled with (r >> 1) & 7
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned r16 = (unsigned)lane & 15u, kg = (unsigned)lane >> 4;
+    unsigned xo[2];
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) xo[kh] = r16 * 128u + ((((unsigned)(kh * 4) + kg) ^ ((r16 >> 1) & 7u)) << 4);
+    // K-major image [64 k][128 rows]: lane s = lane & 15 of k-group kg addresses k-row kh*32 + kg*8 + h*4 + (s >> 2), 8 B at row
+    // blk*16 + (s & 3)*4: + (((blk >> 1) ^ kj) << 6) + (((blk & 1) ^ (kg & 1)) << 5); immediates kh*8192 + h*1024
+    const unsigned kj = r16 >> 2;
+    const unsigned klane = kg * 2048u + kj * 256u + (r16 & 3u) * 8u;
+    unsigned kxa[AKM ? NBM : 1], kxb[BKM ? NBN : 1];
+    if constexpr (AKM) {
+#pragma unroll
+        for (int i = 0; i < NBM; ++i) kxa[i] = klane + ((((unsigned)(i >> 1)) ^ kj) << 6) + ((((unsigned)(i & 1)) ^ (kg & 1u)) << 5);
+    }
+    if constexpr (BKM) {
+#pragma unroll
+        for (int i = 0; i < NBN; ++i) {
+            const unsigned blk = (unsigned)(wno + i);
+            kxb[i] = klane + (((blk >> 1) ^ kj) << 6) + (((blk & 1u) ^ (kg & 1u)) << 5);
+        }
+    }
+    const unsigned b_row_off = BKM ? 0u : (unsigned)wno * 2048u;      // row-major image: the wave's first B block inside the slab
+
+    bf16x8 fa[2][NBM], fb[2][NBN];
+    // memory op OP of the fragment set (step slabs a_base / b_base, k-half KH) into buffer BUF: B fragments first.  Every index is a
+    // template-level constant (static_for / integral_constant): the accumulator and fragment arrays must never see a dynamic index, or
+    // they leave the register file -- a pragma-unrolled loop gave that guarantee only up to the unroller's size heuristics
+    constexpr int OPS_B = BKM ? 2 * NBN : NBN, OPS_A = AKM ? 2 * NBM : NBM, NOPS = OPS_A + OPS_B;
+    auto frag_op = [&](auto opc, auto khc, auto bufc, unsigned a_base, unsigned b_base) {
+        constexpr int op = decltype(opc)::value, kh = decltype(khc)::value, buf = decltype(bufc)::value;
+        if constexpr (op < OPS_B) {
+            if constexpr (BKM) lds_read_tr64_h<kh * 8192>(fb[buf][op >> 1], b_base + kxb[op >> 1], op & 1);
+            else lds_read_b128_v<op * 2048>(fb[buf][op], b_base + xo[kh]);
+        } else {
+            constexpr int o = op - OPS_B;
+            if constexpr (AKM) lds_read_tr64_h<kh * 8192>(fa[buf][o >> 1], a_base + kxa[o >> 1], o & 1);
+            else lds_read_b128_v<o * 2048>(fa[buf][o], a_base + xo[kh]);
+        }
+    };
+    // one half of a K-step: NMF MFMAs on buffer BUF; the next fragment set (slabs na / nb_, k-half NKH) is read into the other buffer in
+    // the shadows of the first three quarters of them (op o rides in shadow o * SL / NOPS), and 2 * PPW DMA pieces -- parts P0, P0 + 1 of
+    // the step two ahead, slab offsets d0 / d1 -- in the shadows 5, 12, 19, ...
+    constexpr int SL = NMF * 3 / 4;
+    auto half_step = [&](auto bufc, auto nkhc, auto p0c, unsigned na, unsigned nb_, unsigned d0, unsigned d1, unsigned soa, unsigned sob,
+                         int krem) {
+        constexpr int buf = decltype(bufc)::value, p0 = decltype(p0c)::value;
+        static_for<0, NMF>([&](auto ic) {
+            constexpr int i = decltype(ic)::value, tn = i / NBM, tm = i % NBM;
+            mfma16(acc[tn][tm], fb[buf][tn], fa[buf][tm]);
+            if constexpr (i < SL) {
+                constexpr int o0 = (i * NOPS + SL - 1) / SL, o1 = ((i + 1) * NOPS + SL - 1) / SL;      // ops with o * SL / NOPS == i
+                static_for<o0, (o1 < NOPS ? o1 : NOPS)>([&](auto oc) { frag_op(oc, nkhc, ic_<buf ^ 1>{}, na, nb_); });
+            }
+            if constexpr (i % 7 == 5 && i / 7 < 2 * PPW) {
+                constexpr int q = i / 7;
+                if constexpr (q < PPW) issue1(ic_<p0>{}, q, d0, soa, sob, krem);
+                else issue1(ic_<p0 + 1>{}, q - PPW, d1, soa, sob, krem);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+
+    if constexpr (NW == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // step t0 landed (this wave's pieces); step t0 + 1 may
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                          // still be in flight
+    __builtin_amdgcn_s_barrier();
+    const unsigned a_part = (unsigned)(2 * wm) * SLAB, b_part = (unsigned)(1 + 2 * wnh) * SLAB;
+    static_for<0, NOPS>([&](auto oc) { frag_op(oc, ic_<0>{}, ic_<0>{}, lds0 + a_part, lds0 + b_part + b_row_off); });
+    unsigned base = 0;                                             // slab offset of step t, part 0
+    unsigned soa = (unsigned)(t0 + 2) * soA1, sob = (unsigned)(t0 + 2) * soB1;      // scalar offsets of step t + 2
+    int krem = Kseg - (t0 + 2) * BK;
+    for (int t = t0; t < t1; ++t) {
+        const unsigned a_base = lds0 + wrap(base + a_part), b_base = lds0 + wrap(base + b_part) + b_row_off;
+        const unsigned a_next = lds0 + wrap(base + 4 * SLAB + a_part), b_next = lds0 + wrap(base + 4 * SLAB + b_part) + b_row_off;
+        const unsigned d0 = wrap(base + 8 * SLAB), d1 = wrap(base + 9 * SLAB), d2 = base, d3 = wrap(base + SLAB);   // (t+2: 0..3)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // fragments (t, k-half 0)
+        __builtin_amdgcn_sched_barrier(0);
+        half_step(ic_<0>{}, ic_<1>{}, ic_<0>{}, a_base, b_base, d0, d1, soa, sob, krem);
+        // every fragment read of step t has returned and, with this wave's pieces of step t + 1 landed (all but the 2 PPW newest,
+        // (t+2: 0,1)), the barrier makes step t + 1 visible and step t's slabs free
+        if constexpr (NW == 4) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        half_step(ic_<1>{}, ic_<0>{}, ic_<2>{}, a_next, b_next, d2, d3, soa, sob, krem);
+        base = wrap(base + 4 * SLAB);
+        soa += soA1;
+        sob += soB1;
+        krem -= BK;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");           // the last MFMAs' results are read as soon as the epilogue starts
+    __syncthreads();                                             // every wave's fragment reads done: the LDS becomes epilogue scratch
+
+    if (bid >= full) {
+        const int rt = tile_id - full;
+        float* slabs = sk_slabs + (size_t)rt * S * SK_SLAB_FLOATS;
+        sk_store16<NBN, NBM, NW * 64>(acc, slabs + (size_t)part * SK_SLAB_FLOATS, tid);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned int ticket = __hip_atomic_fetch_add(sk_cnt + rt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ticket == (unsigned)(S - 1)) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __hip_atomic_store(sk_cnt + rt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            *reinterpret_cast<volatile unsigned int*>(smem) = ticket;
+        }
+        __syncthreads();
+        const unsigned int ticket = *reinterpret_cast<volatile unsigned int*>(smem);
+        if (__builtin_amdgcn_readfirstlane(ticket) != (unsigned)(S - 1)) return;
+        __syncthreads();
+        if (S == 2) {
+            sk_add16<NBN, NBM, NW * 64>(acc, slabs + (size_t)(part ^ 1) * SK_SLAB_FLOATS, tid);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NBN; ++i)
+#pragma unroll
+                for (int j = 0; j < NBM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int p = 0; p < S; ++p) sk_add16<NBN, NBM, NW * 64>(acc, slabs + (size_t)p * SK_SLAB_FLOATS, tid);
+        }
+    }
+    // epilogue: the wave tile goes through the wave-private strip in 64 x 64 passes.  Block (tn, tm): lane l holds row tm*16 + (l & 15),
+    // columns tn*16 + 4*(l >> 4) .. + 3 -> one 16-B strip write per block (8 consecutive lanes = 8 rows of pitch 272 B: conflict-free)
+    char* strip = smem + wave * EPI_STRIP;
+    const int mw0 = m0 + wm * 128, nw0 = n0 + wn * (NBN * 16);
+#pragma unroll
+    for (int pm = 0; pm < 2; ++pm)
+#pragma unroll
+        for (int pn = 0; pn < NBN / 4; ++pn) {
+#pragma unroll
+            for (int tm4 = 0; tm4 < 4; ++tm4)
+#pragma unroll
+                for (int tn4 = 0; tn4 < 4; ++tn4)
+                    *reinterpret_cast<f32x4*>(strip + (tm4 * 16 + (lane & 15)) * EPI_PITCH + (tn4 * 16 + 4 * (lane >> 4)) * 4) =
+                        acc[pn * 4 + tn4][pm * 4 + tm4];
+            epi_readback64<SWIGLU>(strip, C, M, N, ldc, bias, res, ldr, flags, mw0 + pm * 64, nw0 + pn * 64, lane);
+        }
+}
+
 // split-K workspace (caller-owned, see mantis_gemm_workspace_bytes): [ticket counters: (#CU + 1) u32, padded to 256 B][#CU fp32
 // slabs of 256 x 256].  Zero-initialised by the caller ONCE; every launch leaves the counters at zero (the last arriver of a
 // tile resets its ticket), so one workspace serves any number of stream-ordered launches.  No allocation, no global state here.
@@ -813,7 +1169,13 @@ static int gemm_pick_variant(int M, int N, int K) {
     return ring <= gen ? 12 : 1;
 }
 
-template <bool AKM, bool BKM, bool SWIGLU = false>
+// ring kernel per shape (measured, profiles/r03_gemm_ring_variants.md)
+static int ring_variant_for(int M, int N, int K, bool akm, bool bkm) {
+    (void)M; (void)N; (void)K; (void)akm; (void)bkm;
+    return 12;
+}
+
+template <bool AKM, bool BKM, bool SWIGLU = false, int R16 = 0>       // R16: 0 = the 32x32x16 kernel, 4 / 8 = ring16 with that many waves
 static int launch_gemm_ring(hipStream_t s, const bf16_t* A, const bf16_t* B, bf16_t* C, int M, int N, int K, long lda, long ldb,
                             long ldc, const bf16_t* bias, const bf16_t* res, long ldr, int flags, void* ws, long ws_bytes) {
     const int tiles_m = cdiv(M, 256), tiles_n = cdiv(N, 256), nk = cdiv(K, BK);
@@ -830,9 +1192,25 @@ static int launch_gemm_ring(hipStream_t s, const bf16_t* A, const bf16_t* B, bf1
         cnt = (unsigned int*)ws;
         slabs = (float*)((char*)ws + sk_cnt_bytes(cus));
     }
-    MANTIS_LAUNCH((gemm_nt_ring_kernel<AKM, BKM, SWIGLU>), dim3(grid), dim3(512), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias, res, ldr, flags,
-                       tiles_m, tiles_n, full, S, slabs, cnt);
+    if constexpr (R16 != 0) {
+        MANTIS_LAUNCH((gemm_nt_ring16_kernel<R16, AKM, BKM, SWIGLU>), dim3(grid), dim3(R16 * 64), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias,
+                           res, ldr, flags, tiles_m, tiles_n, full, S, slabs, cnt);
+    } else {
+        MANTIS_LAUNCH((gemm_nt_ring_kernel<AKM, BKM, SWIGLU>), dim3(grid), dim3(512), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias, res, ldr, flags,
+                           tiles_m, tiles_n, full, S, slabs, cnt);
+    }
     return mantis_check_launch();
+}
+
+// which ring kernel the automatic choice takes (read once): MANTIS_GEMM_RING = 12 (8 waves, 32x32x16), 13 (4 waves x 128x128, 16x16x32) or
+// 14 (8 waves x 128x64, 16x16x32) -- A/B measurements; the default is the measured per-shape choice of ring_variant_for()
+static int default_ring_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MANTIS_GEMM_RING");
+        v = (e && e[0] == '1' && e[1] >= '2' && e[1] <= '4' && e[2] == 0) ? 10 + (e[1] - '0') : 0;
+    }
+    return v;
 }
 
 extern "C" {
@@ -874,39 +1252,49 @@ int mantis_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, 
     }
     hipStream_t s = (hipStream_t)stream;
     int variant = (flags & EPI_VARIANT_MASK) >> EPI_VARIANT_SHIFT;
-    if (variant == 0) variant = (flags & EPI_SWIGLU_BWD) ? 12 : gemm_pick_variant(M, N, K);
-    if ((flags & EPI_SWIGLU_BWD) && (variant != 12 || akm || !bkm)) return MANTIS_EUNSUPPORTED;
-    // the ring kernel addresses its operands through buffer descriptors: unsigned 32-bit num_records, unsigned 32-bit lane offset and
+    // variant 12 = the 8-wave ring kernel (32x32x16 MFMA), 13 / 14 = the ring16 kernel (16x16x32 MFMA) with 4 / 8 waves: same tile, same
+    // work split, same results up to the accumulation order inside a K-step
+    if (variant == 0) {
+        variant = (flags & EPI_SWIGLU_BWD) ? 12 : gemm_pick_variant(M, N, K);
+        if (variant == 12) variant = default_ring_variant() ? default_ring_variant() : ring_variant_for(M, N, K, akm, bkm);
+    }
+    const bool ring = variant >= 12 && variant <= 14, big = variant == 2;
+    if ((flags & EPI_SWIGLU_BWD) && (!ring || akm || !bkm)) return MANTIS_EUNSUPPORTED;
+    // the ring kernels address their operands through buffer descriptors: unsigned 32-bit num_records, unsigned 32-bit lane offset and
     // unsigned 32-bit scalar K-step offset (the hardware adds them to the 48-bit base without wrapping).  An operand of 4 GiB or more
-    // would wrap silently -> such shapes go to the generic kernel (64-bit addresses) when the choice is ours, and are refused when the
+    // would wrap silently -> such shapes go to the generic kernel (64-bit addresses) when the choice is ours, and are refused when a
     // ring kernel was asked for explicitly.  (The first guard stood at 2 GiB; the lm_head logits of 8192 rows x 152064 columns, 2.5 GB,
     // then fell to the generic kernel at 0.34 PFLOP/s.  `gemm_operand_over_2gib` checks the 2-4 GiB range against the generic kernel.)
-    if (variant == 12) {
+    if (ring) {
         const long a_bytes = (long)(akm ? K : M) * (long)lda * 2, b_bytes = (long)(bkm ? K : N) * (long)ldb * 2;
         const long lim = (1L << 32) - (1L << 16);
         if (a_bytes >= lim || b_bytes >= lim) {
             if ((flags & EPI_VARIANT_MASK) || (flags & EPI_SWIGLU_BWD)) return MANTIS_EUNSUPPORTED;
             variant = 1;
+            return mantis_gemm_bf16_nt(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, flags | (1 << EPI_VARIANT_SHIFT), workspace,
+                                       workspace_bytes, stream);
         }
     }
 #define GEMM_ARGS s, (const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C, M, N, K, (long)lda, (long)ldb, (long)ldc, \
                   (const bf16_t*)bias, (const bf16_t*)residual, (long)ldr, flags
 #define RING_ARGS GEMM_ARGS, workspace, (long)workspace_bytes
-    // variant 1 = 128x128 generic kernel, 2 = 256x256 generic kernel, 12 = 256x256 ring kernel (default for well-quantised shapes)
-    const bool ring = variant == 12, big = variant == 2;
+    // variant 1 = 128x128 generic kernel, 2 = 256x256 generic kernel, 12 / 13 = 256x256 ring kernels (default for well-quantised shapes)
     if (!ring && !big && variant != 1) return MANTIS_EINVAL;
+#define RING_DISPATCH(AK, BK_, SW) (variant == 13 ? launch_gemm_ring<AK, BK_, SW, 4>(RING_ARGS) \
+                                    : variant == 14 ? launch_gemm_ring<AK, BK_, SW, 8>(RING_ARGS) : launch_gemm_ring<AK, BK_, SW, 0>(RING_ARGS))
     if (akm && bkm)
-        return ring ? launch_gemm_ring<true, true>(RING_ARGS)
+        return ring ? RING_DISPATCH(true, true, false)
                     : big ? launch_gemm<256, 256, 128, 64, true, true>(GEMM_ARGS) : launch_gemm<128, 128, 64, 64, true, true>(GEMM_ARGS);
-    if (flags & EPI_SWIGLU_BWD) return launch_gemm_ring<false, true, true>(RING_ARGS);
+    if (flags & EPI_SWIGLU_BWD) return RING_DISPATCH(false, true, true);
     if (bkm)
-        return ring ? launch_gemm_ring<false, true>(RING_ARGS)
+        return ring ? RING_DISPATCH(false, true, false)
                     : big ? launch_gemm<256, 256, 128, 64, false, true>(GEMM_ARGS) : launch_gemm<128, 128, 64, 64, false, true>(GEMM_ARGS);
     if (akm)
-        return ring ? launch_gemm_ring<true, false>(RING_ARGS)
+        return ring ? RING_DISPATCH(true, false, false)
                     : big ? launch_gemm<256, 256, 128, 64, true, false>(GEMM_ARGS) : launch_gemm<128, 128, 64, 64, true, false>(GEMM_ARGS);
-    return ring ? launch_gemm_ring<false, false>(RING_ARGS)
+    return ring ? RING_DISPATCH(false, false, false)
                 : big ? launch_gemm<256, 256, 128, 64, false, false>(GEMM_ARGS) : launch_gemm<128, 128, 64, 64, false, false>(GEMM_ARGS);
+#undef RING_DISPATCH
 #undef RING_ARGS
 #undef GEMM_ARGS
 }

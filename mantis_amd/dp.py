@@ -49,6 +49,11 @@ class GradReducer:
         self._force = os.environ.get("MANTIS_DP_FORCE") == "1" and dist.is_initialized()
         self.stats = dict(steps=0, buckets=0, bytes=0, exposed_ms=[])
         self._wait_events = []
+        if self.active and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 8:
+            import warnings
+            warnings.warn("GPU_MAX_HW_QUEUES < 8: RCCL's stream may share a hardware queue with the compute stream, which serialises the "
+                          "bucket collectives with the backward's kernels (no overlap; profiles/r03_dp_world1.md).  Import mantis_amd before "
+                          "the first GPU call, or export GPU_MAX_HW_QUEUES=8.")
 
     @property
     def active(self):

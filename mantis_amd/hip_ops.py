@@ -260,7 +260,7 @@ def linear_dx(dy, w, k=None):
     return gemm_nt(dy, wt, k=wt.shape[1] if k is None else k)
 
 
-def linear_dx_swiglu(dy, w_down, gu):
+def linear_dx_swiglu(dy, w_down, gu, variant=0):
     """dgu[M, 2I] = swiglu_bwd(dy[M, d] @ w_down[d, I], gu[M, 2I]) in one launch: the SwiGLU backward runs in the GEMM epilogue
     (the [M, I] activation gradient never goes to HBM)."""
     _chk2d(dy, "dy"), _chk2d(w_down, "w_down"), _chk2d(gu, "gu")
@@ -275,7 +275,7 @@ def linear_dx_swiglu(dy, w_down, gu):
         e0.record()
     wsp, wsn = _gemm_workspace()
     rc = _L.mantis_gemm_bf16_nt(_p(dy), dy.stride(0), _p(w_down), w_down.stride(0), _p(dgu), dgu.stride(0), M, I, d, None, _p(gu),
-                                gu.stride(0), 64 | 8192, wsp, wsn, _stream())
+                                gu.stride(0), 64 | 8192 | (variant << 8), wsp, wsn, _stream())
     _lib.check(rc, f"gemm+swiglu_bwd M={M} I={I} d={d}")
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
@@ -404,10 +404,12 @@ def attn_fwd_qkv(q, k, v, B, Lseq, H, Hkv, hd, kmask, scale, causal, want_lse=Tr
     return o, lse
 
 
-def attn_bwd_qkv(q, k, v, o, do, lse, dq, dk, dv, B, Lseq, H, Hkv, hd, kmask, scale, causal, kstart=None, qend=None):
-    """Gradients w.r.t. q, k, v written into the given row views dq [B*L, H*hd], dk / dv [B*L, Hkv*hd] (any row stride)."""
+def attn_bwd_qkv(q, k, v, o, do, lse, dq, dk, dv, B, Lseq, H, Hkv, hd, kmask, scale, causal, kstart=None, qend=None, no_workspace=False):
+    """Gradients w.r.t. q, k, v written into the given row views dq [B*L, H*hd], dk / dv [B*L, Hkv*hd] (any row stride).
+    no_workspace (tests): withhold the per-query-head workspace, which holds GQA geometries to the group dK/dV kernel where it exists."""
     dsum = torch.empty((B, H, Lseq), dtype=torch.float32, device=q.device)     # rowsum(dO * O): filled by the dQ kernel
-    ws = torch.empty((2, B * Lseq, H * hd), dtype=BF16, device=q.device) if _L.mantis_attn_bwd_needs_workspace(H, Hkv, hd) else None
+    ws = torch.empty((2, B * Lseq, H * hd), dtype=BF16, device=q.device) if (_L.mantis_attn_bwd_needs_workspace(H, Hkv, hd) and
+                                                                              not no_workspace) else None
     rc = _L.mantis_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(do), _p(kmask), _p(kstart), _p(qend), _p(lse), _p(dsum), _p(dq), _p(dk),
                             _p(dv), _p(ws), B, Lseq,
                             H, Hkv, hd, q.stride(0), k.stride(0), v.stride(0), o.stride(0), do.stride(0), dq.stride(0), dk.stride(0),
@@ -427,12 +429,13 @@ def attn_fwd(qkv, B, Lseq, H, Hkv, hd, kmask, scale, causal, want_lse=True, ksta
     return attn_fwd_qkv(q, k, v, B, Lseq, H, Hkv, hd, kmask, scale, causal, want_lse, kstart=kstart)
 
 
-def attn_bwd(qkv, o, do, lse, B, Lseq, H, Hkv, hd, kmask, scale, causal, kstart=None, qend=None):
+def attn_bwd(qkv, o, do, lse, B, Lseq, H, Hkv, hd, kmask, scale, causal, kstart=None, qend=None, no_workspace=False):
     """Returns dqkv [B*L, (H+2Hkv)*hd] (gradient w.r.t. the post-RoPE q, k and v)."""
     dqkv = torch.empty_like(qkv)
     q, k, v = _split_qkv(qkv, H, Hkv, hd)
     dq, dk, dv = _split_qkv(dqkv, H, Hkv, hd)
-    attn_bwd_qkv(q, k, v, o, do, lse, dq, dk, dv, B, Lseq, H, Hkv, hd, kmask, scale, causal, kstart=kstart, qend=qend)
+    attn_bwd_qkv(q, k, v, o, do, lse, dq, dk, dv, B, Lseq, H, Hkv, hd, kmask, scale, causal, kstart=kstart, qend=qend,
+                 no_workspace=no_workspace)
     return dqkv
 
 

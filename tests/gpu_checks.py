@@ -41,7 +41,7 @@ GEMM_SHAPES = [(128, 128, 64), (32, 32, 16), (54, 64, 64), (300, 200, 72), (257,
                (520, 1152, 4304), (1024, 302, 256), (77, 40, 8)]
 
 
-def check_gemm(M, N, K_, flags="plain"):
+def check_gemm(M, N, K_, flags="plain", variant=0):
     k = K()
     a, b = rnd(M, K_, seed=1), rnd(N, K_, seed=2, scale=0.1)
     bias = rnd(N, seed=3) if "bias" in flags else None
@@ -49,8 +49,8 @@ def check_gemm(M, N, K_, flags="plain"):
     act = {"gelu": "gelu", "tanh": "gelu_pytorch_tanh", "quick": "quick_gelu"}.get(flags.split("+")[-1]) if "+" in flags else None
     ref = R.gemm_nt(a, b, bias=bias, act=act, residual=res)
     out = k.gemm_nt(a.to(DEV), b.to(DEV), bias=None if bias is None else bias.to(DEV), act=act,
-                    residual=None if res is None else res.to(DEV))
-    return close(out, ref, 1e-2, f"gemm {M}x{N}x{K_} {flags}")
+                    residual=None if res is None else res.to(DEV), variant=variant)
+    return close(out, ref, 1e-2, f"gemm {M}x{N}x{K_} {flags} v{variant}")
 
 
 def check_gemm_accumulate_padded():
@@ -66,7 +66,7 @@ def check_gemm_accumulate_padded():
     return close(c[:, :N], ref[:, :N], 1e-2, "gemm accumulate, ldc > N, N % 4 != 0")
 
 
-def check_gemm_operand_over_2gib():
+def check_gemm_operand_over_2gib(ring=12):
     """Ring kernel with an operand between 2 and 4 GiB (32-bit unsigned buffer offsets): row-major A of 2.2 GB, and the same data read
     K-major, against the generic kernel's 64-bit addressing -- in particular the rows / k-rows that lie beyond the 2 GiB mark."""
     k = K()
@@ -76,15 +76,15 @@ def check_gemm_operand_over_2gib():
     assert a.numel() * 2 > (1 << 31)
     b = (torch.randn(N, Kk, device=DEV, generator=g, dtype=torch.float32) * 0.05).to(BF)
     ref = k.gemm_nt(a, b, variant=1)
-    out = k.gemm_nt(a, b, variant=12)
-    r1 = close(out, ref, 5e-3, "ring vs generic, A row-major > 2 GiB")
+    out = k.gemm_nt(a, b, variant=ring)
+    r1 = close(out, ref, 5e-3, f"ring v{ring} vs generic, A row-major > 2 GiB")
     close(out[-300:], ref[-300:], 5e-3, "rows beyond the 2 GiB mark")
     # the same buffer as a K-major operand: C2[Kk-part, N2] = a^T-view . w ; take A = a as [K'=M, M'=Kk] K-major with a narrow M' window
     a2 = a[:, :1024]                                     # [K' = 8448, M' = 1024], row stride 131072: the window's last rows lie > 2 GiB in
     w = (torch.randn(N, M, device=DEV, generator=g, dtype=torch.float32) * 0.05).to(BF)      # [N, K']
     ref2 = k.gemm_nt(a2, w, a_kmajor=True, variant=1)
-    out2 = k.gemm_nt(a2, w, a_kmajor=True, variant=12)
-    return max(r1, close(out2, ref2, 5e-3, "ring vs generic, A K-major spanning > 2 GiB"))
+    out2 = k.gemm_nt(a2, w, a_kmajor=True, variant=ring)
+    return max(r1, close(out2, ref2, 5e-3, f"ring v{ring} vs generic, A K-major spanning > 2 GiB"))
 
 
 def check_transpose():
@@ -134,12 +134,20 @@ def check_linear_dx_swiglu(M, d, I):
     dy, w, gu = rnd(M, d, seed=21), rnd(d, I, seed=22, scale=0.1), rnd(M, 2 * I, seed=23)
     fused = k.linear_dx_swiglu(dy.to(DEV), w.to(DEV), gu.to(DEV))
     r = close(fused, R.linear_dx_swiglu(dy, w, gu), 1e-2, f"linear_dx_swiglu {M}x{d}x{I}")
-    unfused = k.swiglu_bwd(k.gemm_nt(dy.to(DEV), w.to(DEV), b_kmajor=True, variant=12), gu.to(DEV))
-    assert torch.equal(fused, unfused), "fused SwiGLU-backward epilogue differs from GEMM + swiglu_bwd"
+    # the same main loop without the fused epilogue, per ring kernel (the 16x16x32 and 32x32x16 MFMA shapes sum k in a different order,
+    # so each fused form is compared with the unfused launch of the SAME variant); the automatic choice must be one of them
+    gud, dyd, wd = gu.to(DEV), dy.to(DEV), w.to(DEV)
+    same = []
+    for v in (12, 13, 14):
+        f_v = k.linear_dx_swiglu(dyd, wd, gud, variant=v)
+        unfused = k.swiglu_bwd(k.gemm_nt(dyd, wd, b_kmajor=True, variant=v), gud)
+        assert torch.equal(f_v, unfused), f"fused SwiGLU-backward epilogue (ring variant {v}) differs from GEMM + swiglu_bwd"
+        same.append(torch.equal(f_v, fused))
+    assert any(same), "the automatic fused launch equals none of the ring variants"
     return r
 
 
-def check_gemm_ksplit_deterministic():
+def check_gemm_ksplit_deterministic(ring=12):
     """Shapes whose last tile round is incomplete run the K-split path (slab reduction by the last arriver): results must not
     depend on which workgroup arrives last -> repeated launches are bit-identical, and agree with the oracle; S = 2 and S > 2."""
     k = K()
@@ -149,9 +157,9 @@ def check_gemm_ksplit_deterministic():
                        (2816, 2816, 2048)):     # 121 tiles -> S = 2
         a, b = rnd(M, K_, seed=31), rnd(N, K_, seed=32, scale=0.1)
         ad, bd = a.to(DEV), b.to(DEV)
-        outs = [k.gemm_nt(ad, bd, variant=12) for _ in range(4)]
+        outs = [k.gemm_nt(ad, bd, variant=ring) for _ in range(4)]
         for o in outs[1:]:
-            assert torch.equal(o, outs[0]), f"K-split GEMM {M}x{N}x{K_} is not bitwise reproducible"
+            assert torch.equal(o, outs[0]), f"K-split GEMM v{ring} {M}x{N}x{K_} is not bitwise reproducible"
         worst = max(worst, close(outs[0][:300], R.gemm_nt(a[:300], b), 1e-2, f"gemm k-split {M}x{N}x{K_}"))
         assert k._L.mantis_gemm_pick_variant(M, N, K_) in (1, 12)
     return worst
@@ -1373,6 +1381,105 @@ def check_attn_fullsize(mask):
     return worst
 
 
+def _attn_vs_oracle_per_sample(B, L, H, Hkv, hd, causal, km, ks, qe, tag, backward=True, no_workspace=False, seed=91):
+    """Attention forward (+ backward) at full size vs the oracle on ALL rows, one sample at a time on the host (bounds the oracle's
+    [H, L, L] fp32 temporaries)."""
+    k = K()
+    qkv = rnd(B * L, (H + 2 * Hkv) * hd, seed=seed)
+    do = rnd(B * L, H * hd, seed=seed + 1)
+    if km is not None:
+        do = do * km.reshape(B * L, 1).to(BF)
+    scale = hd ** -0.5
+    dev = lambda t: None if t is None else t.to(DEV)
+    qd = qkv.to(DEV)
+    o, lse = k.attn_fwd(qd, B, L, H, Hkv, hd, dev(km), scale, causal, kstart=dev(ks))
+    d = k.attn_bwd(qd, o, do.to(DEV), lse, B, L, H, Hkv, hd, dev(km), scale, causal, kstart=dev(ks), qend=dev(qe),
+                   no_workspace=no_workspace).cpu() if backward else None
+    o, lse = o.cpu(), lse.cpu()
+    worst = 0.0
+    cuts = [0, H * hd, (H + Hkv) * hd, (H + 2 * Hkv) * hd]
+    for b in range(B):
+        rows = slice(b * L, (b + 1) * L)
+        kmb = None if km is None else km[b:b + 1]
+        ksb = None if ks is None else ks[b:b + 1]
+        oref, lref = R.attn_fwd(qkv[rows], 1, L, H, Hkv, hd, kmb, scale, causal, kstart=ksb)
+        valid = torch.ones(L, dtype=torch.bool) if kmb is None else kmb[0].bool()
+        worst = max(worst, close(o[rows][valid], oref[valid], 2e-2, f"attn_fwd {tag} b={b}"))
+        close(lse[b][:, valid], lref[0][:, valid], 2e-3, f"lse {tag}")
+        # per-row bound too: one wrong 128-row query tile must not hide in the global norm
+        e = (o[rows][valid].float() - oref[valid].float()).norm(dim=1) / (oref[valid].float().norm(dim=1) + 1e-20)
+        assert float(e.max()) < 6e-2, f"attn_fwd {tag}: worst row rel err {float(e.max()):.3e}"
+        if backward:
+            dref = R.attn_bwd(qkv[rows], oref, do[rows], lref, 1, L, H, Hkv, hd, kmb, scale, causal, kstart=ksb)
+            for i, n in enumerate(("dq", "dk", "dv")):
+                worst = max(worst, close(d[rows, cuts[i]:cuts[i + 1]], dref[:, cuts[i]:cuts[i + 1]], 3e-2, f"attn_bwd {n} {tag} b={b}"))
+            del dref
+        del oref, lref
+    return worst
+
+
+def check_attn_cfg5_decoder(B, no_workspace):
+    """BASELINE configs[4] decoder attention: Qwen2-7B geometry, GQA 28/4 x 128, causal, L = 4096, forward + backward on all rows.
+    (B = 2 with workspace: the group dK/dV kernel by grid size; B = 1 with workspace: the per-query-head dK/dV + group reduce;
+    B = 1 without: the group kernel forced) -- both sides of the dispatch decision in attn.hip launch_bwd."""
+    return _attn_vs_oracle_per_sample(B, 4096, 28, 4, 128, True, None, None, None, f"cfg5 decoder 28/4x128 L4096 B{B} ws={not no_workspace}",
+                                      no_workspace=no_workspace)
+
+
+def check_attn_cfg5_tower():
+    """BASELINE configs[4] tower attention: two 1288 x 952 images = 6256 patches each as a batch of 2, 16 heads x 80, non-causal
+    (the largest oracle case so far had L = 1000)."""
+    return _attn_vs_oracle_per_sample(2, 6256, 16, 16, 80, False, None, None, None, "cfg5 tower 16x80 L6256", backward=False)
+
+
+def check_attn_cfg4_packed_row():
+    """BASELINE configs[3] decoder attention on one packed 4096-token row (Mistral geometry 32/8 x 128): two samples of 2048 + 1900
+    tokens and a padded tail of 148 -- segment bounds + key mask, forward + backward on all rows."""
+    L = 4096
+    ks, qe = _segment_bounds(1, L, [[2048, 3948]])
+    km = torch.ones(1, L, dtype=torch.int32)
+    km[0, 3948:] = 0
+    return _attn_vs_oracle_per_sample(1, L, 32, 8, 128, True, km, ks, qe, "cfg4 packed row 32/8x128 L4096")
+
+
+def check_attn_cfg4_perceiver():
+    """BASELINE configs[3] perceiver attention at its own size: 16 images, 1024 context + 64 latent rows = 1088 keys, 16/4 heads x 96,
+    non-causal with a key mask (three images with padded patches), forward + backward."""
+    B, L = 16, 1088
+    km = torch.ones(B, L, dtype=torch.int32)
+    km[3, 700:1024] = 0
+    km[7, 512:1024] = 0
+    km[15, 1000:1024] = 0
+    return _attn_vs_oracle_per_sample(B, L, 16, 4, 96, False, km, None, None, "cfg4 perceiver 16/4x96 L1088 I16")
+
+
+QWEN_STEP_FP8_SHAPES = [  # (name, M, N, K, fmt_a, epi): the ten fp8 GEMMs of one Qwen2-7B decoder layer at 4096 tokens (profiles/r02_experiments.md)
+    ("qkv_fwd", 4096, 4608, 3584, 0, "bias"), ("o_fwd", 4096, 3584, 3584, 0, "res"), ("gu_fwd", 4096, 37888, 3584, 0, "plain"),
+    ("down_fwd", 4096, 3584, 18944, 0, "res"), ("dx_gu", 4096, 3584, 37888, 1, "plain"), ("dx_qkv", 4096, 3584, 4608, 1, "plain"),
+    ("dw_qkv", 4608, 3584, 4096, 1, "acc"), ("dw_o", 3584, 3584, 4096, 1, "acc"), ("dw_gu", 37888, 3584, 4096, 1, "acc"),
+    ("dw_down", 3584, 18944, 4096, 1, "acc")]
+
+
+def check_fp8_gemm_qwen_step_shape(name, M, N, K_, fmt_a, epi):
+    """The fp8 GEMM at one of the Qwen2-VL step's own shapes (auto dispatch: ring kernel + remainder strip) vs the oracle's restatement
+    on identical fp8 bytes, every row."""
+    k = K()
+    a, b = rnd(M, K_, seed=M + K_), rnd(N, K_, seed=N + K_ + 1, scale=0.05)
+    aq, bq = R.fp8_quantize(a, fmt_a, transposed=False), R.fp8_quantize(b, 0, transposed=False)
+    del a, b
+    bias = rnd(N, seed=3) if "bias" in epi else None
+    res = rnd(M, N, seed=4) if "res" in epi else None
+    c0 = rnd(M, N, seed=5) if "acc" in epi else None
+    ref = R.gemm_fp8_nt(aq.q, aq.dequant, bq.q, bq.dequant, fmt_a, bias=bias, residual=res, out=None if c0 is None else c0.clone(),
+                        accumulate=c0 is not None)
+    out = k.gemm_fp8_nt(aq.q.to(DEV), aq.dequant.to(DEV), bq.q.to(DEV), bq.dequant.to(DEV), fmt_a, bias=None if bias is None else bias.to(DEV),
+                        residual=None if res is None else res.to(DEV), out=None if c0 is None else c0.to(DEV), accumulate=c0 is not None)
+    r = close(out, ref, 5e-3, f"gemm_fp8 {name} {M}x{N}x{K_}")
+    err = (out.float().cpu() - ref.float()).norm(dim=1) / (ref.float().norm(dim=1) + 1e-30)
+    assert float(err.max()) < 2e-2, f"gemm_fp8 {name}: worst row rel err {float(err.max()):.3e} at row {int(err.argmax())}"
+    return r
+
+
 def check_gemm_fullsize(M, N, K_, a_km, b_km):
     """The 256x256 ring kernel (incl. its split-K remainder round) at the step's own shapes, ALL rows against the oracle."""
     k = K()
@@ -1464,6 +1571,18 @@ def all_checks():
         c[f"gemm_kmajor_{M}x{N}x{K_}_{int(akm)}{int(bkm)}_v{v}"] = (lambda M=M, N=N, K_=K_, akm=akm, bkm=bkm, v=v: check_gemm_kmajor(M, N, K_, akm, bkm, v))
     c["gemm_ksplit_deterministic"] = check_gemm_ksplit_deterministic
     c["gemm_operand_over_2gib"] = check_gemm_operand_over_2gib
+    # the 16x16x32 ring kernels asked for explicitly (13 = 4 waves x 128x128, 14 = 8 waves x 128x64): every operand layout at ragged
+    # M / N / K (K tails, one and two K-steps, M and N below one tile), every epilogue, the K-split reduction, operands beyond 2 GiB
+    for v in (13, 14):
+        for (M, N, K_, akm, bkm) in [(1000, 520, 333 * 8, True, True), (1000, 1152, 4304, False, True), (600, 520, 1000, True, False),
+                                     (520, 600, 1000, False, False), (304, 200, 72, True, True), (300, 200, 72, False, True),
+                                     (304, 200, 56, True, False), (77, 40, 8, False, False), (257, 388, 1152, False, False),
+                                     (1024, 302, 256, False, False), (520, 776, 136, True, True), (2816, 2304, 1152, True, True)]:
+            c[f"gemm_ring16_v{v}_{M}x{N}x{K_}_{int(akm)}{int(bkm)}"] = (lambda M=M, N=N, K_=K_, akm=akm, bkm=bkm, v=v: check_gemm_kmajor(M, N, K_, akm, bkm, v))
+        for f in ("bias", "bias+gelu", "bias+tanh", "bias+quick", "res", "bias+res"):
+            c[f"gemm_ring16_v{v}_epi_{f}"] = (lambda f=f, v=v: check_gemm(300, 200, 72, f, v))
+        c[f"gemm_ring16_v{v}_ksplit_deterministic"] = lambda v=v: check_gemm_ksplit_deterministic(v)
+        c[f"gemm_ring16_v{v}_operand_over_2gib"] = lambda v=v: check_gemm_operand_over_2gib(v)
     c["linear_dx_dw"] = check_linear_dx_dw
     c["linear_dx_swiglu_333x64x176"] = lambda: check_linear_dx_swiglu(333, 64, 176)
     c["linear_dx_swiglu_700x768x3072"] = lambda: check_linear_dx_swiglu(700, 768, 3072)
@@ -1545,6 +1664,16 @@ def all_checks():
                                  (2 * I, d, M, True, True),          # dW of gate|up (TN: both activations K-major)
                                  (d, I, M, True, True)]:             # dW of down_proj (TN)
         c[f"fullsize_gemm_{m}x{n}x{k_}_{int(akm)}{int(bkm)}"] = (lambda m=m, n=n, k_=k_, akm=akm, bkm=bkm: check_gemm_fullsize(m, n, k_, akm, bkm))
+    # BASELINE configs[3] / [4] shapes against the oracle (round-2 verdict: the cfg4 / cfg5 analogue of the cfg2 fullsize_* checks)
+    c["fullsize_attn_cfg5_decoder_b2"] = lambda: check_attn_cfg5_decoder(2, False)
+    c["fullsize_attn_cfg5_decoder_b1_perhead"] = lambda: check_attn_cfg5_decoder(1, False)
+    c["fullsize_attn_cfg5_decoder_b1_group_forced"] = lambda: check_attn_cfg5_decoder(1, True)
+    c["fullsize_attn_cfg5_tower"] = check_attn_cfg5_tower
+    c["fullsize_attn_cfg4_packed_row"] = check_attn_cfg4_packed_row
+    c["fullsize_attn_cfg4_perceiver"] = check_attn_cfg4_perceiver
+    for a in QWEN_STEP_FP8_SHAPES:
+        c[f"fullsize_fp8_gemm_{a[0]}"] = (lambda a=a: check_fp8_gemm_qwen_step_shape(*a))
+    c["fullsize_fp8_dx_swiglu_4096x3584x18944"] = lambda: check_fp8_dx_swiglu(4096, 3584, 18944, 1)
     c["fullsize_linear_dx_swiglu"] = check_linear_dx_swiglu_fullsize
     c["fullsize_ce_128258"] = check_ce_fullsize
     c["fullsize_rmsnorm_5624x4096"] = check_rmsnorm_fullsize
