@@ -109,6 +109,19 @@ int mantis_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, 
  * ring kernel's deterministic split-K remainder round uses it; every launch leaves it zeroed-for-reuse, so one buffer per stream
  * serves all stream-ordered launches).  M = N = K = 0: the largest requirement of any shape on the current device (~64 MB). */
 int mantis_gemm_workspace_bytes(int M, int N, int K);
+/* Forward projections with a two-column epilogue fused in (16x16x32 ring kernels 13 / 14, NT layout).
+ *   mode 1 (SwiGLU): B = [gate | up] weight [2 I, K], N = 2 I: C = A . B^T [M, 2 I] exactly as mantis_gemm_bf16_nt writes it AND
+ *                    aux0 = silu(gate) * up [M, I] (bf16, row stride aux_ld) exactly as mantis_swiglu_fwd computes it (replaces
+ *                    transformers LlamaMLP's act_fn(gate_proj(x)) * up_proj(x), modeling_llama.py:163-176, as ONE launch)
+ *   mode 2 (RoPE):   q|k|v projection, heads of 128 columns, optional bias: columns [0, aux_n) leave with the rotary embedding applied
+ *                    (aux0 = cos, aux1 = sin, bf16 [M, 64], row stride aux_ld), exactly as mantis_rope_apply(backward = 0) would
+ *                    rotate them in a second pass (apply_rotary_pos_emb, modeling_llama.py:138-160)
+ * variant 0 = per-shape choice, 13 / 14 forced.  MANTIS_EUNSUPPORTED for shapes outside the fused kernels' conditions (N % 256, I % 128,
+ * aux_n % 128, 16-B alignment, operands < 4 GiB): the caller then issues the two launches. */
+int mantis_gemm_bf16_nt_fused(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
+                              const void* bias /*nullable*/, int mode, void* aux0, const void* aux1 /*mode 2*/, int64_t aux_ld, int aux_n,
+                              int variant, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* tile family the auto heuristic (flags bits 8-11 == 0) picks: 12 = a 256x256 ring kernel (12 or 13, see above), 1 = 128x128 generic kernel */
 int mantis_gemm_pick_variant(int M, int N, int K);
 
@@ -176,6 +189,15 @@ int mantis_cast_pad_rows(const float* in, void* out, int64_t rows, int K, int64_
 int mantis_vit_assemble(const void* patch_out, const void* pos_emb, const void* cls_emb /*nullable*/, void* out, int I, int N,
                         int d, void* stream);
 int mantis_drop_cls(const void* in, void* out, int I, int N, int d, void* stream);
+/* NaViT image preparation on the device (replaces the host loop of /root/reference/mantis/models/idefics2/modeling_idefics2.py:1636-1639
+ * padding-image detection, :1653-1658 pixel mask -> patch mask, :190-210 bucketised position ids), one workgroup per image slot:
+ * pixels fp32 [n, C, H, W] (16-B aligned, C*H*W % 4 == 0), pixel_mask uint8 [n, H, W] or NULL (= all attended); bucket int32
+ * [tab_n, tab_n]: bucket[m][j] = bucketize(arange(0, 1 - 1e-6, 1 / m), boundaries, right = True)[j], built by the caller with the
+ * reference's own float arithmetic.  Outputs int32: real[n] (1 = has a non-zero pixel), patch_mask[n, (H/P)*(W/P)], pos_ids[same],
+ * status[n] (1 = attended patches do not form an nh x nw grid, where the reference raises). */
+int mantis_navit_prepare(const float* pixels, const uint8_t* pixel_mask, int n_images, int C, int H, int W, int P, int side,
+                         const int32_t* bucket, int tab_n, int32_t* real, int32_t* patch_mask, int32_t* pos_ids, int32_t* status,
+                         void* stream);
 
 /* ---- optimizer: HF:trainer.py:1785-1796 + clip :2535-2545, AdamW over flat buffers */
 int mantis_adamw(void* param_bf16, const void* grad_bf16, float* master, float* exp_avg, float* exp_avg_sq, int64_t n,

@@ -37,6 +37,7 @@ SIGNATURES = {
     "mantis_rope_apply": [P, P, P, L, I, I, L, I, P],
     "mantis_transpose": [P, P, I, I, I, L, L, I, I, L, L, L, L, P],
     "mantis_gemm_bf16_nt": [P, L, P, L, P, L, I, I, I, P, P, L, I, P, L, P],
+    "mantis_gemm_bf16_nt_fused": [P, L, P, L, P, L, I, I, I, P, I, P, P, L, I, I, P, L, P],
     "mantis_gemm_workspace_bytes": [I, I, I],
     "mantis_gemm_pick_variant": [I, I, I],
     "mantis_fp8_quantize_ws_floats": [],
@@ -53,6 +54,7 @@ SIGNATURES = {
     "mantis_cast_pad_rows": [P, P, L, I, L, I, P],
     "mantis_vit_assemble": [P, P, P, P, I, I, I, P],
     "mantis_drop_cls": [P, P, I, I, I, P],
+    "mantis_navit_prepare": [P, P, I, I, I, I, I, I, P, I, P, P, P, P, P],
     "mantis_adamw": [P, P, P, P, P, L, F, F, F, F, F, F, F, P, P],
     "mantis_sumsq_partials": [L],
     "mantis_sumsq": [P, L, P, P, I, P],

@@ -843,12 +843,25 @@ __device__ __forceinline__ void sk_add16(f32x4 (&acc)[NBN][NBM], const float* __
 
 // NW = 4: 2 x 2 waves of 128 x 128 (one wave per SIMD, the coolest loop: variant 13); NW = 8: 2 x 4 waves of 128 x 64 (two waves per
 // SIMD: the 8-wave kernel's latency hiding and epilogue width under the 16x16x32 shape: variant 14)
-template <int NW, bool AKM, bool BKM, bool SWIGLU = false>
+// PAIR (forward epilogue fusions that need TWO output columns in one lane; NT only): every 256-column tile is built from 128 "features"
+// phi, each a pair of output columns (first(phi), first(phi) + pair_dist); the B rows are fetched so that a wave's columns are
+// [its features' first columns | the same features' second columns], and the epilogue meets both in one lane through two strips.
+//   PAIR_SWIGLU (1): B = [gate | up] rows, N = 2 I; first(phi) = tile*128 + phi, pair_dist = I: C = [gate | up] as the unfused GEMM writes
+//                    it AND aux0 = silu(gate) * up [M, I] (row stride aux_ld) -- swiglu_fwd's arithmetic, the 322 MB re-read gone
+//   PAIR_ROPE   (2): q|k|v projection, heads of 128: first(phi) = n0 + (phi >> 6)*128 + (phi & 63), pair_dist = 64: columns below aux_n get
+//                    the rotary embedding (aux0 = cos, aux1 = sin, bf16 [M, 64], row stride aux_ld) with rope_apply's bf16 rounding
+//                    sequence (modeling_llama.py:157-158) before they are stored; columns from aux_n on (v) are stored as they are
+#define PAIR_NONE 0
+#define PAIR_SWIGLU 1
+#define PAIR_ROPE 2
+template <int NW, bool AKM, bool BKM, bool SWIGLU = false, int PAIR = PAIR_NONE>
 __global__ __launch_bounds__(NW * 64) void gemm_nt_ring16_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C, int M, int N, int K, long lda, long ldb,
     long ldc, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res, long ldr, int flags, int tiles_m, int tiles_n,
-    int full, int S, float* __restrict__ sk_slabs, unsigned int* __restrict__ sk_cnt) {
+    int full, int S, float* __restrict__ sk_slabs, unsigned int* __restrict__ sk_cnt, bf16_t* __restrict__ aux0,
+    const bf16_t* __restrict__ aux1, long aux_ld, int aux_n) {
     static_assert(NW == 4 || NW == 8, "4 waves of 128 x 128 or 8 waves of 128 x 64");
+    static_assert(PAIR == PAIR_NONE || (!AKM && !BKM && !SWIGLU), "the pair epilogues are forward (NT) fusions");
     constexpr int NBM = 8, NBN = NW == 4 ? 8 : 4;          // 16 x 16 blocks per wave along M / N
     constexpr int SLAB = 16384, RING = 10 * SLAB, PPW = 16 / NW, NMF = NBN * NBM;
     __shared__ __attribute__((aligned(16))) char smem[RING];
@@ -882,6 +895,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring16_kernel(
     const int in_g = tile_id - g * per_group;
     const int m0 = (first_m + in_g % gsz) * 256, n0 = (in_g / gsz) * 256;
     const int Kseg = (t1 * BK < K) ? t1 * BK : K;
+    // pair modes: first output column of feature phi (0 .. 127) of this tile, and the distance to its partner column
+    const int pair_dist = PAIR == PAIR_SWIGLU ? (N >> 1) : 64;
+    auto pair_first = [&](int phi) { return PAIR == PAIR_SWIGLU ? (n0 >> 1) + phi : n0 + (phi >> 6) * 128 + (phi & 63); };
 
     f32x4 acc[NBN][NBM];       // acc[tn][tm]: block (n block tn, m block tm)
 #pragma unroll
@@ -916,7 +932,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring16_kernel(
                 kcB[j] = chunk * 8;
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
-                    int grow = n0 + half * 128 + piece * 8 + rl;
+                    const int r = piece * 8 + rl;                  // row of this half of the tile's B operand, 0 .. 127
+                    int grow = n0 + half * 128 + r;
+                    if constexpr (PAIR != PAIR_NONE) {
+                        // a wave's 2 G rows = [G first columns | G second columns] of its G features (G = 64 / 32 for 4 / 8 waves)
+                        constexpr int G = NBN * 8;
+                        const int phi = half * 64 + (r / (2 * G)) * G + (r % G), second = (r / G) & 1;
+                        grow = pair_first(phi) + second * pair_dist;
+                    }
                     grow = grow < N ? grow : N - 1;
                     voB[half][j] = (unsigned)(((long)grow * ldb + chunk * 8) * 2);
                 }
@@ -1106,6 +1129,111 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring16_kernel(
     // columns tn*16 + 4*(l >> 4) .. + 3 -> one 16-B strip write per block (8 consecutive lanes = 8 rows of pitch 272 B: conflict-free)
     char* strip = smem + wave * EPI_STRIP;
     const int mw0 = m0 + wm * 128, nw0 = n0 + wn * (NBN * 16);
+    if constexpr (PAIR != PAIR_NONE) {
+        // two strips per wave (8 x 2 x 17 KiB <= 160 KiB): A = the first columns, B = the second columns of the wave's G features.
+        //   4 waves: per 64-row pass pm, A[row][c] = first(m = pm*64 + row, phi = phi0 + c), c < 64
+        //   8 waves: one pass,           A[row][c] = first(m = (c >> 5)*64 + row, phi = phi0 + (c & 31))
+        // so lane (rr, cc) of the read-back meets the first and second column of the same (m, 8 features) at the same strip position
+        constexpr int G = NBN * 8;
+        char* sa = smem + (2 * wave) * EPI_STRIP;
+        char* sb = sa + EPI_STRIP;
+        const int phi0 = wn * G;
+        const int rr = lane >> 3, cc = lane & 7;
+        const bool has_bias = flags & EPI_BIAS;
+#pragma unroll
+        for (int pass = 0; pass < (NW == 4 ? 2 : 1); ++pass) {
+            if constexpr (NW == 4) {
+#pragma unroll
+                for (int tm4 = 0; tm4 < 4; ++tm4)
+#pragma unroll
+                    for (int tn4 = 0; tn4 < 4; ++tn4) {
+                        const int off = (tm4 * 16 + (lane & 15)) * EPI_PITCH + (tn4 * 16 + 4 * (lane >> 4)) * 4;
+                        *reinterpret_cast<f32x4*>(sa + off) = acc[tn4][pass * 4 + tm4];
+                        *reinterpret_cast<f32x4*>(sb + off) = acc[4 + tn4][pass * 4 + tm4];
+                    }
+            } else {
+#pragma unroll
+                for (int tm = 0; tm < 8; ++tm)
+#pragma unroll
+                    for (int tn2 = 0; tn2 < 2; ++tn2) {
+                        const int off = ((tm & 3) * 16 + (lane & 15)) * EPI_PITCH + ((tm >> 2) * 32 + tn2 * 16 + 4 * (lane >> 4)) * 4;
+                        *reinterpret_cast<f32x4*>(sa + off) = acc[tn2][tm];
+                        *reinterpret_cast<f32x4*>(sb + off) = acc[2 + tn2][tm];
+                    }
+            }
+            const int phi = phi0 + (NW == 4 ? cc * 8 : (cc & 3) * 8);
+            const int col1 = pair_first(phi), col2 = col1 + pair_dist;
+            float b1[8], b2[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                b1[e] = has_bias ? bf2f(bias[col1 + e]) : 0.f;
+                b2[e] = has_bias ? bf2f(bias[col2 + e]) : 0.f;
+            }
+#pragma unroll 2
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 8 + rr;
+                const int m = mw0 + (NW == 4 ? pass * 64 : (cc >> 2) * 64) + row;
+                const f32x4 alo = *reinterpret_cast<const f32x4*>(sa + row * EPI_PITCH + cc * 32);
+                const f32x4 ahi = *reinterpret_cast<const f32x4*>(sa + row * EPI_PITCH + cc * 32 + 16);
+                const f32x4 blo = *reinterpret_cast<const f32x4*>(sb + row * EPI_PITCH + cc * 32);
+                const f32x4 bhi = *reinterpret_cast<const f32x4*>(sb + row * EPI_PITCH + cc * 32 + 16);
+                if (m >= M) continue;
+                float v1[8] = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+                float v2[8] = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
+                if (has_bias) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        v1[e] += b1[e];
+                        v2[e] += b2[e];
+                    }
+                }
+                u32x4 o1, o2;
+                if constexpr (PAIR == PAIR_SWIGLU) {
+                    // gate, up rounded to bf16 as the unfused GEMM stores them; a = bf16(bf16(silu(gate)) * up) as swiglu_fwd_kernel
+                    u32x4 oa;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o1[e] = pack_bf2(v1[2 * e], v1[2 * e + 1]);
+                        o2[e] = pack_bf2(v2[2 * e], v2[2 * e + 1]);
+                        const float g0 = bf2f_lo(o1[e]), g1 = bf2f_hi(o1[e]);
+                        const float s0 = bf2f(f2bf(g0 * (1.f / (1.f + __expf(-g0))))), s1 = bf2f(f2bf(g1 * (1.f / (1.f + __expf(-g1)))));
+                        oa[e] = pack_bf2(s0 * bf2f_lo(o2[e]), s1 * bf2f_hi(o2[e]));
+                    }
+                    *reinterpret_cast<u32x4*>(aux0 + (long)m * aux_ld + col1) = oa;
+                } else {
+                    u32x4 vc, vs;
+                    const bool rot = col1 < aux_n;
+                    if (rot) {
+                        vc = *reinterpret_cast<const u32x4*>(aux0 + (long)m * aux_ld + (phi & 63));
+                        vs = *reinterpret_cast<const u32x4*>(aux1 + (long)m * aux_ld + (phi & 63));
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned w1 = pack_bf2(v1[2 * e], v1[2 * e + 1]);
+                        const unsigned w2 = pack_bf2(v2[2 * e], v2[2 * e + 1]);
+                        if (rot) {
+                            const float x1[2] = {bf2f_lo(w1), bf2f_hi(w1)}, x2[2] = {bf2f_lo(w2), bf2f_hi(w2)};
+                            const float cs[2] = {bf2f_lo(vc[e]), bf2f_hi(vc[e])}, sn[2] = {bf2f_lo(vs[e]), bf2f_hi(vs[e])};
+                            float r1[2], r2[2];
+#pragma unroll
+                            for (int h2 = 0; h2 < 2; ++h2) {
+                                r1[h2] = bf2f(f2bf(x1[h2] * cs[h2])) - bf2f(f2bf(x2[h2] * sn[h2]));
+                                r2[h2] = bf2f(f2bf(x2[h2] * cs[h2])) + bf2f(f2bf(x1[h2] * sn[h2]));
+                            }
+                            o1[e] = pack_bf2(r1[0], r1[1]);
+                            o2[e] = pack_bf2(r2[0], r2[1]);
+                        } else {
+                            o1[e] = w1;
+                            o2[e] = w2;
+                        }
+                    }
+                }
+                *reinterpret_cast<u32x4*>(C + (long)m * ldc + col1) = o1;
+                *reinterpret_cast<u32x4*>(C + (long)m * ldc + col2) = o2;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int pm = 0; pm < 2; ++pm)
 #pragma unroll
@@ -1170,14 +1298,21 @@ static int gemm_pick_variant(int M, int N, int K) {
 }
 
 // ring kernel per shape (measured, profiles/r03_gemm_ring_variants.md)
+// (1x MI355X, the fifteen GEMMs of a Mantis-8B decoder layer + head, every layout): the 8-wave 16x16x32 kernel (14) is 2-7 % faster than
+// the 32x32x16 one (12) on twelve of them and within 3 % on the rest; the 4-wave kernel (13) is faster still -- 4-5 % over 14 -- where the
+// main loop is all there is: row-major operands (NT) and a long per-CU K walk (rounds x K-steps), and slower everywhere else (its
+// prologue, epilogue and K-split reduction run on half the waves)
 static int ring_variant_for(int M, int N, int K, bool akm, bool bkm) {
-    (void)M; (void)N; (void)K; (void)akm; (void)bkm;
-    return 12;
+    if (akm || bkm) return 14;
+    const long tiles = (long)cdiv(M, 256) * cdiv(N, 256);
+    const long rounds = (tiles + num_cus() - 1) / num_cus();
+    return rounds * cdiv(K, BK) >= 400 ? 13 : 14;
 }
 
-template <bool AKM, bool BKM, bool SWIGLU = false, int R16 = 0>       // R16: 0 = the 32x32x16 kernel, 4 / 8 = ring16 with that many waves
+template <bool AKM, bool BKM, bool SWIGLU = false, int R16 = 0, int PAIR = PAIR_NONE>       // R16: 0 = the 32x32x16 kernel, 4 / 8 = ring16 waves
 static int launch_gemm_ring(hipStream_t s, const bf16_t* A, const bf16_t* B, bf16_t* C, int M, int N, int K, long lda, long ldb,
-                            long ldc, const bf16_t* bias, const bf16_t* res, long ldr, int flags, void* ws, long ws_bytes) {
+                            long ldc, const bf16_t* bias, const bf16_t* res, long ldr, int flags, void* ws, long ws_bytes,
+                            bf16_t* aux0 = nullptr, const bf16_t* aux1 = nullptr, long aux_ld = 0, int aux_n = 0) {
     const int tiles_m = cdiv(M, 256), tiles_n = cdiv(N, 256), nk = cdiv(K, BK);
     const long ntiles = (long)tiles_m * tiles_n;
     const int cus = num_cus();
@@ -1193,8 +1328,8 @@ static int launch_gemm_ring(hipStream_t s, const bf16_t* A, const bf16_t* B, bf1
         slabs = (float*)((char*)ws + sk_cnt_bytes(cus));
     }
     if constexpr (R16 != 0) {
-        MANTIS_LAUNCH((gemm_nt_ring16_kernel<R16, AKM, BKM, SWIGLU>), dim3(grid), dim3(R16 * 64), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias,
-                           res, ldr, flags, tiles_m, tiles_n, full, S, slabs, cnt);
+        MANTIS_LAUNCH((gemm_nt_ring16_kernel<R16, AKM, BKM, SWIGLU, PAIR>), dim3(grid), dim3(R16 * 64), 0, s, A, B, C, M, N, K, lda, ldb, ldc,
+                           bias, res, ldr, flags, tiles_m, tiles_n, full, S, slabs, cnt, aux0, aux1, aux_ld, aux_n);
     } else {
         MANTIS_LAUNCH((gemm_nt_ring_kernel<AKM, BKM, SWIGLU>), dim3(grid), dim3(512), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias, res, ldr, flags,
                            tiles_m, tiles_n, full, S, slabs, cnt);
@@ -1297,6 +1432,39 @@ int mantis_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, 
 #undef RING_DISPATCH
 #undef RING_ARGS
 #undef GEMM_ARGS
+}
+
+// Forward projections with a two-column epilogue fused in (ring16 kernels, NT layout, see PAIR_* at the kernel):
+//   mode 1 (SwiGLU): A = x [M, K], B = [gate | up] weight [2 I, K] -> C = x . B^T [M, 2 I] as mantis_gemm_bf16_nt writes it, and
+//                    aux0 = silu(gate) * up [M, I] (bf16, row stride aux_ld) as mantis_swiglu_fwd computes it; N = 2 I, I % 128 == 0
+//   mode 2 (RoPE):   q|k|v projection with heads of 128 columns, optional bias: columns [0, aux_n) leave with the rotary embedding applied
+//                    (aux0 = cos, aux1 = sin: bf16 [M, 64], row stride aux_ld) exactly as mantis_rope_apply(forward) would rotate them
+//                    afterwards; N % 256 == 0, aux_n % 128 == 0
+// Returns MANTIS_EUNSUPPORTED for shapes outside these conditions: the caller then runs the two launches.
+int mantis_gemm_bf16_nt_fused(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
+                              const void* bias, int mode, void* aux0, const void* aux1, int64_t aux_ld, int aux_n, int variant,
+                              void* workspace, int64_t workspace_bytes, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || (mode != PAIR_SWIGLU && mode != PAIR_ROPE) || !aux0) return MANTIS_EINVAL;
+    if (lda % 8 || ldb % 8 || ldc % 8 || ldc < N || lda < K || ldb < K || K % 8 || (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15))
+        return MANTIS_EUNSUPPORTED;
+    if (aux_ld % 8 || ((uintptr_t)aux0 & 15)) return MANTIS_EUNSUPPORTED;
+    if (mode == PAIR_SWIGLU && (N % 256 || aux_ld < N / 2 || bias)) return MANTIS_EUNSUPPORTED;
+    if (mode == PAIR_ROPE && (N % 256 || aux_n % 128 || aux_n > N || aux_n < 0 || !aux1 || aux_ld < 64 || ((uintptr_t)aux1 & 15)))
+        return MANTIS_EUNSUPPORTED;
+    const long lim = (1L << 32) - (1L << 16);
+    if ((long)M * lda * 2 >= lim || (long)N * ldb * 2 >= lim) return MANTIS_EUNSUPPORTED;
+    if (variant == 0) variant = default_ring_variant() >= 13 ? default_ring_variant() : ring_variant_for(M, N, K, false, false);
+    if (variant != 13 && variant != 14) return MANTIS_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int flags = bias ? EPI_BIAS : 0;
+#define PAIR_ARGS s, (const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C, M, N, K, (long)lda, (long)ldb, (long)ldc, (const bf16_t*)bias, \
+                  (const bf16_t*)nullptr, 0L, flags, workspace, (long)workspace_bytes, (bf16_t*)aux0, (const bf16_t*)aux1, (long)aux_ld, aux_n
+    if (mode == PAIR_SWIGLU)
+        return variant == 13 ? launch_gemm_ring<false, false, false, 4, PAIR_SWIGLU>(PAIR_ARGS)
+                             : launch_gemm_ring<false, false, false, 8, PAIR_SWIGLU>(PAIR_ARGS);
+    return variant == 13 ? launch_gemm_ring<false, false, false, 4, PAIR_ROPE>(PAIR_ARGS)
+                         : launch_gemm_ring<false, false, false, 8, PAIR_ROPE>(PAIR_ARGS);
+#undef PAIR_ARGS
 }
 
 }  // extern "C"

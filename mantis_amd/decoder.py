@@ -28,13 +28,11 @@ def decoder_forward(K, lm, tc, x, B, L, position_ids, kmask, kstart=None, comput
     for i in range(tc.num_hidden_layers):
         lw = lm["layers"][i]
         n1, rstd1 = K.rmsnorm_fwd(x, lw["ln1"], eps)
-        qkv = K.gemm_nt(n1, lw["qkv"], bias=lw.get("qkv_b"))
-        K.rope_apply_(qkv, cos, sin, H + Hkv, hd)
+        qkv = K.linear_qkv_rope(n1, lw["qkv"], lw.get("qkv_b"), cos, sin, H + Hkv, hd)      # RoPE in the projection's epilogue (hd 128)
         o, lse = K.attn_fwd(qkv, B, L, H, Hkv, hd, kmask, scale, True, kstart=kstart)
         x_mid = K.gemm_nt(o, lw["o"], residual=x)
         n2, rstd2 = K.rmsnorm_fwd(x_mid, lw["ln2"], eps)
-        gu = K.gemm_nt(n2, lw["gu"])
-        a = K.swiglu_fwd(gu)
+        gu, a = K.linear_gu_swiglu(n2, lw["gu"])                                            # SwiGLU in the projection's epilogue
         x_out = K.gemm_nt(a, lw["down"], residual=x_mid)
         if compute_grads:
             # 288 GB of HBM: keep the cheap-to-recompute tensors too (n1, n2, a: +370 MB per layer) instead of re-running

@@ -260,6 +260,59 @@ def linear_dx(dy, w, k=None):
     return gemm_nt(dy, wt, k=wt.shape[1] if k is None else k)
 
 
+import os as _os
+FUSE_FWD_EPILOGUES = _os.environ.get("MANTIS_NO_FUSE") != "1"      # A/B switch (measurements / tests): off = always the two-launch forms
+
+
+def _gemm_fused(a, b, out, mode, aux0, aux1, aux_ld, aux_n, bias, variant, extra_bytes):
+    """mantis_gemm_bf16_nt_fused; returns False when the library declines the shape (the caller runs the unfused launches)."""
+    M, K = a.shape
+    N = b.shape[0]
+    prof = KERNEL_TIMER
+    if prof is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+    wsp, wsn = _gemm_workspace()
+    rc = _L.mantis_gemm_bf16_nt_fused(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, _p(bias), mode, _p(aux0),
+                                      _p(aux1), aux_ld, aux_n, variant, wsp, wsn, _stream())
+    if rc == -2:
+        return False
+    _lib.check(rc, f"gemm_fused mode={mode} M={M} N={N} K={K}")
+    if prof is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        prof.append(("gemm_nt_kernel", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N) + extra_bytes, e0, e1))
+    return True
+
+
+def linear_gu_swiglu(x, w_gu, variant=0, amax_parts=None):
+    """(gu [M, 2I], a [M, I]) = (x . [gate | up]^T, silu(gate) * up): the SwiGLU activation runs in the epilogue of the projection (one
+    launch, the 2I-wide result is not read back); shapes the fused kernel declines take gemm_nt + swiglu_fwd (same results)."""
+    _chk2d(x, "x"), _chk2d(w_gu, "w_gu")
+    M, I2 = x.shape[0], w_gu.shape[0]
+    if FUSE_FWD_EPILOGUES and amax_parts is None and I2 % 256 == 0:
+        gu = torch.empty((M, I2), dtype=BF16, device=x.device)
+        a = torch.empty((M, I2 // 2), dtype=BF16, device=x.device)
+        if _gemm_fused(x, w_gu, gu, 1, a, None, a.stride(0), 0, None, variant, 2.0 * M * (I2 // 2)):
+            return gu, a
+    gu = gemm_nt(x, w_gu)
+    return gu, swiglu_fwd(gu, amax_parts=amax_parts)
+
+
+def linear_qkv_rope(x, w_qkv, bias, cos, sin, n_rope_heads, hd, variant=0):
+    """qkv [M, N] = x . w_qkv^T (+ bias) with the rotary embedding already applied to the first n_rope_heads heads (q and k): RoPE runs in
+    the epilogue of the projection for head dim 128; other geometries take gemm_nt + rope_apply_ (same results)."""
+    _chk2d(x, "x"), _chk2d(w_qkv, "w_qkv")
+    M, N = x.shape[0], w_qkv.shape[0]
+    if (FUSE_FWD_EPILOGUES and hd == 128 and N % 256 == 0 and cos.dtype == BF16 and cos.dim() == 2 and cos.shape == (M, 64)
+            and cos.stride(1) == 1 and sin.shape == cos.shape and sin.stride() == cos.stride()):
+        qkv = torch.empty((M, N), dtype=BF16, device=x.device)
+        if _gemm_fused(x, w_qkv, qkv, 2, cos, sin, cos.stride(0), n_rope_heads * hd, bias, variant, 4.0 * M * 64):
+            return qkv
+    qkv = gemm_nt(x, w_qkv, bias=bias)
+    return rope_apply_(qkv, cos, sin, n_rope_heads, hd)
+
+
 def linear_dx_swiglu(dy, w_down, gu, variant=0):
     """dgu[M, 2I] = swiglu_bwd(dy[M, d] @ w_down[d, I], gu[M, 2I]) in one launch: the SwiGLU backward runs in the GEMM epilogue
     (the [M, I] activation gradient never goes to HBM)."""
@@ -549,6 +602,23 @@ def vit_assemble(patch_out, pos_emb, cls_emb, I, N):
     out = torch.empty((I * nt, d), dtype=BF16, device=patch_out.device)
     _lib.check(_L.mantis_vit_assemble(_p(patch_out), _p(pos_emb), _p(cls_emb), _p(out), I, N, d, _stream()), "vit_assemble")
     return out
+
+
+def navit_prepare(pixels, pixel_mask, patch, side, bucket):
+    """pixels fp32 [n, C, H, W] on the device, pixel_mask uint8/bool [n, H, W] or None, bucket int32 [tab_n, tab_n] (device).
+    -> (real int32 [n], patch_mask int32 [n, ph*pw], pos_ids int32 [n, ph*pw], status int32 [n]), all on the device."""
+    n, C, H, W = pixels.shape
+    npatch = (H // patch) * (W // patch)
+    dev = pixels.device
+    real = torch.empty((n,), dtype=torch.int32, device=dev)
+    pm = torch.empty((n, npatch), dtype=torch.int32, device=dev)
+    pos = torch.empty((n, npatch), dtype=torch.int32, device=dev)
+    status = torch.empty((n,), dtype=torch.int32, device=dev)
+    if pixel_mask is not None:
+        pixel_mask = pixel_mask.to(torch.uint8).contiguous()
+    _lib.check(_L.mantis_navit_prepare(_p(pixels), _p(pixel_mask), n, C, H, W, patch, side, _p(bucket), bucket.shape[0], _p(real), _p(pm),
+                                       _p(pos), _p(status), _stream()), "navit_prepare")
+    return real, pm, pos, status
 
 
 def drop_cls(x, I, N):

@@ -267,40 +267,54 @@ class Idefics2Engine:
         return self.step(inputs["input_ids"], inputs["attention_mask"], inputs.get("labels"), inputs.get("pixel_values"),
                          inputs.get("pixel_attention_mask"), **kw)
 
-    # ------------------------------------------------------------------ host-side integer preparation (tiny, data dependent)
+    # ------------------------------------------------------------------ NaViT image preparation (device kernel + one tiny readback)
+    def _bucket_table(self, tab_n, dev):
+        """bucket[n][j] = the reference's bucketised fractional coordinate j of n attended patches along one side (:190-210), built ONCE per
+        (patches per side, table size) with the reference's own float32 torch ops -- torch.arange with the 0-dim tensor step that
+        `1 / nb_patches` is there, torch.bucketize(right=True) -- so the device kernel's table lookups give bit-identical ids."""
+        key = (tab_n, str(dev))
+        cache = self.__dict__.setdefault("_bucket_cache", {})
+        t = cache.get(key)
+        if t is None:
+            side = self.cfg.vision_config.image_size // self.cfg.vision_config.patch_size
+            boundaries = torch.arange(1 / side, 1.0, 1 / side)
+            tab = torch.zeros((tab_n, tab_n), dtype=torch.int32)
+            for n in range(1, tab_n):
+                frac = torch.arange(0, 1 - 1e-6, 1 / torch.tensor(n))
+                b = torch.bucketize(frac, boundaries, right=True)
+                tab[n, : min(n, b.numel())] = b[:n].to(torch.int32)
+            t = cache[key] = tab.to(dev)
+        return t
+
     def _prepare_images(self, pixel_values, pixel_attention_mask):
-        """Padding-image removal (:1636-1639), pixel mask -> patch mask (:1653-1658), bucketised NaViT position ids (:190-210).
-        Integer / boolean bookkeeping on the host copy of the batch (the shapes of everything downstream depend on it); the
-        fractional-coordinate arithmetic repeats the reference's float32 torch ops so the ids are bit-identical."""
+        """Padding-image removal (:1636-1639), pixel mask -> patch mask (:1653-1658), bucketised NaViT position ids (:190-210) by ONE device
+        kernel over the uploaded pixels (K.navit_prepare); the host reads back only the per-image `real` flags and status words (the
+        shapes of everything downstream depend on the number of real images) -- round 2 did all of it on the host: a count_nonzero over
+        ~38 MB of fp32 pixels and a Python loop with bucketize per image, every step.
+        -> (pixels fp32 [I, C, H, W] on the device, pos_ids int32 [I, N], tower key mask int32 [I, N] or None, key mask int32 [I, N])"""
         vc = self.cfg.vision_config
         P = vc.patch_size
+        dev = self.m.device
         pv = torch.as_tensor(pixel_values)
         Bm = pv.shape[0] * pv.shape[1]
-        pv = pv.reshape(Bm, *pv.shape[2:])
-        real = torch.count_nonzero(pv.reshape(Bm, -1), dim=1) != 0
-        idx = torch.nonzero(real).reshape(-1)
-        pv = pv[idx]
-        I, _, Hh, Ww = pv.shape
-        if pixel_attention_mask is None:
-            pm = torch.ones((I, Hh, Ww), dtype=torch.bool)
-        else:
-            pm = torch.as_tensor(pixel_attention_mask).bool().reshape(Bm, Hh, Ww)[idx]
-        sub = pm.unfold(1, P, P).unfold(2, P, P)
-        patch_mask = sub.sum(dim=(-1, -2)) > 0                                   # [I, ph, pw]
+        pv = pv.reshape(Bm, *pv.shape[2:]).to(dev, non_blocking=True).to(torch.float32).contiguous()
+        Hh, Ww = pv.shape[2:]
+        pm_in = None
+        if pixel_attention_mask is not None:
+            pm_in = torch.as_tensor(pixel_attention_mask).reshape(Bm, Hh, Ww).to(dev, non_blocking=True)
         side = vc.image_size // P
-        boundaries = torch.arange(1 / side, 1.0, 1 / side)
-        ph, pw = patch_mask.shape[1:]
-        pos = torch.zeros((I, ph * pw), dtype=torch.int64)
-        for i in range(I):
-            m = patch_mask[i]
-            nh, nw = m[:, 0].sum(), m[0].sum()
-            fh = torch.arange(0, 1 - 1e-6, 1 / nh)
-            fw = torch.arange(0, 1 - 1e-6, 1 / nw)
-            bh = torch.bucketize(fh, boundaries, right=True)
-            bw = torch.bucketize(fw, boundaries, right=True)
-            pos[i][m.reshape(-1)] = (bh[:, None] * side + bw).flatten()
-        km = patch_mask.reshape(I, -1)
-        return pv, pos.to(torch.int32), (None if bool(km.all()) else km.to(torch.int32)), km.to(torch.int32)
+        tab_n = max(side, Hh // P, Ww // P) + 1
+        real, pm, pos, status = K.navit_prepare(pv, pm_in, P, side, self._bucket_table(tab_n, dev))
+        flags = torch.stack([real, status, pm.amin(dim=1)]).cpu()     # the step's one host readback (3 x Bm ints)
+        real_h = flags[0] != 0
+        if bool(((flags[1] != 0) & real_h).any()):
+            raise ValueError("pixel_attention_mask: the attended patches of an image do not form an (rows x columns) grid -- the reference's "
+                             "position-id assignment (modeling_idefics2.py:207) fails on such a mask")
+        if not bool(real_h.all()):
+            idx = torch.nonzero(real_h).reshape(-1).to(dev)
+            pv, pm, pos = pv.index_select(0, idx), pm.index_select(0, idx), pos.index_select(0, idx)
+        all_attended = bool((flags[2][real_h] != 0).all())        # every patch of every real image attended: the tower needs no key mask
+        return pv, pos, (None if all_attended else pm), pm
 
     # ------------------------------------------------------------------ vision tower (frozen, forward only)
     def vision_forward(self, pix, pos_ids, kmask):
@@ -335,8 +349,7 @@ class Idefics2Engine:
         dev = feats.device
         nl, H, Hkv, hd = pc.resampler_n_latents, pc.resampler_n_heads, pc.num_key_value_heads, pc.resampler_head_dim
         eps = tc.rms_norm_eps
-        gu = K.gemm_nt(feats, cw["mp_gu"])
-        a = K.swiglu_fwd(gu)
+        gu, a = K.linear_gu_swiglu(feats, cw["mp_gu"])
         ctx = K.gemm_nt(a, cw["mp_down"])
         if record is not None:
             record["modality_projection_out"] = ctx.view(I, N, -1)
@@ -345,7 +358,7 @@ class Idefics2Engine:
         ctx_idx = (base + torch.arange(N, dtype=torch.int32)[None]).reshape(-1).to(dev)
         lat_idx = (base + N + torch.arange(nl, dtype=torch.int32)[None]).reshape(-1).to(dev)
         lat_src = torch.arange(nl, dtype=torch.int32).repeat(I).to(dev)
-        kmask = torch.cat([km_all, torch.ones((I, nl), dtype=torch.int32)], dim=1).contiguous().to(dev)     # :1293-1296
+        kmask = torch.cat([km_all.to(dev), torch.ones((I, nl), dtype=torch.int32, device=dev)], dim=1).contiguous()     # :1293-1296
         lat = K.gather_rows(cw["latents"], lat_src)
         saved = []
         for lw in cw["layers"]:
@@ -359,8 +372,7 @@ class Idefics2Engine:
             o_lat = K.gather_rows(o_all, lat_idx)
             lat_mid = K.gemm_nt(o_lat, lw["o"], residual=lat)
             n2, rstd2 = K.rmsnorm_fwd(lat_mid, lw["post_norm"], eps)
-            gu2 = K.gemm_nt(n2, lw["gu"])
-            a2 = K.swiglu_fwd(gu2)
+            gu2, a2 = K.linear_gu_swiglu(n2, lw["gu"])
             lat_out = K.gemm_nt(a2, lw["down"], residual=lat_mid)
             saved.append((lat, rstd_l, rstd_c, hs, qkv, o_all, lse, o_lat, lat_mid, rstd2, n2, gu2, a2))
             lat = lat_out
@@ -421,10 +433,9 @@ class Idefics2Engine:
         n_rows = 0
         is_img = ids_cpu == IMG
         if pixel_values is not None:
-            pv, pos_ids, vit_kmask, km_all = self._prepare_images(pixel_values, pixel_attention_mask)
-            pix = pv.to(dev, non_blocking=True).to(torch.float32).contiguous()
+            pix, pos_ids, vit_kmask, km_all = self._prepare_images(pixel_values, pixel_attention_mask)
             I = pix.shape[0]
-            feats, N = self.vision_forward(pix, pos_ids.to(dev), None if vit_kmask is None else vit_kmask.to(dev))
+            feats, N = self.vision_forward(pix, pos_ids, vit_kmask)
             if record is not None:
                 record["vision_last_hidden_state"] = feats.view(I, N, -1)
             img, cctx = self.connector_forward(feats, I, N, km_all, record)

@@ -164,6 +164,15 @@ def linear_dx(dy, w, k=None):
     return (_f(dy)[:, :n] @ _f(w)).to(dy.dtype)
 
 
+def linear_gu_swiglu(x, w_gu, variant=0, amax_parts=None):
+    gu = gemm_nt(x, w_gu)
+    return gu, swiglu_fwd(gu)
+
+
+def linear_qkv_rope(x, w_qkv, bias, cos, sin, n_rope_heads, hd, variant=0):
+    return rope_apply_(gemm_nt(x, w_qkv, bias=bias), cos, sin, n_rope_heads, hd)
+
+
 def linear_dx_swiglu(dy, w_down, gu):
     return swiglu_bwd(linear_dx(dy, w_down), gu)
 
@@ -490,6 +499,27 @@ def vit_assemble(patch_out, pos_emb, cls_emb, I, N):
         x = torch.cat([_f(cls_emb).expand(I, 1, d), x], dim=1)
     x = x + _f(pos_emb)[None]
     return x.reshape(-1, d).to(patch_out.dtype)
+
+
+def navit_prepare(pixels, pixel_mask, patch, side, bucket):
+    """Restates /root/reference/mantis/models/idefics2/modeling_idefics2.py:1636-1639 (padding images are all zero), :1653-1658 (pixel mask
+    -> patch mask) and :190-210 (bucketised position ids) through oracle/idefics2_ref.py; `bucket` (the product's table) is NOT used."""
+    from . import idefics2_ref as I2
+    n = pixels.shape[0]
+    nb = pixels.shape[1:].numel()
+    real = ((pixels == 0.0).reshape(n, -1).sum(dim=1) != nb).to(torch.int32)
+    pmask = torch.ones((n,) + tuple(pixels.shape[2:]), dtype=torch.bool) if pixel_mask is None else pixel_mask.bool()
+    pm = I2.patch_mask_from_pixel_mask(pmask, patch)
+    status = torch.zeros(n, dtype=torch.int32)
+    pos = torch.zeros((n, pm.shape[1] * pm.shape[2]), dtype=torch.int32)
+    for i in range(n):
+        nh, nw = int(pm[i][:, 0].sum()), int(pm[i][0].sum())
+        if int(pm[i].sum()) != nh * nw:
+            status[i] = 1
+            continue
+        if nh * nw:
+            pos[i] = I2.bucketized_position_ids(pm[i:i + 1], side)[0].to(torch.int32)
+    return real, pm.reshape(n, -1).to(torch.int32), pos, status
 
 
 def drop_cls(x, I, N):

@@ -147,6 +147,42 @@ def check_linear_dx_swiglu(M, d, I):
     return r
 
 
+def check_linear_gu_swiglu_fused(M, d, I, variant):
+    """Projection + SwiGLU in one launch (pair epilogue of the 16x16x32 ring kernels): gu and a vs the oracle, and BIT-identical to the
+    two-launch form (same ring variant for the GEMM, then swiglu_fwd)."""
+    k = K()
+    x, w = rnd(M, d, seed=61), rnd(2 * I, d, seed=62, scale=0.1)
+    xd, wd = x.to(DEV), w.to(DEV)
+    gu, a = k.linear_gu_swiglu(xd, wd, variant=variant)
+    gref, aref = R.linear_gu_swiglu(x, w)
+    r = max(close(gu, gref, 1e-2, f"fused gu {M}x{d}x{I} v{variant}"), close(a, aref, 1e-2, f"fused swiglu out {M}x{d}x{I} v{variant}"))
+    gu2 = k.gemm_nt(xd, wd, variant=variant)
+    assert torch.equal(gu, gu2), f"fused SwiGLU-forward epilogue: gate|up differs from the plain GEMM (variant {variant})"
+    assert torch.equal(a, k.swiglu_fwd(gu2)), f"fused SwiGLU-forward epilogue: activation differs from swiglu_fwd (variant {variant})"
+    return r
+
+
+def check_linear_qkv_rope_fused(M, d, H, Hkv, bias, variant):
+    """q|k|v projection with RoPE in the epilogue (head dim 128; v heads pass through): vs the oracle, and BIT-identical to gemm_nt (+ bias)
+    followed by rope_apply_ on the q and k heads."""
+    k = K()
+    hd = 128
+    N = (H + 2 * Hkv) * hd
+    x, w = rnd(M, d, seed=71), rnd(N, d, seed=72, scale=0.1)
+    b = rnd(N, seed=73) if bias else None
+    pos = torch.arange(M, dtype=torch.int64) % 977
+    inv = 1.0 / (500000.0 ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+    cd, sd = k.rope_table(pos.to(DEV), inv.to(DEV))
+    cr, sr = cd.cpu(), sd.cpu()                          # the tables themselves are checked by the rope_* cases
+    xd, wd, bd = x.to(DEV), w.to(DEV), None if b is None else b.to(DEV)
+    out = k.linear_qkv_rope(xd, wd, bd, cd, sd, H + Hkv, hd, variant=variant)
+    ref = R.linear_qkv_rope(x, w, b, cr, sr, H + Hkv, hd)
+    r = close(out, ref, 1e-2, f"fused qkv+rope {M}x{d} {H}/{Hkv} bias={bias} v{variant}")
+    two = k.rope_apply_(k.gemm_nt(xd, wd, bias=bd, variant=variant), cd, sd, H + Hkv, hd)
+    assert torch.equal(out, two), f"fused RoPE epilogue differs from gemm_nt + rope_apply_ (variant {variant})"
+    return r
+
+
 def check_gemm_ksplit_deterministic(ring=12):
     """Shapes whose last tile round is incomplete run the K-split path (slab reduction by the last arriver): results must not
     depend on which workgroup arrives last -> repeated launches are bit-identical, and agree with the oracle; S = 2 and S > 2."""
@@ -832,6 +868,46 @@ def check_idefics2_packed():
             assert c > 0.995 and Hh.rel_l2(g, og) < 6e-2, (name, c, Hh.rel_l2(g, og))
             worst = min(worst, c)
     return 1.0 - worst
+
+
+def check_navit_prepare():
+    """Device-side NaViT image preparation (padding-image flags, pixel mask -> patch mask, bucketised position ids) bit-exact vs the oracle's
+    restatement of modeling_idefics2.py:1636-1658 / :190-210: no mask, rectangular masks of every aspect, all-zero padding images, a
+    -0.0-only image (== 0.0 in the reference), and a non-rectangular mask (status 1 where the reference raises)."""
+    k = K()
+    worst = 0.0
+    g = torch.Generator().manual_seed(5)
+    for (n, Hh_, Ww_, P, side, masked) in [(5, 28, 42, 14, 4, True), (3, 448, 448, 14, 32, False), (6, 56, 56, 14, 4, True), (4, 98, 70, 14, 7, True)]:
+        pix = torch.randn(n, 3, Hh_, Ww_, generator=g)
+        pix[1] = 0.0                                      # padding image
+        if n > 3:
+            pix[3] = -0.0                                 # negative zeros only: still a padding image
+        pm = None
+        if masked:
+            pm = torch.zeros(n, Hh_, Ww_, dtype=torch.bool)
+            for i in range(n):
+                hh = int(torch.randint(1, Hh_ + 1, (1,), generator=g))
+                ww = int(torch.randint(1, Ww_ + 1, (1,), generator=g))
+                pm[i, :hh, :ww] = True
+            pm[0] = True
+        tab_n = max(side, Hh_ // P, Ww_ // P) + 1
+        boundaries = torch.arange(1 / side, 1.0, 1 / side)
+        tab = torch.zeros((tab_n, tab_n), dtype=torch.int32)
+        for m in range(1, tab_n):
+            b = torch.bucketize(torch.arange(0, 1 - 1e-6, 1 / torch.tensor(m)), boundaries, right=True)
+            tab[m, : min(m, b.numel())] = b[:m].to(torch.int32)
+        ref = R.navit_prepare(pix, pm, P, side, tab)
+        out = k.navit_prepare(pix.to(DEV), None if pm is None else pm.to(DEV), P, side, tab.to(DEV))
+        for name, a, b in zip(("real", "patch_mask", "pos_ids", "status"), out, ref):
+            assert torch.equal(a.cpu(), b), f"navit_prepare {name} differs ({n}x{Hh_}x{Ww_})"
+    # a mask whose attended patches are not a grid: the reference's assignment raises; the kernel reports it
+    pix = torch.randn(2, 3, 56, 56, generator=g)
+    pm = torch.ones(2, 56, 56, dtype=torch.bool)
+    pm[1, 14:28, 14:28] = False
+    tab = torch.zeros((5, 5), dtype=torch.int32)
+    out = k.navit_prepare(pix.to(DEV), pm.to(DEV), 14, 4, tab.to(DEV))
+    assert out[3].cpu().tolist() == [0, 1] and R.navit_prepare(pix, pm, 14, 4, tab)[3].tolist() == [0, 1]
+    return worst
 
 
 def check_idefics2_full_width():
@@ -1583,6 +1659,11 @@ def all_checks():
             c[f"gemm_ring16_v{v}_epi_{f}"] = (lambda f=f, v=v: check_gemm(300, 200, 72, f, v))
         c[f"gemm_ring16_v{v}_ksplit_deterministic"] = lambda v=v: check_gemm_ksplit_deterministic(v)
         c[f"gemm_ring16_v{v}_operand_over_2gib"] = lambda v=v: check_gemm_operand_over_2gib(v)
+    for v in (13, 14):
+        for (M, d, I) in [(333, 64, 128), (700, 768, 3072), (520, 256, 1152)]:
+            c[f"linear_gu_swiglu_fused_v{v}_{M}x{d}x{I}"] = (lambda M=M, d=d, I=I, v=v: check_linear_gu_swiglu_fused(M, d, I, v))
+        for (M, d, H, Hkv, bias) in [(333, 64, 2, 1, False), (700, 512, 4, 2, True), (1000, 256, 6, 1, True)]:
+            c[f"linear_qkv_rope_fused_v{v}_{M}x{d}_{H}_{Hkv}_{int(bias)}"] = (lambda M=M, d=d, H=H, Hkv=Hkv, bias=bias, v=v: check_linear_qkv_rope_fused(M, d, H, Hkv, bias, v))
     c["linear_dx_dw"] = check_linear_dx_dw
     c["linear_dx_swiglu_333x64x176"] = lambda: check_linear_dx_swiglu(333, 64, 176)
     c["linear_dx_swiglu_700x768x3072"] = lambda: check_linear_dx_swiglu(700, 768, 3072)
@@ -1674,6 +1755,9 @@ def all_checks():
     for a in QWEN_STEP_FP8_SHAPES:
         c[f"fullsize_fp8_gemm_{a[0]}"] = (lambda a=a: check_fp8_gemm_qwen_step_shape(*a))
     c["fullsize_fp8_dx_swiglu_4096x3584x18944"] = lambda: check_fp8_dx_swiglu(4096, 3584, 18944, 1)
+    c["navit_prepare"] = check_navit_prepare
+    c["fullsize_linear_gu_swiglu_fused"] = lambda: check_linear_gu_swiglu_fused(CFG2["M"], CFG2["d"], CFG2["I"], 0)
+    c["fullsize_linear_qkv_rope_fused"] = lambda: check_linear_qkv_rope_fused(CFG2["M"], CFG2["d"], CFG2["H"], CFG2["Hkv"], False, 0)
     c["fullsize_linear_dx_swiglu"] = check_linear_dx_swiglu_fullsize
     c["fullsize_ce_128258"] = check_ce_fullsize
     c["fullsize_rmsnorm_5624x4096"] = check_rmsnorm_fullsize

@@ -168,3 +168,24 @@ def test_dp2_gradients_are_the_mean_of_the_per_rank_gradients(cpu_backend):
         g = model.grad_arena.float().numpy().copy()
         acc = g if acc is None else acc + g
     assert Hh.rel_l2(res[0][2], acc / 2) < 1e-2                                        # bf16 rounding of the averaged buckets
+
+
+def test_bucket_table_reproduces_the_reference_position_ids():
+    """The device kernel (csrc/vit.hip navit_prepare_kernel) takes the NaViT position ids from a host-built table:
+    pos[k-th attended patch] = tab[nh][k // nw] * side + tab[nw][k % nw].  The table + formula must equal the reference's per-image float
+    arithmetic (oracle/idefics2_ref.bucketized_position_ids, modeling_idefics2.py:190-210) for every (nh, nw) up to the largest grid."""
+    from oracle.idefics2_ref import bucketized_position_ids
+    model = Hh.build_idefics2_product("cpu")
+    vc = model.config.vision_config
+    side = vc.image_size // vc.patch_size
+    big = max(side, 9)
+    tab = model.engine._bucket_table(big + 1, "cpu")
+    for nh in range(1, big + 1):
+        for nw in range(1, big + 1):
+            pm = torch.zeros(1, big, big, dtype=torch.bool)
+            pm[0, :nh, :nw] = True
+            ref = bucketized_position_ids(pm, side)[0]
+            k = torch.arange(nh * nw)
+            got = torch.zeros(big * big, dtype=torch.int64)
+            got[pm[0].reshape(-1)] = (tab[nh][k // nw].long() * side + tab[nw][k % nw].long())
+            assert torch.equal(got, ref), (nh, nw)
