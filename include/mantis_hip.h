@@ -160,6 +160,16 @@ int mantis_attn_fwd(const void* Q, const void* K, const void* V, const int32_t* 
                     int B, int L, int H, int Hkv, int hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale, int causal,
                     void* stream);
 int mantis_attn_dsum(const void* dO, const void* O, float* Dsum, int B, int L, int H, int hd, int64_t ldo, void* stream);
+/* Cross attention (non-causal): Lq query rows per batch entry (Q, O, dO, dQ: [B*Lq, ...]; LSE, Dsum fp32 [B, H, Lq]) over Lk keys (K, V, dK,
+ * dV: [B*Lk, ...]; kmask int32 [B, Lk] or NULL).  The Idefics2 perceiver resampler: 64 latent queries over concat[context, latents]
+ * (/root/reference/mantis/models/idefics2/modeling_idefics2.py:812-912).  Same kernels, head dims, strides and status codes as
+ * mantis_attn_fwd / mantis_attn_bwd; the backward's workspace is 2 * B*Lk*H*hd bf16 when H > Hkv. */
+int mantis_attn_fwd_cross(const void* Q, const void* K, const void* V, const int32_t* kmask, void* O, float* LSE, int B, int Lq, int Lk,
+                          int H, int Hkv, int hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale, void* stream);
+int mantis_attn_bwd_cross(const void* Q, const void* K, const void* V, const void* O, const void* dO, const int32_t* kmask,
+                          const float* LSE, float* Dsum, void* dQ, void* dK, void* dV, void* workspace, int B, int Lq, int Lk, int H,
+                          int Hkv, int hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ld_out, int64_t ldo, int64_t lddq,
+                          int64_t lddk, int64_t lddv, float scale, void* stream);
 /* workspace: 2*B*L*H*hd bf16 (per-query-head dK/dV partials, reduced over the GQA group) when
  * mantis_attn_bwd_needs_workspace(H, Hkv, hd) says so, else unused/NULL: not for H == Hkv, and not for hd 128 with H = 4 Hkv
  * (Llama-3), which always runs the GQA-aware dK/dV kernel (one workgroup per (64-key block, KV head) walks the group's query heads

@@ -49,6 +49,8 @@ SIGNATURES = {
     "mantis_attn_dsum": [P, P, P, I, I, I, I, L, P],
     "mantis_attn_bwd": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, L, L, L, L, L, L, L, L, F, I, P],
     "mantis_attn_bwd_needs_workspace": [I, I, I],
+    "mantis_attn_fwd_cross": [P, P, P, P, P, P, I, I, I, I, I, I, L, L, L, L, F, P],
+    "mantis_attn_bwd_cross": [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, L, L, L, L, L, L, L, L, F, P],
     "mantis_ce_fwd_bwd": [P, P, I, I, L, F, F, I, P, P, P, P, P],
     "mantis_im2col": [P, P, I, I, I, I, I, I, P],
     "mantis_cast_pad_rows": [P, P, L, I, L, I, P],

@@ -194,7 +194,7 @@ __device__ __forceinline__ void xcd_tile_map(int gx, int gy, int& x, int& y, int
 template <int HD, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                        const bf16_t* __restrict__ V, const int* __restrict__ kmask,
-                                                       bf16_t* __restrict__ O, float* __restrict__ LSE, int L, int H, int Hkv,
+                                                       bf16_t* __restrict__ O, float* __restrict__ LSE, int L, int Lk, int H, int Hkv,
                                                        long ldq, long ldk, long ldv, long ldo, float scale,
                                                        const int* __restrict__ kstart) {
     using C = AttnCfg<HD>;
@@ -234,10 +234,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
         for (int e = 0; e < 16; ++e) oacc[d][e] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    const int kend = CAUSAL ? (qblk0 + 128 < L ? qblk0 + 128 : L) : L;
+    const int kend = CAUSAL ? (qblk0 + 128 < L ? qblk0 + 128 : L) : Lk;      // Lk: number of keys (== L except for cross attention)
     const int ntiles = (kend + 63) / 64;
-    const bf16_t* Kb = K + (long)b * L * ldk + (long)hk * HD;
-    const bf16_t* Vb = V + (long)b * L * ldv + (long)hk * HD;
+    const bf16_t* Kb = K + (long)b * Lk * ldk + (long)hk * HD;
+    const bf16_t* Vb = V + (long)b * Lk * ldv + (long)hk * HD;
 
     // tile t -> LDS buffer (t & 1): global -> registers -> LDS in one go (registers are only live across the copy, so the kernel
     // fits 2 waves per SIMD; the copy of tile t+1 overlaps the MFMA work of the co-resident workgroup / partner waves)
@@ -245,23 +245,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
         const int key0 = t * 64;
         char* base = smem + (t & 1) * BUF;
         if constexpr (Y::DMA) {
-            stage_tile_dma<64>(Kb + (long)key0 * ldk, ldk, L - key0, base);
-            stage_tile_dma<64>(Vb + (long)key0 * ldv, ldv, L - key0, base + TILE);
+            stage_tile_dma<64>(Kb + (long)key0 * ldk, ldk, Lk - key0, base);
+            stage_tile_dma<64>(Vb + (long)key0 * ldv, ldv, Lk - key0, base + TILE);
         } else {
             {
                 TileRegs<64, C::NCH> rk;
-                rk.load(Kb + (long)key0 * ldk, ldk, L - key0, HD);
+                rk.load(Kb + (long)key0 * ldk, ldk, Lk - key0, HD);
                 rk.store(base, C::PITCH);
             }
             {
                 TileRegs<64, C::NCH> rv;
-                rv.load(Vb + (long)key0 * ldv, ldv, L - key0, HD);
+                rv.load(Vb + (long)key0 * ldv, ldv, Lk - key0, HD);
                 rv.store(base + TILE, C::PITCH);
             }
         }
         if (threadIdx.x < 64) {     // wave 0: additive key bias (0 / -inf) + one flag "this tile has a masked key"
             const int key = key0 + threadIdx.x;
-            const bool ok = key < L && (kmask == nullptr || kmask[(long)b * L + key] != 0);
+            const bool ok = key < Lk && (kmask == nullptr || kmask[(long)b * Lk + key] != 0);
             float* bp = reinterpret_cast<float*>(base + 2 * TILE);
             bp[threadIdx.x] = ok ? 0.f : -INFINITY;
             const unsigned long long okm = __ballot(ok);
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     auto stage_bias = [&](int t) {
         if (threadIdx.x < 64) {
             const int key = t * 64 + threadIdx.x;
-            const bool ok = key < L && (kmask == nullptr || kmask[(long)b * L + key] != 0);
+            const bool ok = key < Lk && (kmask == nullptr || kmask[(long)b * Lk + key] != 0);
             float* bp = reinterpret_cast<float*>(smem + (t & 1) * BUF + 2 * TILE);
             bp[threadIdx.x] = ok ? 0.f : -INFINITY;
             const unsigned long long okm = __ballot(ok);
@@ -300,8 +300,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
         } else {
             if (more) {
                 const int kn = (t + 1) * 64;
-                nk_regs.load(Kb + (long)kn * ldk, ldk, L - kn, HD);
-                nv_regs.load(Vb + (long)kn * ldv, ldv, L - kn, HD);
+                nk_regs.load(Kb + (long)kn * ldk, ldk, Lk - kn, HD);
+                nv_regs.load(Vb + (long)kn * ldv, ldv, Lk - kn, HD);
                 stage_bias(t + 1);
             }
         }
@@ -495,7 +495,7 @@ template <int HD, bool CAUSAL>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                           const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
                                                           const int* __restrict__ kmask, const float* __restrict__ LSE,
-                                                          float* __restrict__ Dsum, bf16_t* __restrict__ dQ, int L, int H,
+                                                          float* __restrict__ Dsum, bf16_t* __restrict__ dQ, int L, int Lk, int H,
                                                           int Hkv, long ldq, long ldk, long ldv, long ldo, long lddq, float scale,
                                                           const bf16_t* __restrict__ Ofwd, long ldout,
                                                           const int* __restrict__ kstart) {
@@ -559,10 +559,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[d][e] = 0.f;
 
-    const int kend = CAUSAL ? (qblk0 + 128 < L ? qblk0 + 128 : L) : L;
+    const int kend = CAUSAL ? (qblk0 + 128 < L ? qblk0 + 128 : L) : Lk;
     const int ntiles = (kend + 63) / 64;
-    const bf16_t* Kb = K + (long)b * L * ldk + (long)hk * HD;
-    const bf16_t* Vb = V + (long)b * L * ldv + (long)hk * HD;
+    const bf16_t* Kb = K + (long)b * Lk * ldk + (long)hk * HD;
+    const bf16_t* Vb = V + (long)b * Lk * ldv + (long)hk * HD;
 
     // tile t -> LDS buffer (t & 1): global -> registers -> LDS in one go (registers are only live across the copy, so the kernel
     // fits 2 waves per SIMD; the copy of tile t+1 overlaps the MFMA work of the co-resident workgroup / partner waves)
@@ -570,23 +570,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
         const int key0 = t * 64;
         char* base = smem + (t & 1) * BUF;
         if constexpr (Y::DMA) {
-            stage_tile_dma<64>(Kb + (long)key0 * ldk, ldk, L - key0, base);
-            stage_tile_dma<64>(Vb + (long)key0 * ldv, ldv, L - key0, base + TILE);
+            stage_tile_dma<64>(Kb + (long)key0 * ldk, ldk, Lk - key0, base);
+            stage_tile_dma<64>(Vb + (long)key0 * ldv, ldv, Lk - key0, base + TILE);
         } else {
             {
                 TileRegs<64, C::NCH> rk;
-                rk.load(Kb + (long)key0 * ldk, ldk, L - key0, HD);
+                rk.load(Kb + (long)key0 * ldk, ldk, Lk - key0, HD);
                 rk.store(base, C::PITCH);
             }
             {
                 TileRegs<64, C::NCH> rv;
-                rv.load(Vb + (long)key0 * ldv, ldv, L - key0, HD);
+                rv.load(Vb + (long)key0 * ldv, ldv, Lk - key0, HD);
                 rv.store(base + TILE, C::PITCH);
             }
         }
         if (threadIdx.x < 64) {     // wave 0: additive key bias (0 / -inf) + one flag "this tile has a masked key"
             const int key = key0 + threadIdx.x;
-            const bool ok = key < L && (kmask == nullptr || kmask[(long)b * L + key] != 0);
+            const bool ok = key < Lk && (kmask == nullptr || kmask[(long)b * Lk + key] != 0);
             float* bp = reinterpret_cast<float*>(base + 2 * TILE);
             bp[threadIdx.x] = ok ? 0.f : -INFINITY;
             const unsigned long long okm = __ballot(ok);
@@ -688,7 +688,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
                                                               const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
                                                               const int* __restrict__ kmask, const float* __restrict__ LSE,
                                                               const float* __restrict__ Dsum, bf16_t* __restrict__ dKp,
-                                                              bf16_t* __restrict__ dVp, int L, int H, int Hkv, long ldq, long ldk,
+                                                              bf16_t* __restrict__ dVp, int L, int Lk, int H, int Hkv, long ldq, long ldk,
                                                               long ldv, long ldo, long ldpk, long ldpv, float scale,
                                                               const int* __restrict__ kstart, const int* __restrict__ qend) {
     using C = AttnCfg<HD>;
@@ -702,12 +702,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hh = lane >> 5, lk = lane & 31;
     const int kg = wave / D::DS, dh = wave % D::DS;
     int bx, h, b;
-    xcd_tile_map((L + D::KEYS - 1) / D::KEYS, H, bx, h, b);
+    xcd_tile_map((Lk + D::KEYS - 1) / D::KEYS, H, bx, h, b);          // L queries, Lk keys (== L except for cross attention)
     const int hk = h / (H / Hkv);
     const int kblk0 = bx * D::KEYS, k0 = kblk0 + kg * 32, key = k0 + lk;   // causal: key block 0 is the heaviest, first
-    const int keyc = key < L ? key : L - 1;
+    const int keyc = key < Lk ? key : Lk - 1;
     const float c = scale * LOG2E;
-    const bool key_ok = key < L && (kmask == nullptr || kmask[(long)b * L + keyc] != 0);
+    const bool key_ok = key < Lk && (kmask == nullptr || kmask[(long)b * Lk + keyc] != 0);
 
     bf16x8 kf[C::NKS], vf[C::NKS];
 #pragma unroll
@@ -715,8 +715,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
         const int ch = ks * 2 + hh;
         u32x4 a = {0u, 0u, 0u, 0u}, w = {0u, 0u, 0u, 0u};
         if (ch * 8 < HD) {
-            a = *reinterpret_cast<const u32x4*>(K + ((long)b * L + keyc) * ldk + (long)hk * HD + ch * 8);
-            w = *reinterpret_cast<const u32x4*>(V + ((long)b * L + keyc) * ldv + (long)hk * HD + ch * 8);
+            a = *reinterpret_cast<const u32x4*>(K + ((long)b * Lk + keyc) * ldk + (long)hk * HD + ch * 8);
+            w = *reinterpret_cast<const u32x4*>(V + ((long)b * Lk + keyc) * ldv + (long)hk * HD + ch * 8);
         }
         kf[ks] = as_bf16x8(a);
         vf[ks] = as_bf16x8(w);
@@ -733,7 +733,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
         __shared__ int s_qlim;
         if (threadIdx.x == 0) s_qlim = 0;
         __syncthreads();
-        if (threadIdx.x < D::KEYS && kblk0 + (int)threadIdx.x < L) atomicMax(&s_qlim, qend[(long)b * L + kblk0 + threadIdx.x]);
+        if (threadIdx.x < D::KEYS && kblk0 + (int)threadIdx.x < Lk) atomicMax(&s_qlim, qend[(long)b * Lk + kblk0 + threadIdx.x]);
         __syncthreads();
         qlim = s_qlim < L ? s_qlim : L;
     }
@@ -835,9 +835,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    if (key < L) {
-        bf16_t* kp = dKp + ((long)b * L + key) * ldpk + (long)(H == Hkv ? hk : h) * HD;
-        bf16_t* vp = dVp + ((long)b * L + key) * ldpv + (long)(H == Hkv ? hk : h) * HD;
+    if (key < Lk) {
+        bf16_t* kp = dKp + ((long)b * Lk + key) * ldpk + (long)(H == Hkv ? hk : h) * HD;
+        bf16_t* vp = dVp + ((long)b * Lk + key) * ldpv + (long)(H == Hkv ? hk : h) * HD;
 #pragma unroll
         for (int d = 0; d < D::NDW; ++d)
 #pragma unroll
@@ -1327,13 +1327,13 @@ static inline bool attn_dkv_group_kernel_ok(int G) { return G >= 2 && (G % 2 == 
 
 template <int HD>
 static int launch_fwd(bool causal, dim3 grid, hipStream_t s, const bf16_t* Q, const bf16_t* K, const bf16_t* V, const int* kmask,
-                      bf16_t* O, float* LSE, int L, int H, int Hkv, long ldq, long ldk, long ldv, long ldo, float scale,
+                      bf16_t* O, float* LSE, int L, int Lk, int H, int Hkv, long ldq, long ldk, long ldv, long ldo, float scale,
                       const int* kstart) {
     if (causal)
-        MANTIS_LAUNCH((attn_fwd_kernel<HD, true>), grid, dim3(256), 0, s, Q, K, V, kmask, O, LSE, L, H, Hkv, ldq, ldk, ldv,
+        MANTIS_LAUNCH((attn_fwd_kernel<HD, true>), grid, dim3(256), 0, s, Q, K, V, kmask, O, LSE, L, Lk, H, Hkv, ldq, ldk, ldv,
                            ldo, scale, kstart);
     else
-        MANTIS_LAUNCH((attn_fwd_kernel<HD, false>), grid, dim3(256), 0, s, Q, K, V, kmask, O, LSE, L, H, Hkv, ldq, ldk, ldv,
+        MANTIS_LAUNCH((attn_fwd_kernel<HD, false>), grid, dim3(256), 0, s, Q, K, V, kmask, O, LSE, L, Lk, H, Hkv, ldq, ldk, ldv,
                            ldo, scale, kstart);
     return mantis_check_launch();
 }
@@ -1341,9 +1341,9 @@ static int launch_fwd(bool causal, dim3 grid, hipStream_t s, const bf16_t* Q, co
 template <int HD>
 static int launch_bwd(bool causal, hipStream_t s, const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* dO,
                       const int* kmask, const float* LSE, float* Dsum, bf16_t* dQ, bf16_t* dK, bf16_t* dV, bf16_t* ws, int B,
-                      int L, int H, int Hkv, long ldq, long ldk, long ldv, long ldo, long lddq, long lddk, long lddv, float scale,
+                      int L, int Lk, int H, int Hkv, long ldq, long ldk, long ldv, long ldo, long lddq, long lddk, long lddv, float scale,
                       const bf16_t* Ofwd, long ldout, const int* kstart, const int* qend) {
-    const dim3 gq(cdiv(L, 128) * H * B), gk(cdiv(L, DkvCfg<HD>::KEYS) * H * B);
+    const dim3 gq(cdiv(L, 128) * H * B), gk(cdiv(Lk, DkvCfg<HD>::KEYS) * H * B);       // L queries, Lk keys per batch entry
     const int G = H / Hkv;
     if constexpr (HD == 128) {
         // GQA-aware dK/dV (no HBM partials, no group reduce); dQ as before (it also publishes Dsum).  Its grid is one workgroup per
@@ -1352,12 +1352,12 @@ static int launch_bwd(bool causal, hipStream_t s, const bf16_t* Q, const bf16_t*
         // other group sizes than Llama's take it only when the grid is either tiny or at least two rounds deep
         const long nwg = (long)cdiv(L, 64) * Hkv * B;
         const int cus = attn_num_cus();
-        if (attn_dkv_group_kernel_ok(G) && (G == 4 || nwg >= 2L * cus || nwg <= cus / 2 || ws == nullptr)) {
+        if (Lk == L && attn_dkv_group_kernel_ok(G) && (G == 4 || nwg >= 2L * cus || nwg <= cus / 2 || ws == nullptr)) {
             if (causal)
-                MANTIS_LAUNCH((attn_bwd_dq_kernel<HD, true>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, L, H, Hkv,
+                MANTIS_LAUNCH((attn_bwd_dq_kernel<HD, true>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, L, Lk, H, Hkv,
                                    ldq, ldk, ldv, ldo, lddq, scale, Ofwd, ldout, kstart);
             else
-                MANTIS_LAUNCH((attn_bwd_dq_kernel<HD, false>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, L, H, Hkv,
+                MANTIS_LAUNCH((attn_bwd_dq_kernel<HD, false>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, L, Lk, H, Hkv,
                                    ldq, ldk, ldv, ldo, lddq, scale, Ofwd, ldout, kstart);
             const dim3 g4(cdiv(L, 64) * Hkv * B);
 #define DKV_G4(C_, S_) MANTIS_LAUNCH((attn_bwd_dkv_g4_kernel<C_, S_>), g4, dim3(256), 0, s, Q, K, V, dO, kmask, kstart, qend, LSE, \
@@ -1369,19 +1369,19 @@ static int launch_bwd(bool causal, hipStream_t s, const bf16_t* Q, const bf16_t*
         }
     }
     if (G > 1 && ws == nullptr) return MANTIS_EINVAL;
-    const long rows = (long)B * L;
+    const long rows = (long)B * Lk;
     bf16_t* pk = G == 1 ? dK : ws;
     bf16_t* pv = G == 1 ? dV : ws + rows * H * HD;
     const long ldpk = G == 1 ? lddk : (long)H * HD, ldpv = G == 1 ? lddv : (long)H * HD;
     if (causal) {
-        MANTIS_LAUNCH((attn_bwd_dq_kernel<HD, true>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, L, H, Hkv, ldq,
+        MANTIS_LAUNCH((attn_bwd_dq_kernel<HD, true>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, L, Lk, H, Hkv, ldq,
                            ldk, ldv, ldo, lddq, scale, Ofwd, ldout, kstart);
-        MANTIS_LAUNCH((attn_bwd_dkv_kernel<HD, true>), gk, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, pk, pv, L, H, Hkv,
+        MANTIS_LAUNCH((attn_bwd_dkv_kernel<HD, true>), gk, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, pk, pv, L, Lk, H, Hkv,
                            ldq, ldk, ldv, ldo, ldpk, ldpv, scale, kstart, qend);
     } else {
-        MANTIS_LAUNCH((attn_bwd_dq_kernel<HD, false>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, L, H, Hkv, ldq,
+        MANTIS_LAUNCH((attn_bwd_dq_kernel<HD, false>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, L, Lk, H, Hkv, ldq,
                            ldk, ldv, ldo, lddq, scale, Ofwd, ldout, kstart);
-        MANTIS_LAUNCH((attn_bwd_dkv_kernel<HD, false>), gk, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, pk, pv, L, H, Hkv,
+        MANTIS_LAUNCH((attn_bwd_dkv_kernel<HD, false>), gk, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, pk, pv, L, Lk, H, Hkv,
                            ldq, ldk, ldv, ldo, ldpk, ldpv, scale, kstart, qend);
     }
     if (G > 1) {
@@ -1398,16 +1398,36 @@ extern "C" {
 
 // Q [B,L,H,hd] (row stride ldq), K,V [B,L,Hkv,hd] (ldk, ldv), kmask int32[B,L] or NULL, O [B,L,H,hd] (ldo),
 // LSE fp32 [B,H,L] or NULL.  hd in {16, 64, 72, 96, 128} (96: the Idefics2 perceiver resampler).
+static int attn_fwd_impl(const void* Q, const void* K, const void* V, const int32_t* kmask, const int32_t* kstart, void* O, float* LSE,
+                         int B, int L, int Lk, int H, int Hkv, int hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale,
+                         int causal, void* stream);
+
 int mantis_attn_fwd(const void* Q, const void* K, const void* V, const int32_t* kmask, const int32_t* kstart, void* O, float* LSE,
                     int B, int L, int H, int Hkv, int hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale, int causal,
                     void* stream) {
+    return attn_fwd_impl(Q, K, V, kmask, kstart, O, LSE, B, L, L, H, Hkv, hd, ldq, ldk, ldv, ldo, scale, causal, stream);
+}
+
+// Cross attention: Lq query rows per batch entry (Q, O: [B*Lq, ...], LSE [B, H, Lq]) over Lk keys (K, V: [B*Lk, ...], kmask int32 [B, Lk]
+// or NULL), non-causal.  The Idefics2 perceiver resampler's attention of 64 latent queries over concat[context, latents]
+// (/root/reference/mantis/models/idefics2/modeling_idefics2.py:812-912).
+int mantis_attn_fwd_cross(const void* Q, const void* K, const void* V, const int32_t* kmask, void* O, float* LSE, int B, int Lq, int Lk,
+                          int H, int Hkv, int hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale, void* stream) {
+    if (Lk <= 0) return MANTIS_EINVAL;
+    return attn_fwd_impl(Q, K, V, kmask, nullptr, O, LSE, B, Lq, Lk, H, Hkv, hd, ldq, ldk, ldv, ldo, scale, 0, stream);
+}
+
+static int attn_fwd_impl(const void* Q, const void* K, const void* V, const int32_t* kmask, const int32_t* kstart, void* O, float* LSE,
+                         int B, int L, int Lk, int H, int Hkv, int hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale,
+                         int causal, void* stream) {
     if (B <= 0 || L <= 0 || H <= 0 || Hkv <= 0 || H % Hkv) return MANTIS_EINVAL;
+    if (causal && Lk != L) return MANTIS_EINVAL;
     if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4) return MANTIS_EUNSUPPORTED;
     if (kstart != nullptr && !causal) return MANTIS_EUNSUPPORTED;     // a lower key bound alone is a block-diagonal mask only under causality
     const dim3 grid(cdiv(L, 128) * H * B);
     hipStream_t s = (hipStream_t)stream;
 #define FWD(HD) return launch_fwd<HD>(causal != 0, grid, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, kmask, \
-                                      (bf16_t*)O, LSE, L, H, Hkv, (long)ldq, (long)ldk, (long)ldv, (long)ldo, scale, kstart)
+                                      (bf16_t*)O, LSE, L, Lk, H, Hkv, (long)ldq, (long)ldk, (long)ldv, (long)ldo, scale, kstart)
     switch (hd) {
         case 16: FWD(16);
         case 64: FWD(64);
@@ -1439,17 +1459,42 @@ int mantis_attn_dsum(const void* dO, const void* O, float* Dsum, int B, int L, i
 // (hd 128, H = 4 Hkv; see mantis_attn_bwd_workspace_bytes).  kstart / qend (both or neither): segment bounds of packed samples.
 // O (optional): the forward output [B*L, H*hd] (row stride ld_out).  If given, D = rowsum(dO * O) is computed inside the dQ kernel and
 // written to Dsum (then a [B,H,L] fp32 scratch/output); if NULL, Dsum must hold it already (mantis_attn_dsum).
+static int attn_bwd_impl(const void* Q, const void* K, const void* V, const void* O, const void* dO, const int32_t* kmask,
+                         const int32_t* kstart, const int32_t* qend, const float* LSE, float* Dsum, void* dQ, void* dK, void* dV,
+                         void* workspace, int B, int L, int Lk, int H, int Hkv, int hd, int64_t ldq, int64_t ldk, int64_t ldv,
+                         int64_t ld_out, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, float scale, int causal, void* stream);
+
 int mantis_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const int32_t* kmask,
                     const int32_t* kstart, const int32_t* qend, const float* LSE, float* Dsum, void* dQ, void* dK, void* dV,
                     void* workspace, int B, int L, int H, int Hkv, int hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ld_out,
                     int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, float scale, int causal, void* stream) {
+    return attn_bwd_impl(Q, K, V, O, dO, kmask, kstart, qend, LSE, Dsum, dQ, dK, dV, workspace, B, L, L, H, Hkv, hd, ldq, ldk, ldv, ld_out,
+                         ldo, lddq, lddk, lddv, scale, causal, stream);
+}
+
+// Backward of mantis_attn_fwd_cross: dQ [B*Lq, H*hd], dK / dV [B*Lk, Hkv*hd]; Dsum fp32 [B, H, Lq] scratch; workspace 2 * B*Lk*H*hd bf16
+// when H > Hkv (per-query-head dK/dV partials, summed over the GQA group afterwards).
+int mantis_attn_bwd_cross(const void* Q, const void* K, const void* V, const void* O, const void* dO, const int32_t* kmask,
+                          const float* LSE, float* Dsum, void* dQ, void* dK, void* dV, void* workspace, int B, int Lq, int Lk, int H,
+                          int Hkv, int hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ld_out, int64_t ldo, int64_t lddq,
+                          int64_t lddk, int64_t lddv, float scale, void* stream) {
+    if (Lk <= 0 || !O) return MANTIS_EINVAL;
+    return attn_bwd_impl(Q, K, V, O, dO, kmask, nullptr, nullptr, LSE, Dsum, dQ, dK, dV, workspace, B, Lq, Lk, H, Hkv, hd, ldq, ldk, ldv,
+                         ld_out, ldo, lddq, lddk, lddv, scale, 0, stream);
+}
+
+static int attn_bwd_impl(const void* Q, const void* K, const void* V, const void* O, const void* dO, const int32_t* kmask,
+                         const int32_t* kstart, const int32_t* qend, const float* LSE, float* Dsum, void* dQ, void* dK, void* dV,
+                         void* workspace, int B, int L, int Lk, int H, int Hkv, int hd, int64_t ldq, int64_t ldk, int64_t ldv,
+                         int64_t ld_out, int64_t ldo, int64_t lddq, int64_t lddk, int64_t lddv, float scale, int causal, void* stream) {
     if (B <= 0 || L <= 0 || H <= 0 || Hkv <= 0 || H % Hkv || !Dsum) return MANTIS_EINVAL;
+    if (causal && Lk != L) return MANTIS_EINVAL;
     if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8 || lddq % 4 || lddk % 8 || lddv % 8 || (O && ld_out % 8)) return MANTIS_EUNSUPPORTED;
     if ((kstart == nullptr) != (qend == nullptr)) return MANTIS_EINVAL;
     if (kstart != nullptr && !causal) return MANTIS_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
 #define BWD(HD) return launch_bwd<HD>(causal != 0, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dO, \
-                                      kmask, LSE, Dsum, (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV, (bf16_t*)workspace, B, L, H, Hkv, \
+                                      kmask, LSE, Dsum, (bf16_t*)dQ, (bf16_t*)dK, (bf16_t*)dV, (bf16_t*)workspace, B, L, Lk, H, Hkv, \
                                       (long)ldq, (long)ldk, (long)ldv, (long)ldo, (long)lddq, (long)lddk, (long)lddv, scale, \
                                       (const bf16_t*)O, (long)ld_out, kstart, qend)
     switch (hd) {

@@ -1130,38 +1130,33 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring16_kernel(
     char* strip = smem + wave * EPI_STRIP;
     const int mw0 = m0 + wm * 128, nw0 = n0 + wn * (NBN * 16);
     if constexpr (PAIR != PAIR_NONE) {
-        // two strips per wave (8 x 2 x 17 KiB <= 160 KiB): A = the first columns, B = the second columns of the wave's G features.
-        //   4 waves: per 64-row pass pm, A[row][c] = first(m = pm*64 + row, phi = phi0 + c), c < 64
-        //   8 waves: one pass,           A[row][c] = first(m = (c >> 5)*64 + row, phi = phi0 + (c & 31))
-        // so lane (rr, cc) of the read-back meets the first and second column of the same (m, 8 features) at the same strip position
+        // 4 waves: two strips per wave (8 x 17 KiB <= 160 KiB), A = the first columns, B = the second columns of the wave's 64 features; per
+        //          64-row pass, lane (rr = lane >> 3, cc = lane & 7) meets both columns of (row it*8 + rr, features cc*8 ..) at the same
+        //          position of the two strips
+        // 8 waves: one strip per wave (8 x 17 KiB): its 64 columns are [32 first | 32 second] -- the plain strip fill; per 64-row pass, lane
+        //          (r16 = lane >> 2, fg = lane & 3) reads the first columns at fg*8 and the second ones at 32 + fg*8 of row it*16 + r16
         constexpr int G = NBN * 8;
-        char* sa = smem + (2 * wave) * EPI_STRIP;
-        char* sb = sa + EPI_STRIP;
+        char* sa = smem + (NW == 4 ? 2 * wave : wave) * EPI_STRIP;
+        char* sb = NW == 4 ? sa + EPI_STRIP : sa + 32 * 4;
         const int phi0 = wn * G;
-        const int rr = lane >> 3, cc = lane & 7;
+        const int rr = NW == 4 ? lane >> 3 : lane >> 2, cc = NW == 4 ? lane & 7 : lane & 3;
+        constexpr int RPI = NW == 4 ? 8 : 16;              // rows per read-back iteration
         const bool has_bias = flags & EPI_BIAS;
 #pragma unroll
-        for (int pass = 0; pass < (NW == 4 ? 2 : 1); ++pass) {
-            if constexpr (NW == 4) {
+        for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-                for (int tm4 = 0; tm4 < 4; ++tm4)
+            for (int tm4 = 0; tm4 < 4; ++tm4)
 #pragma unroll
-                    for (int tn4 = 0; tn4 < 4; ++tn4) {
-                        const int off = (tm4 * 16 + (lane & 15)) * EPI_PITCH + (tn4 * 16 + 4 * (lane >> 4)) * 4;
+                for (int tn4 = 0; tn4 < 4; ++tn4) {
+                    const int off = (tm4 * 16 + (lane & 15)) * EPI_PITCH + (tn4 * 16 + 4 * (lane >> 4)) * 4;
+                    if constexpr (NW == 4) {
                         *reinterpret_cast<f32x4*>(sa + off) = acc[tn4][pass * 4 + tm4];
                         *reinterpret_cast<f32x4*>(sb + off) = acc[4 + tn4][pass * 4 + tm4];
+                    } else {
+                        *reinterpret_cast<f32x4*>(sa + off) = acc[tn4][pass * 4 + tm4];      // blocks 0,1 = first, 2,3 = second columns
                     }
-            } else {
-#pragma unroll
-                for (int tm = 0; tm < 8; ++tm)
-#pragma unroll
-                    for (int tn2 = 0; tn2 < 2; ++tn2) {
-                        const int off = ((tm & 3) * 16 + (lane & 15)) * EPI_PITCH + ((tm >> 2) * 32 + tn2 * 16 + 4 * (lane >> 4)) * 4;
-                        *reinterpret_cast<f32x4*>(sa + off) = acc[tn2][tm];
-                        *reinterpret_cast<f32x4*>(sb + off) = acc[2 + tn2][tm];
-                    }
-            }
-            const int phi = phi0 + (NW == 4 ? cc * 8 : (cc & 3) * 8);
+                }
+            const int phi = phi0 + cc * 8;
             const int col1 = pair_first(phi), col2 = col1 + pair_dist;
             float b1[8], b2[8];
 #pragma unroll
@@ -1170,9 +1165,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring16_kernel(
                 b2[e] = has_bias ? bf2f(bias[col2 + e]) : 0.f;
             }
 #pragma unroll 2
-            for (int it = 0; it < 8; ++it) {
-                const int row = it * 8 + rr;
-                const int m = mw0 + (NW == 4 ? pass * 64 : (cc >> 2) * 64) + row;
+            for (int it = 0; it < 64 / RPI; ++it) {
+                const int row = it * RPI + rr;
+                const int m = mw0 + pass * 64 + row;
                 const f32x4 alo = *reinterpret_cast<const f32x4*>(sa + row * EPI_PITCH + cc * 32);
                 const f32x4 ahi = *reinterpret_cast<const f32x4*>(sa + row * EPI_PITCH + cc * 32 + 16);
                 const f32x4 blo = *reinterpret_cast<const f32x4*>(sb + row * EPI_PITCH + cc * 32);

@@ -470,6 +470,28 @@ def attn_bwd_qkv(q, k, v, o, do, lse, dq, dk, dv, B, Lseq, H, Hkv, hd, kmask, sc
     _lib.check(rc, f"attn_bwd hd={hd}")
 
 
+def attn_fwd_cross(q, k, v, B, Lq, Lk, H, Hkv, hd, kmask, scale):
+    """Non-causal cross attention: q [B*Lq, >=H*hd] over k / v [B*Lk, >=Hkv*hd] row views (any row stride), kmask int32 [B, Lk] or None.
+    Returns o [B*Lq, H*hd], lse fp32 [B, H, Lq]."""
+    _chk2d(q, "q"), _chk2d(k, "k"), _chk2d(v, "v")
+    o = torch.empty((B * Lq, H * hd), dtype=BF16, device=q.device)
+    lse = torch.empty((B, H, Lq), dtype=torch.float32, device=q.device)
+    rc = _L.mantis_attn_fwd_cross(_p(q), _p(k), _p(v), _p(kmask), _p(o), _p(lse), B, Lq, Lk, H, Hkv, hd, q.stride(0), k.stride(0),
+                                  v.stride(0), o.stride(0), float(scale), _stream())
+    _lib.check(rc, f"attn_fwd_cross hd={hd}")
+    return o, lse
+
+
+def attn_bwd_cross(q, k, v, o, do, lse, dq, dk, dv, B, Lq, Lk, H, Hkv, hd, kmask, scale):
+    """Backward of attn_fwd_cross into the given row views dq [B*Lq, H*hd], dk / dv [B*Lk, Hkv*hd] (any row stride)."""
+    dsum = torch.empty((B, H, Lq), dtype=torch.float32, device=q.device)
+    ws = torch.empty((2, B * Lk, H * hd), dtype=BF16, device=q.device) if H != Hkv else None
+    rc = _L.mantis_attn_bwd_cross(_p(q), _p(k), _p(v), _p(o), _p(do), _p(kmask), _p(lse), _p(dsum), _p(dq), _p(dk), _p(dv), _p(ws), B,
+                                  Lq, Lk, H, Hkv, hd, q.stride(0), k.stride(0), v.stride(0), o.stride(0), do.stride(0), dq.stride(0),
+                                  dk.stride(0), dv.stride(0), float(scale), _stream())
+    _lib.check(rc, f"attn_bwd_cross hd={hd}")
+
+
 def _split_qkv(qkv, H, Hkv, hd):
     return qkv[:, : H * hd], qkv[:, H * hd: (H + Hkv) * hd], qkv[:, (H + Hkv) * hd: (H + 2 * Hkv) * hd]
 

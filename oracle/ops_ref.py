@@ -349,6 +349,47 @@ def attn_bwd(qkv, o, do, lse, B, Lseq, H, Hkv, hd, kmask, scale, causal, kstart=
     return out
 
 
+def attn_fwd_cross(q, k, v, B, Lq, Lk, H, Hkv, hd, kmask, scale):
+    """Restates the perceiver attention of /root/reference/mantis/models/idefics2/modeling_idefics2.py:812-912 (eager path :873-905): Lq
+    queries per batch entry over Lk keys, GQA by repeat, fp32 softmax, non-causal, key mask."""
+    qh = q[:, : H * hd].reshape(B, Lq, H, hd).transpose(1, 2)
+    kh = k[:, : Hkv * hd].reshape(B, Lk, Hkv, hd).transpose(1, 2)
+    vh = v[:, : Hkv * hd].reshape(B, Lk, Hkv, hd).transpose(1, 2)
+    s = _scores(qh, kh, scale, False, kmask, H, Hkv)
+    lse = torch.logsumexp(s, dim=-1)
+    p = torch.exp(s - lse[..., None]).nan_to_num(0.0)
+    rep = H // Hkv
+    vv = vh.repeat_interleave(rep, dim=1) if rep > 1 else vh
+    o = torch.matmul(p, _f(vv)).transpose(1, 2).reshape(B * Lq, H * hd).to(q.dtype)
+    lse = torch.where(torch.isinf(lse) & (lse < 0), torch.full_like(lse, float("inf")), lse)
+    return o, lse
+
+
+def attn_bwd_cross(q, k, v, o, do, lse, dq, dk, dv, B, Lq, Lk, H, Hkv, hd, kmask, scale):
+    qh = q[:, : H * hd].reshape(B, Lq, H, hd).transpose(1, 2)
+    kh = k[:, : Hkv * hd].reshape(B, Lk, Hkv, hd).transpose(1, 2)
+    vh = v[:, : Hkv * hd].reshape(B, Lk, Hkv, hd).transpose(1, 2)
+    rep = H // Hkv
+    s = _scores(qh, kh, scale, False, kmask, H, Hkv)
+    p = torch.exp(s - lse[..., None]).nan_to_num(0.0)
+    dO = _f(do).reshape(B, Lq, H, hd).transpose(1, 2)
+    O = _f(o).reshape(B, Lq, H, hd).transpose(1, 2)
+    vv = _f(vh).repeat_interleave(rep, dim=1) if rep > 1 else _f(vh)
+    kk = _f(kh).repeat_interleave(rep, dim=1) if rep > 1 else _f(kh)
+    dsum = (dO * O).sum(-1, keepdim=True)
+    dP = torch.matmul(dO, vv.transpose(-1, -2))
+    dS = p * (dP - dsum) * scale
+    gq = torch.matmul(dS, kk)
+    gk = torch.matmul(dS.transpose(-1, -2), _f(qh))
+    gv = torch.matmul(p.transpose(-1, -2), dO)
+    if rep > 1:
+        gk = gk.reshape(B, Hkv, rep, Lk, hd).sum(2)
+        gv = gv.reshape(B, Hkv, rep, Lk, hd).sum(2)
+    dq.copy_(gq.transpose(1, 2).reshape(B * Lq, H * hd).to(dq.dtype))
+    dk.copy_(gk.transpose(1, 2).reshape(B * Lk, Hkv * hd).to(dk.dtype))
+    dv.copy_(gv.transpose(1, 2).reshape(B * Lk, Hkv * hd).to(dv.dtype))
+
+
 def attn_fwd_qkv(q, k, v, B, Lseq, H, Hkv, hd, kmask, scale, causal, want_lse=True, kstart=None, out=None):
     o, lse = attn_fwd(torch.cat([q[:, : H * hd], k[:, : Hkv * hd], v[:, : Hkv * hd]], dim=1), B, Lseq, H, Hkv, hd, kmask, scale, causal,
                       want_lse, kstart=kstart)

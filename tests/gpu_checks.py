@@ -320,6 +320,43 @@ def check_attn_bwd(B, L, H, Hkv, hd, causal, mask):
     return worst
 
 
+def check_attn_cross(B, Lq, Lk, H, Hkv, hd, masked):
+    """Cross attention (Lq queries over Lk keys per batch entry, non-causal, optional key mask; q, k, v with their own row strides -- k and v
+    as column slices of one fused projection output) forward + backward vs the oracle's restatement of the perceiver attention."""
+    k = K()
+    q = rnd(B * Lq, H * hd, seed=Lq + hd)
+    kv = rnd(B * Lk, 2 * Hkv * hd, seed=Lk + hd + 1)
+    do = rnd(B * Lq, H * hd, seed=Lq + 9)
+    km = None
+    if masked:
+        km = torch.ones(B, Lk, dtype=torch.int32)
+        g = torch.Generator().manual_seed(Lk)
+        for b in range(B):
+            n = int(torch.randint(0, Lk // 2, (1,), generator=g))
+            if n:
+                km[b, Lk // 3: Lk // 3 + n] = 0
+    scale = hd ** -0.5
+    kk, vv = kv[:, : Hkv * hd], kv[:, Hkv * hd:]
+    oref, lref = R.attn_fwd_cross(q, kk, vv, B, Lq, Lk, H, Hkv, hd, km, scale)
+    dqr, dkvr = torch.empty_like(q), torch.empty_like(kv)
+    R.attn_bwd_cross(q, kk, vv, oref, do, lref, dqr, dkvr[:, : Hkv * hd], dkvr[:, Hkv * hd:], B, Lq, Lk, H, Hkv, hd, km, scale)
+    qd, kvd, kmd = q.to(DEV), kv.to(DEV), None if km is None else km.to(DEV)
+    o, lse = k.attn_fwd_cross(qd, kvd[:, : Hkv * hd], kvd[:, Hkv * hd:], B, Lq, Lk, H, Hkv, hd, kmd, scale)
+    tag = f"cross attn B{B} Lq{Lq} Lk{Lk} H{H}/{Hkv} hd{hd} mask={masked}"
+    worst = close(o, oref, 2e-2, f"{tag} o")
+    close(lse, lref, 2e-3, f"{tag} lse")
+    dq, dkv = torch.empty_like(qd), torch.empty_like(kvd)
+    k.attn_bwd_cross(qd, kvd[:, : Hkv * hd], kvd[:, Hkv * hd:], o, do.to(DEV), lse, dq, dkv[:, : Hkv * hd], dkv[:, Hkv * hd:], B, Lq, Lk, H, Hkv,
+                     hd, kmd, scale)
+    worst = max(worst, close(dq, dqr, 3e-2, f"{tag} dq"), close(dkv[:, : Hkv * hd], dkvr[:, : Hkv * hd], 3e-2, f"{tag} dk"),
+                close(dkv[:, Hkv * hd:], dkvr[:, Hkv * hd:], 3e-2, f"{tag} dv"))
+    return worst
+
+
+ATTN_CROSS_CASES = [(2, 64, 80, 16, 4, 96, True), (3, 16, 33, 4, 2, 96, False), (2, 64, 200, 4, 4, 64, True), (1, 130, 70, 8, 2, 128, False),
+                    (2, 20, 300, 4, 1, 16, True), (16, 64, 1088, 16, 4, 96, True)]      # last: the Mantis-8B-Idefics2 perceiver at its own size
+
+
 def _segment_bounds(B, L, cuts):
     """cuts: per batch row, sorted interior boundaries.  -> kstart[b, q] (first position of q's segment), qend[b, k] (one past its last)."""
     ks = torch.zeros(B, L, dtype=torch.int32)
@@ -1755,6 +1792,8 @@ def all_checks():
     for a in QWEN_STEP_FP8_SHAPES:
         c[f"fullsize_fp8_gemm_{a[0]}"] = (lambda a=a: check_fp8_gemm_qwen_step_shape(*a))
     c["fullsize_fp8_dx_swiglu_4096x3584x18944"] = lambda: check_fp8_dx_swiglu(4096, 3584, 18944, 1)
+    for a in ATTN_CROSS_CASES:
+        c["attn_cross_" + "_".join(map(str, a))] = (lambda a=a: check_attn_cross(*a))
     c["navit_prepare"] = check_navit_prepare
     c["fullsize_linear_gu_swiglu_fused"] = lambda: check_linear_gu_swiglu_fused(CFG2["M"], CFG2["d"], CFG2["I"], 0)
     c["fullsize_linear_qkv_rope_fused"] = lambda: check_linear_qkv_rope_fused(CFG2["M"], CFG2["d"], CFG2["H"], CFG2["Hkv"], False, 0)
