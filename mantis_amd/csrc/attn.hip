@@ -152,8 +152,19 @@ template <int N> __device__ __forceinline__ void wait_lgkm() {
     else if constexpr (N == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
     else if constexpr (N == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
     else if constexpr (N == 5) asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
-    else asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+    else if constexpr (N == 7) asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+    else if constexpr (N == 9) asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory");
+    else if constexpr (N == 11) asm volatile("s_waitcnt lgkmcnt(11)" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
 }
+// fragments requested ahead of their consumer in the hd-128 forward / dQ loops: with 3 (rounds 1-2) an MFMA's operand had 96 cycles to come
+// back from the LDS, less than the loaded LDS latency, and the S and P.V phases ran at the LDS' pace; 6 hides ~190 cycles
+#ifndef ATTN_FRAG_DEPTH
+#define ATTN_FRAG_DEPTH 6
+#endif
 // K-fragment i = sb * 8 + ks of a 64-key tile: row sb * 32 + (lane & 31), chunk ks * 2 + h; kaddr[ks] holds the sb = 0 address
 template <int I>
 __device__ __forceinline__ void issue_kfrag(bf16x8& dst, const unsigned (&kaddr)[8]) {
@@ -312,7 +323,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
             for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) s[sb][e] = 0.f;
-            FragU fb4[4];                       // fragment ring shared by the S phase (K rows) and the P.V phase (V^T)
+            constexpr int FD = ATTN_FRAG_DEPTH;
+            FragU fb4[8];                       // fragment ring (FD in flight) shared by the S phase (K rows) and the P.V phase (V^T)
             unsigned vaddr[4], vaddr8[4];
             if constexpr (Y::DMA) {
                 const unsigned ldsK = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)sK;
@@ -331,21 +343,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
                     }
                 }
                 // S = K.Q^T: 16 MFMAs, K fragment i + 3 requested in the shadow of MFMA i
-                issue_kfrag<0>(fb4[0].f, kaddr);
-                issue_kfrag<1>(fb4[1].f, kaddr);
-                issue_kfrag<2>(fb4[2].f, kaddr);
+                static_for<0, FD>([&](auto ic) { issue_kfrag<decltype(ic)::value>(fb4[decltype(ic)::value & 7].f, kaddr); });
                 static_for<0, 16>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
-                    wait_lgkm<(15 - i) < 2 ? (15 - i) : 2>();      // requested so far: fragments <= i + 2
+                    wait_lgkm<(15 - i) < FD - 1 ? (15 - i) : FD - 1>();      // requested so far: fragments <= i + FD - 1
                     __builtin_amdgcn_sched_barrier(0);
-                    s[i >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb4[i & 3].f, qf[i & 7], s[i >> 3], 0, 0, 0);
-                    if constexpr (i + 3 < 16) issue_kfrag<i + 3>(fb4[(i + 3) & 3].f, kaddr);
+                    s[i >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb4[i & 7].f, qf[i & 7], s[i >> 3], 0, 0, 0);
+                    if constexpr (i + FD < 16) issue_kfrag<i + FD>(fb4[(i + FD) & 7].f, kaddr);
                     __builtin_amdgcn_sched_barrier(0);
                 });
-                // the first three V^T fragments travel while the softmax runs
-                issue_vfrag<0>(fb4[0], vaddr, vaddr8);
-                issue_vfrag<1>(fb4[1], vaddr, vaddr8);
-                issue_vfrag<2>(fb4[2], vaddr, vaddr8);
+                // the first FD V^T fragments travel while the softmax runs
+                static_for<0, FD>([&](auto jc) { issue_vfrag<decltype(jc)::value>(fb4[decltype(jc)::value & 7], vaddr, vaddr8); });
             } else {
 #pragma unroll
                 for (int sb = 0; sb < 2; ++sb)
@@ -416,10 +424,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
                 for (int g = 0; g < 4; ++g) pfr[g] = pack_frag(s[g >> 1], g & 1);
                 static_for<0, 16>([&](auto jc) {
                     constexpr int j = decltype(jc)::value;
-                    wait_lgkm<((15 - j) < 2 ? (15 - j) : 2) * 2>();      // requested so far: fragments <= j + 2 (two reads each)
+                    wait_lgkm<((15 - j) < FD - 1 ? (15 - j) : FD - 1) * 2>();      // requested so far: fragments <= j + FD - 1 (two reads each)
                     __builtin_amdgcn_sched_barrier(0);
-                    oacc[j & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb4[j & 3].f, pfr[j >> 2], oacc[j & 3], 0, 0, 0);
-                    if constexpr (j + 3 < 16) issue_vfrag<j + 3>(fb4[(j + 3) & 3], vaddr, vaddr8);
+                    oacc[j & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb4[j & 7].f, pfr[j >> 2], oacc[j & 3], 0, 0, 0);
+                    if constexpr (j + FD < 16) issue_vfrag<j + FD>(fb4[(j + FD) & 7], vaddr, vaddr8);
                     __builtin_amdgcn_sched_barrier(0);
                 });
             } else {
