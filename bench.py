@@ -15,7 +15,7 @@ Prints ONE JSON line (rank 0) with the driver's fields plus
   ms_per_step_median / p10 / p90   per-step HIP-event durations over the K timed steps
   roofline      dominant kernel (the bf16 MFMA GEMM family): algorithmic FLOPs / HIP-event time per launch, live in the timed
                 steps; `traffic` (memory-side bytes per launch) and `mfma_busy_pct` come from the tracked PMC summary
-                profiles/r02_pmc_step.json written by tools/pmc_step_report.py from rocprofv3 passes of this same command
+                profiles/r03_pmc_step.json written by tools/pmc_step_report.py from rocprofv3 passes of this same command
   cpu_baseline  the oracle's CPU restatement of the same training_step ("port"), timed on this host's cores on a bounded
                 sample (1 sample, 1 ViT + {1,2} LLM layers + lm_head) and extrapolated linearly in depth; fp32 is `value`,
                 the bf16 leg is reported beside it
@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 FLOP_PER_SAMPLE = 1.351e14      # SURVEY.md section 8d (ViT fwd x1, projector + LLM fwd+bwd x3, causal attention at 1/2)
 PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_FP8_TFLOPS = 5000.0        # MI355X dense fp8 MFMA (MX-scaled K = 64 / 128 forms; MI355X_MICROARCH.md)
-PMC_JSON = os.path.join(ROOT, "profiles", "r02_pmc_step.json")   # tools/pmc_step_report.py output (offline PMC passes, tracked)
+PMC_JSON = os.path.join(ROOT, "profiles", "r03_pmc_step.json")   # tools/pmc_step_report.py output (offline PMC passes, tracked)
 PMC_JSON_QWEN_FP8 = os.path.join(ROOT, "profiles", "r02_pmc_qwen2vl_fp8.json")   # same, for `--config qwen2_vl_7b --precision fp8`
 
 
@@ -576,7 +576,7 @@ def main():
                         peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4), bf16_gemm_family=bf16_family,
                         traffic=gf.get("traffic_bytes_per_launch"),
                         traffic_note=None if not gf else "bytes/launch on the L2 memory side (Infinity-Cache hits included), rocprofv3 PMC passes of "
-                        "this command summarised in profiles/r02_pmc_step.json by tools/pmc_step_report.py",
+                        "this command summarised in profiles/r03_pmc_step.json by tools/pmc_step_report.py",
                         algorithmic_bytes_per_launch=round(tot_by / len(timer)),
                         mfma_busy_pct=((pmc or {}).get("step") or {}).get("mfma_busy_pct"),
                         launches_per_step=len(timer) // args.steps,

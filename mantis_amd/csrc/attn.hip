@@ -160,10 +160,11 @@ template <int N> __device__ __forceinline__ void wait_lgkm() {
     else if constexpr (N == 11) asm volatile("s_waitcnt lgkmcnt(11)" ::: "memory");
     else asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
 }
-// fragments requested ahead of their consumer in the hd-128 forward / dQ loops: with 3 (rounds 1-2) an MFMA's operand had 96 cycles to come
-// back from the LDS, less than the loaded LDS latency, and the S and P.V phases ran at the LDS' pace; 6 hides ~190 cycles
+// fragments requested ahead of their consumer in the hd-128 forward loop.  Measured on 1x MI355X (round 3, tools/attn_fwd_bench.py, Llama-3
+// geometry B = 2, L = 2812, 32/8 x 128): depth 3 191-194 us, 4 201 us, 5 198 us, 6 208 us -- deeper rings cost registers (the kernel sits at
+// the 256-VGPR limit of two waves per SIMD: 8-20 B/lane of scratch from depth 5 on) and buy nothing: the loop is not LDS-latency bound
 #ifndef ATTN_FRAG_DEPTH
-#define ATTN_FRAG_DEPTH 6
+#define ATTN_FRAG_DEPTH 3
 #endif
 // K-fragment i = sb * 8 + ks of a 64-key tile: row sb * 32 + (lane & 31), chunk ks * 2 + h; kaddr[ks] holds the sb = 0 address
 template <int I>

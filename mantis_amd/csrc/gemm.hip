@@ -1051,15 +1051,19 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring16_kernel(
         static_for<0, NMF>([&](auto ic) {
             constexpr int i = decltype(ic)::value, tn = i / NBM, tm = i % NBM;
             mfma16(acc[tn][tm], fb[buf][tn], fa[buf][tm]);
+#ifndef RING16_PROBE_NO_FRAGS
             if constexpr (i < SL) {
                 constexpr int o0 = (i * NOPS + SL - 1) / SL, o1 = ((i + 1) * NOPS + SL - 1) / SL;      // ops with o * SL / NOPS == i
                 static_for<o0, (o1 < NOPS ? o1 : NOPS)>([&](auto oc) { frag_op(oc, nkhc, ic_<buf ^ 1>{}, na, nb_); });
             }
+#endif
+#ifndef RING16_PROBE_NO_DMA              // timing probes only (tools/r03 experiments): results are wrong with any of these defined
             if constexpr (i % 7 == 5 && i / 7 < 2 * PPW) {
                 constexpr int q = i / 7;
                 if constexpr (q < PPW) issue1(ic_<p0>{}, q, d0, soa, sob, krem);
                 else issue1(ic_<p0 + 1>{}, q - PPW, d1, soa, sob, krem);
             }
+#endif
             __builtin_amdgcn_sched_barrier(0);
         });
     };
@@ -1083,7 +1087,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring16_kernel(
         // (t+2: 0,1)), the barrier makes step t + 1 visible and step t's slabs free
         if constexpr (NW == 4) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+#ifndef RING16_PROBE_NO_BARRIER
         __builtin_amdgcn_s_barrier();
+#endif
         __builtin_amdgcn_sched_barrier(0);
         half_step(ic_<1>{}, ic_<0>{}, ic_<2>{}, a_next, b_next, d2, d3, soa, sob, krem);
         base = wrap(base + 4 * SLAB);

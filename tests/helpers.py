@@ -235,14 +235,25 @@ def check_qwen2vl_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-3
             assert np.linalg.norm(g) < 1e-6, name
             continue
         one_d = p.dim() == 1 and grad_cos_1d is not None
-        assert c >= (grad_cos_1d if one_d else grad_cos) and r <= (grad_rel_1d if one_d else grad_rel), (name, c, r)
+        kbias = one_d and name.endswith("k_proj.bias")            # fp8 variant: the near-cancelling key-bias gradient (FP8_COS_KBIAS)
+        assert c >= ((min(grad_cos_1d, FP8_COS_KBIAS) if kbias else grad_cos_1d) if one_d else grad_cos) and \
+            r <= (grad_rel_1d if one_d else grad_rel), (name, c, r)
     return report
 
 
 # ----------------------------------------------------------------------------------------------------------- fp8 variant, any path
-def check_fp8_grads_against_oracle(model, oracle, loss, oloss, loss_rtol=1e-2, cos_2d=0.95, cos_1d=0.85):
+FP8_COS_2D, FP8_COS_1D, FP8_COS_KBIAS, FP8_GRAD_REL_2D, FP8_ACT_REL = 0.97, 0.93, 0.85, 0.25, 0.12
+# The stated tolerance of the fp8-linear variant, set FROM MEASUREMENT (round 3; CPU emulation of the exact fp8 arithmetic on the four
+# Qwen2-VL goldens: weight-matrix gradient cosine 0.9814-0.9846 min / rel-L2 <= 0.193, 1-D parameters 0.959-0.987 min; GPU kernels: the
+# same to within fp8 rounding flips, worst 1-D value 0.908): matrices >= 0.97 and rel-L2 <= 0.25, biases / norm weights >= 0.93 -- except
+# the KEY bias, >= 0.85: its gradient is a near-cancelling sum (a constant added to every key shifts all scores of a query alike, up to
+# RoPE), i.e. mostly quantisation noise of e5m2 dS, and it is the one that measured 0.908 / 0.959.  Activations rel-L2 <= 0.12, loss 1e-2.
+
+
+def check_fp8_grads_against_oracle(model, oracle, loss, oloss, loss_rtol=1e-2, cos_2d=FP8_COS_2D, cos_1d=FP8_COS_1D):
     """The stated tolerance of the fp8-linear variant (per-tensor e4m3 activations / weights, e5m2 output gradients) against the fp32
-    oracle of the reference: loss 1e-2 relative, weight-matrix gradient cosine >= 0.95, bias / norm-weight gradient cosine >= 0.85."""
+    oracle of the reference: loss 1e-2 relative, weight-matrix gradient cosine >= 0.97, bias / norm-weight gradient cosine >= 0.93
+    (key bias 0.85, see FP8_COS_KBIAS)."""
     assert abs(float(loss) - float(oloss)) <= loss_rtol * abs(float(oloss)), (float(loss), float(oloss))
     worst = 1.0
     for name, p in model.named_parameters():
@@ -253,6 +264,7 @@ def check_fp8_grads_against_oracle(model, oracle, loss, oloss, loss_rtol=1e-2, c
         if og is None or np.linalg.norm(og.numpy()) < 1e-12:
             continue
         c = cosine(g, og.numpy())
-        assert c >= (cos_2d if p.dim() > 1 else cos_1d), (name, c)
+        bar = cos_2d if p.dim() > 1 else (min(cos_1d, FP8_COS_KBIAS) if name.endswith("k_proj.bias") else cos_1d)
+        assert c >= bar, (name, c)
         worst = min(worst, c)
     return worst

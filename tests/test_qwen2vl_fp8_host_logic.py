@@ -27,8 +27,8 @@ def test_fp8_step_within_stated_tolerance(cpu_backend, case):
     assert model._ensure_grad_arena()
     rec = {}
     out = model.engine.step_from_batch(Hh.qwen2vl_batch(z), compute_grads=True, overwrite_grads=True, need_logits=True, record=rec)
-    Hh.check_qwen2vl_step_against_oracle(model, Hh.build_qwen2vl_oracle_bf16(), z, out, rec, loss_rtol=1e-2, grad_cos=0.95, grad_rel=0.35,
-                                         act_rel=0.15, grad_cos_1d=0.85, grad_rel_1d=0.6)
+    Hh.check_qwen2vl_step_against_oracle(model, Hh.build_qwen2vl_oracle_bf16(), z, out, rec, loss_rtol=1e-2, grad_cos=Hh.FP8_COS_2D,
+                                         grad_rel=Hh.FP8_GRAD_REL_2D, act_rel=Hh.FP8_ACT_REL, grad_cos_1d=Hh.FP8_COS_1D, grad_rel_1d=0.6)
 
 
 @pytest.mark.parametrize("case", ["qwen2vl_b1_img2", "qwen2vl_b2_rightpad"])
@@ -39,8 +39,8 @@ def test_fp8_rowwise_step_within_stated_tolerance(cpu_backend, case):
     assert model._ensure_grad_arena() and model.engine.w8.rowwise
     rec = {}
     out = model.engine.step_from_batch(Hh.qwen2vl_batch(z), compute_grads=True, overwrite_grads=True, need_logits=True, record=rec)
-    Hh.check_qwen2vl_step_against_oracle(model, Hh.build_qwen2vl_oracle_bf16(), z, out, rec, loss_rtol=1e-2, grad_cos=0.95, grad_rel=0.35,
-                                         act_rel=0.15, grad_cos_1d=0.85, grad_rel_1d=0.6)
+    Hh.check_qwen2vl_step_against_oracle(model, Hh.build_qwen2vl_oracle_bf16(), z, out, rec, loss_rtol=1e-2, grad_cos=Hh.FP8_COS_2D,
+                                         grad_rel=Hh.FP8_GRAD_REL_2D, act_rel=Hh.FP8_ACT_REL, grad_cos_1d=Hh.FP8_COS_1D, grad_rel_1d=0.6)
 
 
 def test_rowwise_quantiser_restatement_properties():

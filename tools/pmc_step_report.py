@@ -25,7 +25,7 @@ import os
 import re
 from collections import defaultdict
 
-GEMM_FAMILY = ("gemm_nt_ring_kernel", "gemm_nt_kernel")
+GEMM_FAMILY = ("gemm_nt_ring_kernel", "gemm_nt_ring16_kernel", "gemm_nt_kernel")
 ATTN_FAMILY = ("attn_fwd_kernel", "attn_bwd")
 
 
