@@ -124,38 +124,53 @@ def decoder_backward(K, lm, grads, grads_layers, tc, ctx, hctx, plan, B, L, kmas
     acc = accumulate
     saved, cos, sin, scale = ctx["saved"], ctx["cos"], ctx["sin"], ctx["scale"]
     dx = head_backward(K, lm, grads, hctx, plan, B, L, acc, on_bucket_ready)
+    # The weight-gradient GEMMs are off the critical path (nothing in the backward reads a dW): with a side stream (opt-in,
+    # hip_ops.side_stream) they queue there, behind the kernel that produced their dY, and their workgroups fill the compute units the
+    # dX chain's kernels leave idle in incomplete tile rounds.  The bucket hooks follow them onto that stream (a bucket is ready when
+    # its dW GEMMs AND the main-stream kernels before the hook are done); the caller's stream joins at the end.
+    side = K.side_stream()
+
+    def off_path(fn, *inputs):
+        if side is None:
+            fn()
+        else:
+            side.run(fn, *inputs)
+
+    def bucket(key):
+        if on_bucket_ready is not None:
+            off_path(lambda: on_bucket_ready(key))
+
     for i in reversed(range(tc.num_hidden_layers)):
         lw = lm["layers"][i]
         lg_ = grads_layers[i]
         x_in, rstd1, qkv, o, lse, x_mid, rstd2, gu, n1, n2, a = saved.pop()
         if lg_["down"] is not None:
-            K.linear_dw(dx, a, lg_["down"], acc)
-        if on_bucket_ready is not None:
-            on_bucket_ready(("layer", i, "down"))
+            off_path(lambda dx=dx, a=a: K.linear_dw(dx, a, lg_["down"], acc), dx, a)
+        bucket(("layer", i, "down"))
         dgu = K.linear_dx_swiglu(dx, lw["down"], gu)     # dact = dx . W_down and the SwiGLU backward in one launch
         del a, gu
         if lg_["gu"] is not None:
-            K.linear_dw(dgu, n2, lg_["gu"], acc)
-        if on_bucket_ready is not None:
-            on_bucket_ready(("layer", i, "gu"))
+            off_path(lambda dgu=dgu, n2=n2: K.linear_dw(dgu, n2, lg_["gu"], acc), dgu, n2)
+        bucket(("layer", i, "gu"))
         dn2 = K.linear_dx(dgu, lw["gu"])
         del dgu, n2
         dx_mid = K.rmsnorm_bwd(dn2, x_mid, lw["ln2"], rstd2, dx, lg_["ln2"], acc)
         del dn2, dx
         if lg_["o"] is not None:
-            K.linear_dw(dx_mid, o, lg_["o"], acc)
+            off_path(lambda dx_mid=dx_mid, o=o: K.linear_dw(dx_mid, o, lg_["o"], acc), dx_mid, o)
         do = K.linear_dx(dx_mid, lw["o"])
         dqkv = K.attn_bwd(qkv, o, do, lse, B, L, H, Hkv, hd, kmask, scale, True, kstart=kstart, qend=qend)
         del do, o
         K.rope_apply_(dqkv, cos, sin, H + Hkv, hd, backward=True)
         if lg_["qkv"] is not None:
-            K.linear_dw(dqkv, n1, lg_["qkv"], acc)
+            off_path(lambda dqkv=dqkv, n1=n1: K.linear_dw(dqkv, n1, lg_["qkv"], acc), dqkv, n1)
         if lg_.get("qkv_b") is not None:
             K.colsum(dqkv, lg_["qkv_b"], acc)
         dn1 = K.linear_dx(dqkv, lw["qkv"])
         del dqkv, n1, qkv
         dx = K.rmsnorm_bwd(dn1, x_in, lw["ln1"], rstd1, dx_mid, lg_["ln1"], acc)
         del dn1, dx_mid, x_in
-        if on_bucket_ready is not None:
-            on_bucket_ready(("layer", i, "attn"))
+        bucket(("layer", i, "attn"))
+    if side is not None:
+        side.join()
     return dx

@@ -683,5 +683,42 @@ def cu_masked_stream(first_cu, n_cus):
     return torch.cuda.ExternalStream(h.value, device=torch.device("cuda", torch.cuda.current_device()))
 
 
+class SideStream:
+    """A second stream for work off the critical path (the weight-gradient GEMMs of the backward): `run(fn, *inputs)` enqueues fn on it
+    behind everything queued on the current stream so far; `join()` makes the current stream wait for it.  With its own hardware queue
+    (GPU_MAX_HW_QUEUES, mantis_amd/__init__.py) its workgroups fill the compute units that the critical path's kernels leave idle in
+    their incomplete last tile rounds."""
+
+    def __init__(self):
+        self.stream = torch.cuda.Stream()
+
+    def run(self, fn, *inputs):
+        ev = torch.cuda.Event()
+        ev.record()
+        self.stream.wait_event(ev)
+        with torch.cuda.stream(self.stream):
+            fn()
+        for t in inputs:                       # the caching allocator must not hand these out again before the side stream is done
+            if t is not None:
+                t.record_stream(self.stream)
+
+    def join(self):
+        torch.cuda.current_stream().wait_stream(self.stream)
+
+
+_SIDE = {}
+
+
+def side_stream():
+    """The process' side stream for the current device when MANTIS_DW_STREAM=1, else None (everything on the current stream)."""
+    if _os.environ.get("MANTIS_DW_STREAM", "0") != "1":
+        return None
+    dev = torch.cuda.current_device()
+    s = _SIDE.get(dev)
+    if s is None:
+        s = _SIDE[dev] = SideStream()
+    return s
+
+
 def synchronize():
     torch.cuda.synchronize()

@@ -164,6 +164,10 @@ def linear_dx(dy, w, k=None):
     return (_f(dy)[:, :n] @ _f(w)).to(dy.dtype)
 
 
+def side_stream():
+    return None
+
+
 def linear_gu_swiglu(x, w_gu, variant=0, amax_parts=None):
     gu = gemm_nt(x, w_gu)
     return gu, swiglu_fwd(gu)

@@ -907,6 +907,35 @@ def check_idefics2_packed():
     return 1.0 - worst
 
 
+def check_dw_side_stream():
+    """MANTIS_DW_STREAM=1 (weight-gradient GEMMs of the decoder backward on a second stream, bucket hooks following them): loss and every
+    gradient bit-identical to the single-stream step, over two accumulating micro-batches, with the hooks seeing every bucket once."""
+    import os
+    from mantis_amd.trainer import MantisHipTrainer
+    z = Hh.load_case("siglip_training_step_ga4")
+    res = []
+    for flag in ("0", "1"):
+        os.environ["MANTIS_DW_STREAM"] = flag
+        try:
+            model, _, _ = Hh.build_product_model("siglip", DEV)
+            tr = MantisHipTrainer(model, gradient_accumulation_steps=2)
+            seen = []
+            losses = []
+            for i in range(2):
+                b = _golden_batch(z, f"mb{i}.")
+                model._ensure_grad_arena()
+                out = model.engine.step_from_batch(b, grad_scale=0.5, loss_scale=0.5, compute_grads=True, overwrite_grads=(i == 0),
+                                                   on_bucket_ready=seen.append)
+                losses.append(out["loss"].clone())
+            torch.cuda.synchronize()
+            res.append((torch.stack(losses).cpu(), model.grad_arena.clone().cpu(), [str(k) for k in seen]))
+        finally:
+            os.environ["MANTIS_DW_STREAM"] = "0"
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), "side-stream dW GEMMs changed the result"
+    assert res[0][2] == res[1][2] and len(res[0][2]) > 4
+    return 0.0
+
+
 def check_navit_prepare():
     """Device-side NaViT image preparation (padding-image flags, pixel mask -> patch mask, bucketised position ids) bit-exact vs the oracle's
     restatement of modeling_idefics2.py:1636-1658 / :190-210: no mask, rectangular masks of every aspect, all-zero padding images, a
@@ -998,7 +1027,7 @@ def check_idefics2_full_width_vs_oracle():
     rec = {}
     out = model.engine.step_from_batch(batch, compute_grads=True, overwrite_grads=True, need_logits=True, record=rec)
     torch.cuda.synchronize()
-    rep = Hh.check_idefics2_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-3, grad_cos=0.99, grad_rel=0.12)
+    rep = Hh.check_idefics2_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-3, grad_cos=0.997, grad_rel=0.08)     # measured 0.99926 / 0.040
     worst = min(c for c, _ in rep.values())
     print(f"    idefics2 full width vs oracle: worst gradient cosine {worst:.5f}, worst rel {max(r for _, r in rep.values()):.4f}", flush=True)
     return 1.0 - worst
@@ -1026,7 +1055,7 @@ def check_qwen2vl_full_width_vs_oracle():
     rec = {}
     out = model.engine.step_from_batch(batch, compute_grads=True, overwrite_grads=True, need_logits=True, record=rec)
     torch.cuda.synchronize()
-    rep = Hh.check_qwen2vl_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-3, grad_cos=0.99, grad_rel=0.12)
+    rep = Hh.check_qwen2vl_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-3, grad_cos=0.997, grad_rel=0.08)      # measured 0.99959 / 0.029
     worst = min(c for c, _ in rep.values())
     print(f"    qwen2-vl full width vs oracle: worst gradient cosine {worst:.5f}, worst rel {max(r for _, r in rep.values()):.4f}", flush=True)
     return 1.0 - worst
@@ -1852,6 +1881,7 @@ def all_checks():
     c["fullsize_fp8_dx_swiglu_4096x3584x18944"] = lambda: check_fp8_dx_swiglu(4096, 3584, 18944, 1)
     for a in ATTN_CROSS_CASES:
         c["attn_cross_" + "_".join(map(str, a))] = (lambda a=a: check_attn_cross(*a))
+    c["dw_side_stream_bitwise"] = check_dw_side_stream
     c["navit_prepare"] = check_navit_prepare
     c["idefics2_full_width_vs_oracle"] = check_idefics2_full_width_vs_oracle
     c["qwen2vl_full_width_vs_oracle"] = check_qwen2vl_full_width_vs_oracle
