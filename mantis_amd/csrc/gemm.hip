@@ -482,6 +482,7 @@ __device__ __forceinline__ void read_frags_km(bf16x8 (&dst)[N_], unsigned slab, 
 // part order -- the result does not depend on who is last (bitwise reproducible), nobody waits (no co-residency assumption),
 // and the counter is left at zero for the next launch.
 #define SK_SLAB_FLOATS (256 * 256)
+#define SK_MAX_ROUNDS 1                      // sub-rounds the remainder tiles' K parts may run as (workspace = SK_MAX_ROUNDS * #CU slabs)
 
 template <int TM, int TN>
 __device__ __forceinline__ void sk_store(const f32x16 (&acc)[TN][TM], float* __restrict__ slab, int tid) {
@@ -1254,7 +1255,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring16_kernel(
 // tile resets its ticket), so one workspace serves any number of stream-ordered launches.  No allocation, no global state here.
 static int g_num_cu[64];
 static inline size_t sk_cnt_bytes(int cus) { return (((size_t)(cus + 1) * sizeof(unsigned int)) + 255) / 256 * 256; }
-static inline size_t sk_ws_bytes(int cus) { return sk_cnt_bytes(cus) + (size_t)cus * SK_SLAB_FLOATS * sizeof(float); }
+static inline size_t sk_ws_bytes(int cus) { return sk_cnt_bytes(cus) + (size_t)SK_MAX_ROUNDS * cus * SK_SLAB_FLOATS * sizeof(float); }
 
 static int num_cus() {
     int dev = 0;
@@ -1269,18 +1270,28 @@ static int num_cus() {
 
 // K parts for the tiles of the ring kernel's incomplete last round: minimise K-steps per part + the measured reduction cost
 // (slab write, publish, S slab reads by the last arriver ~ 8 + 1.7 S K-step equivalents; sc1 write-through slabs instead of the
-// release/acquire pair were measured equal at S = 2 and 12 % slower at S = 8)
+// release/acquire pair were measured equal at S = 2 and 12 % slower at S = 8).  S * rem <= #CU: ONE sub-round of split units.  Round 3
+// tried letting S * rem exceed the CU count (SK_MAX_ROUNDS = 3: for dX of gate|up, 96 remainder tiles x 448 K-steps, S = 8 fills all 256
+// CUs for three short sub-rounds instead of 192 CUs for one long one; the model predicted -15 % on the remainder): measured SLOWER,
+// 984 -> 1216 us on the 8-wave kernel, 1027 -> 1481 us on the 4-wave one -- 768 slabs of 256 KiB written and read back cost far more
+// than the 8 + 1.7 S model extrapolates.  The code path stays (SK_MAX_ROUNDS), the limit is 1.
 static int ring_split(long ntiles, int nk, int cus) {
     const int rem = (int)(ntiles % cus);
     if (!rem) return 1;
-    int smax = cus / rem;
-    if (smax > 8) smax = 8;
-    if (smax > nk / 8) smax = nk / 8;
     int best = 1;
-    double cost = nk;
-    for (int S = 2; S <= smax; ++S) {
-        const double c = (double)nk / S + 8.0 + 1.7 * S;
+    double cost = nk + 5.0, cost1 = -1.0;    // cost1: best single-sub-round split
+    int best1 = 1;
+    for (int S = 2; S <= 8; ++S) {
+        if (nk / S < 8) break;
+        const int rounds = (S * rem + cus - 1) / cus;
+        if (rounds > SK_MAX_ROUNDS) break;
+        const double c = rounds * ((double)nk / S + 5.0) + 8.0 + 1.7 * S;
+        if (rounds == 1 && (cost1 < 0 || c < cost1)) { cost1 = c; best1 = S; }
         if (c < cost) { cost = c; best = S; }
+    }
+    if (best > 1 && (best * rem + cus - 1) / cus > 1) {          // a multi-sub-round split must beat the alternatives clearly
+        const double alt = cost1 > 0 && cost1 < nk + 5.0 ? cost1 : nk + 5.0;
+        if (cost > 0.9 * alt) return cost1 > 0 && cost1 < nk + 5.0 ? best1 : 1;
     }
     return best;
 }
@@ -1293,7 +1304,8 @@ static int gemm_pick_variant(int M, int N, int K) {
     const long t256 = (long)cdiv(M, 256) * cdiv(N, 256), t128 = (long)cdiv(M, 128) * cdiv(N, 128);
     const int S = ring_split(t256, nk, cus);
     const long rem = t256 % cus;
-    const double ring = 1.45 * ((double)(t256 / cus) * (nk + 5.0) + (rem ? (double)nk / S + 5.0 + (S > 1 ? 8.0 + 1.7 * S : 0.0) : 0.0));
+    const int sub = rem ? (int)((S * rem + cus - 1) / cus) : 0;
+    const double ring = 1.45 * ((double)(t256 / cus) * (nk + 5.0) + (rem ? sub * ((double)nk / S + 5.0) + (S > 1 ? 8.0 + 1.7 * S : 0.0) : 0.0));
     const double gen = 1.05 * (double)((t128 + 2 * cus - 1) / (2 * cus)) * (nk + 5.2);
     return ring <= gen ? 12 : 1;
 }

@@ -190,7 +190,8 @@ def check_gemm_ksplit_deterministic(ring=12):
     worst = 0.0
     for (M, N, K_) in ((2000, 2100, 1024),      # 8 x 9 = 72 tiles on 256 CUs -> S = 3
                        (5624, 4096, 1024),      # 352 tiles -> remainder 96 -> S = 2
-                       (2816, 2816, 2048)):     # 121 tiles -> S = 2
+                       (2816, 2816, 2048),      # 121 tiles -> S = 2
+                       (5624, 4096, 24576)):    # 352 tiles, 384 K-steps: long parts (96 remainder tiles x S = 2)
         a, b = rnd(M, K_, seed=31), rnd(N, K_, seed=32, scale=0.1)
         ad, bd = a.to(DEV), b.to(DEV)
         outs = [k.gemm_nt(ad, bd, variant=ring) for _ in range(4)]
