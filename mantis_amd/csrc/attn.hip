@@ -344,22 +344,35 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
                     }
                 }
                 // S = K.Q^T: 16 MFMAs, K fragment i + 3 requested in the shadow of MFMA i
-                static_for<0, FD>([&](auto ic) { issue_kfrag<decltype(ic)::value>(fb4[decltype(ic)::value & 7].f, kaddr); });
+                // slot i computes key block i & 1, k-chunk i >> 1: consecutive MFMAs alternate between the two score accumulators (round 3:
+                // eight back-to-back MFMAs into ONE accumulator wait for each other's result -- PMC: 32 % of the wave cycles were
+                // MFMA-dependency stalls -- ATTN_S_INTERLEAVE=0 restores the old order for A/B)
+#ifndef ATTN_S_INTERLEAVE
+#define ATTN_S_INTERLEAVE 1
+#endif
+                static_for<0, FD>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value, fr = ATTN_S_INTERLEAVE ? (i & 1) * 8 + (i >> 1) : i;
+                    issue_kfrag<fr>(fb4[i & 7].f, kaddr);
+                });
                 static_for<0, 16>([&](auto ic) {
                     constexpr int i = decltype(ic)::value;
+                    constexpr int sb = ATTN_S_INTERLEAVE ? (i & 1) : (i >> 3), ks = ATTN_S_INTERLEAVE ? (i >> 1) : (i & 7);
                     wait_lgkm<(15 - i) < FD - 1 ? (15 - i) : FD - 1>();      // requested so far: fragments <= i + FD - 1
                     __builtin_amdgcn_sched_barrier(0);
-                    s[i >> 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb4[i & 7].f, qf[i & 7], s[i >> 3], 0, 0, 0);
-                    if constexpr (i + FD < 16) issue_kfrag<i + FD>(fb4[(i + FD) & 7].f, kaddr);
+                    s[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb4[i & 7].f, qf[ks], s[sb], 0, 0, 0);
+                    if constexpr (i + FD < 16) {
+                        constexpr int n = i + FD, fr = ATTN_S_INTERLEAVE ? (n & 1) * 8 + (n >> 1) : n;
+                        issue_kfrag<fr>(fb4[n & 7].f, kaddr);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 });
                 // the first FD V^T fragments travel while the softmax runs
                 static_for<0, FD>([&](auto jc) { issue_vfrag<decltype(jc)::value>(fb4[decltype(jc)::value & 7], vaddr, vaddr8); });
             } else {
 #pragma unroll
-                for (int sb = 0; sb < 2; ++sb)
+                for (int ks = 0; ks < C::NKS; ++ks)
 #pragma unroll
-                    for (int ks = 0; ks < C::NKS; ++ks) {
+                    for (int sb = 0; sb < 2; ++sb) {        // alternate the two accumulators (see the hd-128 branch)
                         const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + Y::chunk_off(sb * 32 + lq, ks * 2 + hh));
                         s[sb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[sb], 0, 0, 0);
                     }
