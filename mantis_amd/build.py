@@ -12,8 +12,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libmantis_hip.so")
-SOURCES = ["pack", "norm", "act", "rope", "ce", "vit", "gemm", "gemm_fp8", "attn", "optim"]
+SOURCES = ["pack", "norm", "act", "rope", "ce", "vit", "gemm", "gemm_fp8", "attn", "attn_fwd64", "optim"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"]
+# attn_fwd64: the hand-placed instruction stream wants one VALU instruction per source operation (no v_pk_* packing of f32 pairs)
+EXTRA_FLAGS = {"attn_fwd64": ["-fno-slp-vectorize"]}
+HEADERS = ["common.h", "attn_common.h"]
 
 
 def _hipcc():
@@ -23,12 +26,12 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
-def _digest(path):
+def _digest(path, name):
     h = hashlib.sha1()
-    for p in (path, os.path.join(CSRC, "common.h")):
+    for p in (path, *(os.path.join(CSRC, x) for x in HEADERS)):
         with open(p, "rb") as f:
             h.update(f.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(FLAGS + EXTRA_FLAGS.get(name, [])).encode())
     return h.hexdigest()
 
 
@@ -36,10 +39,10 @@ def _compile(name):
     src = os.path.join(CSRC, name + ".hip")
     obj = os.path.join(OBJ, name + ".o")
     stamp = obj + ".sha1"
-    dig = _digest(src)
+    dig = _digest(src, name)
     if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
         return obj, False
-    cmd = [_hipcc(), *FLAGS, "-c", src, "-o", obj]
+    cmd = [_hipcc(), *FLAGS, *EXTRA_FLAGS.get(name, []), "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {name}.hip:\n{r.stdout}\n{r.stderr}")

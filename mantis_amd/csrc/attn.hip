@@ -21,183 +21,8 @@
 //  * causal work is dispatched heaviest-first; the dK/dV kernel runs one workgroup per (key block, QUERY head) and a small
 //    reduction sums the GQA group, so the grid is H/Hkv times larger than a per-kv-head walk.
 // Algorithmic FLOPs: forward 4*L*Lk*hd per head (half for causal); backward 2.5x forward (+1x recompute of S and dP here).
-#include "common.h"
-#include <type_traits>
 
-#define LOG2E 1.4426950408889634f
-#define LN2 0.6931471805599453f
-
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-
-__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) {
-    union { u32x4 u; bf16x8 b; } c;
-    c.u = v;
-    return c.b;
-}
-
-template <int HD>
-struct AttnCfg {
-    static constexpr int KP = (HD + 15) / 16 * 16;   // contraction length of Q.K^T, zero padded
-    static constexpr int DP = (HD + 31) / 32 * 32;   // output width of P.V, padded to MFMA blocks
-    static constexpr int NKS = KP / 16;
-    static constexpr int NDB = DP / 32;
-    static constexpr int NCK = KP / 8;
-    static constexpr int PITCH = DP * 2 + 16;        // row pitch in bytes (rows hold DP columns so tr reads of pad cols stay in-row)
-    static constexpr int NCH = DP / 8;               // 16-B chunks staged per row
-};
-
-// global -> registers (issue early) and registers -> LDS (write late): a ROWS x NCH-chunk row-major tile, 256 threads.
-// rows >= rows_valid and chunks starting at column >= cols_valid are zero.
-template <int ROWS, int NCH>
-struct TileRegs {
-    static constexpr int N = (ROWS * NCH + 255) / 256;
-    u32x4 v[N];
-    __device__ __forceinline__ void load(const bf16_t* __restrict__ g, long gstride, int rows_valid, int cols_valid) {
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-            const int idx = threadIdx.x + j * 256;
-            const int r = idx / NCH, c = idx - r * NCH;
-            v[j] = u32x4{0u, 0u, 0u, 0u};
-            if (idx < ROWS * NCH && r < rows_valid && c * 8 < cols_valid)
-                v[j] = *reinterpret_cast<const u32x4*>(g + (long)r * gstride + c * 8);
-        }
-    }
-    __device__ __forceinline__ void store(char* lds, int pitch) const {
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-            const int idx = threadIdx.x + j * 256;
-            const int r = idx / NCH, c = idx - r * NCH;
-            if (idx < ROWS * NCH) *reinterpret_cast<u32x4*>(lds + r * pitch + c * 16) = v[j];
-        }
-    }
-};
-
-// LDS tile layouts.  hd == 128: rows are exactly one 256-B bank row, tiles are filled by global_load_lds (fully asynchronous, no
-// staging registers) and 16-B chunk c of row r sits at slot c ^ swz(r), swz(r) = ((r & 3) << 2) | ((r >> 2) & 3):
-//   * the 16 rows of a ds_read_b128 lane group have 16 distinct r & 15 -> 16 distinct slots = all 64 banks once;
-//   * the 4 consecutive rows x 4 consecutive chunks of a ds_read_b64_tr_b16 lane group differ in r & 3 = the slot's upper two
-//     bits -> 16 distinct slots as well (the previous c ^ ((r & 7) << 1) was 2-way conflicted for both: rocprofv3
-//     SQ_LDS_BANK_CONFLICT = 40-50 % of SQ_LDS_IDX_ACTIVE in all three kernels).
-// Other head sizes: padded rows (pitch = row bytes + 16), staged through registers.
-typedef __attribute__((address_space(3))) void lds_void_t;
-
-__device__ __forceinline__ int lds_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
-
-template <int HD>
-struct Lay {
-    static constexpr bool DMA = (HD == 128);
-    static constexpr int PITCH = DMA ? 256 : AttnCfg<HD>::PITCH;
-    __device__ static __forceinline__ int chunk_off(int row, int chunk) {
-        return row * PITCH + (DMA ? ((chunk ^ lds_swz(row)) << 4) : (chunk << 4));
-    }
-};
-
-// ROWS x 128 bf16 tile, 256 threads: each wave issues ROWS/16 global_load_lds of 1 KiB (4 rows); rows >= rows_valid are clamped
-// (their scores are masked / their outputs never stored).
-template <int ROWS>
-__device__ __forceinline__ void stage_tile_dma(const bf16_t* __restrict__ g, long gstride, int rows_valid, char* lds) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int PER = ROWS / 16;
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        const int piece = wave * PER + j;
-        int row = piece * 4 + (lane >> 4);
-        const int c = (lane & 15) ^ lds_swz(row);
-        row = row < rows_valid ? row : rows_valid - 1;
-        __builtin_amdgcn_global_load_lds(g + (long)row * gstride + c * 8, (lds_void_t*)(lds + piece * 1024), 16, 0, 0);
-    }
-}
-
-// A-operand fragment with the contraction index running over ROWS of a row-major LDS tile: lane (i = col0 + (lane & 31), h)
-// receives rows {row0 + 4h + 0..3, row0 + 8 + 4h + 0..3} of column i -- two hardware-transposing reads.
-template <int HD>
-__device__ __forceinline__ bf16x8 read_tr_frag(const char* tile, int row0, int col0, int lane) {
-    const int s = lane & 15, g16 = (lane >> 4) & 1, h = lane >> 5;
-    const int row = row0 + 4 * h + (s >> 2), col = col0 + 16 * g16 + (s & 3) * 4;
-    const int off = Lay<HD>::chunk_off(row, col >> 3) + (col & 7) * 2;
-    // row + 8: same r & 3, (r >> 2) & 3 flips its upper bit -> slot ^ 2 -> byte offset ^ 32 (tile bases are 256-B aligned)
-    const int off8 = Lay<HD>::DMA ? ((off + 8 * Lay<HD>::PITCH) ^ 32) : off + 8 * Lay<HD>::PITCH;
-    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + off));
-    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tile + off8));
-    union { s16x4 s2[2]; bf16x8 f; } u;
-    u.s2[0] = a;
-    u.s2[1] = b;
-    return u.f;
-}
-
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
-// Hand-placed LDS fragment reads for the hd == 128 kernels (the compiler neither counts nor moves them; every use is guarded by an
-// explicit counted s_waitcnt lgkmcnt): they sit in the shadow of the MFMAs, 2-3 fragments ahead of their consumer.
-template <int OFF>
-__device__ __forceinline__ void asm_read_b128(bf16x8& dst, unsigned addr) {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
-}
-template <int OFF>
-__device__ __forceinline__ void asm_read_tr64(s16x4& dst, unsigned addr) {
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
-}
-union FragU { s16x4 h[2]; bf16x8 f; };
-template <int N> __device__ __forceinline__ void wait_lgkm() {
-    if constexpr (N == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    else if constexpr (N == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
-    else if constexpr (N == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
-    else if constexpr (N == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-    else if constexpr (N == 5) asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
-    else if constexpr (N == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-    else if constexpr (N == 7) asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-    else if constexpr (N == 9) asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory");
-    else if constexpr (N == 10) asm volatile("s_waitcnt lgkmcnt(10)" ::: "memory");
-    else if constexpr (N == 11) asm volatile("s_waitcnt lgkmcnt(11)" ::: "memory");
-    else asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
-}
-// fragments requested ahead of their consumer in the hd-128 forward loop.  Measured on 1x MI355X (round 3, tools/attn_fwd_bench.py, Llama-3
-// geometry B = 2, L = 2812, 32/8 x 128): depth 3 191-194 us, 4 201 us, 5 198 us, 6 208 us -- deeper rings cost registers (the kernel sits at
-// the 256-VGPR limit of two waves per SIMD: 8-20 B/lane of scratch from depth 5 on) and buy nothing: the loop is not LDS-latency bound
-#ifndef ATTN_FRAG_DEPTH
-#define ATTN_FRAG_DEPTH 3
-#endif
-// K-fragment i = sb * 8 + ks of a 64-key tile: row sb * 32 + (lane & 31), chunk ks * 2 + h; kaddr[ks] holds the sb = 0 address
-template <int I>
-__device__ __forceinline__ void issue_kfrag(bf16x8& dst, const unsigned (&kaddr)[8]) {
-    asm_read_b128<(I >> 3) * 32 * 256>(dst, kaddr[I & 7]);
-}
-// V^T fragment j = (sb * 2 + cp) * 4 + d: rows (sb * 2 + cp) * 16 + ..., d-block d; vaddr / vaddr8 hold the row-block-0 addresses
-template <int J>
-__device__ __forceinline__ void issue_vfrag(FragU& dst, const unsigned (&vaddr)[4], const unsigned (&vaddr8)[4]) {
-    asm_read_tr64<(J >> 2) * 16 * 256>(dst.h[0], vaddr[J & 3]);
-    asm_read_tr64<(J >> 2) * 16 * 256>(dst.h[1], vaddr8[J & 3]);
-}
-
-__device__ __forceinline__ bf16x8 pack_frag(const f32x16& s, int cp) {
-    u32x4 u;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) u[e] = pack_bf2(s[8 * cp + 2 * e], s[8 * cp + 2 * e + 1]);
-    return as_bf16x8(u);
-}
-
-// Workgroup -> (x = tile, y = head, z = batch) for a 1-D launch of gx * H * B workgroups.  Hardware sends workgroup i to XCD i % 8
-// (each XCD has a private 4 MiB L2); giving every XCD a CONTIGUOUS range of the (batch, head, tile) order keeps all tiles of a
-// head on one XCD, adjacent in time, so the K/V (forward, dQ) or Q/dO (dK/dV) rows they all stream are fetched from HBM once
-// instead of once per tile (rocprofv3 FETCH_SIZE of the dK/dV kernel at L = 2812: 2.0 GB per launch with the plain 3-D grid).
-__device__ __forceinline__ void xcd_tile_map(int gx, int gy, int& x, int& y, int& z) {
-    const int total = gridDim.x, lin = blockIdx.x;
-    const int q = total >> 3, r = total & 7, xcd = lin & 7;
-    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
-    x = v % gx;
-    const int t = v / gx;
-    y = t % gy;
-    z = t / gy;
-}
+#include "attn_common.h"
 
 // ------------------------------------------------------------------------------------------------ forward
 // grid (ceil(L/128), H, B); 4 waves x 32 query rows; KV tiles of 64 keys, double buffered.
@@ -218,7 +43,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hh = lane >> 5, lq = lane & 31;
     const int gx = (L + 127) >> 7;
     int bx, h, b;
-    xcd_tile_map(gx, H, bx, h, b);
+    xcd_tile_map(gx, H, bx, h, b, CAUSAL);
     const int hk = h / (H / Hkv);
     const int qb = CAUSAL ? (gx - 1 - bx) : bx;   // causal: longest rows first
     const int qblk0 = qb * 128, q0 = qblk0 + wave * 32, q = q0 + lq;
@@ -253,9 +78,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 
     // tile t -> LDS buffer (t & 1): global -> registers -> LDS in one go (registers are only live across the copy, so the kernel
     // fits 2 waves per SIMD; the copy of tile t+1 overlaps the MFMA work of the co-resident workgroup / partner waves)
+    // the key-mask word of a tile is fetched one stage() call ahead of its use (stage calls walk consecutive tiles): a load issued
+    // here, behind the tile's DMA, would be waited for with vmcnt(0) -- wave 0 would sit out the whole DMA round trip on every tile
+    // (measured on the Llama-3 geometry, round 3: forward 169 us without a key mask, 207 us with one)
+    auto key_live = [&](int t) -> bool {
+        const int key = t * 64 + (int)threadIdx.x;
+        return threadIdx.x < 64 && key < Lk && (kmask == nullptr || kmask[(long)b * Lk + key] != 0);
+    };
+    bool live_next = key_live(t_first);
     auto stage = [&](int t) {
         const int key0 = t * 64;
         char* base = smem + (t & 1) * BUF;
+        const bool ok = live_next;
+        live_next = key_live(t + 1);
         if constexpr (Y::DMA) {
             stage_tile_dma<64>(Kb + (long)key0 * ldk, ldk, Lk - key0, base);
             stage_tile_dma<64>(Vb + (long)key0 * ldv, ldv, Lk - key0, base + TILE);
@@ -272,8 +107,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
             }
         }
         if (threadIdx.x < 64) {     // wave 0: additive key bias (0 / -inf) + one flag "this tile has a masked key"
-            const int key = key0 + threadIdx.x;
-            const bool ok = key < Lk && (kmask == nullptr || kmask[(long)b * Lk + key] != 0);
             float* bp = reinterpret_cast<float*>(base + 2 * TILE);
             bp[threadIdx.x] = ok ? 0.f : -INFINITY;
             const unsigned long long okm = __ballot(ok);
@@ -284,9 +117,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     // LDS AFTER it, so the HBM / L2 latency rides behind the compute instead of stalling the wave in front of it (24 VGPRs at hd 72 /
     // 80 / 96); the key bias words of the next tile go to its (free) LDS buffer right away
     auto stage_bias = [&](int t) {
+        const bool ok = live_next;
+        live_next = key_live(t + 1);
         if (threadIdx.x < 64) {
-            const int key = t * 64 + threadIdx.x;
-            const bool ok = key < Lk && (kmask == nullptr || kmask[(long)b * Lk + key] != 0);
             float* bp = reinterpret_cast<float*>(smem + (t & 1) * BUF + 2 * TILE);
             bp[threadIdx.x] = ok ? 0.f : -INFINITY;
             const unsigned long long okm = __ballot(ok);
@@ -530,7 +363,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hh = lane >> 5, lq = lane & 31;
     const int gx = (L + 127) >> 7;
     int bx, h, b;
-    xcd_tile_map(gx, H, bx, h, b);
+    xcd_tile_map(gx, H, bx, h, b, CAUSAL);
     const int hk = h / (H / Hkv);
     const int qb = CAUSAL ? (gx - 1 - bx) : bx;
     const int qblk0 = qb * 128, q0 = qblk0 + wave * 32, q = q0 + lq;
@@ -588,9 +421,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 
     // tile t -> LDS buffer (t & 1): global -> registers -> LDS in one go (registers are only live across the copy, so the kernel
     // fits 2 waves per SIMD; the copy of tile t+1 overlaps the MFMA work of the co-resident workgroup / partner waves)
+    // the key-mask word of a tile is fetched one stage() call ahead of its use (stage calls walk consecutive tiles): a load issued
+    // here, behind the tile's DMA, would be waited for with vmcnt(0) -- wave 0 would sit out the whole DMA round trip on every tile
+    // (measured on the Llama-3 geometry, round 3: forward 169 us without a key mask, 207 us with one)
+    auto key_live = [&](int t) -> bool {
+        const int key = t * 64 + (int)threadIdx.x;
+        return threadIdx.x < 64 && key < Lk && (kmask == nullptr || kmask[(long)b * Lk + key] != 0);
+    };
+    bool live_next = key_live(t_first);
     auto stage = [&](int t) {
         const int key0 = t * 64;
         char* base = smem + (t & 1) * BUF;
+        const bool ok = live_next;
+        live_next = key_live(t + 1);
         if constexpr (Y::DMA) {
             stage_tile_dma<64>(Kb + (long)key0 * ldk, ldk, Lk - key0, base);
             stage_tile_dma<64>(Vb + (long)key0 * ldv, ldv, Lk - key0, base + TILE);
@@ -607,8 +450,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
             }
         }
         if (threadIdx.x < 64) {     // wave 0: additive key bias (0 / -inf) + one flag "this tile has a masked key"
-            const int key = key0 + threadIdx.x;
-            const bool ok = key < Lk && (kmask == nullptr || kmask[(long)b * Lk + key] != 0);
             float* bp = reinterpret_cast<float*>(base + 2 * TILE);
             bp[threadIdx.x] = ok ? 0.f : -INFINITY;
             const unsigned long long okm = __ballot(ok);
@@ -724,7 +565,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hh = lane >> 5, lk = lane & 31;
     const int kg = wave / D::DS, dh = wave % D::DS;
     int bx, h, b;
-    xcd_tile_map((Lk + D::KEYS - 1) / D::KEYS, H, bx, h, b);          // L queries, Lk keys (== L except for cross attention)
+    xcd_tile_map((Lk + D::KEYS - 1) / D::KEYS, H, bx, h, b, CAUSAL);  // L queries, Lk keys (== L except for cross attention)
     const int hk = h / (H / Hkv);
     const int kblk0 = bx * D::KEYS, k0 = kblk0 + kg * 32, key = k0 + lk;   // causal: key block 0 is the heaviest, first
     const int keyc = key < Lk ? key : Lk - 1;
@@ -943,7 +784,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_g4_kernel(
     // and keeps the two streams' barrier counts equal).  G = 4: Llama-3 / Mistral; G = 7: Qwen2-7B.
     const int G = H / Hkv, NH = (G + 1) >> 1;
     int bx, hk, b;
-    xcd_tile_map((L + 63) >> 6, Hkv, bx, hk, b);
+    xcd_tile_map((L + 63) >> 6, Hkv, bx, hk, b, CAUSAL);
     const int kblk0 = bx * 64, k0 = kblk0 + kb * 32, key = k0 + lk;
     const int keyc = key < L ? key : L - 1;
     const float c = scale * LOG2E;
@@ -1347,10 +1188,30 @@ static int attn_num_cus() {
 // group sizes served by attn_bwd_dkv_g4_kernel: every even G, odd G from 5 on (one dummy head slot in G + 1: at most 1/6 wasted)
 static inline bool attn_dkv_group_kernel_ok(int G) { return G >= 2 && (G % 2 == 0 || G >= 5); }
 
+// attn_fwd64.hip: the hd-128 forward with 64 query rows per wave
+int mantis_attn_fwd64_launch(bool causal, int B, hipStream_t s, const bf16_t* Q, const bf16_t* K, const bf16_t* V, const int* kmask,
+                             bf16_t* O, float* LSE, int L, int Lk, int H, int Hkv, long ldq, long ldk, long ldv, long ldo, float scale,
+                             const int* kstart);
+
+// MANTIS_ATTN_FWD64 = 1 (read once): the hd-128 forward runs on attn_fwd64_kernel (64 query rows per wave)
+static int attn_fwd64_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MANTIS_ATTN_FWD64");
+        v = (e && e[0] == '1') ? 1 : 0;
+    }
+    return v;
+}
+
 template <int HD>
 static int launch_fwd(bool causal, dim3 grid, hipStream_t s, const bf16_t* Q, const bf16_t* K, const bf16_t* V, const int* kmask,
                       bf16_t* O, float* LSE, int L, int Lk, int H, int Hkv, long ldq, long ldk, long ldv, long ldo, float scale,
                       const int* kstart) {
+    if constexpr (HD == 128) {
+        if (attn_fwd64_enabled() && Lk <= 65536)      // the kernel's per-tile liveness table holds 1024 tiles
+            return mantis_attn_fwd64_launch(causal, (int)(grid.x / (cdiv(L, 128) * H)), s, Q, K, V, kmask, O, LSE, L, Lk, H, Hkv, ldq, ldk,
+                                            ldv, ldo, scale, kstart);
+    }
     if (causal)
         MANTIS_LAUNCH((attn_fwd_kernel<HD, true>), grid, dim3(256), 0, s, Q, K, V, kmask, O, LSE, L, Lk, H, Hkv, ldq, ldk, ldv,
                            ldo, scale, kstart);
