@@ -76,8 +76,8 @@ constexpr int VF = 192;
     "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252",    \
     "a253", "a254", "a255"
 
-// Timing probes (wrong results; tools/build_probe_lib.sh): FWD64_PROBE_NO_VMWAIT (no wait for the ring), FWD64_PROBE_NO_EXP (no
-// exp / sum / pack fillers), FWD64_PROBE_NO_DMA (no ring refill in the loop)
+// Timing probes (wrong results; tools/build_probe_lib.sh): FWD64_PROBE_TIMING (s_memtime stamps into the LSE buffer), FWD64_PROBE_NO_VMWAIT (no wait for the ring), FWD64_PROBE_NO_EXP (no
+// exp / sum / pack fillers), FWD64_PROBE_NO_DMA (no ring refill in the loop), FWD64_PROBE_NO_LDS (no fragment reads), FWD64_PROBE_NO_MAX, FWD64_PROBE_NO_BARRIER
 // ---- instruction helpers (the compiler counts and schedules none of these; see the wait / hazard notes at the call sites)
 template <int KF, int QF>     // scores, C = 0: S^T(key block) = K fragment KF . Q fragment QF
 __device__ __forceinline__ void mfma_s0(f32x16& d) {
@@ -96,10 +96,16 @@ __device__ __forceinline__ void mfma_o(const u32x4& p) {
 }
 template <int KF, int OFF>
 __device__ __forceinline__ void lds_read_k(unsigned addr) {                                 // K fragment KF -> its AGPRs
+#ifdef FWD64_PROBE_NO_LDS
+    return;
+#endif
     asm volatile("ds_read_b128 a[%0:%1], %2 offset:%3" : : "n"(AK + 4 * KF), "n"(AK + 4 * KF + 3), "v"(addr), "i"(OFF));
 }
 template <int J, int OFF>
 __device__ __forceinline__ void lds_read_vt(unsigned addr, unsigned addr8) {                // V^T fragment J: two transposing reads
+#ifdef FWD64_PROBE_NO_LDS
+    return;
+#endif
     asm volatile("ds_read_b64_tr_b16 v[%0:%1], %4 offset:%6\n\tds_read_b64_tr_b16 v[%2:%3], %5 offset:%6"
                  :
                  : "n"(VF + 4 * J), "n"(VF + 4 * J + 1), "n"(VF + 4 * J + 2), "n"(VF + 4 * J + 3), "v"(addr), "v"(addr8), "i"(OFF)
@@ -149,11 +155,23 @@ __device__ __forceinline__ float pair_max(float v) {
     return max2(a, b);
 }
 
+#define WIN_P(sm, I) (((I) % 3) == 0 ? (sm).pw0 : ((I) % 3) == 1 ? (sm).pw1 : (sm).pw2)
+#define WIN_T(sm, I) (((I) % 3) == 0 ? (sm).tw0 : ((I) % 3) == 1 ? (sm).tw1 : (sm).tw2)
+
 struct Softmax {          // per 32-row block, per lane (one query row per lane pair)
-    float m;              // running max (exp2 domain), -inf before the first live key
-    float negm;           // -(m), 0 while m = -inf
-    float mth;            // m + LAZY_TH
+    float m;              // reference max of the exponent (exp2 domain): P = exp2(S c - m); -inf until the row's first live key
+    float negm;           // -m, 0 while m = -inf
+    float th;             // a tile whose largest exponent S c - m exceeds th raises m: LAZY_TH, -inf while m = -inf (any live key sets m)
     float l;              // this lane's share of the running sum
+    // P and exponent of the last three elements (the sum, the bf16 pair and the max trail the exp by one element).  Scalars, and no two
+    // P words adjacent: an indexed member, or a pair that can be fetched as one <2 x float>, keeps the struct in memory (which the
+    // backend then "promotes" to LDS)
+    float pw0;
+    float l0;             // l before the current tile (for the fix-up)
+    float pw1;
+    float tm;             // largest exponent of the current tile so far
+    float pw2;
+    float tw0, tw1, tw2;
 };
 
 // one 64-row block of one (batch, head)
@@ -165,6 +183,9 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(const bf16_t* __rest
                                                             const int* __restrict__ kstart) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * NS * TILE + MAX_TILES * 8];
 
+#ifdef FWD64_PROBE_TIMING
+    const unsigned long long T0 = __builtin_amdgcn_s_memtime();
+#endif
     const int lane = threadIdx.x & 63, hh = lane >> 5, lq = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int gx = (L + 255) >> 8;
@@ -175,41 +196,9 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(const bf16_t* __rest
     const int qblk0 = qbi * 256, q0w = qblk0 + wave * 64;
     const float c = scale * LOG2E;
 
-    // ---- this wave's rows; their Q fragments go to a[AQ ..] (this statement also declares the whole accumulator file as used)
-    asm volatile("" ::: AGPR_ALL);
-    int q[2], ks_q[2];
-    {
-        u32x4 qreg[2][8];       // all 16 loads in flight, then the writes
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-            q[blk] = q0w + blk * 32 + lq;
-            const int qc = q[blk] < L ? q[blk] : L - 1;
-            ks_q[blk] = kstart ? kstart[(long)b * L + qc] : 0;
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks)
-                qreg[blk][ks] = *reinterpret_cast<const u32x4*>(Q + ((long)b * L + qc) * ldq + (long)h * HD + (ks * 2 + hh) * 8);
-        }
-        asm volatile("" : "+v"(qreg[0][0]), "+v"(qreg[0][1]), "+v"(qreg[0][2]), "+v"(qreg[0][3]), "+v"(qreg[0][4]), "+v"(qreg[0][5]),
-                     "+v"(qreg[0][6]), "+v"(qreg[0][7]), "+v"(qreg[1][0]), "+v"(qreg[1][1]), "+v"(qreg[1][2]), "+v"(qreg[1][3]),
-                     "+v"(qreg[1][4]), "+v"(qreg[1][5]), "+v"(qreg[1][6]), "+v"(qreg[1][7]));
-        static_for<0, 16>([&](auto ic) __attribute__((always_inline)) {
-            constexpr int blk = decltype(ic)::value >> 3, ks = decltype(ic)::value & 7;
-            agpr_write<AQ + 32 * blk + 4 * ks + 0>(qreg[blk][ks][0]);
-            agpr_write<AQ + 32 * blk + 4 * ks + 1>(qreg[blk][ks][1]);
-            agpr_write<AQ + 32 * blk + 4 * ks + 2>(qreg[blk][ks][2]);
-            agpr_write<AQ + 32 * blk + 4 * ks + 3>(qreg[blk][ks][3]);
-        });
-    }
-    // wave-uniform sample-start bounds: no key below ks_min is live for any row, keys below ks_max[blk] need the pre-pass
-    int ks_min = 0, ks_max[2] = {0, 0};
-    if (kstart) {
-        ks_min = -(int)wave_max((float)-(ks_q[0] < ks_q[1] ? ks_q[0] : ks_q[1]));     // exact below 2^24
-        ks_max[0] = (int)wave_max((float)ks_q[0]);
-        ks_max[1] = (int)wave_max((float)ks_q[1]);
-        ks_min = __builtin_amdgcn_readfirstlane(ks_min);
-        ks_max[0] = __builtin_amdgcn_readfirstlane(ks_max[0]);
-        ks_max[1] = __builtin_amdgcn_readfirstlane(ks_max[1]);
-    }
+    // ---- prologue order: the key range, the first DMA pieces (K(f), V(f), K(f+1)), the Q rows and the key mask words all in flight
+    // together, the rest of the ring behind them, register initialisation under the round trip
+    asm volatile("" ::: AGPR_ALL);      // (declares the whole accumulator file as used)
     const int t_first = __builtin_amdgcn_readfirstlane(kstart ? (kstart[(long)b * L + (qblk0 < L ? qblk0 : L - 1)] >> 6) : 0);
     const int kend = CAUSAL ? (qblk0 + 256 < Lk ? qblk0 + 256 : Lk) : Lk;
     const int ntiles = (kend + 63) >> 6;
@@ -250,6 +239,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(const bf16_t* __rest
         rows = rows < 0 ? 0 : rows;
         int nrec = ((rows - 1) * ld + HD) * 2;
         nrec = rows > 0 ? nrec : 0;
+        nrec = __builtin_amdgcn_readfirstlane(nrec);      // the clamp may be selected as v_med3: without this the descriptor lives in VGPRs and every DMA piece becomes a waterfall loop
         return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (long)key0 * ld), 0, nrec, 0x00020000);
     };
     // piece J of this wave's four -> ring slot `slot`
@@ -262,6 +252,26 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(const bf16_t* __rest
         lds_void* d = (lds_void*)(smem + ring_off + slot * TILE + (wave * 4 + J) * 1024);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, d, 16, vo[J], 0, 0, 0);
     };
+    // ---- K(f), V(f), K(f+1) first: what barrier(f) and the first K fragment reads wait for
+    {
+        const __amdgpu_buffer_rsrc_t rk0 = tile_desc(Kb, (int)ldk, t_first), rv0 = tile_desc(Vb, (int)ldv, t_first),
+                                     rk1 = tile_desc(Kb, (int)ldk, t_first + 1);
+        static_for<0, 4>([&](auto j) __attribute__((always_inline)) { dma_piece(rk0, voK, OFF_K, 0, j); });
+        static_for<0, 4>([&](auto j) __attribute__((always_inline)) { dma_piece(rv0, voV, OFF_V, 0, j); });
+        static_for<0, 4>([&](auto j) __attribute__((always_inline)) { dma_piece(rk1, voK, OFF_K, 1, j); });
+    }
+    // ---- this wave's rows: Q loads (the fragments go to a[AQ ..] further down)
+    int q[2], ks_q[2];
+    u32x4 qreg[2][8];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        q[blk] = q0w + blk * 32 + lq;
+        const int qc = q[blk] < L ? q[blk] : L - 1;
+        ks_q[blk] = kstart ? kstart[(long)b * L + qc] : 0;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+            qreg[blk][ks] = *reinterpret_cast<const u32x4*>(Q + ((long)b * L + qc) * ldq + (long)h * HD + (ks * 2 + hh) * 8);
+    }
     // key-liveness word of tile t (padding mask and the Lk tail): wave w ballots tiles f + w, f + w + 4, ... into LDS, eight loads in
     // flight at a time
     {
@@ -282,11 +292,16 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(const bf16_t* __rest
         }
     }
     const unsigned bits_addr = lds0 + OFF_BITS;
-    auto tile_bits = [&](int t) __attribute__((always_inline)) -> unsigned long long {     // asm: the compiler must see no LDS read in the loop
-        u32x2 w;
-        asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(w) : "v"(bits_addr + (unsigned)(t - t_first) * 8u) : "memory");
-        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)w[1]) << 32) |
-               (unsigned)__builtin_amdgcn_readfirstlane((int)w[0]);
+    // asm: the compiler must see no LDS read in the loop.  The word of tile t+1 is requested right behind barrier(t) and collected at the
+    // top of the next step, behind the lgkmcnt(0) that closes every step.
+    u32x2 bits_w;
+    auto request_bits = [&](int t) __attribute__((always_inline)) {
+        asm volatile("ds_read_b64 %0, %1" : "=v"(bits_w) : "v"(bits_addr + (unsigned)(t - t_first) * 8u));
+    };
+    auto collect_bits = [&]() __attribute__((always_inline)) -> unsigned long long {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bits_w));
+        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)bits_w[1]) << 32) |
+               (unsigned)__builtin_amdgcn_readfirstlane((int)bits_w[0]);
     };
 
     // ---- accumulators and softmax state
@@ -296,75 +311,75 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(const bf16_t* __rest
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {      // the "previous tile" of the first one: P = 0 -- elements 0 .. 9 "already converted", the rest -inf
-            sA[sb][e] = 0.f;
-            sB[sb][e] = (sb == 0 && e < 10) ? 0.f : -INFINITY;
-        }
+        for (int e = 0; e < 16; ++e) { sA[sb][e] = -INFINITY; sB[sb][e] = -INFINITY; }      // the "previous tile" of the first one: P = 0
 #pragma unroll
     for (int g = 0; g < 4; ++g) { pA[g] = u32x4{0u, 0u, 0u, 0u}; pB[g] = u32x4{0u, 0u, 0u, 0u}; }
     static_for<0, 16>([&](auto j) __attribute__((always_inline)) { vf_zero4<VF + 4 * decltype(j)::value>(); });      // V^T fragments
-    Softmax smA{-INFINITY, 0.f, -INFINITY, 0.f}, smB{-INFINITY, 0.f, -INFINITY, 0.f};
+    Softmax smA, smB;
+    smA.m = -INFINITY, smA.negm = 0.f, smA.th = -INFINITY, smA.l = 0.f, smA.l0 = 0.f, smA.tm = -INFINITY;
+    smA.pw0 = smA.pw1 = smA.pw2 = 0.f, smA.tw0 = smA.tw1 = smA.tw2 = -INFINITY;
+    smB.m = -INFINITY, smB.negm = 0.f, smB.th = -INFINITY, smB.l = 0.f, smB.l0 = 0.f, smB.tm = -INFINITY;
+    smB.pw0 = smB.pw1 = smB.pw2 = 0.f, smB.tw0 = smB.tw1 = smB.tw2 = -INFINITY;
 
     // ---- softmax pieces
-    // max of a block's 32 scores per lane, in five pieces (one per MFMA gap), then: raise the running max when a row exceeds it by more
-    // than LAZY_TH (rare: rescale O and l)
-    float mx0, mx1;
-    auto max_part = [&](auto kc, f32x16 (&s)[2]) __attribute__((always_inline)) {
-        constexpr int k = decltype(kc)::value;
-        if constexpr (k == 0) {
-            mx0 = max3(s[0][0], s[0][1], s[0][2]);
-            mx1 = max3(s[1][0], s[1][1], s[1][2]);
-            mx0 = max3(mx0, s[0][3], s[0][4]);
-            mx1 = max3(mx1, s[1][3], s[1][4]);
-        } else if constexpr (k < 3) {
-            constexpr int r = 5 + (k - 1) * 4;
-            mx0 = max3(mx0, s[0][r], s[0][r + 1]);
-            mx1 = max3(mx1, s[1][r], s[1][r + 1]);
-            mx0 = max3(mx0, s[0][r + 2], s[0][r + 3]);
-            mx1 = max3(mx1, s[1][r + 2], s[1][r + 3]);
-        } else {
-            mx0 = max3(mx0, s[0][13], s[0][14]);
-            mx1 = max3(mx1, s[1][13], s[1][14]);
-            mx0 = max3(mx0, s[0][15], s[1][15]);
-            mx0 = max2(mx0, mx1);
-        }
-    };
-    auto max_finish = [&](Softmax& sm, auto obc) __attribute__((always_inline)) {
-        constexpr int OB = decltype(obc)::value;
-        const float mxc = pair_max(mx0) * c;
-        const bool upd = mxc > sm.mth;
-        if (__builtin_expect(__any(upd), 0)) {
-            const float m_new = upd ? mxc : sm.m;
-            const float alpha = upd ? __builtin_amdgcn_exp2f(sm.m - m_new) : 1.f;      // m = -inf: 0 (and l, O are still 0)
-            sm.l *= alpha;
-            sm.m = m_new;
-            sm.negm = m_new == -INFINITY ? 0.f : -m_new;
-            sm.mth = m_new + LAZY_TH;
-            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");       // this O's last MFMA is at least a phase back; belt and braces
-            static_for<0, 16>([&](auto r) __attribute__((always_inline)) { agpr_scale4<OB + 4 * decltype(r)::value>(alpha); });
-            asm volatile("s_nop 2" ::: "memory");                  // accvgpr_write -> MFMA src C
-        }
-    };
-    // score element E of a block: P = exp2(S * c - m); the add into the running sum and the bf16 pair of the P fragment trail by one
-    // element (nothing right behind the v_exp depends on it: no transcendental-result wait state); exp_flush closes element 31
+    // Score element E of a block: P = exp2(S c - m) against the row's CURRENT reference max -- no max pass in front of the exps.  The
+    // tile's largest exponent is collected on the side (one v_max3 per two elements) and checked once, after element 31: only if some
+    // row's exceeds th is the tile redone against a raised m (softmax_fixup; S is left intact for that -- P goes to a three-element
+    // window and the bf16 fragment).  Rare: the first live tile of a row, then whenever a row's max grows by more than LAZY_TH.
+    // The add into the running sum, the bf16 pair and the max trail the exp by one element: nothing right behind a v_exp depends on it.
     auto exp_elem = [&](auto ec, f32x16 (&s)[2], Softmax& sm, u32x4 (&p)[4]) __attribute__((always_inline)) {
         constexpr int E = decltype(ec)::value;
 #ifdef FWD64_PROBE_NO_EXP
         return;
 #endif
-        const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[E >> 4][E & 15], c, sm.negm));
-        if constexpr (E > 0) sm.l += s[(E - 1) >> 4][(E - 1) & 15];
-        if constexpr (E >= 2 && (E & 1) == 0) {
-            p[(E - 2) >> 3][((E - 2) & 7) >> 1] = pack_bf2(s[(E - 2) >> 4][(E - 2) & 15], s[(E - 1) >> 4][(E - 1) & 15]);
-            asm volatile("" : "+v"(p[(E - 2) >> 3]));       // pins: the code sinker would move all of this to the fragment's consumer
+        if constexpr (E == 0) {
+            sm.l0 = sm.l;
+            sm.tm = -INFINITY;
         }
-        s[E >> 4][E & 15] = pe;
-        asm volatile("" : "+v"(s[E >> 4]), "+v"(sm.l));
+        if constexpr (E > 0) sm.l += WIN_P(sm, (E - 1));
+        if constexpr (E >= 2 && (E & 1) == 0) {
+            p[(E - 2) >> 3][((E - 2) & 7) >> 1] = pack_bf2(WIN_P(sm, (E - 2)), WIN_P(sm, (E - 1)));
+            sm.tm = max3(sm.tm, WIN_T(sm, (E - 2)), WIN_T(sm, (E - 1)));
+            asm volatile("" : "+v"(p[(E - 2) >> 3]), "+v"(sm.tm));       // pins: the code sinker would move all of this to the consumer
+        }
+        WIN_T(sm, E) = __builtin_fmaf(s[E >> 4][E & 15], c, sm.negm);
+        WIN_P(sm, E) = __builtin_amdgcn_exp2f(WIN_T(sm, E));
+        asm volatile("" : "+v"(WIN_P(sm, E)), "+v"(sm.l));
     };
-    auto exp_flush = [&](f32x16 (&s)[2], Softmax& sm, u32x4 (&p)[4]) __attribute__((always_inline)) {
-        sm.l += s[1][15];
-        p[3][3] = pack_bf2(s[1][14], s[1][15]);
+    // the tile against a raised reference max (wave-uniform branch, rare): P, the fragments and the tile's sum again from S; l and O
+    // (which does not hold this tile yet) rescaled
+    auto softmax_fixup = [&](f32x16 (&s)[2], Softmax& sm, u32x4 (&p)[4], auto obc) __attribute__((always_inline)) {
+        constexpr int OB = decltype(obc)::value;
+        const float tmax = pair_max(sm.tm);
+        const bool upd = tmax > sm.th;
+        const float m_new = upd ? tmax - sm.negm : sm.m;
+        const float alpha = upd ? __builtin_amdgcn_exp2f(sm.m - m_new) : 1.f;      // m = -inf: 0 (l0 and O are still 0)
+        sm.m = m_new;
+        sm.negm = m_new == -INFINITY ? 0.f : -m_new;
+        sm.th = upd ? LAZY_TH : sm.th;
+        float lsum = 0.f;
+#pragma unroll
+        for (int E = 0; E < 32; E += 2) {
+            const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[E >> 4][E & 15], c, sm.negm));
+            const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[E >> 4][(E & 15) + 1], c, sm.negm));
+            lsum += p0 + p1;
+            p[E >> 3][(E & 7) >> 1] = pack_bf2(p0, p1);
+        }
+        sm.l = sm.l0 * alpha + lsum;
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");       // this O's last MFMA is at least a phase back; belt and braces
+        static_for<0, 16>([&](auto r) __attribute__((always_inline)) { agpr_scale4<OB + 4 * decltype(r)::value>(alpha); });
+        asm volatile("s_nop 2" ::: "memory");                  // accvgpr_write -> MFMA src C
+    };
+    // element 31's trailing work, then the check
+    auto exp_finish = [&](f32x16 (&s)[2], Softmax& sm, u32x4 (&p)[4], auto obc) __attribute__((always_inline)) {
+#ifdef FWD64_PROBE_NO_EXP
+        return;
+#endif
+        sm.l += WIN_P(sm, 31);
+        p[3][3] = pack_bf2(WIN_P(sm, 30), WIN_P(sm, 31));
+        sm.tm = max3(sm.tm, WIN_T(sm, 30), WIN_T(sm, 31));
         asm volatile("" : "+v"(p[3]), "+v"(sm.l));
+        if (__builtin_expect(__any(sm.tm > sm.th), 0)) softmax_fixup(s, sm, p, obc);
     };
     // mask pre-pass: dead scores -> -inf (key padding bits, causal, sample start); keys of element (sb, r): sb*32 + (r&3) + 8*(r>>2) + 4*hh
     auto mask_scores = [&](f32x16 (&s)[2], int blk, int key0, unsigned long long bits) __attribute__((always_inline)) {
@@ -385,22 +400,42 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(const bf16_t* __rest
             }
     };
 
-    // ---- prologue: K(f) | V(f) K(f+1) | V(f+1) K(f+2) | V(f+2) K(f+3) in this order; K(f) and the liveness words must be there for the
-    // K fragment reads / the first step, the rest is what the steady-state count expects to find in flight
-    static_for<0, NS>([&](auto ic) __attribute__((always_inline)) {
+    // ---- the rest of the ring: V(f+1) K(f+2) | V(f+2) K(f+3) -- what the steady-state count expects to find in flight
+    static_for<2, NS>([&](auto ic) __attribute__((always_inline)) {
         constexpr int i = decltype(ic)::value;
-        if constexpr (i > 0) {
-            const __amdgpu_buffer_rsrc_t rv = tile_desc(Vb, (int)ldv, t_first + i - 1);
-            static_for<0, 4>([&](auto j) __attribute__((always_inline)) { dma_piece(rv, voV, OFF_V, i - 1, j); });
-        }
-        const __amdgpu_buffer_rsrc_t rk = tile_desc(Kb, (int)ldk, t_first + i);
+        const __amdgpu_buffer_rsrc_t rv = tile_desc(Vb, (int)ldv, t_first + i - 1), rk = tile_desc(Kb, (int)ldk, t_first + i);
+        static_for<0, 4>([&](auto j) __attribute__((always_inline)) { dma_piece(rv, voV, OFF_V, i - 1, j); });
         static_for<0, 4>([&](auto j) __attribute__((always_inline)) { dma_piece(rk, voK, OFF_K, i, j); });
     });
-    asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");      // K(f); the liveness words (ds_write)
+    asm volatile("" : "+v"(qreg[0][0]), "+v"(qreg[0][1]), "+v"(qreg[0][2]), "+v"(qreg[0][3]), "+v"(qreg[0][4]), "+v"(qreg[0][5]),
+                 "+v"(qreg[0][6]), "+v"(qreg[0][7]), "+v"(qreg[1][0]), "+v"(qreg[1][1]), "+v"(qreg[1][2]), "+v"(qreg[1][3]),
+                 "+v"(qreg[1][4]), "+v"(qreg[1][5]), "+v"(qreg[1][6]), "+v"(qreg[1][7]));
+    static_for<0, 16>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int blk = decltype(ic)::value >> 3, ks = decltype(ic)::value & 7;
+        agpr_write<AQ + 32 * blk + 4 * ks + 0>(qreg[blk][ks][0]);
+        agpr_write<AQ + 32 * blk + 4 * ks + 1>(qreg[blk][ks][1]);
+        agpr_write<AQ + 32 * blk + 4 * ks + 2>(qreg[blk][ks][2]);
+        agpr_write<AQ + 32 * blk + 4 * ks + 3>(qreg[blk][ks][3]);
+    });
+    // wave-uniform sample-start bounds: no key below ks_min is live for any row, keys below ks_max[blk] need the pre-pass
+    int ks_min = 0, ks_max[2] = {0, 0};
+    if (kstart) {
+        ks_min = -(int)wave_max((float)-(ks_q[0] < ks_q[1] ? ks_q[0] : ks_q[1]));     // exact below 2^24
+        ks_max[0] = (int)wave_max((float)ks_q[0]);
+        ks_max[1] = (int)wave_max((float)ks_q[1]);
+        ks_min = __builtin_amdgcn_readfirstlane(ks_min);
+        ks_max[0] = __builtin_amdgcn_readfirstlane(ks_max[0]);
+        ks_max[1] = __builtin_amdgcn_readfirstlane(ks_max[1]);
+    }
+    asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");      // K(f), V(f), K(f+1); the liveness words (ds_write)
     __builtin_amdgcn_s_barrier();      // raw: __syncthreads() is a fence and would drain the whole ring (vmcnt(0))
+    request_bits(t_first);
     static_for<0, 16>([&](auto i) __attribute__((always_inline)) { lds_read_k<i.value, (i.value >> 3) * 32 * 256>(kaddr[i.value & 7]); });
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 2" ::: "memory");      // also: accvgpr_write (Q fragments, O = 0) -> MFMA operand
 
+#ifdef FWD64_PROBE_TIMING
+    const unsigned long long T1 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- one tile, ring slot SLOT = (t - t_first) & 1.  Gap n = MFMA n of the tile plus its fillers.
     auto tile = [&](auto slotc, int t, bool active, bool maskA, bool maskB, unsigned long long bits_t) __attribute__((always_inline)) {
         constexpr int SLOT = decltype(slotc)::value;
@@ -409,14 +444,14 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(const bf16_t* __rest
         constexpr int VD = (SLOT + NS - 1) % NS, KD = SLOT;                     // slots the DMA of V(t+NS-1) / K(t+NS) goes to
         const int key0 = t * 64;
         if (active) {
-            // Ph1: S_A(t) | B elements 10 .. 31 of the previous tile
+            // Ph1: S_A(t) | B elements 14 .. 31 of the previous tile, its check
             static_for<0, 16>([&](auto i) __attribute__((always_inline)) {
                 constexpr int I = i.value, ks = I >> 1, sb = I & 1;
                 if constexpr (ks == 0) mfma_s0<sb * 8 + ks, ks>(sA[sb]);
                 else mfma_s<sb * 8 + ks, ks>(sA[sb]);
-                constexpr int e0 = 10 + (I * 22) / 16, e1 = 10 + ((I + 1) * 22) / 16;
+                constexpr int e0 = 14 + (I * 18) / 16, e1 = 14 + ((I + 1) * 18) / 16;
                 static_for<e0, e1>([&](auto e) __attribute__((always_inline)) { exp_elem(e, sB, smB, pB); });
-                if constexpr (I == 15) exp_flush(sB, smB, pB);
+                if constexpr (I == 15) exp_finish(sB, smB, pB, std::integral_constant<int, AO + 64>{});
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
@@ -425,9 +460,12 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(const bf16_t* __rest
 #ifndef FWD64_PROBE_NO_VMWAIT
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
 #endif
+#ifndef FWD64_PROBE_NO_BARRIER
         __builtin_amdgcn_s_barrier();
+#endif
+        request_bits(t + 1);
         if (active) {
-            // Ph2: O_B += V(t-1)^T.P_B(t-1) | V^T fragments of tile t (fragment j is free once MFMA j has issued) | max(A), A elements 0 .. 9
+            // Ph2: O_B += V(t-1)^T.P_B(t-1) | V^T fragments of tile t (fragment j is free once MFMA j has issued) | A elements 0 .. 13
             static_for<0, 16>([&](auto j) __attribute__((always_inline)) {
                 constexpr int J = j.value;
                 mfma_o<AO + 64 + 16 * (J & 3), J>(pB[J >> 2]);
@@ -436,28 +474,23 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(const bf16_t* __rest
                     asm volatile("" : "+v"(sA[0]), "+v"(sA[1]));        // S_A's last MFMA is two gaps back: readable from here on
                     if (__builtin_expect(maskA, 0)) mask_scores(sA, 0, key0, bits_t);
                 }
-                if constexpr (J >= 1 && J <= 4) max_part(std::integral_constant<int, J - 1>{}, sA);
-                if constexpr (J == 5) max_finish(smA, std::integral_constant<int, AO>{});
-                if constexpr (J >= 6) exp_elem(std::integral_constant<int, J - 6>{}, sA, smA, pA);
+                if constexpr (J >= 2) exp_elem(std::integral_constant<int, J - 2>{}, sA, smA, pA);
                 __builtin_amdgcn_sched_barrier(0);
             });
-            // Ph3: S_B(t) | the DMA of V(t+NS-1) and K(t+NS) | A elements 10 .. 31
+            // Ph3: S_B(t) | the DMA of V(t+NS-1) | A elements 14 .. 31, A's check
             const __amdgpu_buffer_rsrc_t rv = tile_desc(Vb, (int)ldv, t + NS - 1), rk = tile_desc(Kb, (int)ldk, t + NS);
             static_for<0, 16>([&](auto i) __attribute__((always_inline)) {
                 constexpr int I = i.value, ks = I >> 1, sb = I & 1;
                 if constexpr (ks == 0) mfma_s0<sb * 8 + ks, 8 + ks>(sB[sb]);
                 else mfma_s<sb * 8 + ks, 8 + ks>(sB[sb]);
-                if constexpr ((I & 1) == 0) {
-                    if constexpr (I < 8) dma_piece(rv, voV, OFF_V, VD, std::integral_constant<int, I / 2>{});
-                    else dma_piece(rk, voK, OFF_K, KD, std::integral_constant<int, I / 2 - 4>{});
-                }
-                constexpr int e0 = 10 + (I * 22) / 16, e1 = 10 + ((I + 1) * 22) / 16;
+                if constexpr ((I & 3) == 1) dma_piece(rv, voV, OFF_V, VD, std::integral_constant<int, I / 4>{});
+                constexpr int e0 = 14 + (I * 18) / 16, e1 = 14 + ((I + 1) * 18) / 16;
                 static_for<e0, e1>([&](auto e) __attribute__((always_inline)) { exp_elem(e, sA, smA, pA); });
-                if constexpr (I == 15) exp_flush(sA, smA, pA);
+                if constexpr (I == 15) exp_finish(sA, smA, pA, std::integral_constant<int, AO>{});
                 __builtin_amdgcn_sched_barrier(0);
             });
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // V^T fragments (issued a phase ago)
-            // Ph4: O_A += V(t)^T.P_A(t) | K fragments of tile t+1 | max(B), B elements 0 .. 9
+            // Ph4: O_A += V(t)^T.P_A(t) | K fragments of tile t+1, then the DMA of K(t+NS) | B elements 0 .. 13
             static_for<0, 16>([&](auto j) __attribute__((always_inline)) {
                 constexpr int J = j.value;
                 mfma_o<AO + 16 * (J & 3), J>(pA[J >> 2]);
@@ -465,13 +498,12 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(const bf16_t* __rest
                     lds_read_k<2 * J, KN + ((2 * J) >> 3) * 32 * 256>(kaddr[(2 * J) & 7]);
                     lds_read_k<2 * J + 1, KN + ((2 * J + 1) >> 3) * 32 * 256>(kaddr[(2 * J + 1) & 7]);
                 }
+                if constexpr (J >= 9 && (J & 1) == 1) dma_piece(rk, voK, OFF_K, KD, std::integral_constant<int, (J - 9) / 2>{});
                 if constexpr (J == 1) {
                     asm volatile("" : "+v"(sB[0]), "+v"(sB[1]));
                     if (__builtin_expect(maskB, 0)) mask_scores(sB, 1, key0, bits_t);
                 }
-                if constexpr (J >= 1 && J <= 4) max_part(std::integral_constant<int, J - 1>{}, sB);
-                if constexpr (J == 5) max_finish(smB, std::integral_constant<int, AO + 64>{});
-                if constexpr (J >= 6) exp_elem(std::integral_constant<int, J - 6>{}, sB, smB, pB);
+                if constexpr (J >= 2) exp_elem(std::integral_constant<int, J - 2>{}, sB, smB, pB);
                 __builtin_amdgcn_sched_barrier(0);
             });
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // K fragments of tile t+1
@@ -486,7 +518,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(const bf16_t* __rest
     };
     auto step = [&](auto slotc, int t) __attribute__((always_inline)) {
         const int key0 = t * 64;
-        const unsigned long long bits = tile_bits(t);
+        const unsigned long long bits = collect_bits();
         const bool active = !(CAUSAL && key0 > q0w + 63) && bits != 0ull && key0 + 63 >= ks_min;
         const bool part = bits != ~0ull;
         const bool maskA = part || (CAUSAL && key0 + 63 > q0w) || key0 < ks_max[0];
@@ -502,10 +534,13 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(const bf16_t* __rest
         if (t + 3 >= ntiles) break;
         step(std::integral_constant<int, 3>{}, t + 3);
     }
+#ifdef FWD64_PROBE_TIMING
+    const unsigned long long T2 = __builtin_amdgcn_s_memtime();
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the ring's last (empty) DMA pieces must not outlive the workgroup's LDS
-    // ---- drain: the last live tile's block B -- elements 10 .. 31, then O_B += V^T.P_B
-    static_for<10, 32>([&](auto e) __attribute__((always_inline)) { exp_elem(e, sB, smB, pB); });
-    exp_flush(sB, smB, pB);
+    // ---- drain: the last live tile's block B -- elements 14 .. 31 and the check, then O_B += V^T.P_B
+    static_for<14, 32>([&](auto e) __attribute__((always_inline)) { exp_elem(e, sB, smB, pB); });
+    exp_finish(sB, smB, pB, std::integral_constant<int, AO + 64>{});
     asm volatile("s_nop 1" : "+v"(pB[0]), "+v"(pB[1]), "+v"(pB[2]), "+v"(pB[3]));
     static_for<0, 16>([&](auto j) __attribute__((always_inline)) { mfma_o<AO + 64 + 16 * (j.value & 3), j.value>(pB[j.value >> 2]); });
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");      // MFMA result -> v_accvgpr_read
@@ -528,6 +563,17 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(const bf16_t* __rest
     };
     store_block(std::integral_constant<int, 0>{}, smA);
     store_block(std::integral_constant<int, 1>{}, smB);
+#ifdef FWD64_PROBE_TIMING      // per wave: prologue / loop / epilogue cycles and the tile count, over the LSE words of its first rows
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long T3 = __builtin_amdgcn_s_memtime();
+    if (lane == 0 && LSE && q0w + 3 < L) {
+        float* w = LSE + ((long)b * H + h) * L + q0w;
+        w[0] = (float)(T1 - T0);
+        w[1] = (float)(T2 - T1);
+        w[2] = (float)(T3 - T2);
+        w[3] = (float)(ntiles - t_first);
+    }
+#endif
 }
 
 }  // namespace
