@@ -1193,12 +1193,14 @@ int mantis_attn_fwd64_launch(bool causal, int B, hipStream_t s, const bf16_t* Q,
                              bf16_t* O, float* LSE, int L, int Lk, int H, int Hkv, long ldq, long ldk, long ldv, long ldo, float scale,
                              const int* kstart);
 
-// MANTIS_ATTN_FWD64 = 1 (read once): the hd-128 forward runs on attn_fwd64_kernel (64 query rows per wave)
-static int attn_fwd64_enabled() {
+// The hd-128 forward runs on attn_fwd64_kernel (64 query rows per wave) from 1024 query rows on; MANTIS_ATTN_FWD64 = 0 (read once) keeps
+// attn_fwd_kernel<128> for every length, = 1 forces attn_fwd64 for every length.  Same-box A/B, round 3, Llama-3 step geometry (B 2,
+// L 2812, 32/8 heads): 197 vs 210 us without a key mask, 188 vs 215 us with one; Qwen2-7B geometry (L 4096, 28/4): 139 vs 176 us.
+static int attn_fwd64_mode() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("MANTIS_ATTN_FWD64");
-        v = (e && e[0] == '1') ? 1 : 0;
+        v = (e && e[0] == '0') ? 0 : (e && e[0] == '1') ? 1 : 2;
     }
     return v;
 }
@@ -1208,7 +1210,8 @@ static int launch_fwd(bool causal, dim3 grid, hipStream_t s, const bf16_t* Q, co
                       bf16_t* O, float* LSE, int L, int Lk, int H, int Hkv, long ldq, long ldk, long ldv, long ldo, float scale,
                       const int* kstart) {
     if constexpr (HD == 128) {
-        if (attn_fwd64_enabled() && Lk <= 65536)      // the kernel's per-tile liveness table holds 1024 tiles
+        const int mode = attn_fwd64_mode();
+        if ((mode == 1 || (mode == 2 && L >= 1024)) && Lk <= 65536)      // the kernel's per-tile liveness table holds 1024 tiles
             return mantis_attn_fwd64_launch(causal, (int)(grid.x / (cdiv(L, 128) * H)), s, Q, K, V, kmask, O, LSE, L, Lk, H, Hkv, ldq, ldk,
                                             ldv, ldo, scale, kstart);
     }

@@ -44,6 +44,13 @@ def decoder_forward(K, lm, tc, x, B, L, position_ids, kmask, kstart=None, comput
     return x, dict(saved=saved, cos=cos, sin=sin, scale=scale)
 
 
+def no_padding(attention_mask_cpu, grown, L):
+    """True when every row of the batch fills the whole (merged) sequence length L: attention_mask_cpu [B, T] on the host, `grown` the
+    rows each sample gains in the merge (LLaVA path: (#image placeholders) * (patches - 1); 0 where placeholders are pre-expanded).
+    Then the merged key mask is all ones and the attention kernels can run without one (kmask = None is DEFINED as all keys live)."""
+    return bool(((attention_mask_cpu != 0).sum(-1) + grown == L).all())
+
+
 def compact_ce_rows(plan, input_ids_cpu, attention_mask_cpu, labels, image_token, ignore_index, dev, vocab_size=None,
                     refuse_image_targets=False):
     """Shrink the plan's cross-entropy lists (one entry per (b, t) token) to the entries that can actually carry a label, so the final

@@ -181,11 +181,13 @@ class LlavaEngine:
                     f" the number of image given to the model is {I}. This prevents correct indexing and breaks batch generation.")
             kmax = int((ids_cpu == cfg.image_token_index).sum(-1).max())
             L = kmax * (N - 1) + T
+            grown = (ids_cpu == cfg.image_token_index).sum(-1) * (N - 1)      # rows each sample's placeholders add in the merge
             plan = K.pack_plan(ids_d, attn_d, lab_d, N, I, cfg.image_token_index, pad_id, ign, L)
         else:
             # text-only: the reference skips the merge; positions default to arange (HF LlamaModel)
             L = T
             plan = K.pack_plan(ids_d, attn_d, lab_d, 1, 0, -(2 ** 62), pad_id, ign, L)
+            grown = 0
             plan.position_ids = torch.arange(T, device=dev, dtype=torch.int64)[None].expand(B, T).contiguous()
         kstart = qend = None
         if segment_ids is not None:
@@ -205,7 +207,9 @@ class LlavaEngine:
                           merged_labels=plan.labels, merged_position_ids=plan.position_ids)
 
         # ---- rows H, I: Llama decoder, final norm, lm_head, masked shifted CE (decoder.py, shared with the Idefics2 path)
-        kmask = plan.kmask
+        # a batch without a single pad position needs no key mask (decided on the host copy of the batch: no device sync): the attention
+        # kernels then skip the per-tile mask words altogether
+        kmask = None if D.no_padding(am_cpu, grown, L) else plan.kmask
         x, dctx = D8.forward(K, self, m.lm, tc, x, B, L, plan.position_ids, kmask, kstart, compute_grads, record)
         loss, count, logits_full, hctx = D.head_and_loss(K, m.lm, tc, x, plan, B, L, labels is not None, grad_scale, loss_scale,
                                                          compute_grads, need_logits, record)

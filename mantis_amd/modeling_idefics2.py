@@ -472,7 +472,7 @@ class Idefics2Engine:
         x = K.pack_rows_fwd(plan, ids_d, m.lm["embed"], img)
         if record is not None and img is not None:
             record["merged_embeds"] = x.view(B, T, -1)
-        kmask = plan.kmask
+        kmask = None if D.no_padding(am_cpu, 0, T) else plan.kmask      # no pad position in the batch: no key mask (host-side decision)
         x, dctx = D8.forward(K, self, m.lm, tc, x, B, T, plan.position_ids, kmask, kstart, compute_grads, record)
         loss, count, logits_full, hctx = D.head_and_loss(K, m.lm, tc, x, plan, B, T, labels is not None, grad_scale, loss_scale,
                                                          compute_grads, need_logits, record)

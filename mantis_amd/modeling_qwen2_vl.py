@@ -447,7 +447,7 @@ class Qwen2VLEngine:
         # multimodal RoPE (:156-170, :207-213): rotary frequency j reads the temporal / height / width id by section
         sec = torch.repeat_interleave(torch.arange(3, dtype=torch.int32), torch.tensor(tc.rope_parameters["mrope_section"])).to(dev)
         rope = K.rope_table_sections(pos3.reshape(3, B * T).to(dev), D.inv_freq(tc.head_dim, tc.rope_theta).to(dev), sec)
-        kmask = plan.kmask
+        kmask = None if D.no_padding(am_cpu, 0, T) else plan.kmask      # no pad position in the batch: no key mask (host-side decision)
         x, dctx = D8.forward(K, self, m.lm, tc, x, B, T, None, kmask, kstart, compute_grads, record, rope=rope)
         loss, count, logits_full, hctx = D.head_and_loss(K, m.lm, tc, x, plan, B, T, labels is not None, grad_scale, loss_scale,
                                                          compute_grads, need_logits, record)

@@ -286,3 +286,19 @@ def test_norm_overlap_is_off_when_the_reducer_is_not_nccl(cpu_backend, monkeypat
     model, _, _ = Hh.build_product_model("siglip", "cpu")
     MantisHipTrainer(model, reducer=Red(), optimizer=Opt()).training_step(model, _batch(z))
     assert not Opt.began
+
+
+def test_no_padding_decides_the_key_mask_on_the_host():
+    """decoder.no_padding: a batch whose every row fills the merged length needs no key mask (the attention kernels define kmask = None
+    as 'all keys live'); one pad position, or one shorter sample, keeps it."""
+    import torch
+    from mantis_amd import decoder as D
+    am = torch.ones(2, 10, dtype=torch.int64)
+    assert D.no_padding(am, 0, 10)
+    assert D.no_padding(am, torch.tensor([6, 6]), 16)            # LLaVA merge: both samples grow by the same number of patch rows
+    assert not D.no_padding(am, torch.tensor([6, 3]), 16)        # the sample with fewer images is padded in the merge
+    am[1, -1] = 0
+    assert not D.no_padding(am, 0, 10)
+    am = torch.ones(1, 4, dtype=torch.int64)
+    am[0, 0] = 0                                                   # left padding
+    assert not D.no_padding(am, 0, 4)
