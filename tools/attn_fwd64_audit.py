@@ -1,5 +1,7 @@
 """Audit of attn_fwd64.hip's build: the kernel's asm statements own the accumulator file by register NUMBER, so the compiler must not
-put anything there.  Fails if a v_accvgpr_* or an AGPR operand appears outside ;;#ASMSTART .. ;;#ASMEND, or (optionally) on scratch use.
+put anything there.  Fails if a v_accvgpr_* or an AGPR operand appears outside ;;#ASMSTART .. ;;#ASMEND, if the compiler's own code touches
+v192-v255 (the V^T fragments: the clobber lists keep values from LIVING there across the asm statements, they do not stop a short-lived
+temporary between two of them), or (optionally) on scratch use.
 
     python tools/attn_fwd64_audit.py [--allow-scratch]
 """
@@ -44,6 +46,12 @@ def main():
                 bad.append((n, t))
             if "scratch_" in t:
                 scratch += 1
+            code = t.split(";")[0]
+            regs = [int(m.group(1)) for m in re.finditer(r"\bv(\d+)\b", code)]
+            for m in re.finditer(r"\bv\[(\d+):(\d+)\]", code):
+                regs += [int(m.group(1)), int(m.group(2))]
+            if any(r >= 192 for r in regs):
+                bad.append((n, "v192+ outside asm: " + t))
     print(f"compiler AGPR uses outside asm: {len(bad)}; scratch instructions: {scratch}")
     for n, t in bad[:20]:
         print(f"  {n}: {t}")
