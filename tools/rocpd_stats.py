@@ -7,8 +7,9 @@ import sys
 
 
 def short(name):
-    name = re.sub(r"\(.*$", "", name)
     name = re.sub(r"^void ", "", name)
+    name = name.replace("(anonymous namespace)::", "")
+    name = re.sub(r"\(.*$", "", name)
     return name[:70]
 
 
