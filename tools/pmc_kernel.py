@@ -11,7 +11,7 @@ from collections import defaultdict
 
 
 def short(n):
-    n = re.sub(r"^void ", "", n)
+    n = re.sub(r"^void ", "", n).replace("(anonymous namespace)::", "")
     return re.sub(r"\(.*$", "", n)[:60]
 
 
