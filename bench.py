@@ -449,10 +449,12 @@ def main():
     if args.prefetch and opt is not None and hasattr(model.engine, "prefetch_vision"):
         # CU partition: clip + AdamW on `--adam-cus` compute units (HBM-bound: 192 CUs stream as fast as 256), the next batch's frozen
         # tower on the others -- the two masked streams run side by side (tools/cu_mask_probe.hip)
+        # `--adam-cus 0`: no CU partition -- the tower on a plain side stream beside the optimizer pass on the compute stream
         total = K.num_cus()
-        n_adam = min(max(args.adam_cus, 1), total - 8)
-        opt.stream = K.cu_masked_stream(0, n_adam)
-        trainer.prefetch_stream = K.cu_masked_stream(n_adam, total - n_adam)
+        if args.adam_cus > 0:
+            n_adam = min(max(args.adam_cus, 1), total - 8)
+            opt.stream = K.cu_masked_stream(0, n_adam)
+            trainer.prefetch_stream = K.cu_masked_stream(n_adam, total - n_adam)
     n_batches = args.recycle_batches or (args.warmup + args.steps)
     make = synthetic_batch_idefics2 if idefics else synthetic_batch
     if qwen:
