@@ -1069,6 +1069,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring16_kernel(
         });
     };
 
+    // 8 waves: the second-dispatched half (waves 4-7, each sharing a SIMD with one of 0-3) loses the instruction arbitration on every
+    // segment at equal priority; one static s_setprio 1 for it (no per-segment flips).  Round 3, same box, two alternating runs: headline
+    // step 284.3 / 284.4 -> 282.8 / 282.1 ms; per shape within +-1.5 % either way (profiles/r03_experiments.md, 16)
+    if constexpr (NW == 8) {
+        if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+    }
     if constexpr (NW == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // step t0 landed (this wave's pieces); step t0 + 1 may
     else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                          // still be in flight
     __builtin_amdgcn_s_barrier();
