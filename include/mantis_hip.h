@@ -213,12 +213,6 @@ int mantis_navit_prepare(const float* pixels, const uint8_t* pixel_mask, int n_i
 int mantis_adamw(void* param_bf16, const void* grad_bf16, float* master, float* exp_avg, float* exp_avg_sq, int64_t n,
                  float lr, float beta1, float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2,
                  const float* grad_scale_dev /*nullable: multiply grads by *grad_scale_dev (clip)*/, void* stream);
-/* The same update with the fp32 state packed: `state` = ceil(total / 512) chunks of 1536 floats, chunk c = [master | exp_avg | exp_avg_sq]
- * (512 floats each) of elements 512 c .. 512 c + 511 of the optimizer's element space; this call updates the n elements from
- * `state_off` on (both multiples of 8).  10 % faster than the five-array form (fewer concurrent DRAM streams); optimizer-private layout. */
-int mantis_adamw_packed(void* param_bf16, const void* grad_bf16, float* state, int64_t n, int64_t state_off, float lr, float beta1,
-                        float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2,
-                        const float* grad_scale_dev /*nullable*/, void* stream);
 int mantis_sumsq_partials(int64_t n);
 int mantis_sumsq(const void* x_bf16, int64_t n, float* partials_ws, float* out /*[1], += */, int accumulate, void* stream);
 int mantis_clip_scale(const float* sumsq, float max_norm, float* scale_out, float* norm_out, void* stream);

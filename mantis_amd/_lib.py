@@ -58,7 +58,6 @@ SIGNATURES = {
     "mantis_drop_cls": [P, P, I, I, I, P],
     "mantis_navit_prepare": [P, P, I, I, I, I, I, I, P, I, P, P, P, P, P],
     "mantis_adamw": [P, P, P, P, P, L, F, F, F, F, F, F, F, P, P],
-    "mantis_adamw_packed": [P, P, P, L, L, F, F, F, F, F, F, F, P, P],
     "mantis_sumsq_partials": [L],
     "mantis_sumsq": [P, L, P, P, I, P],
     "mantis_clip_scale": [P, F, P, P, P],

@@ -43,50 +43,6 @@ __global__ void adamw_kernel(bf16_t* __restrict__ p16, const bf16_t* __restrict_
     }
 }
 
-// The same update with the three fp32 state arrays interleaved in 6 KiB chunks: chunk c of `state` holds elements 512 c .. 512 c + 511
-// as [master 512 floats | exp_avg 512 | exp_avg_sq 512].  The pass is HBM-bound with reads and writes 1 : 1; with the state packed it
-// streams through two read and two write streams instead of four and four, and runs 10 % faster (tools/adamw_layout_probe.hip, round 3,
-// 1 Gi elements: 5.45 TB/s with five separate arrays, 6.02 TB/s packed; one 8 KiB record holding the gradient and the bf16 parameter as
-// well: 5.15 TB/s).  `e8` = index of the segment's first 8-element vector in the state's element space.
-#define ADAMW_CHUNK 512
-__global__ void adamw_packed_kernel(bf16_t* __restrict__ p16, const bf16_t* __restrict__ g16, float* __restrict__ state, long n8, long e8,
-                                    float lr, float b1, float b2, float eps, float wd, float bc1, float bc2,
-                                    const float* __restrict__ gscale) {
-    const float gs = gscale ? *gscale : 1.f;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
-        const long j = e8 + i;
-        float* base = state + (j >> 6) * (3 * ADAMW_CHUNK) + (j & 63) * 8;
-        const u32x4 g = *reinterpret_cast<const u32x4*>(g16 + i * 8);
-        f32x4 pa = *reinterpret_cast<f32x4*>(base), pb = *reinterpret_cast<f32x4*>(base + 4);
-        f32x4 ma = *reinterpret_cast<f32x4*>(base + ADAMW_CHUNK), mb = *reinterpret_cast<f32x4*>(base + ADAMW_CHUNK + 4);
-        f32x4 va = *reinterpret_cast<f32x4*>(base + 2 * ADAMW_CHUNK), vb = *reinterpret_cast<f32x4*>(base + 2 * ADAMW_CHUNK + 4);
-        float gf[8], pf[8], mf[8], vf[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            gf[2 * e] = bf2f_lo(g[e]) * gs; gf[2 * e + 1] = bf2f_hi(g[e]) * gs;
-            pf[e] = pa[e]; pf[4 + e] = pb[e]; mf[e] = ma[e]; mf[4 + e] = mb[e]; vf[e] = va[e]; vf[4 + e] = vb[e];
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {      // the arithmetic of adamw_kernel, operation for operation
-            pf[e] *= (1.f - lr * wd);
-            mf[e] = b1 * mf[e] + (1.f - b1) * gf[e];
-            vf[e] = b2 * vf[e] + (1.f - b2) * gf[e] * gf[e];
-            const float denom = sqrtf(vf[e] / bc2) + eps;
-            pf[e] -= (lr / bc1) * (mf[e] / denom);
-        }
-        u32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            o[e] = pack_bf2(pf[2 * e], pf[2 * e + 1]);
-            pa[e] = pf[e]; pb[e] = pf[4 + e]; ma[e] = mf[e]; mb[e] = mf[4 + e]; va[e] = vf[e]; vb[e] = vf[4 + e];
-        }
-        *reinterpret_cast<f32x4*>(base) = pa; *reinterpret_cast<f32x4*>(base + 4) = pb;
-        *reinterpret_cast<f32x4*>(base + ADAMW_CHUNK) = ma; *reinterpret_cast<f32x4*>(base + ADAMW_CHUNK + 4) = mb;
-        *reinterpret_cast<f32x4*>(base + 2 * ADAMW_CHUNK) = va; *reinterpret_cast<f32x4*>(base + 2 * ADAMW_CHUNK + 4) = vb;
-        *reinterpret_cast<u32x4*>(p16 + i * 8) = o;
-    }
-}
-
 #define SUMSQ_BLOCKS 8192
 __global__ void sumsq_partial_kernel(const bf16_t* __restrict__ x, long n8, float* __restrict__ partial) {
     __shared__ float red[16];
@@ -126,21 +82,6 @@ int mantis_adamw(void* param_bf16, const void* grad_bf16, float* master, float* 
     MANTIS_LAUNCH(adamw_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (bf16_t*)param_bf16,
                        (const bf16_t*)grad_bf16, master, exp_avg, exp_avg_sq, (long)(n / 8), lr, beta1, beta2, eps,
                        weight_decay, bias_corr1, bias_corr2, grad_scale_dev);
-    return mantis_check_launch();
-}
-
-// AdamW with the optimizer state packed (adamw_packed_kernel): `state` = ceil(total / 512) chunks of 1536 floats covering the optimizer's
-// whole element space, `state_off` = position of this segment's first element in that space (a multiple of 8, like n).
-int mantis_adamw_packed(void* param_bf16, const void* grad_bf16, float* state, int64_t n, int64_t state_off, float lr, float beta1,
-                        float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, const float* grad_scale_dev,
-                        void* stream) {
-    if ((n % 8) || (state_off % 8) || state_off < 0) return MANTIS_EUNSUPPORTED;
-    if (n == 0) return MANTIS_OK;
-    long g = (n / 8 + 255) / 256;
-    g = g > 131072 ? 131072 : g;
-    MANTIS_LAUNCH(adamw_packed_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (bf16_t*)param_bf16, (const bf16_t*)grad_bf16,
-                       state, (long)(n / 8), (long)(state_off / 8), lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2,
-                       grad_scale_dev);
     return mantis_check_launch();
 }
 

@@ -658,19 +658,6 @@ def adamw_flat(param, grad, master, m, v, lr, beta1, beta2, eps, wd, step, grad_
     _lib.check(rc, "adamw")
 
 
-ADAMW_CHUNK = 512      # elements per chunk of the packed optimizer state: [master | exp_avg | exp_avg_sq], 512 floats each
-
-
-def adamw_packed(param, grad, state, state_off, lr, beta1, beta2, eps, wd, step, grad_scale=None):
-    """adamw_flat with the fp32 state packed in 6 KiB chunks (`state`: [n_chunks, 3, 512] fp32, contiguous); this call updates the
-    param.numel() elements that start at element `state_off` of the state's element space."""
-    bc1 = 1.0 - beta1 ** step
-    bc2 = 1.0 - beta2 ** step
-    rc = _L.mantis_adamw_packed(_p(param), _p(grad), _p(state), param.numel(), int(state_off), lr, beta1, beta2, eps, wd, bc1, bc2,
-                                _p(grad_scale), _stream())
-    _lib.check(rc, "adamw_packed")
-
-
 def grad_sumsq(x, out, accumulate=False, ws=None):
     if ws is None:
         ws = torch.empty((_L.mantis_sumsq_partials(x.numel()),), dtype=torch.float32, device=x.device)

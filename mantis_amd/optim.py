@@ -4,7 +4,7 @@ Reference behaviour being replaced: `clip_grad_norm_(max_grad_norm=1.0)` + `opti
 HF loop (transformers/trainer.py:1785-1796, :2535-2545) with the hyper-parameters of
 /root/reference/mantis/train/scripts/train_mllava.sh:162-165 (AdamW, lr 1e-5, wd 0), which the reference executes through
 DeepSpeed's fused Adam with fp32 master weights.  Here: one sum-of-squares launch, one scalar kernel, one AdamW launch
-over the whole trainable arena (fp32 state packed in 6 KiB chunks); the clip coefficient stays on the device (no host sync)."""
+over the whole trainable arena; the clip coefficient stays on the device (no host sync)."""
 import torch
 
 from . import hip_ops as K
@@ -20,11 +20,9 @@ class FusedAdamW:
         self._segments = self._plan(names)
         n = model.grad_arena.numel()
         dev = model.device
-        # fp32 master weights and the two Adam moments, PACKED: chunk c of `state` = [master | exp_avg | exp_avg_sq] (512 floats each) of
-        # elements 512 c .. 512 c + 511 in gradient-arena order -- the optimizer pass is HBM-bound and streams 10 % faster through one
-        # state array than through three (hip_ops.adamw_packed, csrc/optim.hip).  `master` / `exp_avg` / `exp_avg_sq` gather copies.
-        self._n = n
-        self.state = torch.zeros(((n + K.ADAMW_CHUNK - 1) // K.ADAMW_CHUNK, 3, K.ADAMW_CHUNK), dtype=torch.float32, device=dev)
+        self.master = torch.empty(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.resync_master()
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.last_grad_norm = None
@@ -49,36 +47,9 @@ class FusedAdamW:
         the parameters, so a stale master would silently undo the load.  `step()` calls this itself when the model's
         `_param_version` moved; Adam moments are kept."""
         m = self.model
-        C = K.ADAMW_CHUNK
         for p_off, g_off, cnt in self._segments:
-            src = m.arena[p_off:p_off + cnt]
-            lo, hi = g_off, g_off + cnt
-            # [lo, hi) of the element space = a partial head chunk, whole chunks, a partial tail chunk
-            head_end = min(hi, (lo + C - 1) // C * C)
-            if head_end > lo:
-                self.state[lo // C, 0, lo % C: lo % C + (head_end - lo)].copy_(src[:head_end - lo])
-            body_end = max(head_end, hi // C * C)
-            if body_end > head_end:
-                self.state[head_end // C: body_end // C, 0, :].copy_(src[head_end - lo: body_end - lo].view(-1, C))
-            if hi > body_end:
-                self.state[body_end // C, 0, : hi - body_end].copy_(src[body_end - lo:])
+            self.master[g_off:g_off + cnt].copy_(m.arena[p_off:p_off + cnt])
         self._seen_version = getattr(m, "_param_version", 0)
-
-    def _gather(self, which):
-        return self.state[:, which, :].reshape(-1)[: self._n].clone()
-
-    @property
-    def master(self):
-        """fp32 master weights in gradient-arena order (a gathered COPY of the packed state: for inspection / tests)."""
-        return self._gather(0)
-
-    @property
-    def exp_avg(self):
-        return self._gather(1)
-
-    @property
-    def exp_avg_sq(self):
-        return self._gather(2)
 
     # ---- gradient norm overlapped with the backward (the reference's clip_grad_norm_ is a separate pass over all gradients,
     # HF:trainer.py:2535-2545).  The engine reports every gradient bucket the moment its last kernel is enqueued (the same hook the
@@ -146,8 +117,9 @@ class FusedAdamW:
             self._norm_ready = False
             scale, self.last_grad_norm = K.clip_scale(self._sumsq, self.max_grad_norm)
         for p_off, g_off, cnt in self._segments:
-            K.adamw_packed(m.arena[p_off:p_off + cnt], m.grad_arena[g_off:g_off + cnt], self.state, g_off, self.lr, self.betas[0],
-                           self.betas[1], self.eps, self.wd, self.step_count, grad_scale=scale)
+            K.adamw_flat(m.arena[p_off:p_off + cnt], m.grad_arena[g_off:g_off + cnt], self.master[g_off:g_off + cnt],
+                         self.exp_avg[g_off:g_off + cnt], self.exp_avg_sq[g_off:g_off + cnt], self.lr, self.betas[0],
+                         self.betas[1], self.eps, self.wd, self.step_count, grad_scale=scale)
 
     def zero_grad(self, set_to_none=True):
         """model.zero_grad() of the HF loop: dropping the .grad views lets the next backward overwrite instead of accumulate."""

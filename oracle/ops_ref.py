@@ -582,21 +582,6 @@ def adamw_flat(param, grad, master, m, v, lr, beta1, beta2, eps, wd, step, grad_
     param.copy_(master.to(param.dtype))
 
 
-
-ADAMW_CHUNK = 512
-
-
-def adamw_packed(param, grad, state, state_off, lr, beta1, beta2, eps, wd, step, grad_scale=None):
-    """hip_ops.adamw_packed: the same update on the packed state ([n_chunks, 3, 512]: master | exp_avg | exp_avg_sq per 512 elements),
-    restated through adamw_flat on gathered copies."""
-    n = param.numel()
-    idx = torch.arange(state_off, state_off + n)
-    c, w = idx // ADAMW_CHUNK, idx % ADAMW_CHUNK
-    st = state.view(-1, 3, ADAMW_CHUNK)
-    master, m, v = st[c, 0, w].clone(), st[c, 1, w].clone(), st[c, 2, w].clone()
-    adamw_flat(param, grad, master, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=grad_scale)
-    st[c, 0, w], st[c, 1, w], st[c, 2, w] = master, m, v
-
 def grad_sumsq(x, out, accumulate=False, ws=None):
     s = _f(x).pow(2).sum()
     out[0] = out[0] + s if accumulate else s

@@ -572,48 +572,6 @@ def check_optim():
     return r
 
 
-def check_adamw_packed():
-    """mantis_adamw_packed (fp32 state packed in chunks of [master | exp_avg | exp_avg_sq] x 512) against mantis_adamw on the same data:
-    the same arithmetic operation for operation -> bit-identical state and parameters.  Two segments at offsets that are multiples of
-    8 but not of 512 (chunks straddled at both ends), a clip scale, three steps; elements outside the segments must stay untouched."""
-    k = K()
-    C = k.ADAMW_CHUNK
-    total = 5 * C
-    segs = [(24, 8 * 150), (24 + 8 * 150 + 8 * 17, 8 * 90)]        # (state offset, elements)
-    gen = torch.Generator().manual_seed(5)
-    state = torch.randn(total // C, 3, C, generator=gen)
-    state[:, 2, :].abs_()                                           # exp_avg_sq >= 0
-    st_d = state.to(DEV)
-    scale = torch.tensor([0.37], device=DEV)
-    worst = 0.0
-    for si, (off, n) in enumerate(segs):
-        idx = torch.arange(off, off + n)
-        c, w = idx // C, idx % C
-        p32 = state[c, 0, w].clone().to(DEV)
-        m, v = state[c, 1, w].clone().to(DEV), state[c, 2, w].clone().to(DEV)
-        g = rnd(n, seed=20 + si, scale=0.02).to(DEV)
-        pf, pp = p32.to(BF), p32.to(BF)
-        for step in (1, 2, 3):
-            k.adamw_flat(pf, g, p32, m, v, 1e-3, 0.9, 0.999, 1e-8, 0.01, step, grad_scale=scale)
-            k.adamw_packed(pp, g, st_d, off, 1e-3, 0.9, 0.999, 1e-8, 0.01, step, grad_scale=scale)
-        got = st_d.cpu()
-        assert torch.equal(got[c, 0, w], p32.cpu()) and torch.equal(got[c, 1, w], m.cpu()) and torch.equal(got[c, 2, w], v.cpu()), si
-        assert torch.equal(pp.cpu(), pf.cpu()), si
-        state[c, 0, w], state[c, 1, w], state[c, 2, w] = p32.cpu(), m.cpu(), v.cpu()
-    assert torch.equal(st_d.cpu(), state), "elements outside the segments were touched"
-    # and against the oracle's restatement
-    st_o = state.clone()
-    off, n = segs[0]
-    g = rnd(n, seed=31, scale=0.02)
-    po = torch.zeros(n, dtype=BF)
-    pdv = po.to(DEV)
-    R.adamw_packed(po, g, st_o, off, 1e-3, 0.9, 0.999, 1e-8, 0.0, 4)
-    k.adamw_packed(pdv, g.to(DEV), st_d, off, 1e-3, 0.9, 0.999, 1e-8, 0.0, 4)
-    worst = max(worst, close(st_d, st_o, 1e-5, "packed state vs oracle"))
-    close(pdv, po, 1e-3, "packed adamw bf16 param")
-    return worst
-
-
 # ------------------------------------------------------------------------------------------------------------- whole step
 MODEL_CASES = ["siglip_b1_img1", "siglip_b1_img4", "siglip_b2_equal_rightpad", "siglip_b2_unequal_quirk", "siglip_b1_text_only",
                "clip_b2_equal_rightpad"]
@@ -1855,7 +1813,6 @@ def all_checks():
     c["ce_32002"] = lambda: check_ce(40, 32002, 0.5)
     c["vit_front"] = check_vit_front
     c["optim"] = check_optim
-    c["optim_adamw_packed_state"] = check_adamw_packed
     for case in MODEL_CASES:
         c["model_step_" + case] = (lambda case=case: check_model_step(case))
     c["training_step_contract_ga1"] = lambda: check_training_step_contract(1)
