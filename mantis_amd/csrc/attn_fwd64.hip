@@ -15,11 +15,13 @@
 //         Ph1  S_A(t)   = K(t).Q_A^T            Ph2  O_B += V(t-1)^T.P_B(t-1)
 //         Ph3  S_B(t)   = K(t).Q_B^T            Ph4  O_A += V(t)^T.P_A(t)
 //     so that each block's softmax has two phases of the OTHER block's MFMAs to hide in (A: Ph2-Ph3, B: Ph4-Ph1 of the next tile); the
-//     fillers are dealt out per MFMA gap: ~1 score element (fma, exp2, add, half a cvt_pk) + the max chain of the other block + the LDS
-//     fragment reads + the LDS-DMA issues = ~5.3 instructions per gap (the measured budget of a 32-cycle gap is 5);
-//   * running max with a lazy threshold (the max is only raised, and O / l rescaled, when a row's tile max exceeds it by more than 8 in
-//     the exp2 domain: P <= 256, exact in fp32 / bf16 relative precision) -- the rescale of an AGPR-resident O costs 3 instructions per
-//     element, so it has to be rare, and it is (first tile of a row, then almost never);
+//     fillers are dealt out per MFMA gap: one score element (fma, exp2, add, half a cvt_pk, half a max3) + the LDS fragment reads + the
+//     LDS-DMA issues.  Measured (tools/mfma_filler_probe.hip): a gap hides ~28 cycles of issue -- VALU 4, v_exp 8, LDS read 8, DMA
+//     piece ~54 -- so at hd 128 this loop is ISSUE-bound (~2500 cycles of issue per 2048 cycles of MFMA), not MFMA-bound;
+//   * no max pass: the exps run against the row's CURRENT reference max m; the tile's largest exponent is collected on the side and
+//     checked once per block and tile; only when a row exceeds m by more than 8 (exp2 domain: P <= 256, exact in fp32 / bf16 relative
+//     precision) is the tile redone against a raised m and O / l rescaled (the scores stay intact for that).  Rare -- the first live
+//     tile of a row, then almost never -- which it has to be: rescaling an AGPR-resident O costs 3 instructions per element;
 //   * masks (key padding, causal diagonal, packed-sample start) are a pre-pass over the scores on the tiles that need one, so the
 //     common stream is branch-free arithmetic; tiles with no live key for the wave (beyond its diagonal, all padding, before its
 //     sample) skip the compute and only keep the workgroup's barrier / DMA protocol.
