@@ -26,11 +26,11 @@ import re
 from collections import defaultdict
 
 GEMM_FAMILY = ("gemm_nt_ring_kernel", "gemm_nt_ring16_kernel", "gemm_nt_kernel")
-ATTN_FAMILY = ("attn_fwd_kernel", "attn_bwd")
+ATTN_FAMILY = ("attn_fwd_kernel", "attn_fwd64_kernel", "attn_bwd")
 
 
 def short(name):
-    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "")
     name = re.sub(r"\(.*$", "", name)
     return name[:72]
 
