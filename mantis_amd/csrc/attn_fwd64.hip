@@ -176,7 +176,9 @@ struct Softmax {          // per 32-row block, per lane (one query row per lane 
     float tw0, tw1, tw2;
 };
 
-// one 64-row block of one (batch, head)
+}  // namespace
+
+// one 64-row block of one (batch, head)   (outside the anonymous namespace: profilers then print the kernel's plain name)
 template <bool CAUSAL>
 __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                             const bf16_t* __restrict__ V, const int* __restrict__ kmask,
@@ -577,8 +579,6 @@ __global__ __launch_bounds__(256, 1) void attn_fwd64_kernel(const bf16_t* __rest
     }
 #endif
 }
-
-}  // namespace
 
 int mantis_attn_fwd64_launch(bool causal, int B, hipStream_t s, const bf16_t* Q, const bf16_t* K, const bf16_t* V, const int* kmask,
                              bf16_t* O, float* LSE, int L, int Lk, int H, int Hkv, long ldq, long ldk, long ldv, long ldo, float scale,
