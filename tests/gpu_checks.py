@@ -405,6 +405,30 @@ ATTN_SEG_CASES = [(1, 300, 8, 2, 128, [[70, 71, 200]], True, None), (2, 200, 4, 
                   (1, 190, 8, 2, 128, [[95]], True, "right"), (2, 130, 4, 2, 16, [[], [65]], True, "left"),
                   (1, 300, 7, 1, 128, [[70, 71, 200]], True, None), (1, 257, 14, 2, 128, [[100, 228]], True, "right")]
 
+def check_attn_fwd_dynamic_range():
+    """The hd-128 forward on scores with a large dynamic range (L >= 1024: the 64-rows-per-wave kernel, whose exps run against a lazily
+    raised reference max): logits that GROW along the keys by ~0.35 per key from -190 to +190 (exp2 domain) -- every causal row's max
+    sits at its own diagonal, so the reference max has to be raised on nearly every tile -- and, second half of the heads, logits that
+    FALL along the keys (the first tile sets the max, everything later underflows against it, as it does in fp32 softmax)."""
+    k = K()
+    B, L, H, Hkv, hd = 1, 1100, 4, 2, 128
+    g = torch.Generator().manual_seed(77)
+    qkv = torch.randn(B * L, (H + 2 * Hkv) * hd, generator=g) * 0.05
+    ramp = torch.linspace(-1.0, 1.0, L)
+    q = qkv[:, : H * hd].view(L, H, hd)
+    kk = qkv[:, H * hd: (H + Hkv) * hd].view(L, Hkv, hd)
+    q[:, :, 0] = 12.0                                         # q . k = 12 * 12 * ramp * sign = +-144 ramp; x hd^-0.5 x log2e -> +-18.4 .. in
+    kk[:, 0, 0] = 12.0 * ramp * 8.0                           # natural-log units: +-102 (kv head 0: rising), exp2 units +-147
+    kk[:, 1, 0] = -12.0 * ramp * 8.0                          # kv head 1: falling
+    qkv = qkv.to(BF)
+    oref, lref = R.attn_fwd(qkv, B, L, H, Hkv, hd, None, hd ** -0.5, True)
+    o, lse = k.attn_fwd(qkv.to(DEV), B, L, H, Hkv, hd, None, hd ** -0.5, True)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+    r = close(o, oref, 2e-2, "attn_fwd dynamic range o")
+    close(lse, lref, 2e-3, "attn_fwd dynamic range lse")
+    return r
+
+
 ATTN_FWD_CASES = [(2, 54, 4, 2, 16, True, "right"), (2, 54, 4, 2, 16, True, "left"), (3, 17, 4, 4, 16, False, None),
                   (2, 197, 12, 12, 64, False, None), (2, 577, 16, 16, 72, False, None), (1, 323, 12, 12, 64, True, None),
                   (1, 700, 8, 2, 128, True, "right"), (1, 128, 4, 1, 128, True, None), (1, 129, 2, 2, 64, True, "left"),
@@ -1798,6 +1822,7 @@ def all_checks():
     c["layernorm"] = check_layernorm
     c["acts"] = check_acts
     c["rope"] = check_rope
+    c["attn_fwd_dynamic_range_hd128"] = check_attn_fwd_dynamic_range
     for a in ATTN_FWD_CASES:
         c["attn_fwd_" + "_".join(map(str, a))] = (lambda a=a: check_attn_fwd(*a))
     for a in ATTN_BWD_CASES:
