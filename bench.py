@@ -170,6 +170,45 @@ def _pct(xs, q):
     return xs[lo] + (xs[hi] - xs[lo]) * (i - lo)
 
 
+def write_gemm_table(path, entries, steps, config, step_ms):
+    """The in-step bf16 GEMM table: one row per (M, N, K, layout, epilogue) over the launches of the timed steps, from the HIP events
+    recorded around every launch on the launch stream (hip_ops.KERNEL_TIMER).  Layout: NT = x . W^T (forward), NN = dY . W (dX),
+    TN = dY^T . X (dW).  Written as markdown; the last row is the family (= roofline.achieved)."""
+    groups = {}
+    for x in entries:
+        key = x[5] if len(x) > 5 else ("?",)
+        groups.setdefault(key, []).append((x[3].elapsed_time(x[4]) * 1e3, x[1]))       # (us, flops)
+    fam_us = sum(u for v in groups.values() for u, _ in v)
+    fam_fl = sum(f for v in groups.values() for _, f in v)
+    rows = []
+    for key, v in groups.items():
+        us = [u for u, _ in v]
+        tot_us, fl = sum(us), sum(f for _, f in v)
+        rows.append((tot_us, key, len(v) / steps, tot_us / len(v), min(us), max(us), fl / tot_us / 1e6))
+    rows.sort(key=lambda r: -r[0])
+    by_lay = {}
+    for tot_us, key, *_ in rows:
+        lay = key[3] if len(key) > 3 else "?"
+        fl = sum(f for _, f in groups[key])
+        a = by_lay.setdefault(lay, [0.0, 0.0])
+        a[0] += tot_us
+        a[1] += fl
+    with open(path, "w") as fh:
+        fh.write(f"# in-step bf16 GEMM table -- `bench.py --config {config}`, {steps} timed steps, step {step_ms:.1f} ms\n\n"
+                 "HIP events around every launch of the timed steps (the numbers `roofline.achieved` is built from).  "
+                 "NT = forward, NN = dX, TN = dW.\n\n"
+                 "| M x N x K | layout | epilogue | launches/step | mean us | min us | max us | TFLOP/s | frac of 2.5 PF | ms/step | % of family |\n"
+                 "|---|---|---|---|---|---|---|---|---|---|---|\n")
+        for tot_us, key, n, mean, lo, hi, tf in rows:
+            shape = " x ".join(str(k) for k in key[:3]) if len(key) > 3 else "?"
+            fh.write(f"| {shape} | {key[3] if len(key) > 3 else '?'} | {key[4] if len(key) > 4 else '?'} | {n:g} | {mean:.1f} | {lo:.1f} | {hi:.1f} | "
+                     f"{tf:.0f} | {tf / PEAK_BF16_TFLOPS:.3f} | {tot_us / steps / 1e3:.2f} | {100 * tot_us / fam_us:.1f} |\n")
+        fh.write("\n| layout | ms/step | TFLOP/s | frac of 2.5 PF |\n|---|---|---|---|\n")
+        for lay, (u, fl) in sorted(by_lay.items()):
+            fh.write(f"| {lay} | {u / steps / 1e3:.2f} | {fl / u / 1e6:.0f} | {fl / u / 1e6 / PEAK_BF16_TFLOPS:.3f} |\n")
+        fh.write(f"| family | {fam_us / steps / 1e3:.2f} | {fam_fl / fam_us / 1e6:.0f} | {fam_fl / fam_us / 1e6 / PEAK_BF16_TFLOPS:.3f} |\n")
+
+
 def cpu_baseline(cfg_name):
     """Oracle ("port") timing on the host cores; bounded sample, depth extrapolated.  Returns the cpu_baseline object."""
     import torch
@@ -359,6 +398,10 @@ def main():
     ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--gemm-table", default=None, metavar="PATH",
+                    help="write the in-step bf16 GEMM table (per shape x layout x epilogue: launches per step, mean / min / max us from the "
+                         "HIP events around every launch of the timed steps, TFLOP/s, fraction of the bf16 MFMA peak, share of the family) "
+                         "as markdown to PATH")
     ap.add_argument("--recycle-batches", type=int, default=0, help="0 = a fresh synthetic batch every step (default); n > 0 = cycle n batches")
     args = ap.parse_args()
 
@@ -488,8 +531,7 @@ def main():
             return 0                          # one slot per image token: the merged length equals T
         N = (cfg.vision_config.image_size // cfg.vision_config.patch_size) ** 2
         return int((bt["input_ids"] == cfg.image_token_index).sum()) * (N - 1)
-    timed_batches = [batches[(args.warmup + i) % len(batches)] for i in range(args.steps)]
-    skipped_head_rows = sum(_head_rows(bt) for bt in timed_batches) / max(1, len(timed_batches))
+    timed_batches = []          # the batches the timed loop actually feeds (filled by one_step)
 
     split = []          # (start, after training_step, after optimizer) events per timed step
     losses = []
@@ -503,6 +545,7 @@ def main():
         if timed:
             ev[1].record()
             losses.append(loss)
+            timed_batches.append(batches[i % len(batches)])
         if opt is not None:
             opt.step()
             opt.zero_grad(set_to_none=True)
@@ -541,6 +584,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     loss_vals = [float(x) for x in losses]
+    skipped_head_rows = sum(_head_rows(bt) for bt in timed_batches) / max(1, len(timed_batches))
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
         value = world * B * args.steps / elapsed
@@ -553,36 +597,45 @@ def main():
                 pmc = json.load(fh)
         roof = None
         if timer:
-            tot_ms = sum(e0.elapsed_time(e1) for _, _, _, e0, e1 in timer)
-            tot_fl = sum(f for _, f, _, _, _ in timer)
-            tot_by = sum(b for _, _, b, _, _ in timer)
-            ach = tot_fl / (tot_ms * 1e-3) / 1e12
+            def _family(entries):
+                t_ms = sum(x[3].elapsed_time(x[4]) for x in entries)
+                return t_ms, sum(x[1] for x in entries), sum(x[2] for x in entries)
+            all_gemms = timer                                        # every GEMM launch of the timed steps (bf16 and fp8)
+            if args.gemm_table:
+                write_gemm_table(args.gemm_table, [x for x in all_gemms if x[0] == "gemm_nt_kernel"], args.steps, args.config, ms)
             gf = (pmc or {}).get("gemm_family") or {}
-            kname, peak = "gemm_nt_ring_kernel + gemm_nt_kernel (bf16 MFMA GEMM family, csrc/gemm.hip)", PEAK_BF16_TFLOPS
+            kname, peak = ("gemm_nt_ring16_kernel + gemm_nt_ring_kernel + gemm_nt_kernel (bf16 MFMA GEMM family: every launch of "
+                           "mantis_gemm_bf16_nt / _fused, csrc/gemm.hip)"), PEAK_BF16_TFLOPS
             bf16_family = None
+            family = all_gemms
             if precision != "bf16":
                 # dominant kernel of this configuration: the fp8 MFMA GEMM (decoder linears); the bf16 family (tower, merger, lm_head)
                 # is reported beside it
-                f8 = [x for x in timer if x[0] == "gemm_fp8_nt_kernel"]
-                b16 = [x for x in timer if x[0] != "gemm_fp8_nt_kernel"]
-                b_ms = sum(e0.elapsed_time(e1) for _, _, _, e0, e1 in b16)
-                bf16_family = dict(achieved=round(sum(x[1] for x in b16) / (b_ms * 1e-3) / 1e12, 1), peak=PEAK_BF16_TFLOPS,
-                                   launches_per_step=len(b16) // args.steps, gemm_ms_per_step=round(b_ms / args.steps, 1))
-                timer = f8
-                tot_ms = sum(e0.elapsed_time(e1) for _, _, _, e0, e1 in timer)
-                tot_fl = sum(f for _, f, _, _, _ in timer)
-                tot_by = sum(b for _, _, b, _, _ in timer)
-                ach = tot_fl / (tot_ms * 1e-3) / 1e12
-                kname, peak = "gemm_fp8_nt_kernel (fp8 e4m3/e5m2 MFMA GEMM, csrc/gemm_fp8.hip)", PEAK_FP8_TFLOPS
+                f8 = [x for x in all_gemms if x[0] == "gemm_fp8_nt_kernel"]
+                b16 = [x for x in all_gemms if x[0] != "gemm_fp8_nt_kernel"]
+                if b16:
+                    b_ms, b_fl, _ = _family(b16)
+                    bf16_family = dict(achieved=round(b_fl / (b_ms * 1e-3) / 1e12, 1), peak=PEAK_BF16_TFLOPS,
+                                       launches_per_step=len(b16) // args.steps, gemm_ms_per_step=round(b_ms / args.steps, 1))
+                if f8:                                               # no fp8 launch (every shape declined): the bf16 family stays the subject
+                    family = f8
+                    kname, peak = "gemm_fp8_nt_kernel (fp8 e4m3/e5m2 MFMA GEMM, csrc/gemm_fp8.hip)", PEAK_FP8_TFLOPS
+            tot_ms, tot_fl, tot_by = _family(family)
+            ach = tot_fl / (tot_ms * 1e-3) / 1e12
+            # traffic / MFMA-busy come from PMC passes, which this run does not make: the LIVE fields are null; what the builder's own
+            # PMC passes of the same command measured (another box, another day) is carried under a separately named key
             roof = dict(bound="mfma", kernel=kname, achieved=round(ach, 1),
                         peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4), bf16_gemm_family=bf16_family,
-                        traffic=gf.get("traffic_bytes_per_launch"),
-                        traffic_note=None if not gf else "bytes/launch on the L2 memory side (Infinity-Cache hits included), rocprofv3 PMC passes of "
-                        "this command summarised in profiles/r03_pmc_step.json by tools/pmc_step_report.py",
-                        algorithmic_bytes_per_launch=round(tot_by / len(timer)),
-                        mfma_busy_pct=((pmc or {}).get("step") or {}).get("mfma_busy_pct"),
-                        launches_per_step=len(timer) // args.steps,
-                        avg_launch_us=round(1e3 * tot_ms / len(timer), 1), gemm_ms_per_step=round(tot_ms / args.steps, 1),
+                        traffic=None, mfma_busy_pct=None,
+                        pmc_static=None if not pmc else dict(
+                            source=os.path.relpath(pmc_path, os.path.dirname(os.path.abspath(__file__))),
+                            note="NOT measured by this run: rocprofv3 PMC passes of this command on the builder's box, summarised by "
+                                 "tools/pmc_step_report.py; bytes/launch on the L2 memory side (Infinity-Cache hits included)",
+                            traffic_bytes_per_launch=gf.get("traffic_bytes_per_launch"),
+                            mfma_busy_pct=((pmc or {}).get("step") or {}).get("mfma_busy_pct")),
+                        algorithmic_bytes_per_launch=round(tot_by / len(family)),
+                        launches_per_step=len(family) // args.steps,
+                        avg_launch_us=round(1e3 * tot_ms / len(family), 1), gemm_ms_per_step=round(tot_ms / args.steps, 1),
                         step_model_flops_note="step_model_tflops / *_frac_of_peak divide the REFERENCE's algorithmic FLOPs per sample (SURVEY 8d: "
                                                "lm_head and loss on every sequence row) by the measured time; this path runs lm_head on the labelled "
                                                "rows only, so its launched FLOPs are lower -- `achieved` counts launched GEMM work only",
@@ -595,7 +648,7 @@ def main():
                 # (fp8 lines: sum_i flops_i / peak_i -- the fp8 GEMM family at the fp8 peak, everything else at the bf16 peak)
                 tc_ = cfg.text_config
                 launched = flop_per_sample * B - 3.0 * 2.0 * tc_.hidden_size * tc_.vocab_size * skipped_head_rows
-                f8_fl = (sum(x[1] for x in timer) / args.steps) if precision != "bf16" else 0.0
+                f8_fl = (sum(x[1] for x in all_gemms if x[0] == "gemm_fp8_nt_kernel") / args.steps) if precision != "bf16" else 0.0
                 t_roof = f8_fl / (PEAK_FP8_TFLOPS * 1e12) + (launched - f8_fl) / (PEAK_BF16_TFLOPS * 1e12)
                 roof.update(step_launched_flops=launched,
                             step_launched_tflops=round(launched / (ms * 1e-3) / 1e12, 1),

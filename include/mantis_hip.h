@@ -36,6 +36,16 @@ int mantis_pack_plan(const int64_t* input_ids, const int64_t* attention_mask, co
                      int64_t ignore_index, int L, int32_t* src, int64_t* out_mask, int64_t* out_labels, int64_t* out_pos,
                      int32_t* kmask, int32_t* text_pos, int32_t* img_slot, int32_t* ce_row, int32_t* ce_tgt,
                      int32_t* status, void* stream);
+/* The same plan with a placement mode.  mode 0 = mantis_pack_plan (the reference's slot search, including its mis-placement of the
+ * image rows of a right-padded sample that holds fewer images than the batch maximum: modeling_llava.py:343-345, hidden in the
+ * reference by the bs = 1 assert of processing_llava.py:277-285).  mode 1 = `fix_unequal_counts`: image j of sample b
+ * occupies [p[b,t_j] - (N-1), p[b,t_j]] whatever the padding side (SURVEY appendix A's index-only formulation); identical to mode 0
+ * when every sample holds the same number of images, and sample by sample identical to the reference run at B = 1. */
+int mantis_pack_plan_mode(const int64_t* input_ids, const int64_t* attention_mask, const int64_t* labels /*nullable*/, int B,
+                          int T, int num_patches, int num_images, int64_t image_token_index, int64_t pad_token_id,
+                          int64_t ignore_index, int L, int mode, int32_t* src, int64_t* out_mask, int64_t* out_labels,
+                          int64_t* out_pos, int32_t* kmask, int32_t* text_pos, int32_t* img_slot, int32_t* ce_row,
+                          int32_t* ce_tgt, int32_t* status, void* stream);
 /* Packed samples (/root/reference/mantis/train/data.py:1546-1671, PackingDataset.pack_batch: several samples concatenated into one
  * row with a block-diagonal 4-D attention mask and position ids restarting per sample).  Runs after mantis_pack_plan on the same
  * arrays; segment_ids int32 [B,T] = sample index of every input token (non-decreasing along a row, rows not padded).  Writes

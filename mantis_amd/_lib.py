@@ -16,6 +16,7 @@ F = ctypes.c_float
 # name -> argtypes (restype is always int).  Mirrors include/mantis_hip.h one-to-one.
 SIGNATURES = {
     "mantis_pack_plan": [P, P, P, I, I, I, I, L, L, L, I, P, P, P, P, P, P, P, P, P, P, P],
+    "mantis_pack_plan_mode": [P, P, P, I, I, I, I, L, L, L, I, I, P, P, P, P, P, P, P, P, P, P, P],
     "mantis_pack_segments": [P, P, P, I, I, I, L, I, P, P, P, P, P, P, P],
     "mantis_pack_rows_fwd": [P, P, P, P, P, I, I, I, I, L, P],
     "mantis_gather_rows": [P, P, P, L, I, P],

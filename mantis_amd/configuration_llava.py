@@ -33,7 +33,12 @@ class LlavaConfig:
 
     def __init__(self, vision_config=None, text_config=None, ignore_index=-100, image_token_index=32000,
                  projector_hidden_act="gelu", vision_feature_select_strategy="default", vision_feature_layer=-2,
-                 vocab_size=32000, pad_token_id=None, **kwargs):
+                 vocab_size=32000, pad_token_id=None, fix_unequal_counts=False, **kwargs):
+        # Not a reference field.  False: image rows are placed exactly as the reference places them, including its mis-placement for a
+        # right-padded batch whose samples hold different numbers of images (modeling_llava.py:343-345; the reference never sees such
+        # a batch: processing_llava.py:277-285 asserts bs = 1).  True: every image lands on its own <image> token's span whatever the
+        # padding side, i.e. each sample gets what the reference computes for it alone.
+        self.fix_unequal_counts = bool(fix_unequal_counts)
         self.ignore_index = ignore_index
         self.image_token_index = image_token_index
         self.projector_hidden_act = projector_hidden_act

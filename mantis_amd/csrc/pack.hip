@@ -43,6 +43,12 @@ __device__ __forceinline__ int block_scan_incl(int v, int* lds, int* total) {
 // status[0] = 0 ok | 1 image-slot count mismatch (reference raises ValueError, modeling_llava.py:347-351)
 //             | 2 L passed by the host differs from max_b k[b]*(N-1)+T (:301)
 // status[1] = number of image slots found, status[2] = number of <image> tokens, status[3] = left_padding
+// FIXED = false: the reference's slot search (:344-345: unwritten rows minus the first pad_b of them), which mis-places the image
+//   rows of a right-padded sample holding fewer images than the batch maximum (masked in the reference by the
+//   bs = 1 assert of processing_llava.py:277-285).  FIXED = true (`fix_unequal_counts`): appendix A's index-only
+//   formulation -- image j of sample b occupies [p[b,t_j] - (N-1), p[b,t_j]] whatever the padding side, every other unwritten slot
+//   stays padding; identical to the reference for equal counts, and sample by sample to the reference run at B = 1.
+template <bool FIXED>
 __global__ __launch_bounds__(PLAN_THREADS) void pack_plan_kernel(
     const long* __restrict__ ids, const long* __restrict__ attn, const long* __restrict__ labels, int B, int T, int N,
     int num_images, long IMG, long PAD, long IGN, int L, int* __restrict__ src, long* __restrict__ out_mask,
@@ -95,6 +101,13 @@ __global__ __launch_bounds__(PLAN_THREADS) void pack_plan_kernel(
         int incl = block_scan_incl(local, lds, &tot);
         const int pad_b = L - 1 - (tot - 1);  // :310 nb_image_pad
         const int shift = left ? pad_b : 0;   // :311-312
+        int img_before = 0, k_b = 0;          // FIXED: <image> tokens of this sample in front of this thread's chunk / in the sample
+        if constexpr (FIXED) {
+            int li = 0;
+            for (int t = t0; t < t1; ++t) li += (idb[t] == IMG);
+            const int ii = block_scan_incl(li, lds, &k_b);
+            img_before = ii - li;
+        }
         // :316-326 initialise the merged row
         for (int p = tid; p < L; p += PLAN_THREADS) {
             src[(long)b * L + p] = -1;
@@ -128,32 +141,51 @@ __global__ __launch_bounds__(PLAN_THREADS) void pack_plan_kernel(
                 text_pos[flat] = -1;
                 ce_row[flat] = -1;
                 ce_tgt[flat] = -100;
-            }
-        }
-        __syncthreads();
-        // :344-345 image slots = unwritten rows minus the first pad_b of them; :353 filled in row-major order
-        const int p0 = tid * perL, p1 = min(L, p0 + perL);
-        int lu = 0;
-        for (int p = p0; p < p1; ++p) lu += (src[(long)b * L + p] == -1);
-        int totu;
-        int inclu = block_scan_incl(lu, lds, &totu);
-        int rank = inclu - lu;  // unwritten rows before p0
-        const int base = sh_base;
-        for (int p = p0; p < p1; ++p) {
-            if (src[(long)b * L + p] == -1) {
-                if (rank >= pad_b) {
-                    const long g = (long)base + (rank - pad_b);
-                    if (g < total_rows) {
-                        src[(long)b * L + p] = IMGBIT | (int)g;
-                        img_slot[g] = b * L + p;
+                if constexpr (FIXED) {
+                    // the N slots that end at p are this image's, feature rows in batch-major, in-sample order (:353)
+                    const long g0 = ((long)sh_base + img_before) * N;
+                    for (int e = 0; e < N; ++e) {
+                        const long g = g0 + e;
+                        const int q = p - (N - 1) + e;
+                        if (g < total_rows) {
+                            src[(long)b * L + q] = IMGBIT | (int)g;
+                            img_slot[g] = b * L + q;
+                        }
+                        out_mask[(long)b * L + q] = 1;  // :354
                     }
-                    out_mask[(long)b * L + p] |= 1;  // :354
+                    ++img_before;
                 }
-                ++rank;
             }
         }
         __syncthreads();
-        if (tid == 0) sh_base = base + max(0, totu - pad_b);
+        const int p0 = tid * perL, p1 = min(L, p0 + perL);
+        if constexpr (FIXED) {
+            if (tid == 0) sh_base += k_b;
+        } else {
+            // :344-345 image slots = unwritten rows minus the first pad_b of them; :353 filled in row-major order
+            int lu = 0;
+            for (int p = p0; p < p1; ++p) lu += (src[(long)b * L + p] == -1);
+            int totu;
+            int inclu = block_scan_incl(lu, lds, &totu);
+            int rank = inclu - lu;  // unwritten rows before p0
+            const int base = sh_base;
+            for (int p = p0; p < p1; ++p) {
+                if (src[(long)b * L + p] == -1) {
+                    if (rank >= pad_b) {
+                        const long g = (long)base + (rank - pad_b);
+                        if (g < total_rows) {
+                            src[(long)b * L + p] = IMGBIT | (int)g;
+                            img_slot[g] = b * L + p;
+                        }
+                        out_mask[(long)b * L + p] |= 1;  // :354
+                    }
+                    ++rank;
+                }
+            }
+            __syncthreads();
+            if (tid == 0) sh_base = base + max(0, totu - pad_b);
+        }
+        __syncthreads();
         // :355 position_ids = cumsum(mask) - 1, 1 where mask == 0
         int lm = 0;
         for (int p = p0; p < p1; ++p) lm += (int)out_mask[(long)b * L + p];
@@ -169,8 +201,9 @@ __global__ __launch_bounds__(PLAN_THREADS) void pack_plan_kernel(
         __syncthreads();
     }
     if (tid == 0) {
-        status[1] = sh_base;
-        if ((long)sh_base != total_rows) status[0] = 1;
+        const long found = FIXED ? (long)sh_base * N : (long)sh_base;     // FIXED counts <image> tokens, the search counts slots
+        status[1] = (int)found;
+        if (found != total_rows) status[0] = 1;
     }
 }
 
@@ -404,18 +437,31 @@ __global__ __launch_bounds__(PLAN_THREADS) void pack_segments_kernel(
 
 extern "C" {
 
+// mode 0 = the reference's placement (mantis_pack_plan), 1 = `fix_unequal_counts` (see pack_plan_kernel)
+int mantis_pack_plan_mode(const int64_t* input_ids, const int64_t* attention_mask, const int64_t* labels, int B, int T,
+                          int num_patches, int num_images, int64_t image_token_index, int64_t pad_token_id,
+                          int64_t ignore_index, int L, int mode, int32_t* src, int64_t* out_mask, int64_t* out_labels,
+                          int64_t* out_pos, int32_t* kmask, int32_t* text_pos, int32_t* img_slot, int32_t* ce_row,
+                          int32_t* ce_tgt, int32_t* status, void* stream) {
+    if (B <= 0 || T <= 0 || L < T || num_patches <= 0 || num_images < 0 || (mode != 0 && mode != 1)) return MANTIS_EINVAL;
+    if ((long)num_images * num_patches >= IMGBIT) return MANTIS_EUNSUPPORTED;
+#define PLAN_ARGS dim3(1), dim3(PLAN_THREADS), 0, (hipStream_t)stream, (const long*)input_ids, (const long*)attention_mask, \
+                  (const long*)labels, B, T, num_patches, num_images, (long)image_token_index, (long)pad_token_id, (long)ignore_index, L, \
+                  src, (long*)out_mask, (long*)out_labels, (long*)out_pos, kmask, text_pos, img_slot, ce_row, ce_tgt, status
+    if (mode == 1) MANTIS_LAUNCH(pack_plan_kernel<true>, PLAN_ARGS);
+    else MANTIS_LAUNCH(pack_plan_kernel<false>, PLAN_ARGS);
+#undef PLAN_ARGS
+    return mantis_check_launch();
+}
+
 int mantis_pack_plan(const int64_t* input_ids, const int64_t* attention_mask, const int64_t* labels, int B, int T,
                      int num_patches, int num_images, int64_t image_token_index, int64_t pad_token_id,
                      int64_t ignore_index, int L, int32_t* src, int64_t* out_mask, int64_t* out_labels,
                      int64_t* out_pos, int32_t* kmask, int32_t* text_pos, int32_t* img_slot, int32_t* ce_row,
                      int32_t* ce_tgt, int32_t* status, void* stream) {
-    if (B <= 0 || T <= 0 || L < T || num_patches <= 0 || num_images < 0) return MANTIS_EINVAL;
-    if ((long)num_images * num_patches >= IMGBIT) return MANTIS_EUNSUPPORTED;
-    MANTIS_LAUNCH(pack_plan_kernel, dim3(1), dim3(PLAN_THREADS), 0, (hipStream_t)stream, (const long*)input_ids,
-                       (const long*)attention_mask, (const long*)labels, B, T, num_patches, num_images,
-                       (long)image_token_index, (long)pad_token_id, (long)ignore_index, L, src, (long*)out_mask,
-                       (long*)out_labels, (long*)out_pos, kmask, text_pos, img_slot, ce_row, ce_tgt, status);
-    return mantis_check_launch();
+    return mantis_pack_plan_mode(input_ids, attention_mask, labels, B, T, num_patches, num_images, image_token_index, pad_token_id,
+                                 ignore_index, L, 0, src, out_mask, out_labels, out_pos, kmask, text_pos, img_slot, ce_row, ce_tgt, status,
+                                 stream);
 }
 
 int mantis_pack_segments(const int64_t* input_ids, const int32_t* segment_ids, const int64_t* merged_mask, int B, int T,

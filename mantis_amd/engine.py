@@ -28,6 +28,22 @@ class PackCountError(ValueError):
     pass
 
 
+_WARNED_UNEQUAL = False
+
+
+def _warn_unequal_counts_once():
+    """a right-padded batch whose samples hold different numbers of images: the reference's slot search (modeling_llava.py:343-345)
+    puts the image rows of the shorter samples into their trailing padding; reproduced bit for bit unless the flag is set"""
+    global _WARNED_UNEQUAL
+    if _WARNED_UNEQUAL:
+        return
+    _WARNED_UNEQUAL = True
+    import warnings
+    warnings.warn("right-padded batch with unequal image counts: image features are placed as the reference places them, i.e. "
+                  "MIS-placed for the samples with fewer images (modeling_llava.py:343-345; the reference only ever runs bs = 1). "
+                  "Set LlavaConfig(fix_unequal_counts=True) for the per-sample-correct placement.", stacklevel=3)
+
+
 class LlavaEngine:
     def __init__(self, model):
         self.m = model
@@ -182,7 +198,10 @@ class LlavaEngine:
             kmax = int((ids_cpu == cfg.image_token_index).sum(-1).max())
             L = kmax * (N - 1) + T
             grown = (ids_cpu == cfg.image_token_index).sum(-1) * (N - 1)      # rows each sample's placeholders add in the merge
-            plan = K.pack_plan(ids_d, attn_d, lab_d, N, I, cfg.image_token_index, pad_id, ign, L)
+            fix = bool(getattr(cfg, "fix_unequal_counts", False))
+            if not fix and B > 1 and int(grown.min()) != int(grown.max()) and bool((ids_cpu[:, -1] == pad_id).any()):
+                _warn_unequal_counts_once()
+            plan = K.pack_plan(ids_d, attn_d, lab_d, N, I, cfg.image_token_index, pad_id, ign, L, fix_unequal_counts=fix)
         else:
             # text-only: the reference skips the merge; positions default to arange (HF LlamaModel)
             L = T

@@ -98,7 +98,9 @@ def gemm_nt(a, b, bias=None, act=None, residual=None, out=None, accumulate=False
         e1.record()
         # algorithmic bytes: both operands read once, the result written once (+ residual / accumulate read)
         by = 2.0 * (M * K + N * K + M * N * (1 + (residual is not None) + bool(accumulate)))
-        prof.append(("gemm_nt_kernel", 2.0 * M * N * K, by, e0, e1))
+        lay = ("T" if a_kmajor else "N") + ("N" if b_kmajor else "T")      # A^T? / B as [N,K] ("T": B^T is applied) -- NT = forward, NN = dX, TN = dW
+        epi = "+".join(x for x, on in (("bias", bias is not None), (str(act), act is not None), ("res", residual is not None), ("acc", accumulate)) if on)
+        prof.append(("gemm_nt_kernel", 2.0 * M * N * K, by, e0, e1, (M, N, K, lay, epi or "-")))
     return out
 
 
@@ -281,7 +283,8 @@ def _gemm_fused(a, b, out, mode, aux0, aux1, aux_ld, aux_n, bias, variant, extra
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        prof.append(("gemm_nt_kernel", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N) + extra_bytes, e0, e1))
+        prof.append(("gemm_nt_kernel", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N) + extra_bytes, e0, e1,
+                     (M, N, K, "NT", ("swiglu" if mode == 1 else "rope") + ("+bias" if bias is not None else ""))))
     return True
 
 
@@ -333,7 +336,7 @@ def linear_dx_swiglu(dy, w_down, gu, variant=0):
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        prof.append(("gemm_nt_kernel", 2.0 * M * I * d, 2.0 * (M * d + I * d + 4 * M * I), e0, e1))
+        prof.append(("gemm_nt_kernel", 2.0 * M * I * d, 2.0 * (M * d + I * d + 4 * M * I), e0, e1, (M, I, d, "NN", "swiglu_bwd")))
     return dgu
 
 
@@ -520,7 +523,11 @@ class PackPlan:
                  "ce_row", "ce_tgt", "status", "kstart", "qend")
 
 
-def pack_plan(input_ids, attention_mask, labels, num_patches, num_images, image_token_index, pad_token_id, ignore_index, L):
+def pack_plan(input_ids, attention_mask, labels, num_patches, num_images, image_token_index, pad_token_id, ignore_index, L,
+              fix_unequal_counts=False):
+    """The integer plan of _merge_input_ids_with_image_features.  fix_unequal_counts=False: the reference's placement bit for bit
+    (including its quirk for right-padded batches with unequal image counts); True: the index-only placement of SURVEY appendix A
+    (mantis_pack_plan_mode, mode 1)."""
     B, T = input_ids.shape
     dev = input_ids.device
     pl = PackPlan()
@@ -536,10 +543,10 @@ def pack_plan(input_ids, attention_mask, labels, num_patches, num_images, image_
     pl.ce_row = torch.empty((B * T,), dtype=torch.int32, device=dev)
     pl.ce_tgt = torch.empty((B * T,), dtype=torch.int32, device=dev)
     pl.status = torch.zeros((4,), dtype=torch.int32, device=dev)
-    rc = _L.mantis_pack_plan(_p(input_ids), _p(attention_mask), _p(labels), B, T, num_patches, num_images, image_token_index,
-                             pad_token_id, ignore_index, L, _p(pl.src), _p(pl.attention_mask), _p(pl.labels),
-                             _p(pl.position_ids), _p(pl.kmask), _p(pl.text_pos), _p(pl.img_slot), _p(pl.ce_row), _p(pl.ce_tgt),
-                             _p(pl.status), _stream())
+    rc = _L.mantis_pack_plan_mode(_p(input_ids), _p(attention_mask), _p(labels), B, T, num_patches, num_images, image_token_index,
+                                  pad_token_id, ignore_index, L, 1 if fix_unequal_counts else 0, _p(pl.src), _p(pl.attention_mask),
+                                  _p(pl.labels), _p(pl.position_ids), _p(pl.kmask), _p(pl.text_pos), _p(pl.img_slot), _p(pl.ce_row),
+                                  _p(pl.ce_tgt), _p(pl.status), _stream())
     _lib.check(rc, "pack_plan")
     return pl
 

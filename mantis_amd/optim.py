@@ -1,23 +1,48 @@
 """Fused AdamW + global-norm clipping over the flat parameter / gradient arenas.
 
-Reference behaviour being replaced: `clip_grad_norm_(max_grad_norm=1.0)` + `optimizer.step()` + `model.zero_grad()` of the
-HF loop (transformers/trainer.py:1785-1796, :2535-2545) with the hyper-parameters of
-/root/reference/mantis/train/scripts/train_mllava.sh:162-165 (AdamW, lr 1e-5, wd 0), which the reference executes through
+Reference behaviour being replaced: `clip_grad_norm_(max_grad_norm=1.0)` + `optimizer.step()` + `lr_scheduler.step()` +
+`model.zero_grad()` of the HF loop (transformers/trainer.py:1785-1796, :2535-2545) with the hyper-parameters of
+/root/reference/mantis/train/scripts/train_mllava.sh:162-165 (AdamW, lr 1e-5, cosine schedule with 3 % warm-up, wd 0), resumed
+from the newest `checkpoint-*` (/root/reference/mantis/train/train_mllava.py:281-294), which the reference executes through
 DeepSpeed's fused Adam with fp32 master weights.  Here: one sum-of-squares launch, one scalar kernel, one AdamW launch
-over the whole trainable arena; the clip coefficient stays on the device (no host sync)."""
+over the whole trainable arena; the clip coefficient stays on the device (no host sync).
+
+`FusedAdamW` IS a `torch.optim.Optimizer` (round 4), so the reference's own loop can drive it:
+  * one `param_group` over the trainable parameters whose `lr` (and betas / eps / weight_decay) is read on EVERY step -- an HF / torch LR
+    scheduler (`get_cosine_schedule_with_warmup`, `LambdaLR`) steers it like any optimizer;
+  * `state_dict()` / `load_state_dict()` carry the step count and the flat fp32 master / exp_avg / exp_avg_sq arenas (the 97 GB of a
+    Mantis-8B run) plus the layout they belong to: `Trainer._save_optimizer_and_scheduler` / `_load_optimizer_and_scheduler`
+    (torch.save / torch.load(weights_only=True)) work unchanged;
+  * `clip_grad_norm(max_norm)` is the fused `clip_grad_norm_`: norm and clip coefficient on the device, applied inside the next `step()`;
+    `trainer.as_hf_trainer()` builds this optimizer in `create_optimizer` and routes the loop's clipping call here."""
 import torch
 
 from . import hip_ops as K
 
+STATE_FORMAT = "mantis_fused_adamw/1"
 
-class FusedAdamW:
-    def __init__(self, model, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0):
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, model, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, no_decay=None):
+        """no_decay: names (or a predicate name -> bool) of the parameters that take no weight decay -- HF's default optimizer exempts
+        biases and norm weights (trainer.py get_decay_parameter_names); `as_hf_trainer()` passes "every 1-D parameter".  None: the decay
+        applies to every parameter (the reference's run has weight_decay 0, where it makes no difference)."""
         self.model = model
-        self.lr, self.betas, self.eps, self.wd, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
+        self.max_grad_norm = max_grad_norm
         self.step_count = 0
         model._ensure_grad_arena()
         names = list(model._grad_key)
-        self._segments = self._plan(names)
+        self._names = names
+        if no_decay is None:
+            nd = lambda n: False
+        elif callable(no_decay):
+            nd = no_decay
+        else:
+            nd_set = set(no_decay)
+            nd = lambda n: n in nd_set
+        self._segments = self._plan(names, nd)
+        super().__init__([{"params": [model._param(n) for n in names]}],
+                         dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         n = model.grad_arena.numel()
         dev = model.device
         self.master = torch.empty(n, dtype=torch.float32, device=dev)
@@ -26,19 +51,33 @@ class FusedAdamW:
         self.resync_master()
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.last_grad_norm = None
+        self._pending_scale = None           # clip coefficient of a clip_grad_norm() call the next step() has to apply
         self._side, self._norm_ws, self._norm_ready = None, None, False
 
-    def _plan(self, names):
-        """Maximal runs where the parameter arena and the gradient arena advance together -> (param_off, grad_off, numel)."""
+    # hyper-parameters live in the param_group (what a scheduler writes); these are read-only conveniences
+    lr = property(lambda self: self.param_groups[0]["lr"])
+    betas = property(lambda self: self.param_groups[0]["betas"])
+    eps = property(lambda self: self.param_groups[0]["eps"])
+    wd = property(lambda self: self.param_groups[0]["weight_decay"])
+
+    def add_param_group(self, param_group):
+        if getattr(self, "param_groups", None):
+            raise NotImplementedError("FusedAdamW runs ONE launch over the model's flat trainable arena: a single param_group "
+                                      "(per-parameter weight-decay exemptions: the `no_decay` argument)")
+        super().add_param_group(param_group)
+
+    def _plan(self, names, no_decay):
+        """Maximal runs where the parameter arena and the gradient arena advance together and the weight-decay exemption does not change
+        -> (param_off, grad_off, numel, decays)."""
         m = self.model
         segs = []
         for n in names:
             cnt = (m._param(n).numel() + 7) // 8 * 8
-            po, go = m._offs[n], m._grad_offs[n]
-            if segs and segs[-1][0] + segs[-1][2] == po and segs[-1][1] + segs[-1][2] == go:
-                segs[-1] = (segs[-1][0], segs[-1][1], segs[-1][2] + cnt)
+            po, go, dec = m._offs[n], m._grad_offs[n], not no_decay(n)
+            if segs and segs[-1][0] + segs[-1][2] == po and segs[-1][1] + segs[-1][2] == go and segs[-1][3] == dec:
+                segs[-1] = (segs[-1][0], segs[-1][1], segs[-1][2] + cnt, dec)
             else:
-                segs.append((po, go, cnt))
+                segs.append((po, go, cnt, dec))
         return segs
 
     def resync_master(self):
@@ -47,9 +86,47 @@ class FusedAdamW:
         the parameters, so a stale master would silently undo the load.  `step()` calls this itself when the model's
         `_param_version` moved; Adam moments are kept."""
         m = self.model
-        for p_off, g_off, cnt in self._segments:
+        for p_off, g_off, cnt, _ in self._segments:
             self.master[g_off:g_off + cnt].copy_(m.arena[p_off:p_off + cnt])
         self._seen_version = getattr(m, "_param_version", 0)
+
+    # ---- checkpoint / resume (train_mllava.py:281-294 resumes from the newest checkpoint-*; HF saves optimizer.state_dict() with torch.save)
+    def _layout(self):
+        m = self.model
+        return [[n, int(m._param(n).numel())] for n in self._names]
+
+    def state_dict(self):
+        """References (no copies) to the flat fp32 state + the step count + the hyper-parameters + the layout the arenas belong to."""
+        g = self.param_groups[0]
+        group = {k: (list(v) if isinstance(v, tuple) else v) for k, v in g.items() if k != "params"}
+        group["params"] = list(range(len(g["params"])))
+        return {"format": STATE_FORMAT, "step": int(self.step_count), "layout": self._layout(), "master": self.master,
+                "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "param_groups": [group]}
+
+    def load_state_dict(self, state_dict):
+        """Resume: step count, fp32 master weights and Adam moments, hyper-parameters (as torch: the checkpoint's lr / betas / eps /
+        weight_decay replace the constructor's; an LR scheduler restores its own state separately).  The masters of the checkpoint are
+        kept as they are -- NOT re-derived from the bf16 parameters, which hold only their rounding -- so a resumed run continues the
+        fp32 trajectory exactly; load the model weights BEFORE the optimizer state (the HF loop does), or call `resync_master()`."""
+        sd = state_dict
+        if sd.get("format") != STATE_FORMAT:
+            raise ValueError(f"not a FusedAdamW state (format {sd.get('format')!r}, expected {STATE_FORMAT!r}); a torch.optim.AdamW state "
+                             "holds per-parameter tensors and cannot be mapped onto the flat arenas")
+        if [list(x) for x in sd["layout"]] != self._layout():
+            raise ValueError("FusedAdamW.load_state_dict: the checkpoint's parameter layout (names / sizes of the trainable parameters, in "
+                             "arena order) differs from this model's")
+        for k in ("master", "exp_avg", "exp_avg_sq"):
+            src = sd[k]
+            if tuple(src.shape) != tuple(getattr(self, k).shape):
+                raise ValueError(f"FusedAdamW.load_state_dict: {k} has {tuple(src.shape)}, expected {tuple(getattr(self, k).shape)}")
+            getattr(self, k).copy_(src)
+        self.step_count = int(sd["step"])
+        g = self.param_groups[0]
+        for k, v in sd["param_groups"][0].items():
+            if k != "params":
+                g[k] = tuple(v) if k == "betas" else v
+        self._seen_version = getattr(self.model, "_param_version", 0)
+        self._pending_scale, self._norm_ready = None, False
 
     # ---- gradient norm overlapped with the backward (the reference's clip_grad_norm_ is a separate pass over all gradients,
     # HF:trainer.py:2535-2545).  The engine reports every gradient bucket the moment its last kernel is enqueued (the same hook the
@@ -92,34 +169,57 @@ class FusedAdamW:
         torch.cuda.current_stream().wait_stream(self._side)
         self._norm_ready = True
 
-    def step(self):
+    def clip_grad_norm(self, max_norm=None):
+        """The fused `clip_grad_norm_`: global L2 norm of the (reduced) gradient arena and the clip coefficient min(1, max_norm / (norm
+        + 1e-6)), both on the device; the coefficient is applied to the gradients INSIDE the next `step()` (one pass over the arena less
+        than scaling them in place).  Returns the norm as a 0-d device tensor (what `accelerator.clip_grad_norm_` returns to the HF
+        loop); `max_norm = inf` measures without clipping."""
+        max_norm = self.max_grad_norm if max_norm is None else max_norm
+        if max_norm is None or max_norm <= 0:
+            max_norm = float("inf")
+        if not self._norm_ready:
+            K.grad_sumsq(self.model.grad_arena, self._sumsq, accumulate=False)
+        self._norm_ready = False
+        self._pending_scale, self.last_grad_norm = K.clip_scale(self._sumsq, min(float(max_norm), 3.0e38))
+        return self.last_grad_norm.reshape(())
+
+    def step(self, closure=None):
         """`self.stream` (optional, e.g. hip_ops.cu_masked_stream): run the pass there -- behind everything queued on the current stream,
         and the current stream resumes behind it -- so that work queued on OTHER streams (the next batch's frozen vision tower on the
         complementary compute units) runs beside it."""
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
         st = getattr(self, "stream", None)
         if st is None:
-            return self._step()
+            self._step()
+            return loss
         cur = torch.cuda.current_stream()
         st.wait_stream(cur)
         with torch.cuda.stream(st):
             self._step()
         cur.wait_stream(st)
+        return loss
 
     def _step(self):
         m = self.model
         if getattr(m, "_param_version", 0) != self._seen_version:
             self.resync_master()
         self.step_count += 1
-        scale = None
-        if self.max_grad_norm is not None and self.max_grad_norm > 0:
+        scale, self._pending_scale = self._pending_scale, None
+        if scale is None and self.max_grad_norm is not None and self.max_grad_norm > 0:
+            # the loop did not clip through clip_grad_norm() (MantisHipTrainer / bench.py): clip here, to the constructor's max_grad_norm
             if not self._norm_ready:                       # no overlap this step (GA window not driven through the hooks, CPU tests)
                 K.grad_sumsq(m.grad_arena, self._sumsq, accumulate=False)
             self._norm_ready = False
             scale, self.last_grad_norm = K.clip_scale(self._sumsq, self.max_grad_norm)
-        for p_off, g_off, cnt in self._segments:
+        g = self.param_groups[0]                            # read every step: an LR scheduler writes g["lr"]
+        lr, (b1, b2), eps, wd = float(g["lr"]), g["betas"], float(g["eps"]), float(g["weight_decay"])
+        for p_off, g_off, cnt, decays in self._segments:
             K.adamw_flat(m.arena[p_off:p_off + cnt], m.grad_arena[g_off:g_off + cnt], self.master[g_off:g_off + cnt],
-                         self.exp_avg[g_off:g_off + cnt], self.exp_avg_sq[g_off:g_off + cnt], self.lr, self.betas[0],
-                         self.betas[1], self.eps, self.wd, self.step_count, grad_scale=scale)
+                         self.exp_avg[g_off:g_off + cnt], self.exp_avg_sq[g_off:g_off + cnt], lr, float(b1), float(b2), eps,
+                         wd if decays else 0.0, self.step_count, grad_scale=scale)
 
     def zero_grad(self, set_to_none=True):
         """model.zero_grad() of the HF loop: dropping the .grad views lets the next backward overwrite instead of accumulate."""

@@ -100,6 +100,50 @@ def as_hf_trainer():
     from transformers import Trainer
 
     class MantisHipHFTrainer(Trainer):
+        """`mantis_fused_optimizer` (class attribute, default True): `create_optimizer` builds `optim.FusedAdamW` from the TrainingArguments
+        (learning_rate, adam_beta1/2, adam_epsilon, weight_decay with HF's exemption of biases and norm weights, max_grad_norm) instead
+        of torch's AdamW, so the loop's `lr_scheduler` (cosine + warm-up in train_mllava.sh:162-165), its checkpoints
+        (`_save_optimizer_and_scheduler`) and its resume (train_mllava.py:281-294) drive the fused clip + AdamW pass; the loop's
+        `clip_grad_norm_` call is routed to `FusedAdamW.clip_grad_norm`."""
+        mantis_fused_optimizer = True
+
+        def _fused(self):
+            from .optim import FusedAdamW
+            opt = self.optimizer
+            while opt is not None and not isinstance(opt, FusedAdamW) and hasattr(opt, "optimizer"):
+                opt = opt.optimizer                   # accelerate.AcceleratedOptimizer
+            return opt if isinstance(opt, FusedAdamW) else None
+
+        def create_optimizer(self, model=None):
+            if self.optimizer is not None or not self.mantis_fused_optimizer:
+                return super().create_optimizer(model) if model is not None else super().create_optimizer()
+            from .optim import FusedAdamW
+            m = self.model if model is None else model
+            inner = m.module if hasattr(m, "module") else m
+            a = self.args
+            self.optimizer = FusedAdamW(inner, lr=a.learning_rate, betas=(a.adam_beta1, a.adam_beta2), eps=a.adam_epsilon,
+                                        weight_decay=a.weight_decay, max_grad_norm=a.max_grad_norm,
+                                        no_decay=lambda n: inner._param(n).dim() <= 1)
+            # transformers < 4.5x clips inline through the accelerator (no _clip_grad_norm method to override): route that call too
+            acc = getattr(self, "accelerator", None)
+            if acc is not None and not getattr(acc, "_mantis_clip_patched", False):
+                plain = acc.clip_grad_norm_
+
+                def clip(parameters, max_norm, norm_type=2):
+                    opt = self._fused()
+                    if opt is None or norm_type != 2:
+                        return plain(parameters, max_norm, norm_type)
+                    return opt.clip_grad_norm(max_norm)
+                acc.clip_grad_norm_ = clip
+                acc._mantis_clip_patched = True
+            return self.optimizer
+
+        def _clip_grad_norm(self, model):
+            opt = self._fused()
+            if opt is None:
+                return super()._clip_grad_norm(model)
+            return opt.clip_grad_norm(self.args.max_grad_norm)
+
         def training_step(self, model, inputs, num_items_in_batch=None):
             ga = getattr(self, "current_gradient_accumulation_steps", None) or self.args.gradient_accumulation_steps
             impl = getattr(self, "_mantis_impl", None)

@@ -240,7 +240,8 @@ class LlavaRef:
             I, N, d = img.shape
             plan = pack_ref.pack_plan(ids.numpy(), attn.numpy(), None if lab is None else lab.numpy(), I, N,
                                       cfg["image_token_index"], cfg["pad_token_id"] if cfg["pad_token_id"] is not None else -1,
-                                      cfg.get("ignore_index", -100))
+                                      cfg.get("ignore_index", -100),
+                                      fix_unequal_counts=bool(cfg.get("fix_unequal_counts", False)))
             B, L = plan["src_kind"].shape
             kind = torch.from_numpy(plan["src_kind"])
             sidx = torch.from_numpy(plan["src_idx"])

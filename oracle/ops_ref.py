@@ -413,10 +413,11 @@ class PackPlan:
     pass
 
 
-def pack_plan(input_ids, attention_mask, labels, num_patches, num_images, image_token_index, pad_token_id, ignore_index, L):
+def pack_plan(input_ids, attention_mask, labels, num_patches, num_images, image_token_index, pad_token_id, ignore_index, L,
+              fix_unequal_counts=False):
     ids = input_ids.numpy()
     pl = pack_ref.pack_plan(ids, attention_mask.numpy(), None if labels is None else labels.numpy(), num_images,
-                            num_patches, image_token_index, pad_token_id, ignore_index)
+                            num_patches, image_token_index, pad_token_id, ignore_index, fix_unequal_counts=fix_unequal_counts)
     assert pl["L"] == L
     B, T = ids.shape
     out = PackPlan()

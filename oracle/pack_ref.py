@@ -23,7 +23,12 @@ class PackCountError(ValueError):
 
 
 def pack_plan(input_ids, attention_mask, labels, num_images, num_patches, image_token_index, pad_token_id,
-              ignore_index=-100):
+              ignore_index=-100, fix_unequal_counts=False):
+    """fix_unequal_counts=False: the reference's placement, including its mis-placement of image rows for a right-padded
+    batch with unequal image counts.  True: SURVEY appendix A's index-only formulation -- image j of
+    sample b occupies [p[b,t_j]-(N-1), p[b,t_j]] whatever the padding side; every other unwritten slot stays padding.  Equal
+    to the reference whenever all samples hold the same number of images (and, sample by sample, to the reference run at
+    B = 1: tests/golden/make_golden_fixcounts.py)."""
     ids = np.asarray(input_ids, dtype=np.int64)
     attn = np.asarray(attention_mask, dtype=np.int64)
     B, T = ids.shape
@@ -53,8 +58,14 @@ def pack_plan(input_ids, attention_mask, labels, num_images, num_patches, image_
         out_lab[bi, tp] = np.asarray(labels, dtype=np.int64)[bi, ti]
     # :344-345 image slots = unwritten rows minus the first nb_image_pad of them, per sample
     unwritten = src_kind == 0
-    rank = np.cumsum(unwritten, -1) - 1
-    slots = unwritten & (rank >= nb_image_pad[:, None])
+    if fix_unequal_counts:
+        slots = np.zeros((B, L), dtype=bool)
+        ib, it = np.nonzero(m)                     # row-major: batch-major, in-sample order = the feature rows' order
+        for b_, t_ in zip(ib, it):
+            slots[b_, p[b_, t_] - (N - 1): p[b_, t_] + 1] = True
+    else:
+        rank = np.cumsum(unwritten, -1) - 1
+        slots = unwritten & (rank >= nb_image_pad[:, None])
     # :347-351
     if int(slots.sum()) != int(num_images) * N:
         raise PackCountError(

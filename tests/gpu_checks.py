@@ -4,6 +4,7 @@ tools/gpu_selftest.py (which runs ALL of them and writes a JSON report instead o
 
 Tolerances: integer / index / copy work bit-exact; bf16 kernels vs the fp32 oracle on the same bf16 inputs:
 relative L2 error <= 1e-2 (bf16 has 8 mantissa bits: ~4e-3 per element), attention 2e-2, gradients 3e-2."""
+import os
 import numpy as np
 import torch
 
@@ -514,6 +515,94 @@ def check_pack_random():
     return 0.0
 
 
+def check_pack_fixed_counts():
+    """SURVEY 8(f4), `fix_unequal_counts` (mantis_pack_plan_mode, mode 1).  (1) the unequal-count batch of the fixture, right- and
+    left-padded: the merged integers equal, sample by sample, what the REFERENCE recorded for that sample alone at B = 1, and every
+    array equals the oracle's; (2) random ragged batches with unequal counts and random padding side, both modes, vs the oracle;
+    (3) equal counts: mode 1 == mode 0; (4) the plain entry mantis_pack_plan == mode 0; (5) a count mismatch is reported."""
+    import ctypes
+    k = K()
+    f = np.load(os.path.join(Hh.G, "siglip_b2_unequal_fixed.npz"))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(torch.int64)
+    fields = ("src", "attention_mask", "labels", "position_ids", "kmask", "text_pos", "img_slot", "ce_row", "ce_tgt")
+    N, I = 16, 3
+    for side in ("right", "left"):
+        ids, am, lab = t(f[f"{side}.input_ids"]), t(f[f"{side}.attention_mask"]), t(f[f"{side}.labels"])
+        L = 2 * (N - 1) + ids.shape[1]
+        pl = k.pack_plan(ids.to(DEV), am.to(DEV), lab.to(DEV), N, I, 298, 299, -100, L, fix_unequal_counts=True)
+        st = pl.status.cpu().tolist()
+        assert st[0] == 0 and st[1] == I * N, st
+        rp = R.pack_plan(ids, am, lab, N, I, 298, 299, -100, L, fix_unequal_counts=True)
+        for fld in fields:
+            assert torch.equal(getattr(pl, fld).cpu(), getattr(rp, fld)), (side, fld)
+        for b in range(2):
+            Lb = f[f"s{b}.merged_attention_mask"].shape[1]
+            sp = slice(0, Lb) if side == "right" else slice(L - Lb, L)
+            assert np.array_equal(pl.attention_mask.cpu().numpy()[b, sp], f[f"s{b}.merged_attention_mask"][0]), (side, b)
+            assert np.array_equal(pl.labels.cpu().numpy()[b, sp], f[f"s{b}.merged_labels"][0]), (side, b)
+            assert np.array_equal(pl.position_ids.cpu().numpy()[b, sp], f[f"s{b}.merged_position_ids"][0]), (side, b)
+    g = np.random.default_rng(17)
+    for trial in range(10):
+        B, T, N = int(g.integers(2, 6)), int(g.integers(8, 1500)), int(g.integers(1, 40))
+        ids = g.integers(0, 1000, size=(B, T))
+        am = np.ones((B, T), np.int64)
+        left = bool(trial % 2)
+        for b in range(B):
+            kimg = int(g.integers(0, 6))
+            npad = int(g.integers(0, min(6, T - 6))) if b > 0 else 0
+            lo, hi = (npad, T - 1) if left else (0, T - npad - 1)
+            pos = g.choice(np.arange(lo, hi), size=min(kimg, hi - lo), replace=False)
+            ids[b, pos] = 5000
+            if npad:
+                sl = slice(0, npad) if left else slice(T - npad, T)
+                ids[b, sl] = 5001
+                am[b, sl] = 0
+        if left:
+            ids[:, -1] = np.where(ids[:, -1] == 5001, 7, ids[:, -1])
+        lab = np.where(g.random((B, T)) < 0.5, ids, -100)
+        I = int((ids == 5000).sum())
+        L = int((ids == 5000).sum(-1).max()) * (N - 1) + T
+        for fix in (True, False):
+            pl = k.pack_plan(t(ids).to(DEV), t(am).to(DEV), t(lab).to(DEV), N, I, 5000, 5001, -100, L, fix_unequal_counts=fix)
+            rp = R.pack_plan(t(ids), t(am), t(lab), N, I, 5000, 5001, -100, L, fix_unequal_counts=fix)
+            if fix or N > 1:       # N = 1: the reference's slot search finds no unwritten row to skip; both sides still agree
+                assert pl.status.cpu().tolist()[0] == 0, (trial, fix, pl.status.cpu().tolist())
+            for fld in fields:
+                assert torch.equal(getattr(pl, fld).cpu(), getattr(rp, fld)), (trial, fix, fld)
+    z, ids, am, lab = _plan_inputs("siglip_b2_equal_rightpad")
+    L = 2 * 15 + ids.shape[1]
+    a = k.pack_plan(ids.to(DEV), am.to(DEV), lab.to(DEV), 16, 4, 298, 299, -100, L, fix_unequal_counts=True)
+    b = k.pack_plan(ids.to(DEV), am.to(DEV), lab.to(DEV), 16, 4, 298, 299, -100, L)
+    for fld in fields:
+        assert torch.equal(getattr(a, fld), getattr(b, fld)), fld
+    # the plain C entry (kept for the ABI) is mode 0
+    from mantis_amd import _lib
+    lib = _lib.load()
+    ids_d, am_d, lab_d = ids.to(DEV), am.to(DEV), lab.to(DEV)
+    o = {n: torch.empty_like(getattr(b, n)) for n in fields}
+    o["img_slot"].fill_(-1)
+    status = torch.zeros(4, dtype=torch.int32, device=DEV)
+    pt = lambda x: ctypes.c_void_p(x.data_ptr())
+    rc = lib.mantis_pack_plan(pt(ids_d), pt(am_d), pt(lab_d), ids.shape[0], ids.shape[1], 16, 4, 298, 299, -100, L, pt(o["src"]),
+                              pt(o["attention_mask"]), pt(o["labels"]), pt(o["position_ids"]), pt(o["kmask"]), pt(o["text_pos"]),
+                              pt(o["img_slot"]), pt(o["ce_row"]), pt(o["ce_tgt"]), pt(status), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    for fld in fields:
+        assert torch.equal(o[fld], getattr(b, fld)), ("mantis_pack_plan", fld)
+    ids = torch.tensor([[1, 5000, 2, 5000, 3]])
+    pl = k.pack_plan(ids.to(DEV), torch.ones_like(ids).to(DEV), ids.to(DEV), 4, 1, 5000, 5001, -100, 2 * 3 + 5, fix_unequal_counts=True)
+    assert pl.status.cpu().tolist()[0] == 1
+    return 0.0
+
+
+def check_model_step_fixed_counts(side):
+    """one step of the product with LlavaConfig(fix_unequal_counts=True) on the unequal-count batch (tests/helpers.py)"""
+    model, _, _ = Hh.build_product_model("siglip", DEV)
+    Hh.check_fixed_counts_step(model, side, DEV)
+    return 0.0
+
+
 def check_gather_scatter_embed():
     k = K()
     x = rnd(50, 64, seed=1)
@@ -799,6 +888,62 @@ def check_optimizer_step_vs_torch():
         # the fp32 master copy is what torch holds (gradient-arena order, every parameter padded to 8 elements): compare it tightly
         flat_ref = torch.cat([torch.nn.functional.pad(tp[n].detach().reshape(-1), (0, (-tp[n].numel()) % 8)) for n in names])
         worst = max(worst, close(opt.master.cpu(), flat_ref, 2e-5, f"fp32 master after step {i + 1}"))
+    return worst
+
+
+def check_fused_optimizer_vs_torch():
+    """FusedAdamW as a torch.optim.Optimizer on the HIP path: an LR scheduler (warm-up + cosine) drives its lr, 5 steps against
+    torch.optim.AdamW + clip_grad_norm_ under the same scheduler (tests/helpers.py)."""
+    return Hh.check_fused_optimizer_vs_torch(DEV, steps=5)
+
+
+def check_fused_optimizer_resume():
+    """state_dict() -> torch.save -> torch.load(weights_only=True) -> load_state_dict() on a fresh model: the resumed run equals the
+    uninterrupted one bit for bit (train_mllava.py:281-294's auto-resume)."""
+    import tempfile
+    return Hh.check_fused_optimizer_resume(DEV, tempfile.mkdtemp())
+
+
+def check_hf_trainer_fused_optimizer():
+    """The reference's loop on the HIP path with ITS optimizer plumbing: `as_hf_trainer()` builds FusedAdamW in create_optimizer and a
+    cosine + warm-up scheduler (train_mllava.sh:162-165); three iterations of training_step -> _clip_grad_norm -> optimizer.step ->
+    lr_scheduler.step -> zero_grad (HF trainer.py:1759-1796) against torch.optim.AdamW + clip_grad_norm_ + the same scheduler on fp32
+    copies fed the same bf16 gradients."""
+    import tempfile
+    import transformers
+    from mantis_amd.trainer import as_hf_trainer
+    from mantis_amd.optim import FusedAdamW
+    z = Hh.load_case("siglip_training_step_ga4")
+    model, _, _ = Hh.build_product_model("siglip", DEV)
+    args = transformers.TrainingArguments(output_dir=tempfile.mkdtemp(), report_to=[], remove_unused_columns=False,
+                                          gradient_accumulation_steps=1, per_device_train_batch_size=1, learning_rate=1e-3,
+                                          weight_decay=0.0, max_grad_norm=1.0, lr_scheduler_type="cosine", warmup_steps=1)
+    tr = as_hf_trainer()(model=model, args=args)
+    tr.create_optimizer_and_scheduler(num_training_steps=6)
+    assert isinstance(tr.optimizer, FusedAdamW)
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    tp = {n: torch.nn.Parameter(model._param(n).detach().float().cpu().clone()) for n in names}
+    topt = torch.optim.AdamW(list(tp.values()), lr=1e-3, betas=(args.adam_beta1, args.adam_beta2), eps=args.adam_epsilon, weight_decay=0.0)
+    tsch = transformers.get_cosine_schedule_with_warmup(topt, 1, 6)
+    worst = 0.0
+    for i in range(3):
+        tr.accelerator.gradient_state._set_sync_gradients(True)
+        loss = tr.training_step(model, _golden_batch(z, f"mb{i}."))
+        assert loss.is_cuda and loss.dim() == 0
+        for n in names:
+            tp[n].grad = model._param(n).grad.detach().float().cpu().clone()
+        total = torch.nn.utils.clip_grad_norm_(list(tp.values()), 1.0)
+        norm = tr._clip_grad_norm(model)
+        assert abs(float(norm) - float(total)) <= 1e-3 * float(total)
+        assert abs(tr.optimizer.param_groups[0]["lr"] - topt.param_groups[0]["lr"]) < 1e-12
+        tr.optimizer.step()
+        topt.step()
+        tr.lr_scheduler.step()
+        tsch.step()
+        model.zero_grad()
+        flat_ref = torch.cat([torch.nn.functional.pad(tp[n].detach().reshape(-1), (0, (-tp[n].numel()) % 8)) for n in names])
+        worst = max(worst, close(tr.optimizer.master.cpu(), flat_ref, 2e-5, f"fp32 master after HF iteration {i + 1}"))
+    assert tr.optimizer.step_count == 3
     return worst
 
 
@@ -1833,6 +1978,7 @@ def all_checks():
                  "siglip_b2_equal_rightpad", "siglip_b2_equal_nopad", "siglip_b2_unequal_quirk", "clip_b2_equal_rightpad"):
         c["pack_golden_" + case] = (lambda case=case: check_pack_golden(case))
     c["pack_random"] = check_pack_random
+    c["pack_fixed_counts"] = check_pack_fixed_counts
     c["gather_scatter_embed"] = check_gather_scatter_embed
     c["ce_300"] = check_ce
     c["ce_32002"] = lambda: check_ce(40, 32002, 0.5)
@@ -1840,6 +1986,11 @@ def all_checks():
     c["optim"] = check_optim
     for case in MODEL_CASES:
         c["model_step_" + case] = (lambda case=case: check_model_step(case))
+    c["model_step_fix_unequal_counts_right"] = lambda: check_model_step_fixed_counts("right")
+    c["model_step_fix_unequal_counts_left"] = lambda: check_model_step_fixed_counts("left")
+    c["fused_optimizer_vs_torch"] = check_fused_optimizer_vs_torch
+    c["fused_optimizer_resume"] = check_fused_optimizer_resume
+    c["hf_trainer_fused_optimizer"] = check_hf_trainer_fused_optimizer
     c["training_step_contract_ga1"] = lambda: check_training_step_contract(1)
     c["training_step_contract_ga4"] = lambda: check_training_step_contract(4)
     c["model_step_projector_only_siglip"] = lambda: check_model_step_projector_only("siglip_b2_equal_rightpad")

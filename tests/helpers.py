@@ -92,6 +92,131 @@ def check_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-3, grad_c
     return report
 
 
+def fixed_counts_case(side):
+    """the unequal-image-count batch of tests/golden/siglip_b2_unequal_fixed.npz as a z-like dict (side = "right" | "left" padding)"""
+    f = np.load(os.path.join(G, "siglip_b2_unequal_fixed.npz"))
+
+    class Z(dict):
+        files = property(lambda self: list(self.keys()))
+    z = Z(input_ids=f[f"{side}.input_ids"], attention_mask=f[f"{side}.attention_mask"], labels=f[f"{side}.labels"],
+          pixel_values=f["pixel_values"], pixel_counts=f["pixel_counts"])
+    return z, f
+
+
+def check_fixed_counts_step(model, side, device):
+    """One step of the PRODUCT on the unequal-count batch with `fix_unequal_counts`: integers equal, sample by sample, what the
+    reference recorded for that sample alone at B = 1; loss / activations / gradients against the oracle with the same flag (which
+    tests/test_oracle_vs_golden.py pins to those B = 1 reference runs)."""
+    z, f = fixed_counts_case(side)
+    model.config.fix_unequal_counts = True
+    oracle = build_oracle_bf16_weights("siglip")
+    oracle.cfg = dict(oracle.cfg, fix_unequal_counts=True)
+    assert model._ensure_grad_arena()
+    rec = {}
+    out = model.engine.step(torch.from_numpy(z["input_ids"]).to(device), torch.from_numpy(z["attention_mask"]).to(device),
+                            torch.from_numpy(z["labels"]).to(device), [p.to(device) for p in pixels_list(z)], compute_grads=True,
+                            overwrite_grads=True, need_logits=True, record=rec)
+    check_step_against_oracle(model, oracle, z, out, rec)
+    L = rec["merged_attention_mask"].shape[1]
+    for b in range(2):
+        Lb = f[f"s{b}.merged_attention_mask"].shape[1]
+        sp = slice(0, Lb) if side == "right" else slice(L - Lb, L)
+        for k in ("merged_attention_mask", "merged_labels", "merged_position_ids"):
+            assert np.array_equal(rec[k].cpu().numpy()[b, sp], f[f"s{b}.{k}"][0]), (k, b)
+        lg = out["logits"].float().cpu().numpy()[b, sp]
+        assert rel_l2(lg, f[f"s{b}.logits"][0]) < 0.08, b       # bf16 product vs the reference's fp32 B = 1 logits
+    return out
+
+
+def _opt_batches(n):
+    z = load_case("siglip_training_step_ga4")
+    return [dict(input_ids=torch.from_numpy(z[f"mb{i % 4}.input_ids"]), attention_mask=torch.from_numpy(z[f"mb{i % 4}.attention_mask"]),
+                 labels=torch.from_numpy(z[f"mb{i % 4}.labels"]), pixel_values=pixels_list(z, f"mb{i % 4}.")) for i in range(n)]
+
+
+def check_fused_optimizer_vs_torch(device, steps=5):
+    """`FusedAdamW` under a torch LR scheduler (linear warm-up + cosine: train_mllava.sh:162-165's shape) against torch.optim.AdamW +
+    clip_grad_norm_ under the SAME scheduler class on fp32 copies, fed the product's bf16 gradients: lr per step equal, fp32 masters
+    within 2e-5 relative, bf16 parameters = bf16(torch's fp32 parameters) up to one rounding.  Returns the worst master error."""
+    from mantis_amd.trainer import MantisHipTrainer
+    from mantis_amd.optim import FusedAdamW
+    model, _, _ = build_product_model("siglip", device)
+    tr = MantisHipTrainer(model, 1)
+    opt = FusedAdamW(model, lr=1e-3, weight_decay=0.01, max_grad_norm=1.0)
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    tp = {n: torch.nn.Parameter(model._param(n).detach().float().cpu().clone()) for n in names}
+    topt = torch.optim.AdamW(list(tp.values()), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+
+    def lam(s, warm=2, total=8):
+        return s / warm if s < warm else 0.5 * (1.0 + np.cos(np.pi * (s - warm) / (total - warm)))
+    sch, tsch = torch.optim.lr_scheduler.LambdaLR(opt, lam), torch.optim.lr_scheduler.LambdaLR(topt, lam)
+    worst, seen = 0.0, []
+    for i, b in enumerate(_opt_batches(steps)):
+        tr.training_step(model, b)
+        for n in names:
+            tp[n].grad = model._param(n).grad.detach().float().cpu().clone()
+        total = torch.nn.utils.clip_grad_norm_(list(tp.values()), 1.0)
+        norm = opt.clip_grad_norm(1.0)
+        assert abs(float(norm) - float(total)) <= 1e-3 * float(total)
+        assert opt.param_groups[0]["lr"] == topt.param_groups[0]["lr"]
+        seen.append(opt.param_groups[0]["lr"])
+        topt.step()
+        opt.step()
+        sch.step()
+        tsch.step()
+        opt.zero_grad(set_to_none=True)
+        flat_ref = torch.cat([torch.nn.functional.pad(tp[n].detach().reshape(-1), (0, (-tp[n].numel()) % 8)) for n in names])
+        err = rel_l2(opt.master.cpu().numpy(), flat_ref.numpy())
+        assert err < 2e-5, (i, err)
+        worst = max(worst, err)
+        for n in names:
+            got = model._param(n).detach().float().cpu()
+            assert torch.equal(got, tp[n].detach().to(torch.bfloat16).float()) or rel_l2(got.numpy(), tp[n].detach().numpy()) < 4e-3, n
+    assert seen[0] == 0.0 and seen[1] == 0.5e-3 and seen[2] == 1e-3 and seen[3] < 1e-3      # the schedule really moved the fused lr
+    return worst
+
+
+def check_fused_optimizer_resume(device, tmpdir):
+    """Auto-resume (train_mllava.py:281-294): 2 steps, save model + optimizer + scheduler the way HF does (torch.save of state_dict()),
+    build everything anew, load, 2 more steps == 4 uninterrupted steps, bit for bit (parameters, fp32 masters, moments, lr)."""
+    import os
+    from mantis_amd.trainer import MantisHipTrainer
+    from mantis_amd.optim import FusedAdamW
+    batches = _opt_batches(4)
+    lam = lambda s: 1.0 / (1.0 + s)
+
+    def fresh():
+        model, _, _ = build_product_model("siglip", device)
+        opt = FusedAdamW(model, lr=1e-3, weight_decay=0.0, max_grad_norm=1.0)
+        return model, opt, torch.optim.lr_scheduler.LambdaLR(opt, lam), MantisHipTrainer(model, 1)
+
+    def run(model, opt, sch, tr, bs):
+        for b in bs:
+            tr.training_step(model, b)
+            opt.clip_grad_norm(1.0)
+            opt.step()
+            sch.step()
+            opt.zero_grad(set_to_none=True)
+    m_a, o_a, s_a, t_a = fresh()
+    run(m_a, o_a, s_a, t_a, batches)                                    # 4 steps straight
+    m_b, o_b, s_b, t_b = fresh()
+    run(m_b, o_b, s_b, t_b, batches[:2])
+    torch.save(o_b.state_dict(), os.path.join(tmpdir, "optimizer.pt"))
+    torch.save(s_b.state_dict(), os.path.join(tmpdir, "scheduler.pt"))
+    torch.save({n: p.detach().cpu() for n, p in m_b.named_parameters()}, os.path.join(tmpdir, "model.pt"))
+    m_c, o_c, s_c, t_c = fresh()
+    m_c.load_reference_state_dict({n: v.float().numpy() for n, v in torch.load(os.path.join(tmpdir, "model.pt")).items()})
+    o_c.load_state_dict(torch.load(os.path.join(tmpdir, "optimizer.pt"), map_location=device, weights_only=True))
+    s_c.load_state_dict(torch.load(os.path.join(tmpdir, "scheduler.pt")))
+    assert o_c.step_count == 2 and o_c.param_groups[0]["lr"] == o_b.param_groups[0]["lr"]
+    run(m_c, o_c, s_c, t_c, batches[2:])
+    assert torch.equal(m_c.arena, m_a.arena), "parameters after resume differ from the uninterrupted run"
+    for k in ("master", "exp_avg", "exp_avg_sq"):
+        assert torch.equal(getattr(o_c, k), getattr(o_a, k)), k
+    assert o_c.step_count == 4 and o_c.param_groups[0]["lr"] == o_a.param_groups[0]["lr"]
+    return 0.0
+
+
 def load_cfg1():
     """cfg1 (Mantis-tiny) fixture recorded from the reference (tests/golden/make_golden_cfg1.py): returns (meta, weights as
     bf16-rounded fp32 tensors regenerated from the stored seed, a z-like dict with the inputs, the fixture itself)."""

@@ -45,6 +45,35 @@ def test_step_matches_oracle(cpu_backend, case):
             assert p.grad is None
 
 
+@pytest.mark.parametrize("side", ["right", "left"])
+def test_fix_unequal_counts_equals_reference_per_sample(cpu_backend, side):
+    """LlavaConfig(fix_unequal_counts=True) on a batch with unequal image counts -> every sample gets what the
+    reference computes for it alone at B = 1 (fixture of tests/golden/make_golden_fixcounts.py)."""
+    model, _, _ = Hh.build_product_model("siglip", "cpu")
+    Hh.check_fixed_counts_step(model, side, "cpu")
+
+
+def test_unequal_counts_without_the_flag_warns_once(cpu_backend):
+    import warnings
+    import mantis_amd.engine as eng
+    z, _ = Hh.fixed_counts_case("right")
+    model, _, _ = Hh.build_product_model("siglip", "cpu")
+    eng._WARNED_UNEQUAL = False
+    args = (torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"]), torch.from_numpy(z["labels"]), Hh.pixels_list(z))
+    with pytest.warns(UserWarning, match="fix_unequal_counts"):
+        model.engine.step(*args, compute_grads=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        model.engine.step(*args, compute_grads=False)          # second time: silent
+    # left padding with unequal counts is placed correctly by the reference itself: no warning
+    eng._WARNED_UNEQUAL = False
+    zl, _ = Hh.fixed_counts_case("left")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        model.engine.step(torch.from_numpy(zl["input_ids"]), torch.from_numpy(zl["attention_mask"]), torch.from_numpy(zl["labels"]),
+                          Hh.pixels_list(zl), compute_grads=False)
+
+
 @pytest.mark.parametrize("case", ["siglip_b2_equal_rightpad", "clip_b2_equal_rightpad"])
 def test_projector_only_stage(cpu_backend, case):
     """The reference's pre-training stage tunes only multi_modal_projector (train_mllava.py:177-181): same training_step, every

@@ -1,0 +1,105 @@
+"""`optim.FusedAdamW` as the optimizer the REFERENCE's own loop can drive (VERDICT r03 missing 3):
+a `torch.optim.Optimizer` whose single param_group's lr is read every step (cosine + warm-up of
+/root/reference/mantis/train/scripts/train_mllava.sh:162-165), with state_dict / load_state_dict for the auto-resume of
+/root/reference/mantis/train/train_mllava.py:281-294, and the HF loop's clip_grad_norm_ routed to the fused norm.
+
+CPU: the product's host logic with the oracle operators in place of the HIP backend (pinned to torch.optim.AdamW +
+clip_grad_norm_ by tests/test_advice_regressions.py::test_adamw_and_clip_oracle_match_torch); the `-m gpu` twins are
+`fused_optimizer_*` in tests/gpu_checks.py."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as Hh
+
+
+@pytest.fixture()
+def cpu_backend(monkeypatch):
+    import mantis_amd.engine as eng
+    import mantis_amd.optim as opt
+    from oracle import ops_ref
+    monkeypatch.setattr(eng, "K", ops_ref)
+    monkeypatch.setattr(opt, "K", ops_ref)
+    return eng
+
+
+def test_schedule_drives_lr_and_matches_torch_adamw(cpu_backend):
+    Hh.check_fused_optimizer_vs_torch("cpu", steps=5)
+
+
+def test_state_dict_round_trip_resumes_the_same_trajectory(cpu_backend, tmp_path):
+    Hh.check_fused_optimizer_resume("cpu", str(tmp_path))
+
+
+def test_is_a_torch_optimizer_with_one_param_group(cpu_backend):
+    from mantis_amd.optim import FusedAdamW
+    model, _, _ = Hh.build_product_model("siglip", "cpu")
+    opt = FusedAdamW(model, lr=3e-4, betas=(0.8, 0.95), eps=1e-7, weight_decay=0.1)
+    assert isinstance(opt, torch.optim.Optimizer) and len(opt.param_groups) == 1
+    g = opt.param_groups[0]
+    assert g["lr"] == 3e-4 and tuple(g["betas"]) == (0.8, 0.95) and g["eps"] == 1e-7 and g["weight_decay"] == 0.1
+    assert {id(p) for p in g["params"]} == {id(p) for p in model.parameters() if p.requires_grad}
+    with pytest.raises(NotImplementedError):
+        opt.add_param_group({"params": [torch.nn.Parameter(torch.zeros(3))]})
+    with pytest.raises(ValueError):
+        opt.load_state_dict(torch.optim.AdamW([torch.nn.Parameter(torch.zeros(3))]).state_dict())
+
+
+def test_no_decay_exempts_the_named_parameters(cpu_backend):
+    """weight decay with HF's exemption rule (biases / norm weights): a zero gradient leaves exempt parameters untouched and shrinks
+    the others by (1 - lr * wd) per step"""
+    from mantis_amd.optim import FusedAdamW
+    model, _, _ = Hh.build_product_model("siglip", "cpu")
+    opt = FusedAdamW(model, lr=0.5, weight_decay=0.5, max_grad_norm=None, no_decay=lambda n: model._param(n).dim() <= 1)
+    assert len(opt._segments) > 3 and {s[3] for s in opt._segments} == {True, False}
+    before = {n: model._param(n).detach().float().clone() for n in opt._names}
+    model.grad_arena.zero_()
+    opt.step()
+    for n in opt._names:
+        got = model._param(n).detach().float()
+        if before[n].dim() <= 1:
+            assert torch.equal(got, before[n]), n
+        else:
+            assert torch.allclose(got, (before[n] * 0.75).to(torch.bfloat16).float(), atol=0, rtol=1e-2), n
+
+
+def test_hf_trainer_builds_the_fused_optimizer_and_routes_clipping(cpu_backend, tmp_path):
+    """The stock loop's pieces around training_step (HF trainer.py:1785-1796): create_optimizer_and_scheduler -> FusedAdamW +
+    cosine / warm-up scheduler; _clip_grad_norm -> the fused norm; optimizer.step(); lr_scheduler.step(); _save / _load of the
+    optimizer state."""
+    transformers = pytest.importorskip("transformers")
+    from mantis_amd.trainer import as_hf_trainer
+    from mantis_amd.optim import FusedAdamW
+    z = Hh.load_case("siglip_training_step_ga4")
+    model, _, _ = Hh.build_product_model("siglip", "cpu")
+    args = transformers.TrainingArguments(output_dir=str(tmp_path), use_cpu=True, report_to=[], remove_unused_columns=False,
+                                          gradient_accumulation_steps=1, learning_rate=1e-3, weight_decay=0.0, max_grad_norm=1.0,
+                                          lr_scheduler_type="cosine", warmup_steps=2)
+    tr = as_hf_trainer()(model=model, args=args)
+    tr.create_optimizer_and_scheduler(num_training_steps=10)
+    assert isinstance(tr.optimizer, FusedAdamW)
+    lrs, norms = [], []
+    for i in range(3):
+        b = dict(input_ids=torch.from_numpy(z[f"mb{i}.input_ids"]), attention_mask=torch.from_numpy(z[f"mb{i}.attention_mask"]),
+                 labels=torch.from_numpy(z[f"mb{i}.labels"]), pixel_values=Hh.pixels_list(z, f"mb{i}."))
+        tr.accelerator.gradient_state._set_sync_gradients(True)
+        tr.training_step(model, b)
+        want = float(torch.cat([p.grad.float().reshape(-1) for p in model.parameters() if p.grad is not None]).norm())
+        norm = tr._clip_grad_norm(model)
+        assert abs(float(norm) - want) <= 1e-4 * want
+        norms.append(float(norm))
+        lrs.append(tr.optimizer.param_groups[0]["lr"])
+        tr.optimizer.step()
+        tr.lr_scheduler.step()
+        model.zero_grad()
+    assert np.allclose(lrs, [0.0, 0.5e-3, 1e-3]) and tr.optimizer.step_count == 3      # warm-up 0 -> 1e-3 over two steps
+    # the accelerator's own entry (older transformers clip inline through it) goes to the fused norm as well
+    tr.accelerator.gradient_state._set_sync_gradients(True)
+    tr.training_step(model, b)
+    n2 = tr.accelerator.clip_grad_norm_(model.parameters(), 1.0)
+    assert n2.dim() == 0 and float(n2) > 0 and tr.optimizer._pending_scale is not None
+    tr._save_optimizer_and_scheduler(str(tmp_path))
+    sd = torch.load(str(tmp_path / "optimizer.pt"), weights_only=True)
+    assert sd["format"] == "mantis_fused_adamw/1" and sd["step"] == 3

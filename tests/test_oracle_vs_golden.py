@@ -15,7 +15,8 @@ from oracle.llava_ref import LlavaRef
 
 G = os.path.join(os.path.dirname(__file__), "golden")
 CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(G, "*.npz"))
-               if not os.path.basename(p).startswith(("weights_", "label_rule", "siglip_training_step", "cfg1_", "collate_ref", "collate_qwen_ref", "pack_batch_ref", "idefics2_", "qwen2vl_")))
+               if not os.path.basename(p).startswith(("weights_", "label_rule", "siglip_training_step", "cfg1_", "collate_ref", "collate_qwen_ref", "pack_batch_ref", "idefics2_", "qwen2vl_",
+                                                        "siglip_b2_unequal_fixed")))
 
 
 def _pixels(z):
@@ -120,6 +121,68 @@ def test_pack_rows_copy_is_bit_exact():
     assert np.array_equal(plan["attention_mask"], z["merged_attention_mask"])
     assert np.array_equal(plan["position_ids"], z["merged_position_ids"])
     assert np.array_equal(plan["labels"], z["merged_labels"])
+
+
+def _valid_span(side, b, L, Lb):
+    """columns of merged row b that hold the sample's own B = 1 sequence (length Lb) in an L-column batch row"""
+    return slice(0, Lb) if side == "right" else slice(L - Lb, L)
+
+
+@pytest.mark.parametrize("side", ["right", "left"])
+def test_fixed_placement_equals_reference_at_batch_size_one(side):
+    """with `fix_unequal_counts` a batch with UNEQUAL image counts gives, sample by sample, what the reference
+    returns for that sample alone at B = 1 (tests/golden/make_golden_fixcounts.py) -- integers exact, logits / loss / gradients
+    at the fp32 bars of this file; the loss of the batch is the label-count-weighted mean of the two B = 1 losses."""
+    z = np.load(os.path.join(G, "siglip_b2_unequal_fixed.npz"))
+    m = LlavaRef.from_npz(os.path.join(G, "weights_siglip.npz"))
+    m.cfg = dict(m.cfg, fix_unequal_counts=True)
+    ids, am, lab = z[f"{side}.input_ids"], z[f"{side}.attention_mask"], z[f"{side}.labels"]
+    px = list(torch.split(torch.from_numpy(z["pixel_values"]), z["pixel_counts"].tolist()))
+    rec = {}
+    loss, logits = m.forward(ids, px, am, lab, record=rec)
+    loss.backward()
+    L = rec["merged_attention_mask"].shape[1]
+    n_lab, want_loss = [], 0.0
+    for b in range(2):
+        Lb = z[f"s{b}.merged_attention_mask"].shape[1]
+        sp = _valid_span(side, b, L, Lb)
+        assert np.array_equal(rec["merged_attention_mask"].numpy()[b, sp], z[f"s{b}.merged_attention_mask"][0])
+        assert np.array_equal(rec["merged_labels"].numpy()[b, sp], z[f"s{b}.merged_labels"][0])
+        assert np.array_equal(rec["merged_position_ids"].numpy()[b, sp], z[f"s{b}.merged_position_ids"][0])
+        rest = np.ones(L, bool)
+        rest[sp] = False                                 # everything outside the sample's own span is padding
+        assert not rec["merged_attention_mask"].numpy()[b, rest].any()
+        assert (rec["merged_labels"].numpy()[b, rest] == -100).all()
+        ref_logits = z[f"s{b}.logits"][0]
+        assert np.allclose(logits.detach().numpy()[b, sp], ref_logits, atol=1e-5 * max(1.0, np.abs(ref_logits).max())), b
+        n = int((z[f"s{b}.merged_labels"][0, 1:] != -100).sum())
+        n_lab.append(n)
+        want_loss += n * float(z[f"s{b}.loss"])
+    want_loss /= sum(n_lab)
+    assert abs(float(loss) - want_loss) <= 1e-6 * abs(want_loss) + 1e-6
+    grads = {k: v.grad for k, v in m.trainable().items() if v.grad is not None}
+    checked = 0
+    for k in [f[len("s0.grad."):] for f in z.files if f.startswith("s0.grad.")]:
+        want = (n_lab[0] * z["s0.grad." + k] + n_lab[1] * z["s1.grad." + k]) / sum(n_lab)
+        if k in grads:
+            assert rel_l2(grads[k].numpy(), want) < 1e-4, k
+            checked += 1
+    assert checked >= 20
+
+
+def test_reference_placement_differs_on_the_right_padded_unequal_batch():
+    """the default (reference-exact) plan mis-places sample 1's image rows on the same batch: the flag is not a no-op"""
+    z = np.load(os.path.join(G, "siglip_b2_unequal_fixed.npz"))
+    a = (z["right.input_ids"], z["right.attention_mask"], z["right.labels"], 3, 16, 298, 299)
+    ref, fixed = pack_ref.pack_plan(*a), pack_ref.pack_plan(*a, fix_unequal_counts=True)
+    assert not np.array_equal(ref["src_kind"], fixed["src_kind"])
+    assert np.array_equal(ref["src_kind"][0], fixed["src_kind"][0])          # the sample with the most images is placed alike
+    # equal counts: the two formulations agree (SURVEY appendix A)
+    e = np.load(os.path.join(G, "siglip_b2_equal_rightpad.npz"))
+    b = (e["input_ids"], e["attention_mask"], e["labels"], 4, 16, 298, 299)
+    p0, p1 = pack_ref.pack_plan(*b), pack_ref.pack_plan(*b, fix_unequal_counts=True)
+    for k in ("src_kind", "src_idx", "attention_mask", "labels", "position_ids"):
+        assert np.array_equal(p0[k], p1[k]), k
 
 
 def test_oracle_matches_cfg1_reference_fixture():
