@@ -394,6 +394,9 @@ def main():
                     help="hand the next batch to training_step: the frozen vision tower of batch i+1 is enqueued on a side stream beside clip "
                          "+ AdamW of step i, the optimizer on --adam-cus compute units and the tower on the rest (CU-masked streams).  Off "
                          "by default: measured slower for every split (headline 297 -> 320-344 ms; profiles/r02_experiments.md)")
+    ap.add_argument("--prefetch-early", action="store_true",
+                    help="with --prefetch: queue the next batch's frozen tower at the START of the step on a stream of the lowest hardware-queue "
+                         "priority, so that it fills the compute units the step's own kernels leave idle (instead of beside the optimizer)")
     ap.add_argument("--adam-cus", type=int, default=192, help="with --prefetch: compute units given to the optimizer pass")
     ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -402,6 +405,8 @@ def main():
                     help="write the in-step bf16 GEMM table (per shape x layout x epilogue: launches per step, mean / min / max us from the "
                          "HIP events around every launch of the timed steps, TFLOP/s, fraction of the bf16 MFMA peak, share of the family) "
                          "as markdown to PATH")
+    ap.add_argument("--gemm-series", default=None, metavar="PATH",
+                    help="write the (shape, layout, epilogue, us) of every bf16 GEMM launch of the LAST timed step, in launch order, as JSON")
     ap.add_argument("--recycle-batches", type=int, default=0, help="0 = a fresh synthetic batch every step (default); n > 0 = cycle n batches")
     args = ap.parse_args()
 
@@ -494,7 +499,10 @@ def main():
         # tower on the others -- the two masked streams run side by side (tools/cu_mask_probe.hip)
         # `--adam-cus 0`: no CU partition -- the tower on a plain side stream beside the optimizer pass on the compute stream
         total = K.num_cus()
-        if args.adam_cus > 0:
+        if args.prefetch_early:
+            trainer.prefetch_early = True
+            trainer.prefetch_stream = K.priority_stream(1)
+        elif args.adam_cus > 0:
             n_adam = min(max(args.adam_cus, 1), total - 8)
             opt.stream = K.cu_masked_stream(0, n_adam)
             trainer.prefetch_stream = K.cu_masked_stream(n_adam, total - n_adam)
@@ -603,6 +611,11 @@ def main():
             all_gemms = timer                                        # every GEMM launch of the timed steps (bf16 and fp8)
             if args.gemm_table:
                 write_gemm_table(args.gemm_table, [x for x in all_gemms if x[0] == "gemm_nt_kernel"], args.steps, args.config, ms)
+            if args.gemm_series:
+                per = len(all_gemms) // args.steps
+                with open(args.gemm_series, "w") as fh:
+                    json.dump([dict(tag=list(x[5]) if len(x) > 5 else None, us=round(x[3].elapsed_time(x[4]) * 1e3, 1))
+                               for x in all_gemms[-per:]], fh)
             gf = (pmc or {}).get("gemm_family") or {}
             kname, peak = ("gemm_nt_ring16_kernel + gemm_nt_ring_kernel + gemm_nt_kernel (bf16 MFMA GEMM family: every launch of "
                            "mantis_gemm_bf16_nt / _fused, csrc/gemm.hip)"), PEAK_BF16_TFLOPS

@@ -107,9 +107,12 @@ int mantis_transpose(const void* in, void* out, int R, int C, int Rpad, int64_t 
  *        | 64 SwiGLU backward fused behind dact = A.B^T: residual = [gate | up][M, 2N], C = [dgate | dup][M, 2N]
  *        | bits 8-11 tile variant (0 = auto) | 4096 A is K-major ([K,M], row stride lda) | 8192 B is K-major ([K,N]):
  *        dX = dY.W uses B K-major (the weight as stored), dW = dY^T.X uses both K-major -- no transposed copies.
- * Tile variants: 1 = 128x128 generic kernel, 2 = 256x256 generic kernel, 12 = 256x256 ring kernel with 8 waves of 32x32x16 MFMAs,
- * 13 = 256x256 ring kernel with 4 waves x (128 x 128) of 16x16x32 MFMAs (the cooler-running shape: the automatic choice's ring kernel
- * unless the process was started with MANTIS_GEMM_RING=12).  The ring kernels address operands through 32-bit buffer descriptors: an
+ * Tile variants: 1 = 128x128 generic kernel, 2 = 256x256 generic kernel, 12 = 256x256 ring kernel with 8 waves x (128 x 64) of
+ * 32x32x16 MFMAs, 13 = 256x256 ring16 kernel with 4 waves x (128 x 128) of 16x16x32 MFMAs, 14 = 256x256 ring16 kernel with 8 waves x
+ * (128 x 64) of 16x16x32 MFMAs.  Automatic choice (variant 0): a fitted cost model picks the 128x128 kernel or a ring kernel
+ * (mantis_gemm_pick_variant: 1 or 12 = "a ring kernel"); among the ring kernels, 14 for every K-major layout and for short per-CU K
+ * walks, 13 for row-major (NT) operands with >= 400 K-steps per CU (rounds x K/64), unless the process was started with
+ * MANTIS_GEMM_RING = 12 | 13 | 14 (forces that ring kernel wherever a ring kernel is chosen; A/B measurements).  The ring kernels address operands through 32-bit buffer descriptors: an
  * operand of >= 4 GiB is routed to the generic kernel when the variant is auto and returns MANTIS_EUNSUPPORTED when a ring variant (or
  * the SwiGLU epilogue) was forced. */
 int mantis_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
@@ -119,6 +122,13 @@ int mantis_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, 
  * ring kernel's deterministic split-K remainder round uses it; every launch leaves it zeroed-for-reuse, so one buffer per stream
  * serves all stream-ordered launches).  M = N = K = 0: the largest requirement of any shape on the current device (~64 MB). */
 int mantis_gemm_workspace_bytes(int M, int N, int K);
+/* CU budget the GEMM tile scheduler plans for (rounds of tiles, the K split of an incomplete last round, the tile variant): cus > 0 sets
+ * it (clamped to [8, #CU of the device]), cus < 0 resets it to the whole device, cus == 0 only queries; returns the budget in effect.
+ * Default: the environment variable MANTIS_GEMM_CUS (read once), else the whole device.  For data-parallel runs: every RCCL channel is a
+ * workgroup that cannot share a CU with a 160-KiB-LDS ring workgroup, so with C channels active plan for #CU - C.  Deterministic for a
+ * given budget; a different budget changes which tiles are K-split, i.e. their fp32 summation order (results agree to bf16 rounding).
+ * The split-K workspace size does not depend on it. */
+int mantis_gemm_cu_budget(int cus);
 /* Forward projections with a two-column epilogue fused in (16x16x32 ring kernels 13 / 14, NT layout).
  *   mode 1 (SwiGLU): B = [gate | up] weight [2 I, K], N = 2 I: C = A . B^T [M, 2 I] exactly as mantis_gemm_bf16_nt writes it AND
  *                    aux0 = silu(gate) * up [M, I] (bf16, row stride aux_ld) exactly as mantis_swiglu_fwd computes it (replaces
@@ -132,7 +142,7 @@ int mantis_gemm_bf16_nt_fused(const void* A, int64_t lda, const void* B, int64_t
                               const void* bias /*nullable*/, int mode, void* aux0, const void* aux1 /*mode 2*/, int64_t aux_ld, int aux_n,
                               int variant, void* workspace, int64_t workspace_bytes, void* stream);
 
-/* tile family the auto heuristic (flags bits 8-11 == 0) picks: 12 = a 256x256 ring kernel (12 or 13, see above), 1 = 128x128 generic kernel */
+/* tile family the auto heuristic (flags bits 8-11 == 0) picks: 12 = a 256x256 ring kernel (which of 12 / 13 / 14: see above), 1 = the 128x128 generic kernel */
 int mantis_gemm_pick_variant(int M, int N, int K);
 
 /* ---- fp8 linears (BASELINE configs[4] "fp8 MFMA"): an accelerated variant of the bf16 nn.Linear of the Qwen2
@@ -231,6 +241,10 @@ int mantis_clip_scale(const float* sumsq, float max_norm, float* scale_out, floa
 /* ---- CU-partitioned streams: the HBM-bound optimizer pass on one share of the compute units, the next batch's frozen vision tower on
  * the rest (software pipelining across HF:trainer.py's training_step -> optimizer.step boundary; same arithmetic, only earlier) */
 int mantis_stream_create_cu_mask(int first_cu, int n_cus, void** stream_out);
+/* A stream with the highest (level < 0), default (0) or lowest (level > 0) hardware-queue priority the device offers (hipStreamCreateWithPriority,
+ * non-blocking); levels_out (nullable) receives {greatest, least}.  Work off the critical path (the backward's weight-gradient GEMMs) queued
+ * on a lowest-priority stream is dispatched where the critical path leaves compute units idle.  The caller owns the stream. */
+int mantis_stream_create_priority(int level, void** stream_out, int* levels_out);
 int mantis_stream_destroy(void* stream);
 
 int mantis_version(void);

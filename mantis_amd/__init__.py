@@ -7,4 +7,34 @@ import os
 # RCCL stream landed on the compute stream's queue and the bucket collectives launched from inside the backward did not overlap a single
 # GEMM (0.0 of 51.9 ms) -- with 8 queues the same run overlaps 82.1 of 85.5 ms.  The variable is read when the HIP runtime initialises
 # (first device call), so it is set at import, before torch touches the GPU; an explicit user setting wins.
+import sys
+
+
+def _hip_already_up():
+    t = sys.modules.get("torch")
+    try:
+        return bool(t is not None and t.cuda.is_initialized())
+    except Exception:
+        return False
+
+
+# what the HIP runtime saw (or will see) when it initialised: the variable only counts if it was in the environment BEFORE the first
+# device call.  dp.GradReducer consults hw_queues_at_init() -- and probes the streams themselves -- instead of re-reading os.environ,
+# which after the setdefault below says 8 even when the runtime came up earlier with its default of 4.
+_HIP_UP_AT_IMPORT = _hip_already_up()
+_QUEUES_ENV_AT_IMPORT = os.environ.get("GPU_MAX_HW_QUEUES")
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+
+def hw_queues_at_init():
+    """Hardware queues the HIP runtime was (or will be) created with, as far as this process can know: the value of
+    GPU_MAX_HW_QUEUES that was in the environment when HIP initialised -- ROCm's default of 4 if HIP was already up when this package
+    was imported and the variable was not set.  A value that does not parse counts as the default."""
+    def parse(v, default):
+        try:
+            return int(str(v).strip())
+        except (TypeError, ValueError):
+            return default
+    if _HIP_UP_AT_IMPORT:
+        return parse(_QUEUES_ENV_AT_IMPORT, 4)
+    return parse(os.environ.get("GPU_MAX_HW_QUEUES"), 4)

@@ -40,6 +40,7 @@ SIGNATURES = {
     "mantis_gemm_bf16_nt": [P, L, P, L, P, L, I, I, I, P, P, L, I, P, L, P],
     "mantis_gemm_bf16_nt_fused": [P, L, P, L, P, L, I, I, I, P, I, P, P, L, I, I, P, L, P],
     "mantis_gemm_workspace_bytes": [I, I, I],
+    "mantis_gemm_cu_budget": [I],
     "mantis_gemm_pick_variant": [I, I, I],
     "mantis_fp8_quantize_ws_floats": [],
     "mantis_fp8_quantize": [P, L, I, L, I, P, L, P, L, P, P, P, I, P],
@@ -63,6 +64,7 @@ SIGNATURES = {
     "mantis_sumsq": [P, L, P, P, I, P],
     "mantis_clip_scale": [P, F, P, P, P],
     "mantis_stream_create_cu_mask": [I, I, P],
+    "mantis_stream_create_priority": [I, P, P],
     "mantis_stream_destroy": [P],
     "mantis_version": [],
 }

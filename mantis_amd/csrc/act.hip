@@ -69,9 +69,9 @@ __global__ void swiglu_bwd_kernel(const bf16_t* __restrict__ dact, const bf16_t*
 __device__ __forceinline__ float act_fwd(float x, int kind) {
     switch (kind) {
         case 0: return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
-        case 1: {
-            const float k = 0.7978845608028654f;
-            return 0.5f * x * (1.f + tanhf(k * (x + 0.044715f * x * x * x)));
+        case 1: {                  // 0.5 x (1 + tanh(u)) == x * sigmoid(2u): the same form as the GEMM epilogue (gemm.hip: gemm_act)
+            const float k2 = 2.f * 0.7978845608028654f;
+            return x * __builtin_amdgcn_rcpf(1.f + __expf(-k2 * (x + 0.044715f * x * x * x)));
         }
         case 2: return x * sigmoidf_(1.702f * x);
         default: return x * sigmoidf_(x);

@@ -37,12 +37,21 @@ __device__ __forceinline__ unsigned int pack_bf2(float lo, float hi) {
 // Wave-wide reductions on the VALU (DPP): xor 1 and xor 2 inside a quad, mirror inside 8 and inside 16 lanes -- every lane of a 16-lane
 // row then holds the row's result -- and the four rows meet through v_readlane.  No LDS round trips and no lane-index registers (the
 // six dependent ds_bpermute of the __shfl_xor form cost rmsnorm_bwd 4-5 us of 61 and seven spilled VGPRs, tools/rmsnorm_bwd_probe.hip).
-// All 64 lanes must be active.  The result is wave-uniform.
+// ALL 64 LANES MUST BE ACTIVE (full EXEC): v_readlane of lanes 0 / 16 / 32 / 48 reads whatever an inactive lane's register holds, so a
+// partially active wave gets a wrong sum silently.  That includes block_sum / block_max below, which call these: every call site
+// (norm, ce, optim, attn_dsum) is wave-uniform by construction; a caller inside a divergent branch must use __shfl_xor instead.
+// -DMANTIS_DEBUG_EXEC makes a violated precondition trap.  The result is wave-uniform.
+#ifdef MANTIS_DEBUG_EXEC
+#define MANTIS_ASSERT_FULL_EXEC() do { if (__builtin_amdgcn_read_exec() != ~0ull) __builtin_trap(); } while (0)
+#else
+#define MANTIS_ASSERT_FULL_EXEC() do { } while (0)
+#endif
 template <int CTRL>
 __device__ __forceinline__ float mantis_dpp(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float wave_sum(float v) {
+    MANTIS_ASSERT_FULL_EXEC();
     v += mantis_dpp<0xB1>(v);         // quad_perm [1,0,3,2]
     v += mantis_dpp<0x4E>(v);         // quad_perm [2,3,0,1]
     v += mantis_dpp<0x141>(v);        // row_half_mirror
@@ -53,6 +62,7 @@ __device__ __forceinline__ float wave_sum(float v) {
     return (r0 + r1) + (r2 + r3);
 }
 __device__ __forceinline__ float wave_max(float v) {
+    MANTIS_ASSERT_FULL_EXEC();
     v = fmaxf(v, mantis_dpp<0xB1>(v));
     v = fmaxf(v, mantis_dpp<0x4E>(v));
     v = fmaxf(v, mantis_dpp<0x141>(v));
@@ -62,7 +72,8 @@ __device__ __forceinline__ float wave_max(float v) {
     const float r2 = __int_as_float(__builtin_amdgcn_readlane(i, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(i, 48));
     return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
-// block-wide sum for blockDim.x <= 1024 (<=16 waves); `red` is >=16 floats of LDS; result broadcast to all threads.
+// block-wide sum for blockDim.x <= 1024 (<=16 waves); `red` is >=16 floats of LDS; result broadcast to all threads.  Every thread of
+// the block must call it with full waves (see wave_sum: blockDim.x % 64 == 0, no divergent caller).
 __device__ __forceinline__ float block_sum(float v, float* red) {
     v = wave_sum(v);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;

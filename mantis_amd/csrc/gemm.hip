@@ -44,9 +44,26 @@
 
 typedef __attribute__((address_space(3))) void lds_void;
 
-// cache policy of the operand-tile DMA: sc0 sc1 (bypass the per-CU vector L1, serve from L2).  A tile is consumed once per CU,
-// so L1 allocation only adds TCP pending-miss stalls (rocprofv3: TCP_PENDING_STALL_CYCLES 44 % of the kernel with default policy)
+template <int V> using ic_ = std::integral_constant<int, V>;
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(ic_<I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// cache policy of the operand-tile DMA (aux operand of buffer_load ... lds on gfx950: 1 = sc0, 2 = nt, 16 = sc1).  DMA_AUX: the generic
+// 128x128 kernel; DMA_AUX_A / DMA_AUX_B: the ring kernels' A (the M-side operand: activations in every layout of the step) and B (the
+// N-side operand: the weight in forward and dX, an activation in dW) streams -- compile-time, so that builds with other policies can be
+// A/B-ed (tools/build_probe_lib.sh gemm <name> -DDMA_AUX_A=17 -DDMA_AUX_B=2; measurements: profiles/r04_experiments.md)
 #define DMA_AUX 0
+#ifndef DMA_AUX_A
+#define DMA_AUX_A 0
+#endif
+#ifndef DMA_AUX_B
+#define DMA_AUX_B 0
+#endif
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page[16];
 
@@ -54,8 +71,10 @@ __device__ __forceinline__ float gemm_act(float x, int kind) {
     switch (kind) {
         case 1: return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
         case 2: {
-            const float k = 0.7978845608028654f;
-            return 0.5f * x * (1.f + tanhf(k * (x + 0.044715f * x * x * x)));
+            // 0.5 x (1 + tanh(u)) == x * sigmoid(2u): one exp and one reciprocal instead of tanhf (which was most of the SigLIP fc1 epilogue:
+            // 40 us of a 136 us launch, profiles/r04_gemm_anatomy.md); |error| <= 2e-7 |x| before the bf16 rounding
+            const float k2 = 2.f * 0.7978845608028654f;
+            return x * __builtin_amdgcn_rcpf(1.f + __expf(-k2 * (x + 0.044715f * x * x * x)));
         }
         case 3: return x / (1.f + __expf(-1.702f * x));
         default: return x;
@@ -324,6 +343,146 @@ __device__ __forceinline__ void epi_readback64(const char* __restrict__ strip, b
             }
         }
     }
+}
+
+// ---- fast read-back of the ring16 kernels (round 4).  The general read-back above takes `flags` at run time: per element it branches on
+// the activation kind, fetches the bias with 2-byte loads and -- what cost most -- loads residual / accumulate / SwiGLU operands one
+// iteration at a time, each a full memory round trip behind an s_waitcnt vmcnt(0): 22 - 33 us per tile with a residual against 7 us
+// without (profiles/r04_gemm_anatomy.md).  Here the epilogue kind is a template parameter (the launcher's run-time switch picks among
+// the handful the step uses), the bias is one 16-B load per lane, and the global operands of a whole 64-row pass are requested up front
+// -- those of the NEXT pass before the current one is computed.  Same arithmetic and rounding order as epi_readback64: bit-identical.
+// Preconditions (else the caller takes the general path): 16-B aligned C / residual, row strides % 8 == 0, all 64 columns inside N.
+#define EPRE_NONE 0
+#define EPRE_RES 1          // + residual[m, n]
+#define EPRE_ACC 2          // + C[m, n] (gradient accumulation)
+#define EPRE_SWIGLU 3       // fused SwiGLU backward: residual = [gate | up]
+template <int G>
+struct EpiPre {
+    u32x4 a[G], b[G];
+};
+// operands of iterations it0 .. it0 + G - 1 of the pass at rows m_base ..
+template <int PRE, int G>
+__device__ __forceinline__ void epi_fast_prefetch(EpiPre<G>& p, const bf16_t* __restrict__ C, int M, int N, long ldc,
+                                                  const bf16_t* __restrict__ res, long ldr, int m_base, int it0, int n, int rr) {
+    if constexpr (PRE != EPRE_NONE) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            int m = m_base + (it0 + i) * 8 + rr;
+            m = m < M ? m : M - 1;                          // rows past M: a harmless in-range address, the store is predicated
+            if constexpr (PRE == EPRE_RES) p.a[i] = *reinterpret_cast<const u32x4*>(res + (long)m * ldr + n);
+            if constexpr (PRE == EPRE_ACC) p.a[i] = *reinterpret_cast<const u32x4*>(C + (long)m * ldc + n);
+            if constexpr (PRE == EPRE_SWIGLU) {
+                p.a[i] = *reinterpret_cast<const u32x4*>(res + (long)m * ldr + n);
+                p.b[i] = *reinterpret_cast<const u32x4*>(res + (long)m * ldr + N + n);
+            }
+        }
+    }
+}
+template <bool BIAS, int ACT, int PRE, int G>
+__device__ __forceinline__ void epi_fast_finish(const EpiPre<G>& p, const char* __restrict__ strip, bf16_t* __restrict__ C, int M, int N,
+                                                long ldc, const float (&bv)[8], int m_base, int it0, int n, int rr, int cc) {
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        const int row = (it0 + i) * 8 + rr;
+        const int m = m_base + row;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(strip + row * EPI_PITCH + cc * 32);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(strip + row * EPI_PITCH + cc * 32 + 16);
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        if constexpr (BIAS) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bv[e];
+        }
+        if constexpr (ACT != 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gemm_act(bf2f(f2bf(v[e])), ACT);
+        }
+        bf16_t* cp = C + (long)m * ldc + n;
+        if constexpr (PRE == EPRE_SWIGLU) {
+            u32x4 og, ou;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gv[2] = {bf2f_lo(p.a[i][e]), bf2f_hi(p.a[i][e])};
+                const float uv[2] = {bf2f_lo(p.b[i][e]), bf2f_hi(p.b[i][e])};
+                float rg[2], ru[2];
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const float dv = bf2f(f2bf(v[2 * e + h2]));
+                    const float sg = 1.f / (1.f + __expf(-gv[h2]));
+                    const float silu = gv[h2] * sg;
+                    rg[h2] = dv * uv[h2] * (sg + silu * (1.f - sg));
+                    ru[h2] = dv * silu;
+                }
+                og[e] = pack_bf2(rg[0], rg[1]);
+                ou[e] = pack_bf2(ru[0], ru[1]);
+            }
+            if (m < M) {
+                *reinterpret_cast<u32x4*>(cp) = og;
+                *reinterpret_cast<u32x4*>(cp + N) = ou;
+            }
+        } else {
+            if constexpr (PRE == EPRE_RES) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[2 * e] = bf2f(f2bf(v[2 * e])) + bf2f_lo(p.a[i][e]);
+                    v[2 * e + 1] = bf2f(f2bf(v[2 * e + 1])) + bf2f_hi(p.a[i][e]);
+                }
+            }
+            if constexpr (PRE == EPRE_ACC) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[2 * e] += bf2f_lo(p.a[i][e]);
+                    v[2 * e + 1] += bf2f_hi(p.a[i][e]);
+                }
+            }
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+            if (m < M) *reinterpret_cast<u32x4*>(cp) = o;
+        }
+    }
+}
+// All passes of a wave's tile through its strip: pass p = (pm, pn) covers rows mw0 + pm*64 .., columns nw0 + pn*64 ..  The pass loop is
+// unrolled: rolled, all 128 / 256 accumulators stay live to the last pass and the register allocator spills hundreds of them.  The
+// global operands travel in groups of G iterations, one group ahead of the arithmetic (G = 8, a whole pass, for residual / accumulate;
+// G = 4 for the SwiGLU backward, which holds two operand sets and whose exp-heavy arithmetic covers the loads of the next half pass --
+// requesting a whole pass up front and then computing measured 4 % slower on dX(down), HBM bursts instead of a stream).
+template <int NBN, int NBM, bool BIAS, int ACT, int PRE>
+__device__ __forceinline__ void epi_fast_run(const f32x4 (&acc)[NBN][NBM], char* __restrict__ strip, bf16_t* __restrict__ C, int M, int N,
+                                             long ldc, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res, long ldr, int mw0,
+                                             int nw0, int lane) {
+    constexpr int PN = NBN / 4, NPASS = 2 * PN;
+    constexpr int G = PRE == EPRE_SWIGLU ? 4 : 8, GPP = 8 / G, NG = NPASS * GPP;
+    const int rr = lane >> 3, cc = lane & 7;
+    char* wr = strip + (lane & 15) * EPI_PITCH + (4 * (lane >> 4)) * 4;
+    EpiPre<G> cur, nxt;
+    epi_fast_prefetch<PRE, G>(cur, C, M, N, ldc, res, ldr, mw0, 0, nw0 + cc * 8, rr);
+    float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    static_for<0, NG>([&](auto gc) {
+        constexpr int g = decltype(gc)::value, pass = g / GPP, sub = g % GPP;
+        constexpr int pm = pass / PN, pn = pass % PN;
+        const int n = nw0 + pn * 64 + cc * 8;
+        if constexpr (g + 1 < NG) {
+            constexpr int p1 = (g + 1) / GPP, s1 = (g + 1) % GPP;
+            epi_fast_prefetch<PRE, G>(nxt, C, M, N, ldc, res, ldr, mw0 + (p1 / PN) * 64, s1 * G, nw0 + (p1 % PN) * 64 + cc * 8, rr);
+        }
+        if constexpr (sub == 0) {
+            if constexpr (BIAS) {
+                const u32x4 b4 = *reinterpret_cast<const u32x4*>(bias + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bv[2 * e] = bf2f_lo(b4[e]);
+                    bv[2 * e + 1] = bf2f_hi(b4[e]);
+                }
+            }
+#pragma unroll
+            for (int tm4 = 0; tm4 < 4; ++tm4)
+#pragma unroll
+                for (int tn4 = 0; tn4 < 4; ++tn4)
+                    *reinterpret_cast<f32x4*>(wr + tm4 * 16 * EPI_PITCH + tn4 * 16 * 4) = acc[pn * 4 + tn4][pm * 4 + tm4];
+        }
+        epi_fast_finish<BIAS, ACT, PRE, G>(cur, strip, C, M, N, ldc, bv, mw0 + pm * 64, sub * G, n, rr, cc);
+        if constexpr (PRE != EPRE_NONE && g + 1 < NG) cur = nxt;
+    });
 }
 
 // Epilogue of the 8-wave 256x256 kernel (32x32x16 accumulators): the MFMA layout gives every lane ONE output row, so storing from
@@ -619,11 +778,11 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(
         if (p & 1) {
             const unsigned vo = (kcB[j] < krem) ? voB[half][j] : OOB;
             const unsigned so = BKM ? (unsigned)t * (unsigned)(BK * 2) * (unsigned)ldb : (unsigned)t * (BK * 2);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, d, 16, vo, so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, d, 16, vo, so, 0, DMA_AUX_B);
         } else {
             const unsigned vo = (kcA[j] < krem) ? voA[half][j] : OOB;
             const unsigned so = AKM ? (unsigned)t * (unsigned)(BK * 2) * (unsigned)lda : (unsigned)t * (BK * 2);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, d, 16, vo, so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, d, 16, vo, so, 0, DMA_AUX_A);
         }
     };
     auto issue = [&](int t, int p) {
@@ -799,14 +958,6 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(
 //   lgkmcnt(0), vmcnt(8), s_barrier: every wave has read all of step t's slabs (free for refill) and step t+1 has landed everywhere
 //   half 1: MFMAs on fragments (t, k-half 1); shadows: read fragments (t+1, k-half 0), issue DMA (t+2: parts 2,3)
 // i.e. one barrier per K-step and a full K-step of lead for every slab, as before.
-template <int V> using ic_ = std::integral_constant<int, V>;
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(ic_<I>{});
-        static_for<I + 1, N>(f);
-    }
-}
 template <int OFF>
 __device__ __forceinline__ void lds_read_b128_v(bf16x8& dst, unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
@@ -830,16 +981,30 @@ __device__ __forceinline__ void sk_store16(const f32x4 (&acc)[NBN][NBM], float* 
 #pragma unroll
         for (int j = 0; j < NBM; ++j) reinterpret_cast<f32x4*>(slab)[(i * NBM + j) * NT + tid] = acc[i][j];
 }
+// acc += slab, eight 16-B loads in flight per lane.  The accumulators live in AGPRs and the compiler's scheduler, minimising register
+// pressure, turned `acc += slab[...]` into load -> s_waitcnt vmcnt(0) -> add, one memory round trip per 16 bytes: 32 - 64 round trips per
+// slab, 27 us (S = 2) to 108 us (S = 8) per last arriver (profiles/r04_gemm_anatomy.md).  The loads are therefore issued by hand (asm
+// volatile keeps them together) and one wait, which names the destinations, stands between them and the adds.
+__device__ __forceinline__ void sk_load8(f32x4 (&v)[8], const f32x4* __restrict__ p, int stride) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[j]) : "v"(p + (long)j * stride) : "memory");
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
+                 :
+                 : "memory");
+}
 template <int NBN, int NBM, int NT>
 __device__ __forceinline__ void sk_add16(f32x4 (&acc)[NBN][NBM], const float* __restrict__ slab, int tid) {
+    static_assert(NBM == 8, "one batch = the eight M blocks of an N block");
 #pragma unroll
-    for (int i = 0; i < NBN; ++i)
+    for (int i = 0; i < NBN; ++i) {
+        f32x4 v[8];
+        sk_load8(v, reinterpret_cast<const f32x4*>(slab) + (long)(i * NBM) * NT + tid, NT);
 #pragma unroll
-        for (int j = 0; j < NBM; ++j) {
-            const f32x4 v = reinterpret_cast<const f32x4*>(slab)[(i * NBM + j) * NT + tid];
+        for (int j = 0; j < NBM; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][j][e] += v[e];
-        }
+            for (int e = 0; e < 4; ++e) acc[i][j][e] += v[j][e];
+    }
 }
 
 // NW = 4: 2 x 2 waves of 128 x 128 (one wave per SIMD, the coolest loop: variant 13); NW = 8: 2 x 4 waves of 128 x 64 (two waves per
@@ -852,6 +1017,14 @@ __device__ __forceinline__ void sk_add16(f32x4 (&acc)[NBN][NBM], const float* __
 //   PAIR_ROPE   (2): q|k|v projection, heads of 128: first(phi) = n0 + (phi >> 6)*128 + (phi & 63), pair_dist = 64: columns below aux_n get
 //                    the rotary embedding (aux0 = cos, aux1 = sin, bf16 [M, 64], row stride aux_ld) with rope_apply's bf16 rounding
 //                    sequence (modeling_llama.py:157-158) before they are stored; columns from aux_n on (v) are stored as they are
+#ifdef RING16_STAMPS
+// timing probe (tools/gemm_anatomy.py; never in the product build): per workgroup {XCC id, HW id, unit info, s_memtime at entry / after the
+// prologue's DMA issue / at the first MFMA / at the end of the K loop / at exit}
+__device__ unsigned long long g_ring16_stamps[8192 * 8];
+#define STAMP(i) do { if (threadIdx.x == 0) stamp_[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 #define PAIR_NONE 0
 #define PAIR_SWIGLU 1
 #define PAIR_ROPE 2
@@ -863,6 +1036,22 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring16_kernel(
     const bf16_t* __restrict__ aux1, long aux_ld, int aux_n) {
     static_assert(NW == 4 || NW == 8, "4 waves of 128 x 128 or 8 waves of 128 x 64");
     static_assert(PAIR == PAIR_NONE || (!AKM && !BKM && !SWIGLU), "the pair epilogues are forward (NT) fusions");
+#ifdef RING16_STAMPS
+    unsigned long long stamp_[5] = {0, 0, 0, 0, 0};
+    struct StampOut {
+        unsigned long long* s; int bid;
+        __device__ ~StampOut() {
+            if (threadIdx.x == 0 && bid < 8192) {
+                unsigned xcc, hw;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+                unsigned long long* o = g_ring16_stamps + (size_t)bid * 8;
+                o[0] = xcc; o[1] = hw; o[2] = s[0]; o[3] = s[1]; o[4] = s[2]; o[5] = s[3]; o[6] = __builtin_amdgcn_s_memtime(); o[7] = s[4];
+            }
+        }
+    } stamp_out_{stamp_, (int)blockIdx.x};
+    STAMP(0);
+#endif
     constexpr int NBM = 8, NBN = NW == 4 ? 8 : 4;          // 16 x 16 blocks per wave along M / N
     constexpr int SLAB = 16384, RING = 10 * SLAB, PPW = 16 / NW, NMF = NBN * NBM;
     __shared__ __attribute__((aligned(16))) char smem[RING];
@@ -983,10 +1172,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring16_kernel(
         lds_void* d = (lds_void*)(smem + doff + wave_dst + j * 1024);
         if constexpr (p & 1) {
             const unsigned vo = (kcB[j] < krem) ? voB[half][j] : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, d, 16, vo, sob, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, d, 16, vo, sob, 0, DMA_AUX_B);
         } else {
             const unsigned vo = (kcA[j] < krem) ? voA[half][j] : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, d, 16, vo, soa, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, d, 16, vo, soa, 0, DMA_AUX_A);
         }
     };
     {   // prologue: steps t0 (slabs 0-3) and t0 + 1 (slabs 4-7), all four parts each
@@ -1002,6 +1191,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring16_kernel(
         });
     }
 
+    STAMP(1);
     // fragment addresses.  Row-major image: lane (r, kg) reads 16 B of row blk*16 + r at chunk kh*4 + kg, swizzled with (r >> 1) & 7
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const unsigned r16 = (unsigned)lane & 15u, kg = (unsigned)lane >> 4;
@@ -1078,6 +1268,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring16_kernel(
     if constexpr (NW == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");      // step t0 landed (this wave's pieces); step t0 + 1 may
     else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                          // still be in flight
     __builtin_amdgcn_s_barrier();
+    STAMP(2);
     const unsigned a_part = (unsigned)(2 * wm) * SLAB, b_part = (unsigned)(1 + 2 * wnh) * SLAB;
     static_for<0, NOPS>([&](auto oc) { frag_op(oc, ic_<0>{}, ic_<0>{}, lds0 + a_part, lds0 + b_part + b_row_off); });
     unsigned base = 0;                                             // slab offset of step t, part 0
@@ -1107,6 +1298,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring16_kernel(
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");           // the last MFMAs' results are read as soon as the epilogue starts
     __syncthreads();                                             // every wave's fragment reads done: the LDS becomes epilogue scratch
+    STAMP(3);
+#ifdef RING16_STAMPS
+    if (threadIdx.x == 0) stamp_[4] = ((unsigned long long)(unsigned)tile_id << 32) | ((unsigned)part << 16) | (unsigned)(bid >= full ? S : 1);
+#endif
 
     if (bid >= full) {
         const int rt = tile_id - full;
@@ -1177,7 +1372,21 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring16_kernel(
                 b1[e] = has_bias ? bf2f(bias[col1 + e]) : 0.f;
                 b2[e] = has_bias ? bf2f(bias[col2 + e]) : 0.f;
             }
-#pragma unroll 2
+            // rotary tables of the whole pass requested up front (one memory round trip per pass instead of one per iteration)
+            u32x4 vcs[64 / RPI], vss[64 / RPI];
+            const bool rot = PAIR == PAIR_ROPE && col1 < aux_n;
+            if constexpr (PAIR == PAIR_ROPE) {
+                if (rot) {
+#pragma unroll
+                    for (int it = 0; it < 64 / RPI; ++it) {
+                        int m = mw0 + pass * 64 + it * RPI + rr;
+                        m = m < M ? m : M - 1;
+                        vcs[it] = *reinterpret_cast<const u32x4*>(aux0 + (long)m * aux_ld + (phi & 63));
+                        vss[it] = *reinterpret_cast<const u32x4*>(aux1 + (long)m * aux_ld + (phi & 63));
+                    }
+                }
+            }
+#pragma unroll
             for (int it = 0; it < 64 / RPI; ++it) {
                 const int row = it * RPI + rr;
                 const int m = mw0 + pass * 64 + row;
@@ -1209,12 +1418,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring16_kernel(
                     }
                     *reinterpret_cast<u32x4*>(aux0 + (long)m * aux_ld + col1) = oa;
                 } else {
-                    u32x4 vc, vs;
-                    const bool rot = col1 < aux_n;
-                    if (rot) {
-                        vc = *reinterpret_cast<const u32x4*>(aux0 + (long)m * aux_ld + (phi & 63));
-                        vs = *reinterpret_cast<const u32x4*>(aux1 + (long)m * aux_ld + (phi & 63));
-                    }
+                    const u32x4 vc = vcs[it], vs = vss[it];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const unsigned w1 = pack_bf2(v1[2 * e], v1[2 * e + 1]);
@@ -1241,6 +1445,31 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring16_kernel(
             }
         }
         return;
+    }
+    {
+        // fast read-back (see epi_fast_run) when every column of this wave's tile is inside N and the operands are 16-B vectors; the
+        // epilogue kinds of the step are compile-time variants, anything else takes the general path below
+        const bool needs_res = flags & (EPI_RESIDUAL | EPI_SWIGLU_BWD);
+        const bool vec_ok = !(ldc & 7) && !((uintptr_t)C & 15) && (!needs_res || (!(ldr & 7) && !((uintptr_t)res & 15))) &&
+                            (!(flags & EPI_BIAS) || !((uintptr_t)bias & 15)) && (!(flags & EPI_SWIGLU_BWD) || !(N & 7));
+        if (vec_ok && nw0 + NBN * 16 <= N) {
+#define EPI_FAST(B_, A_, P_) epi_fast_run<NBN, NBM, B_, A_, P_>(acc, strip, C, M, N, ldc, bias, res, ldr, mw0, nw0, lane)
+            if constexpr (!SWIGLU) {      // the SwiGLU-backward read-back stays on the general path: its tile moves 512 KiB (gate, up in; dgate, dup
+                                          // out) and is HBM-bound either way; requesting operands ahead measured 3 - 4 % SLOWER on dX(down) (bursts)
+                switch (flags & (EPI_BIAS | EPI_ACT_MASK | EPI_RESIDUAL | EPI_ACCUM)) {
+                    case 0: EPI_FAST(false, 0, EPRE_NONE); return;
+                    case EPI_RESIDUAL: EPI_FAST(false, 0, EPRE_RES); return;
+                    case EPI_ACCUM: EPI_FAST(false, 0, EPRE_ACC); return;
+                    case EPI_BIAS: EPI_FAST(true, 0, EPRE_NONE); return;
+                    case EPI_BIAS | EPI_RESIDUAL: EPI_FAST(true, 0, EPRE_RES); return;
+                    case EPI_BIAS | (1 << EPI_ACT_SHIFT): EPI_FAST(true, 1, EPRE_NONE); return;
+                    case EPI_BIAS | (2 << EPI_ACT_SHIFT): EPI_FAST(true, 2, EPRE_NONE); return;
+                    case EPI_BIAS | (3 << EPI_ACT_SHIFT): EPI_FAST(true, 3, EPRE_NONE); return;
+                    default: break;
+                }
+            }
+#undef EPI_FAST
+        }
     }
 #pragma unroll
     for (int pm = 0; pm < 2; ++pm)
@@ -1274,6 +1503,24 @@ static int num_cus() {
     return g_num_cu[dev];
 }
 
+// CU budget of the tile scheduler.  Rounds, the K split of an incomplete last round and the kernel choice are planned for plan_cus()
+// compute units: all of the device by default; fewer when something else holds CUs for the length of a GEMM -- every RCCL channel is a
+// workgroup that cannot share a CU with a ring workgroup (160 KiB of LDS each), so with C channels busy a launch planned for 256 CUs
+// runs its "one round" as two.  MANTIS_GEMM_CUS (read once) or mantis_gemm_cu_budget() sets it; the split-K workspace is always sized
+// for the whole device, so any budget fits it.  Results are deterministic for a given budget; across budgets the K-split of the
+// remainder tiles differs, i.e. the fp32 summation order of those tiles (bf16 results agree to rounding, not bit for bit).
+static int g_cu_budget = -1;          // -1: not decided yet (environment), 0: the whole device, > 0: that many
+static int plan_cus() {
+    const int dev = num_cus();
+    if (g_cu_budget < 0) {
+        const char* e = getenv("MANTIS_GEMM_CUS");
+        const int v = e ? atoi(e) : 0;
+        g_cu_budget = v > 0 ? v : 0;
+    }
+    if (g_cu_budget == 0) return dev;
+    return g_cu_budget < 8 ? 8 : (g_cu_budget > dev ? dev : g_cu_budget);
+}
+
 // K parts for the tiles of the ring kernel's incomplete last round: minimise K-steps per part + the measured reduction cost
 // (slab write, publish, S slab reads by the last arriver ~ 8 + 1.7 S K-step equivalents; sc1 write-through slabs instead of the
 // release/acquire pair were measured equal at S = 2 and 12 % slower at S = 8).  S * rem <= #CU: ONE sub-round of split units.  Round 3
@@ -1305,8 +1552,10 @@ static int ring_split(long ntiles, int nk, int cus) {
 //   ring 256x256, 1 workgroup/CU: 1.45 per K-step + 5 K-step equivalents per round (prologue, epilogue, launch)
 //   generic 128x128, 2 workgroups/CU: 1.05 per K-step per round of 2 x #CU tiles + 5.2 equivalents
 static int gemm_pick_variant(int M, int N, int K) {
-    if (M < 512 || N < 512) return 1;
-    const int cus = num_cus(), nk = cdiv(K, BK);
+    // below two tile rows / columns the cost model decides too (M = 504 label rows of the lm_head used to fall to the 128x128 kernel
+    // -- and, on the dX side, to a transposed weight copy: 2.3 ms instead of 0.58 ms); only genuinely small operands skip it
+    if (M < 384 || N < 384) return 1;
+    const int cus = plan_cus(), nk = cdiv(K, BK);
     const long t256 = (long)cdiv(M, 256) * cdiv(N, 256), t128 = (long)cdiv(M, 128) * cdiv(N, 128);
     const int S = ring_split(t256, nk, cus);
     const long rem = t256 % cus;
@@ -1324,7 +1573,7 @@ static int gemm_pick_variant(int M, int N, int K) {
 static int ring_variant_for(int M, int N, int K, bool akm, bool bkm) {
     if (akm || bkm) return 14;
     const long tiles = (long)cdiv(M, 256) * cdiv(N, 256);
-    const long rounds = (tiles + num_cus() - 1) / num_cus();
+    const long rounds = (tiles + plan_cus() - 1) / plan_cus();
     return rounds * cdiv(K, BK) >= 400 ? 13 : 14;
 }
 
@@ -1334,7 +1583,7 @@ static int launch_gemm_ring(hipStream_t s, const bf16_t* A, const bf16_t* B, bf1
                             bf16_t* aux0 = nullptr, const bf16_t* aux1 = nullptr, long aux_ld = 0, int aux_n = 0) {
     const int tiles_m = cdiv(M, 256), tiles_n = cdiv(N, 256), nk = cdiv(K, BK);
     const long ntiles = (long)tiles_m * tiles_n;
-    const int cus = num_cus();
+    const int cus = plan_cus();
     const int rem = (int)(ntiles % cus);
     const int S = ring_split(ntiles, nk, cus);
     const int full = S > 1 ? (int)(ntiles - rem) : (int)ntiles;
@@ -1342,9 +1591,10 @@ static int launch_gemm_ring(hipStream_t s, const bf16_t* A, const bf16_t* B, bf1
     float* slabs = nullptr;
     unsigned int* cnt = nullptr;
     if (S > 1) {
-        if (!ws || ((uintptr_t)ws & 255) || ws_bytes < (long)sk_ws_bytes(cus)) return MANTIS_EINVAL;   // see mantis_gemm_workspace_bytes
+        const int dev_cus = num_cus();            // the workspace layout is that of the whole device, whatever the planning budget
+        if (!ws || ((uintptr_t)ws & 255) || ws_bytes < (long)sk_ws_bytes(dev_cus)) return MANTIS_EINVAL;   // see mantis_gemm_workspace_bytes
         cnt = (unsigned int*)ws;
-        slabs = (float*)((char*)ws + sk_cnt_bytes(cus));
+        slabs = (float*)((char*)ws + sk_cnt_bytes(dev_cus));
     }
     if constexpr (R16 != 0) {
         MANTIS_LAUNCH((gemm_nt_ring16_kernel<R16, AKM, BKM, SWIGLU, PAIR>), dim3(grid), dim3(R16 * 64), 0, s, A, B, C, M, N, K, lda, ldb, ldc,
@@ -1369,6 +1619,13 @@ static int default_ring_variant() {
 
 extern "C" {
 
+#ifdef RING16_STAMPS
+// probe builds only: copy the stamps of the last ring16 launch (n workgroups x 8 u64) to host memory
+int mantis_probe_ring16_stamps(void* host_dst, int n_wg) {
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_ring16_stamps), (size_t)n_wg * 64, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+}
+#endif
+
 // tile variant the auto heuristic picks for C[M,N] over K (12 = 256x256 ring kernel, 1 = 128x128 generic kernel)
 int mantis_gemm_pick_variant(int M, int N, int K) { return gemm_pick_variant(M, N, K); }
 
@@ -1383,7 +1640,16 @@ int mantis_gemm_workspace_bytes(int M, int N, int K) {
     if (M <= 0 && N <= 0 && K <= 0) return (int)sk_ws_bytes(cus);
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
-    return ring_split(t256, cdiv(K, BK), cus) > 1 ? (int)sk_ws_bytes(cus) : 0;
+    return ring_split(t256, cdiv(K, BK), plan_cus()) > 1 ? (int)sk_ws_bytes(cus) : 0;
+}
+
+// CU budget of the GEMM tile scheduler (see plan_cus): cus > 0 sets it (clamped to [8, #CU]), cus < 0 resets it to the whole device,
+// cus == 0 only queries.  Returns the budget now in effect.  Process-wide, like MANTIS_GEMM_CUS, which it overrides; meant to be set once,
+// before the step loop, by whoever knows how many CUs the concurrent collectives hold (dp.GradReducer: MANTIS_GEMM_CUS).
+int mantis_gemm_cu_budget(int cus) {
+    if (cus > 0) g_cu_budget = cus;
+    else if (cus < 0) g_cu_budget = 0;
+    return plan_cus();
 }
 
 int mantis_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,

@@ -157,7 +157,39 @@ __device__ __forceinline__ void f8_epilogue_lds(f32x16 (&acc)[TN][TM], char* __r
                                      acc[tn][pass * 2 + t2][4 * g4 + 2] * scale, acc[tn][pass * 2 + t2][4 * g4 + 3] * scale};
                     *reinterpret_cast<f32x4*>(strip + (t2 * 32 + (lane & 31)) * F8_EPI_PITCH + (tn * 32 + 8 * g4 + 4 * (lane >> 5)) * 4) = v;
                 }
-#pragma unroll 2
+        // round 4 (as in csrc/gemm.hip, profiles/r04_gemm_anatomy.md): with one load per iteration the read-back was a chain of memory
+        // round trips (load -> s_waitcnt vmcnt(0) -> use); when every column of the strip lies inside N (`fastv`, wave-uniform) the
+        // global operands of the whole pass -- residual / accumulate / gate|up rows, bias, per-row and per-column scales -- are requested
+        // up front.  Same arithmetic in the same order.
+        const bool fastv = vec_ok && (nw0 + 64 <= N);
+        u32x4 pa[8], pb[8];
+        float psm[8], bsv[8], sbv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { bsv[e] = 0.f; sbv[e] = 1.f; }
+        if (fastv) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                int m = mw0 + pass * 64 + it * 8 + rr;
+                m = m < M ? m : M - 1;
+                if constexpr (SWIGLU) {
+                    pa[it] = *reinterpret_cast<const u32x4*>(res + (long)m * ldr + n);
+                    pb[it] = *reinterpret_cast<const u32x4*>(res + (long)m * ldr + N + n);
+                } else {
+                    if (flags & F8_EPI_RESIDUAL) pa[it] = *reinterpret_cast<const u32x4*>(res + (long)m * ldr + n);
+                    if (flags & F8_EPI_ACCUM) pb[it] = *reinterpret_cast<const u32x4*>(C + (long)m * ldc + n);
+                }
+                if (flags & F8_EPI_VECSCALE) psm[it] = sa_vec[m];
+            }
+            if (flags & F8_EPI_VECSCALE) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sbv[e] = sb_vec[n + e];
+            }
+            if (flags & F8_EPI_BIAS) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bsv[e] = bf2f(bias[n + e]);
+            }
+        }
+#pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int row = it * 8 + rr;
             const int m = mw0 + pass * 64 + row;
@@ -167,21 +199,31 @@ __device__ __forceinline__ void f8_epilogue_lds(f32x16 (&acc)[TN][TM], char* __r
             float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             const bool full = vec_ok && (n + 8 <= N);
             if (flags & F8_EPI_VECSCALE) {          // per-row scales of both operands (`scale` is 1 then): out[m, n] = acc * (sa[m] * sb[n])
-                const float sm = sa_vec[m];
+                if (fastv) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (n + e < N) v[e] *= sm * sb_vec[n + e];
+                    for (int e = 0; e < 8; ++e) v[e] *= psm[it] * sbv[e];
+                } else {
+                    const float sm = sa_vec[m];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (n + e < N) v[e] *= sm * sb_vec[n + e];
+                }
             }
             if (flags & F8_EPI_BIAS) {
+                if (fastv) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (n + e < N) v[e] += bf2f(bias[n + e]);
+                    for (int e = 0; e < 8; ++e) v[e] += bsv[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (n + e < N) v[e] += bf2f(bias[n + e]);
+                }
             }
             bf16_t* cp = C + (long)m * ldc + n;
             if constexpr (SWIGLU) {
                 if (full) {
-                    const u32x4 g = *reinterpret_cast<const u32x4*>(res + (long)m * ldr + n);
-                    const u32x4 u = *reinterpret_cast<const u32x4*>(res + (long)m * ldr + N + n);
+                    const u32x4 g = fastv ? pa[it] : *reinterpret_cast<const u32x4*>(res + (long)m * ldr + n);
+                    const u32x4 u = fastv ? pb[it] : *reinterpret_cast<const u32x4*>(res + (long)m * ldr + N + n);
                     u32x4 og, ou;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -229,7 +271,7 @@ __device__ __forceinline__ void f8_epilogue_lds(f32x16 (&acc)[TN][TM], char* __r
             if (SWIGLU) continue;
             if (full) {
                 if (flags & F8_EPI_RESIDUAL) {
-                    const u32x4 rv = *reinterpret_cast<const u32x4*>(res + (long)m * ldr + n);
+                    const u32x4 rv = fastv ? pa[it] : *reinterpret_cast<const u32x4*>(res + (long)m * ldr + n);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         v[2 * e] = bf2f(f2bf(v[2 * e])) + bf2f_lo(rv[e]);
@@ -237,7 +279,7 @@ __device__ __forceinline__ void f8_epilogue_lds(f32x16 (&acc)[TN][TM], char* __r
                     }
                 }
                 if (flags & F8_EPI_ACCUM) {
-                    const u32x4 cv = *reinterpret_cast<const u32x4*>(cp);
+                    const u32x4 cv = fastv ? pb[it] : *reinterpret_cast<const u32x4*>(cp);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         v[2 * e] += bf2f_lo(cv[e]);

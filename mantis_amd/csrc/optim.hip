@@ -103,6 +103,22 @@ int mantis_stream_create_cu_mask(int first_cu, int n_cus, void** stream_out) {
     return MANTIS_OK;
 }
 
+// A stream of the LOWEST (level < 0 ... > 0: -1 highest, 0 default, 1 lowest; clamped to what the device offers) hardware-queue
+// priority.  The backward's weight-gradient GEMMs are off the critical path: queued on a lowest-priority stream, their workgroups are
+// dispatched where the critical path's kernels leave compute units idle (incomplete last tile rounds, tile epilogues) instead of
+// sharing every round with them.  levels_out (nullable): {greatest, least} priority values of the device.
+int mantis_stream_create_priority(int level, void** stream_out, int* levels_out) {
+    if (!stream_out) return MANTIS_EINVAL;
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return MANTIS_ELAUNCH;
+    if (levels_out) { levels_out[0] = greatest; levels_out[1] = least; }
+    const int prio = level < 0 ? greatest : (level > 0 ? least : 0);
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio) != hipSuccess) return MANTIS_ELAUNCH;
+    *stream_out = (void*)s;
+    return MANTIS_OK;
+}
+
 int mantis_stream_destroy(void* stream) { return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? MANTIS_OK : MANTIS_ELAUNCH; }
 
 int mantis_sumsq_partials(int64_t n) { return SUMSQ_BLOCKS; }

@@ -49,11 +49,52 @@ class GradReducer:
         self._force = os.environ.get("MANTIS_DP_FORCE") == "1" and dist.is_initialized()
         self.stats = dict(steps=0, buckets=0, bytes=0, exposed_ms=[])
         self._wait_events = []
-        if self.active and int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 8:
-            import warnings
-            warnings.warn("GPU_MAX_HW_QUEUES < 8: RCCL's stream may share a hardware queue with the compute stream, which serialises the "
-                          "bucket collectives with the backward's kernels (no overlap; profiles/r03_dp_world1.md).  Import mantis_amd before "
-                          "the first GPU call, or export GPU_MAX_HW_QUEUES=8.")
+        self.hw_queues = None           # (queues at HIP init, did a probe collective run beside the busy compute stream?, process groups re-created)
+        if self.active:
+            self._check_hardware_queues()
+
+    def _check_hardware_queues(self):
+        """The bucket collectives overlap the backward only if RCCL's stream sits on another HSA hardware queue than the compute stream
+        (profiles/r03_dp_world1.md: on a shared queue 0.0 of 51.9 ms of reduce kernels overlapped a GEMM).  ROCm deals streams onto its
+        GPU_MAX_HW_QUEUES queues round-robin in creation order (profiles/r04_rccl_queue_probe.md: with 8 queues RCCL's stream shares
+        the compute stream's queue exactly when 8 streams were created before it, with the default 4 queues also when none was), so
+        neither the environment nor a count settles it -- the thing itself is tested: on a GPU with RCCL, a tiny all-reduce of the
+        process group is launched while the compute stream is busy for ~15 ms and must complete long before the compute stream does
+        (`rccl_overlap_probe`; collective, every rank runs it at construction and the ranks agree on the verdict).  On a collision a
+        NEW process group over the same ranks is created -- its RCCL stream takes the next queue -- and probed, up to three times;
+        if none overlaps, that is an ERROR (a silently serialised exchange costs ~the whole all-reduce time per step;
+        MANTIS_DP_ALLOW_SHARED_QUEUE=1: warn only).  Fewer than 8 queues at HIP initialisation (mantis_amd.hw_queues_at_init: what the
+        runtime saw, not what os.environ says after the package's own setdefault) only warns: the probe decides."""
+        import warnings
+        import mantis_amd
+        q = mantis_amd.hw_queues_at_init()
+        overlapped, regrouped = None, 0
+        if torch.cuda.is_available() and dist.is_initialized() and dist.get_backend(self.pg) == "nccl":
+            for attempt in range(4):
+                ok = rccl_overlap_probe(self.pg)
+                flag = torch.tensor([1 if ok else 0], device=f"cuda:{torch.cuda.current_device()}", dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)          # one verdict for all ranks
+                overlapped = bool(int(flag.item()))
+                if overlapped or attempt == 3:
+                    break
+                ranks = dist.get_process_group_ranks(self.pg if self.pg is not None else dist.group.WORLD)
+                self.pg = dist.new_group(ranks=ranks, backend="nccl")               # a new communicator: its stream takes the next queue
+                regrouped += 1
+        self.hw_queues = (q, overlapped, regrouped)
+        if q < 8:
+            warnings.warn(f"GPU_MAX_HW_QUEUES was {q} when HIP initialised: with so few hardware queues the side streams of the step (RCCL, "
+                          "gradient norm, prefetch) share queues with the compute stream more often.  Export GPU_MAX_HW_QUEUES=8 (or `import "
+                          "mantis_amd`) BEFORE the first GPU call of the process.")
+        if overlapped is not False:
+            return
+        msg = (f"RCCL's stream shares a hardware queue with the compute stream (GPU_MAX_HW_QUEUES at HIP initialisation: {q}; a probe "
+               f"all-reduce did not run beside a busy compute stream, also not on {regrouped} freshly created process group(s)): the "
+               "bucket collectives would be serialised with the backward's kernels instead of overlapping them "
+               "(profiles/r03_dp_world1.md, profiles/r04_rccl_queue_probe.md).")
+        if os.environ.get("MANTIS_DP_ALLOW_SHARED_QUEUE") == "1":
+            warnings.warn(msg)
+        else:
+            raise RuntimeError(msg + "  (MANTIS_DP_ALLOW_SHARED_QUEUE=1 downgrades this to a warning.)")
 
     @property
     def active(self):
@@ -127,6 +168,76 @@ class GradReducer:
         self.stats["exposed_ms"] += [a.elapsed_time(b) for a, b in self._wait_events]
         self._wait_events = []
         return self.stats["exposed_ms"]
+
+
+def hw_queue_probe(n_streams=7, busy_mib=512, passes=64):
+    """How many of `n_streams` fresh streams execute concurrently with the current stream.  The current stream is kept busy for ~15 ms
+    (elementwise passes over a scratch buffer); each side stream -- warmed first: a stream's hardware queue is created at its first
+    launch, which takes milliseconds -- then runs one tiny kernel.  A side stream on its own hardware queue finishes within microseconds
+    of its launch; one that shares the compute stream's queue finishes after the busy work.  Counted as concurrent: finished in under a
+    quarter of the busy time."""
+    dev = torch.cuda.current_device()
+    busy = torch.empty(busy_mib << 20, dtype=torch.uint8, device=f"cuda:{dev}")
+    tiny = [torch.zeros(64, device=f"cuda:{dev}") for _ in range(n_streams)]
+    side = [torch.cuda.Stream() for _ in range(n_streams)]
+    busy.fill_(1)                                           # first touch outside the timed part
+    for s, t in zip(side, tiny):
+        with torch.cuda.stream(s):
+            t.add_(1.0)                                     # first launch on the stream: creates its queue
+    torch.cuda.synchronize()
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    done = [torch.cuda.Event(enable_timing=True) for _ in side]
+    start.record()
+    for _ in range(passes):
+        busy.add_(1)
+    end.record()
+    for s, t, e in zip(side, tiny, done):
+        with torch.cuda.stream(s):
+            s.wait_event(start)
+            t.add_(1.0)
+            e.record()
+    torch.cuda.synchronize()
+    total = start.elapsed_time(end)
+    return sum(1 for e in done if start.elapsed_time(e) < 0.25 * total)
+
+
+def rccl_overlap_probe(pg=None, attempts=3, busy_mib=512, passes=64, op=None):
+    """Does a collective of process group `pg` execute WHILE the current (compute) stream is busy?  The compute stream runs ~15 ms of
+    elementwise passes; a tiny all-reduce is launched from a helper stream that only waits for the START of that work (so RCCL's stream
+    has no dependency on the busy kernels -- in the step the bucket collectives likewise depend only on kernels already queued), and
+    observer streams time its completion.  A helper or observer stream may itself land on the compute stream's hardware queue (streams
+    are dealt round-robin onto the queues), hence `attempts` rounds with fresh streams: overlap seen in ANY round means RCCL's stream
+    has its own queue.  Collective: every rank of `pg` must call it (same number of all-reduces on every rank, no early exit)."""
+    dev = torch.cuda.current_device()
+    busy = torch.empty(busy_mib << 20, dtype=torch.uint8, device=f"cuda:{dev}")
+    tiny = torch.zeros(64, device=f"cuda:{dev}")
+    busy.fill_(1)
+    op = dist.ReduceOp.AVG if op is None else op            # AVG: what the reducer issues (a kernel even on one rank)
+    dist.all_reduce(tiny, op=op, group=pg)                  # communicator + RCCL stream warm
+    seen = False
+    for _ in range(attempts):
+        launch, obs = torch.cuda.Stream(), [torch.cuda.Stream() for _ in range(2)]
+        for st in [launch] + obs:
+            with torch.cuda.stream(st):
+                tiny.add_(0.0)                              # first launch on a stream creates its queue (milliseconds)
+        torch.cuda.synchronize()
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        done = [torch.cuda.Event(enable_timing=True) for _ in obs]
+        start.record()
+        for _ in range(passes):
+            busy.add_(1)
+        end.record()
+        with torch.cuda.stream(launch):
+            launch.wait_event(start)
+            work = dist.all_reduce(tiny, op=op, group=pg, async_op=True)
+        for st, e in zip(obs, done):
+            with torch.cuda.stream(st):
+                work.wait()
+                e.record()
+        torch.cuda.synchronize()
+        total = start.elapsed_time(end)
+        seen = seen or min(start.elapsed_time(e) for e in done) < 0.25 * total
+    return seen
 
 
 def shard_batch(global_batch_size, rank, world):

@@ -140,7 +140,13 @@ class LlavaEngine:
             feats, N = self.vision_forward(self._pixels_to_device(pv, dev))
             done = torch.cuda.Event()
             done.record(stream)
-        self._prefetched = (pv, feats, N, done)
+        # one slot per in-flight batch: with the early mode (MantisHipTrainer.prefetch_early) the tower of batch i+1 is enqueued before
+        # step i has picked up its own features
+        if not isinstance(getattr(self, "_prefetched", None), dict):
+            self._prefetched = {}
+        self._prefetched[id(pv)] = (pv, feats, N, done)
+        while len(self._prefetched) > 2:                   # a prefetched batch that never arrives must not pile up
+            self._prefetched.pop(next(iter(self._prefetched)))
 
     # ------------------------------------------------------------------------------------------------ full step
     def step(self, input_ids, attention_mask, labels, pixel_values, grad_scale=1.0, loss_scale=1.0, compute_grads=True,
@@ -169,7 +175,8 @@ class LlavaEngine:
         I = 0
         N = 1
         if pixel_values is not None and T != 1:
-            pre, self._prefetched = getattr(self, "_prefetched", None), None
+            slots = getattr(self, "_prefetched", None)
+            pre = slots.pop(id(pixel_values), None) if isinstance(slots, dict) else None
             if pre is not None and pre[0] is pixel_values and record is None:
                 feats, N = pre[1], pre[2]                       # computed ahead on another stream (prefetch_vision)
                 torch.cuda.current_stream().wait_event(pre[3])

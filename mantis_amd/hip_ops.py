@@ -696,8 +696,13 @@ class SideStream:
     (GPU_MAX_HW_QUEUES, mantis_amd/__init__.py) its workgroups fill the compute units that the critical path's kernels leave idle in
     their incomplete last tile rounds."""
 
-    def __init__(self):
-        self.stream = torch.cuda.Stream()
+    def __init__(self, priority=None):
+        """priority: None = a plain torch stream; "low" / "high" = a stream on the lowest- / highest-priority hardware queue the device offers
+        (mantis_stream_create_priority): on "low" the side work only takes compute units the current stream's kernels leave idle."""
+        if priority is None:
+            self.stream = torch.cuda.Stream()
+        else:
+            self.stream = priority_stream({"low": 1, "high": -1}[priority])
 
     def run(self, fn, *inputs):
         ev = torch.cuda.Event()
@@ -713,17 +718,27 @@ class SideStream:
         torch.cuda.current_stream().wait_stream(self.stream)
 
 
+def priority_stream(level):
+    """torch stream on a hardware queue of the highest (level < 0) / default (0) / lowest (level > 0) priority."""
+    import ctypes
+    h = ctypes.c_void_p()
+    _lib.check(_L.mantis_stream_create_priority(int(level), ctypes.byref(h), None), "stream_create_priority")
+    return torch.cuda.ExternalStream(h.value, device=torch.device("cuda", torch.cuda.current_device()))
+
+
 _SIDE = {}
 
 
 def side_stream():
-    """The process' side stream for the current device when MANTIS_DW_STREAM=1, else None (everything on the current stream)."""
-    if _os.environ.get("MANTIS_DW_STREAM", "0") != "1":
+    """The process' side stream for the current device when MANTIS_DW_STREAM is 1 (a plain stream) or "low" (a stream on the
+    lowest-priority hardware queue), else None (everything on the current stream)."""
+    mode = _os.environ.get("MANTIS_DW_STREAM", "0")
+    if mode not in ("1", "low"):
         return None
     dev = torch.cuda.current_device()
     s = _SIDE.get(dev)
     if s is None:
-        s = _SIDE[dev] = SideStream()
+        s = _SIDE[dev] = SideStream("low" if mode == "low" else None)
     return s
 
 

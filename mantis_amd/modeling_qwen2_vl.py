@@ -299,7 +299,7 @@ class Qwen2VLEngine:
         # since the last one), so the fp8 weight copies are reused; any other caller gets a fresh quantisation every step
         self.weights_unchanged = False
         self._side = None                    # side stream of prefetch_vision
-        self._prefetched = None              # (pixel_values object, image rows, done event)
+        self._prefetched = {}                # id(pixel_values object) -> (pixel_values object, image rows, done event)
 
     # ------------------------------------------------------------------ software pipelining of the frozen tower
     def prefetch_vision(self, inputs, after_event=None, stream=None):
@@ -323,7 +323,9 @@ class Qwen2VLEngine:
             img = self.vision_forward(pix, grids)
             done = torch.cuda.Event()
             done.record(stream)
-        self._prefetched = (pv, img, done)
+        self._prefetched[id(pv)] = (pv, img, done)
+        while len(self._prefetched) > 2:                   # a prefetched batch that never arrives must not pile up
+            self._prefetched.pop(next(iter(self._prefetched)))
 
     def step_from_batch(self, inputs, **kw):
         if kw.get("segment_ids") is None and inputs.get("segment_ids") is not None:
@@ -405,7 +407,7 @@ class Qwen2VLEngine:
             if image_grid_thw is None:
                 raise ValueError("pixel_values without image_grid_thw")
             grids = [tuple(int(v) for v in g) for g in torch.as_tensor(image_grid_thw).tolist()]
-            pre, self._prefetched = self._prefetched, None
+            pre = self._prefetched.pop(id(pixel_values), None)
             if pre is not None and pre[0] is pixel_values and record is None:
                 img = pre[1]                                   # computed ahead on the side stream (prefetch_vision)
                 torch.cuda.current_stream().wait_event(pre[2])

@@ -82,6 +82,14 @@ class MantisHipTrainer:
             if batch["labels"].numel() != batch["input_ids"].numel():
                 raise ValueError(f"packed labels {tuple(batch['labels'].shape)} do not cover the packed row {tuple(batch['input_ids'].shape)}")
             batch["labels"] = batch["labels"].reshape(batch["input_ids"].shape)
+        if next_inputs is not None and getattr(self, "prefetch_early", False) and hasattr(model.engine, "prefetch_vision"):
+            # early mode: the next batch's frozen tower is queued BEFORE this step's kernels, on `prefetch_stream` (meant to be a stream of
+            # the lowest hardware-queue priority, hip_ops.priority_stream): its workgroups take the compute units this step's kernels
+            # leave idle (incomplete tile rounds, epilogues) during the whole forward + backward
+            ev = torch.cuda.Event()
+            ev.record()
+            model.engine.prefetch_vision(next_inputs, after_event=ev, stream=getattr(self, "prefetch_stream", None))
+            next_inputs = None
         out = model.engine.step_from_batch(batch, grad_scale=1.0 / ga, loss_scale=1.0 / ga, compute_grads=True,
                                            overwrite_grads=overwrite, on_bucket_ready=hook, segment_ids=seg)
         if reduce_now:

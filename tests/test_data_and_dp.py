@@ -245,3 +245,86 @@ def test_grad_buckets_tile_the_arena_in_backward_order():
     for i in range(model.config.text_config.num_hidden_layers):
         d, g, a = b[("layer", i, "down")], b[("layer", i, "gu")], b[("layer", i, "attn")]
         assert a.data_ptr() < g.data_ptr() < d.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------------ hardware-queue guard
+def test_hw_queues_at_init_reflects_what_the_runtime_saw(monkeypatch):
+    """`import mantis_amd` setdefaults GPU_MAX_HW_QUEUES=8, but that only counts if HIP was not up yet: when torch touched the GPU first
+    the runtime has its default of 4 although os.environ now says 8; a value that does not parse counts as the default."""
+    import mantis_amd
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
+    monkeypatch.setattr(mantis_amd, "_HIP_UP_AT_IMPORT", False)
+    assert mantis_amd.hw_queues_at_init() == 8
+    monkeypatch.setattr(mantis_amd, "_HIP_UP_AT_IMPORT", True)
+    monkeypatch.setattr(mantis_amd, "_QUEUES_ENV_AT_IMPORT", None)
+    assert mantis_amd.hw_queues_at_init() == 4                      # HIP came up before the import, variable absent at that time
+    monkeypatch.setattr(mantis_amd, "_QUEUES_ENV_AT_IMPORT", "16")
+    assert mantis_amd.hw_queues_at_init() == 16                     # the user had exported it: that is what the runtime saw
+    monkeypatch.setattr(mantis_amd, "_QUEUES_ENV_AT_IMPORT", "eight")
+    assert mantis_amd.hw_queues_at_init() == 4
+    monkeypatch.setattr(mantis_amd, "_HIP_UP_AT_IMPORT", False)
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "lots")
+    assert mantis_amd.hw_queues_at_init() == 4
+
+
+def _queue_guard_worker(q):
+    import os
+    import warnings
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", MANTIS_DP_FORCE="1")
+    import torch
+    import torch.distributed as dist
+    import mantis_amd
+    from mantis_amd.dp import GradReducer
+    dist.init_process_group("gloo", rank=0, world_size=1)
+
+    class M:
+        pass
+    out = {}
+    import mantis_amd.dp as dp
+    mantis_amd._HIP_UP_AT_IMPORT, mantis_amd._QUEUES_ENV_AT_IMPORT = True, None       # "torch touched the GPU before the import"
+    with warnings.catch_warnings(record=True) as w:                                   # few queues alone: a warning (the probe decides)
+        warnings.simplefilter("always")
+        r = GradReducer(M())
+        out["warned"] = any("GPU_MAX_HW_QUEUES was 4" in str(x.message) for x in w) and r.hw_queues == (4, None, 0)
+    mantis_amd._HIP_UP_AT_IMPORT = False
+    r = GradReducer(M())
+    out["ok"] = r.hw_queues == (8, None, 0)
+    # the decision logic with the probe's verdicts simulated (gloo has no stream to probe): collision -> new group -> overlap
+    verdicts = iter([False, False, True])
+    real = (dp.rccl_overlap_probe, torch.cuda.is_available, dist.get_backend, dist.new_group, dist.all_reduce)
+    made = []
+    dp.rccl_overlap_probe = lambda pg=None, **k: next(verdicts)
+    dp.torch.cuda.is_available = lambda: True
+    dp.torch.cuda.current_device = lambda: 0
+    dp.dist.get_backend = lambda pg=None: "nccl"
+    dp.dist.new_group = lambda ranks=None, backend=None: (made.append(tuple(ranks)), dist.group.WORLD)[1]
+    dp.dist.all_reduce = lambda t, op=None, group=None: None
+    dp.torch.tensor = lambda v, device=None, dtype=None: torch.as_tensor(v, dtype=dtype)
+    try:
+        r = GradReducer(M())
+        out["regrouped"] = r.hw_queues == (8, True, 2) and made == [(0,), (0,)]
+        verdicts = iter([False] * 4)
+        try:
+            GradReducer(M())
+            out["raised"] = False
+        except RuntimeError as e:
+            out["raised"] = "shares a hardware queue" in str(e)
+    finally:
+        dp.rccl_overlap_probe, dp.torch.cuda.is_available, dp.dist.get_backend, dp.dist.new_group, dp.dist.all_reduce = real
+        dp.torch.tensor = torch.tensor
+    dist.destroy_process_group()
+    q.put(out)
+
+
+def test_grad_reducer_refuses_a_shared_hardware_queue():
+    """an ACTIVE reducer warns when the runtime was initialised with fewer than 8 hardware queues (judged by what the runtime saw, not
+    by os.environ after the package's own setdefault); when the probe collective does not overlap it moves to a fresh process group,
+    and fails if none overlaps"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_queue_guard_worker, args=(q,))
+    p.start()
+    out = q.get(timeout=120)
+    p.join(30)
+    assert out == dict(raised=True, warned=True, ok=True, regrouped=True), out

@@ -64,11 +64,11 @@ def test_gemm_identity_is_exact_in_every_layout(M, N):
     k = _k()
     a = _rnd(M, N, seed=M)                               # K = N, B = identity
     eye = torch.eye(N, device=DEV, dtype=BF)
-    for variant in (1, 2, 12):
+    for variant in (1, 2, 12, 13, 14):                   # 13 / 14: the ring16 kernels the step actually runs
         assert torch.equal(k.gemm_nt(a, eye, variant=variant), a), f"NT variant {variant}"
         assert torch.equal(k.gemm_nt(a, eye, b_kmajor=True, variant=variant), a), f"NN variant {variant}"
     at = a.t().contiguous()                              # [K=N, M]: K-major A
-    for variant in (1, 12):
+    for variant in (1, 12, 13, 14):
         assert torch.equal(k.gemm_nt(at, eye, a_kmajor=True, b_kmajor=True, variant=variant), a), f"TN variant {variant}"
 
 
