@@ -390,13 +390,15 @@ def main():
                     help="finetune: projector + LLM trainable (the headline metric); pretrain: only multi_modal_projector "
                          "(the reference's stage 1, train_mllava.py:177-181)")
     ap.add_argument("--no-pack", action="store_true", help="Idefics2 config: feed the samples as a batch instead of one packed row")
-    ap.add_argument("--prefetch", action="store_true",
-                    help="hand the next batch to training_step: the frozen vision tower of batch i+1 is enqueued on a side stream beside clip "
-                         "+ AdamW of step i, the optimizer on --adam-cus compute units and the tower on the rest (CU-masked streams).  Off "
-                         "by default: measured slower for every split (headline 297 -> 320-344 ms; profiles/r02_experiments.md)")
-    ap.add_argument("--prefetch-early", action="store_true",
-                    help="with --prefetch: queue the next batch's frozen tower at the START of the step on a stream of the lowest hardware-queue "
-                         "priority, so that it fills the compute units the step's own kernels leave idle (instead of beside the optimizer)")
+    ap.add_argument("--vision-prefetch", default="early", choices=["early", "optimizer", "off"],
+                    help="what training_step does with the NEXT batch (what a DataLoader with prefetch_factor already holds).  early (default): "
+                         "its frozen vision tower is queued at the START of the step on a stream of the lowest hardware-queue priority and "
+                         "fills the compute units the step's own kernels leave idle in incomplete tile rounds (measured -4 ... -5 ms per "
+                         "step, profiles/r04_experiments.md 3; every timed step still computes exactly one tower forward: the next "
+                         "batch's instead of its own).  optimizer: queued behind the backward, beside clip + AdamW on CU-masked streams "
+                         "(--adam-cus; measured slower, profiles/r02_experiments.md).  off: every step computes its own tower in line")
+    ap.add_argument("--prefetch", action="store_true", help="alias of --vision-prefetch optimizer (round-2 flag)")
+    ap.add_argument("--prefetch-early", action="store_true", help="alias of --vision-prefetch early")
     ap.add_argument("--adam-cus", type=int, default=192, help="with --prefetch: compute units given to the optimizer pass")
     ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -494,7 +496,12 @@ def main():
     # (+3.5 ms) than the separate pass they replace (-3.2 ms), so the default stays off.
     overlap = opt is not None and os.environ.get("MANTIS_NORM_OVERLAP", "0") == "1"
     trainer = MantisHipTrainer(model, gradient_accumulation_steps=1, reducer=reducer, optimizer=opt if overlap else None)
-    if args.prefetch and opt is not None and hasattr(model.engine, "prefetch_vision"):
+    vmode = "early" if args.prefetch_early else ("optimizer" if args.prefetch else args.vision_prefetch)
+    if not on_gpu or not hasattr(model.engine, "prefetch_vision") or (vmode == "optimizer" and opt is None):
+        vmode = "off"
+    args.prefetch = vmode != "off"
+    args.prefetch_early = vmode == "early"
+    if args.prefetch:
         # CU partition: clip + AdamW on `--adam-cus` compute units (HBM-bound: 192 CUs stream as fast as 256), the next batch's frozen
         # tower on the others -- the two masked streams run side by side (tools/cu_mask_probe.hip)
         # `--adam-cus 0`: no CU partition -- the tower on a plain side stream beside the optimizer pass on the compute stream
@@ -608,7 +615,12 @@ def main():
             def _family(entries):
                 t_ms = sum(x[3].elapsed_time(x[4]) for x in entries)
                 return t_ms, sum(x[1] for x in entries), sum(x[2] for x in entries)
-            all_gemms = timer                                        # every GEMM launch of the timed steps (bf16 and fp8)
+            # every GEMM launch of the timed steps (bf16 and fp8) on the COMPUTE stream.  With --vision-prefetch early the next batch's
+            # frozen tower runs on a lowest-priority side stream, where a launch's event-to-event time is mostly waiting for compute
+            # units: those launches are not "the kernel's launch duration" and are reported beside the family, not inside it
+            main_stream = torch.cuda.current_stream().cuda_stream if on_gpu else None
+            side_gemms = [x for x in timer if len(x) > 6 and x[6] != main_stream]
+            all_gemms = [x for x in timer if not (len(x) > 6 and x[6] != main_stream)]
             if args.gemm_table:
                 write_gemm_table(args.gemm_table, [x for x in all_gemms if x[0] == "gemm_nt_kernel"], args.steps, args.config, ms)
             if args.gemm_series:
@@ -646,6 +658,11 @@ def main():
                                  "tools/pmc_step_report.py; bytes/launch on the L2 memory side (Infinity-Cache hits included)",
                             traffic_bytes_per_launch=gf.get("traffic_bytes_per_launch"),
                             mfma_busy_pct=((pmc or {}).get("step") or {}).get("mfma_busy_pct")),
+                        prefetch_stream_gemms=None if not side_gemms else dict(
+                            note="GEMM launches of the next batch's frozen tower on the lowest-priority prefetch stream (--vision-prefetch "
+                                 "early): event-to-event times there include waiting for compute units, so they are outside `achieved`",
+                            launches_per_step=len(side_gemms) // args.steps, flops_per_step=sum(x[1] for x in side_gemms) / args.steps,
+                            event_ms_per_step=round(sum(x[3].elapsed_time(x[4]) for x in side_gemms) / args.steps, 1)),
                         algorithmic_bytes_per_launch=round(tot_by / len(family)),
                         launches_per_step=len(family) // args.steps,
                         avg_launch_us=round(1e3 * tot_ms / len(family), 1), gemm_ms_per_step=round(tot_ms / args.steps, 1),
@@ -716,7 +733,7 @@ def main():
                                flop_per_sample=flop_per_sample,
                                parallelism=f"dp{world}", optimizer=not args.no_optimizer, stage=args.stage,
                                packed=bool(idefics and not args.no_pack),
-                               vision_prefetch=bool(args.prefetch and hasattr(model.engine, "prefetch_vision"))),
+                               vision_prefetch=vmode),
                    roofline=roof, cpu_baseline=cpu, dp=dp)
         print(json.dumps(out), flush=True)
     if world > 1 or force_dp:

@@ -100,7 +100,7 @@ def gemm_nt(a, b, bias=None, act=None, residual=None, out=None, accumulate=False
         by = 2.0 * (M * K + N * K + M * N * (1 + (residual is not None) + bool(accumulate)))
         lay = ("T" if a_kmajor else "N") + ("N" if b_kmajor else "T")      # A^T? / B as [N,K] ("T": B^T is applied) -- NT = forward, NN = dX, TN = dW
         epi = "+".join(x for x, on in (("bias", bias is not None), (str(act), act is not None), ("res", residual is not None), ("acc", accumulate)) if on)
-        prof.append(("gemm_nt_kernel", 2.0 * M * N * K, by, e0, e1, (M, N, K, lay, epi or "-")))
+        prof.append(("gemm_nt_kernel", 2.0 * M * N * K, by, e0, e1, (M, N, K, lay, epi or "-"), _stream()))
     return out
 
 
@@ -284,7 +284,7 @@ def _gemm_fused(a, b, out, mode, aux0, aux1, aux_ld, aux_n, bias, variant, extra
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
         prof.append(("gemm_nt_kernel", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N) + extra_bytes, e0, e1,
-                     (M, N, K, "NT", ("swiglu" if mode == 1 else "rope") + ("+bias" if bias is not None else ""))))
+                     (M, N, K, "NT", ("swiglu" if mode == 1 else "rope") + ("+bias" if bias is not None else "")), _stream()))
     return True
 
 
@@ -336,7 +336,7 @@ def linear_dx_swiglu(dy, w_down, gu, variant=0):
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        prof.append(("gemm_nt_kernel", 2.0 * M * I * d, 2.0 * (M * d + I * d + 4 * M * I), e0, e1, (M, I, d, "NN", "swiglu_bwd")))
+        prof.append(("gemm_nt_kernel", 2.0 * M * I * d, 2.0 * (M * d + I * d + 4 * M * I), e0, e1, (M, I, d, "NN", "swiglu_bwd"), _stream()))
     return dgu
 
 

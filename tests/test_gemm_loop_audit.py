@@ -1,0 +1,24 @@
+"""Build audit of the ring GEMM kernels' K loops (tools/gemm_loop_audit.py): no register-allocator traffic (`v_accvgpr_*`, `scratch_*`)
+and no stray global accesses between the MFMAs of any ring / ring16 instantiation.  A change elsewhere in the kernel can put them
+there silently (round 4: a K-split reduction variant cost +11 % on every NN launch this way); parity tests cannot see it."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(os.environ.get("MANTIS_SKIP_BUILD_AUDIT") == "1", reason="MANTIS_SKIP_BUILD_AUDIT=1")
+def test_ring_gemm_k_loops_are_clean():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gemm_loop_audit as A
+    asm = A.compile_asm(os.path.join(ROOT, "mantis_amd", "csrc", "gemm.hip"))
+    report, bad = A.audit(asm)
+    assert len(report) >= 19, f"only {len(report)} ring kernels found in the assembly"
+    dirty = [(n, h[:4]) for n, _, h in report if h]
+    assert not dirty and bad == 0, dirty
+    # every ring16 loop carries exactly its 64 (8 waves) or 128 (4 waves) MFMAs per K-step
+    for name, what, _ in report:
+        if "ring16" in name:
+            assert what.endswith("64 MFMAs") or what.endswith("128 MFMAs"), (name, what)
