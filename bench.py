@@ -401,6 +401,9 @@ def main():
     ap.add_argument("--prefetch-early", action="store_true", help="alias of --vision-prefetch early")
     ap.add_argument("--adam-cus", type=int, default=192, help="with --prefetch: compute units given to the optimizer pass")
     ap.add_argument("--no-optimizer", action="store_true")
+    ap.add_argument("--no-norm-fold", action="store_true",
+                    help="keep clip_grad_norm_'s separate pass over the gradients also on a single rank (default there: the sum of squares rides "
+                         "in the weight-gradient GEMMs' epilogues)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--gemm-table", default=None, metavar="PATH",
@@ -495,7 +498,12 @@ def main():
     # separate pass.  Measured on 1x MI355X (profiles/r02_experiments.md): the side-stream kernels cost the concurrent GEMMs more
     # (+3.5 ms) than the separate pass they replace (-3.2 ms), so the default stays off.
     overlap = opt is not None and os.environ.get("MANTIS_NORM_OVERLAP", "0") == "1"
-    trainer = MantisHipTrainer(model, gradient_accumulation_steps=1, reducer=reducer, optimizer=opt if overlap else None)
+    # single rank: the weight-gradient GEMMs of the backward also leave the sum of squares of what they store, so clip_grad_norm_ needs no
+    # pass of its own over the 16 GB of gradients (FusedAdamW.begin_fold; under data parallelism the norm is that of the REDUCED gradient
+    # and the separate pass stays)
+    fold = opt is not None and reducer is None and not overlap and not args.no_norm_fold and on_gpu
+    trainer = MantisHipTrainer(model, gradient_accumulation_steps=1, reducer=reducer, optimizer=opt if overlap else None,
+                               fold_norm_into=opt if fold else None)
     vmode = "early" if args.prefetch_early else ("optimizer" if args.prefetch else args.vision_prefetch)
     if not on_gpu or not hasattr(model.engine, "prefetch_vision") or (vmode == "optimizer" and opt is None):
         vmode = "off"
@@ -733,7 +741,7 @@ def main():
                                flop_per_sample=flop_per_sample,
                                parallelism=f"dp{world}", optimizer=not args.no_optimizer, stage=args.stage,
                                packed=bool(idefics and not args.no_pack),
-                               vision_prefetch=vmode),
+                               vision_prefetch=vmode, grad_norm_folded_into_dw=bool(fold)),
                    roofline=roof, cpu_baseline=cpu, dp=dp)
         print(json.dumps(out), flush=True)
     if world > 1 or force_dp:

@@ -142,6 +142,15 @@ int mantis_gemm_bf16_nt_fused(const void* A, int64_t lda, const void* B, int64_t
                               const void* bias /*nullable*/, int mode, void* aux0, const void* aux1 /*mode 2*/, int64_t aux_ld, int aux_n,
                               int variant, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Weight-gradient GEMM that also leaves the squared norm of its result.  C (+)= A . B^T exactly as mantis_gemm_bf16_nt computes it
+ * (flags: 32 accumulate | 4096 / 8192 K-major operands | bits 8-11 variant 13 / 14, or 0 = automatic) and, for every 256 x 256 output
+ * tile t (the kernel's tile order), tile_sumsq[t] = the sum of the squares of the bf16 values stored in that tile -- after the
+ * accumulation when flag 32 is set.  tile_sumsq holds cdiv(M,256) * cdiv(N,256) floats; every entry is written exactly once.  Replaces,
+ * for the weight gradients, the pass of clip_grad_norm_ (HF trainer.py:2535-2545) over the gradient: the optimizer sums the tile values
+ * (mantis_sum_f32).  Deterministic.  Ring16 kernels only: N % 256 == 0, ldc % 8 == 0, 16-B aligned pointers, no bias / activation /
+ * residual; otherwise MANTIS_EUNSUPPORTED (-2) and the caller runs mantis_gemm_bf16_nt followed by mantis_sumsq. */
+int mantis_gemm_bf16_nt_sumsq(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K, int flags,
+                              float* tile_sumsq, void* workspace, int64_t workspace_bytes, void* stream);
 /* tile family the auto heuristic (flags bits 8-11 == 0) picks: 12 = a 256x256 ring kernel (which of 12 / 13 / 14: see above), 1 = the 128x128 generic kernel */
 int mantis_gemm_pick_variant(int M, int N, int K);
 
@@ -233,6 +242,8 @@ int mantis_navit_prepare(const float* pixels, const uint8_t* pixel_mask, int n_i
 int mantis_adamw(void* param_bf16, const void* grad_bf16, float* master, float* exp_avg, float* exp_avg_sq, int64_t n,
                  float lr, float beta1, float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2,
                  const float* grad_scale_dev /*nullable: multiply grads by *grad_scale_dev (clip)*/, void* stream);
+/* out[0] (+)= sum of x[0 .. n): one workgroup, fixed summation order (the tile partials of mantis_gemm_bf16_nt_sumsq) */
+int mantis_sum_f32(const float* x, int64_t n, float* out, int accumulate, void* stream);
 int mantis_sumsq_partials(int64_t n);
 int mantis_sumsq(const void* x_bf16, int64_t n, float* partials_ws, float* out /*[1], += */, int accumulate, void* stream);
 int mantis_clip_scale(const float* sumsq, float max_norm, float* scale_out, float* norm_out, void* stream);

@@ -39,6 +39,7 @@ SIGNATURES = {
     "mantis_transpose": [P, P, I, I, I, L, L, I, I, L, L, L, L, P],
     "mantis_gemm_bf16_nt": [P, L, P, L, P, L, I, I, I, P, P, L, I, P, L, P],
     "mantis_gemm_bf16_nt_fused": [P, L, P, L, P, L, I, I, I, P, I, P, P, L, I, I, P, L, P],
+    "mantis_gemm_bf16_nt_sumsq": [P, L, P, L, P, L, I, I, I, I, P, P, L, P],
     "mantis_gemm_workspace_bytes": [I, I, I],
     "mantis_gemm_cu_budget": [I],
     "mantis_gemm_pick_variant": [I, I, I],
@@ -60,6 +61,7 @@ SIGNATURES = {
     "mantis_drop_cls": [P, P, I, I, I, P],
     "mantis_navit_prepare": [P, P, I, I, I, I, I, I, P, I, P, P, P, P, P],
     "mantis_adamw": [P, P, P, P, P, L, F, F, F, F, F, F, F, P, P],
+    "mantis_sum_f32": [P, L, P, I, P],
     "mantis_sumsq_partials": [L],
     "mantis_sumsq": [P, L, P, P, I, P],
     "mantis_clip_scale": [P, F, P, P, P],

@@ -37,6 +37,7 @@
 #define EPI_RESIDUAL 16
 #define EPI_ACCUM 32
 #define EPI_SWIGLU_BWD 64                   // C = [dgate | dup][M, 2N] from dact = A.B^T and residual = [gate | up][M, 2N] (ring kernel)
+#define EPI_SUMSQ 128                        // ring16 kernels, through mantis_gemm_bf16_nt_sumsq: tile_sumsq[tile] = sum of squares of the stored tile
 #define EPI_VARIANT_SHIFT 8                 // bits 8-11: tile variant (0 = auto)
 #define EPI_VARIANT_MASK (15 << EPI_VARIANT_SHIFT)
 #define EPI_A_KMAJOR 4096                   // A given as [K, M] (element (m,k) at A[k*lda + m])
@@ -378,9 +379,9 @@ __device__ __forceinline__ void epi_fast_prefetch(EpiPre<G>& p, const bf16_t* __
         }
     }
 }
-template <bool BIAS, int ACT, int PRE, int G>
+template <bool BIAS, int ACT, int PRE, int G, bool SS = false>
 __device__ __forceinline__ void epi_fast_finish(const EpiPre<G>& p, const char* __restrict__ strip, bf16_t* __restrict__ C, int M, int N,
-                                                long ldc, const float (&bv)[8], int m_base, int it0, int n, int rr, int cc) {
+                                                long ldc, const float (&bv)[8], int m_base, int it0, int n, int rr, int cc, float* ss = nullptr) {
 #pragma unroll
     for (int i = 0; i < G; ++i) {
         const int row = (it0 + i) * 8 + rr;
@@ -437,7 +438,17 @@ __device__ __forceinline__ void epi_fast_finish(const EpiPre<G>& p, const char* 
             u32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
-            if (m < M) *reinterpret_cast<u32x4*>(cp) = o;
+            if (m < M) {
+                *reinterpret_cast<u32x4*>(cp) = o;
+                if constexpr (SS) {          // sum of squares of what was stored (the bf16 pairs): one v_dot2c_f32_bf16 per pair, fixed order
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        union { unsigned int u; bf16x2_t b; } c;
+                        c.u = o[e];
+                        *ss = __builtin_amdgcn_fdot2_f32_bf16(c.b, c.b, *ss, false);
+                    }
+                }
+            }
         }
     }
 }
@@ -446,10 +457,10 @@ __device__ __forceinline__ void epi_fast_finish(const EpiPre<G>& p, const char* 
 // global operands travel in groups of G iterations, one group ahead of the arithmetic (G = 8, a whole pass, for residual / accumulate;
 // G = 4 for the SwiGLU backward, which holds two operand sets and whose exp-heavy arithmetic covers the loads of the next half pass --
 // requesting a whole pass up front and then computing measured 4 % slower on dX(down), HBM bursts instead of a stream).
-template <int NBN, int NBM, bool BIAS, int ACT, int PRE>
+template <int NBN, int NBM, bool BIAS, int ACT, int PRE, bool SS = false>
 __device__ __forceinline__ void epi_fast_run(const f32x4 (&acc)[NBN][NBM], char* __restrict__ strip, bf16_t* __restrict__ C, int M, int N,
                                              long ldc, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res, long ldr, int mw0,
-                                             int nw0, int lane) {
+                                             int nw0, int lane, float* ss = nullptr) {
     constexpr int PN = NBN / 4, NPASS = 2 * PN;
     constexpr int G = PRE == EPRE_SWIGLU ? 4 : 8, GPP = 8 / G, NG = NPASS * GPP;
     const int rr = lane >> 3, cc = lane & 7;
@@ -480,7 +491,7 @@ __device__ __forceinline__ void epi_fast_run(const f32x4 (&acc)[NBN][NBM], char*
                 for (int tn4 = 0; tn4 < 4; ++tn4)
                     *reinterpret_cast<f32x4*>(wr + tm4 * 16 * EPI_PITCH + tn4 * 16 * 4) = acc[pn * 4 + tn4][pm * 4 + tm4];
         }
-        epi_fast_finish<BIAS, ACT, PRE, G>(cur, strip, C, M, N, ldc, bv, mw0 + pm * 64, sub * G, n, rr, cc);
+        epi_fast_finish<BIAS, ACT, PRE, G, SS>(cur, strip, C, M, N, ldc, bv, mw0 + pm * 64, sub * G, n, rr, cc, ss);
         if constexpr (PRE != EPRE_NONE && g + 1 < NG) cur = nxt;
     });
 }
@@ -1454,6 +1465,27 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring16_kernel(
                             (!(flags & EPI_BIAS) || !((uintptr_t)bias & 15)) && (!(flags & EPI_SWIGLU_BWD) || !(N & 7));
         if (vec_ok && nw0 + NBN * 16 <= N) {
 #define EPI_FAST(B_, A_, P_) epi_fast_run<NBN, NBM, B_, A_, P_>(acc, strip, C, M, N, ldc, bias, res, ldr, mw0, nw0, lane)
+            if constexpr (!SWIGLU && PAIR == PAIR_NONE) {
+                if (flags & EPI_SUMSQ) {
+                    // weight-gradient launches of mantis_gemm_bf16_nt_sumsq: the squared norm of the stored tile rides along (the optimizer's
+                    // global gradient norm then needs no pass of its own over these 16 GB).  Lane partials in a fixed order, DPP wave sum,
+                    // waves summed in order by thread 0: deterministic.  The entry point guarantees the fast path for every wave.
+                    float ss = 0.f;
+                    if (flags & EPI_ACCUM) epi_fast_run<NBN, NBM, false, 0, EPRE_ACC, true>(acc, strip, C, M, N, ldc, bias, res, ldr, mw0, nw0, lane, &ss);
+                    else epi_fast_run<NBN, NBM, false, 0, EPRE_NONE, true>(acc, strip, C, M, N, ldc, bias, res, ldr, mw0, nw0, lane, &ss);
+                    ss = wave_sum(ss);
+                    float* red = reinterpret_cast<float*>(smem + NW * EPI_STRIP);
+                    if (lane == 0) red[wave] = ss;
+                    __syncthreads();
+                    if (tid == 0) {
+                        float t = 0.f;
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) t += red[w];
+                        reinterpret_cast<float*>(aux0)[tile_id] = t;
+                    }
+                    return;
+                }
+            }
             if constexpr (!SWIGLU) {      // the SwiGLU-backward read-back stays on the general path: its tile moves 512 KiB (gate, up in; dgate, dup
                                           // out) and is HBM-bound either way; requesting operands ahead measured 3 - 4 % SLOWER on dX(down) (bursts)
                 switch (flags & (EPI_BIAS | EPI_ACT_MASK | EPI_RESIDUAL | EPI_ACCUM)) {
@@ -1655,7 +1687,7 @@ int mantis_gemm_cu_budget(int cus) {
 int mantis_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
                         const void* bias, const void* residual, int64_t ldr, int flags, void* workspace, int64_t workspace_bytes,
                         void* stream) {
-    if (M <= 0 || N <= 0 || K <= 0) return MANTIS_EINVAL;
+    if (M <= 0 || N <= 0 || K <= 0 || (flags & EPI_SUMSQ)) return MANTIS_EINVAL;      // bit 7 belongs to mantis_gemm_bf16_nt_sumsq
     const bool akm = flags & EPI_A_KMAJOR, bkm = flags & EPI_B_KMAJOR;
     if (lda % 8 || ldb % 8 || ldc < N) return MANTIS_EUNSUPPORTED;
     const int K8 = (K + 7) / 8 * 8;
@@ -1717,6 +1749,41 @@ int mantis_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, 
 #undef RING_DISPATCH
 #undef RING_ARGS
 #undef GEMM_ARGS
+}
+
+// Weight-gradient GEMM that also leaves the squared norm of its result: C (+)= A . B^T exactly as mantis_gemm_bf16_nt computes it (flags:
+// 32 accumulate | 4096 / 8192 K-major operands | bits 8-11 variant 13 / 14 or 0), and tile_sumsq[t] = sum over the 256 x 256 output tile t
+// (tile ids in the kernel's XCD-grouped order; every one of the cdiv(M,256) * cdiv(N,256) entries is written exactly once) of the squares
+// of the bf16 values stored -- after the accumulation when flag 32 is set.  The optimizer's clip_grad_norm_ (HF trainer.py:2535-2545) then
+// sums tile_sumsq instead of re-reading the gradients.  Deterministic.  Ring16 kernels only: N % 256 == 0, ldc % 8 == 0, C 16-B aligned,
+// no bias / activation / residual; anything else returns MANTIS_EUNSUPPORTED and the caller runs mantis_gemm_bf16_nt + mantis_sumsq.
+int mantis_gemm_bf16_nt_sumsq(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K, int flags,
+                              float* tile_sumsq, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || !tile_sumsq) return MANTIS_EINVAL;
+    if (flags & ~(EPI_ACCUM | EPI_A_KMAJOR | EPI_B_KMAJOR | EPI_VARIANT_MASK)) return MANTIS_EUNSUPPORTED;
+    const bool akm = flags & EPI_A_KMAJOR, bkm = flags & EPI_B_KMAJOR;
+    if (N % 256 || ldc % 8 || ldc < N || lda % 8 || ldb % 8 || (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15)) return MANTIS_EUNSUPPORTED;
+    const int K8 = (K + 7) / 8 * 8;
+    if ((!akm && lda < K8) || (!bkm && ldb < K8) || (akm && lda < M) || (bkm && ldb < N) || (!akm && !bkm && (K % 8))) return MANTIS_EUNSUPPORTED;
+    const long a_bytes = (long)(akm ? K : M) * (long)lda * 2, b_bytes = (long)(bkm ? K : N) * (long)ldb * 2, lim = (1L << 32) - (1L << 16);
+    if (a_bytes >= lim || b_bytes >= lim) return MANTIS_EUNSUPPORTED;
+    int variant = (flags & EPI_VARIANT_MASK) >> EPI_VARIANT_SHIFT;
+    if (variant == 0) {
+        if (gemm_pick_variant(M, N, K) != 12) return MANTIS_EUNSUPPORTED;
+        variant = default_ring_variant() >= 13 ? default_ring_variant() : ring_variant_for(M, N, K, akm, bkm);
+    }
+    if (variant != 13 && variant != 14) return MANTIS_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    const int f = (flags & ~EPI_VARIANT_MASK) | EPI_SUMSQ;
+#define SS_ARGS s, (const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C, M, N, K, (long)lda, (long)ldb, (long)ldc, (const bf16_t*)nullptr, \
+                (const bf16_t*)nullptr, 0L, f, workspace, (long)workspace_bytes, (bf16_t*)tile_sumsq, (const bf16_t*)nullptr, 0L, 0
+#define SS_DISPATCH(AK, BK_) (variant == 13 ? launch_gemm_ring<AK, BK_, false, 4>(SS_ARGS) : launch_gemm_ring<AK, BK_, false, 8>(SS_ARGS))
+    if (akm && bkm) return SS_DISPATCH(true, true);
+    if (bkm) return SS_DISPATCH(false, true);
+    if (akm) return SS_DISPATCH(true, false);
+    return SS_DISPATCH(false, false);
+#undef SS_DISPATCH
+#undef SS_ARGS
 }
 
 // Forward projections with a two-column epilogue fused in (ring16 kernels, NT layout, see PAIR_* at the kernel):

@@ -121,6 +121,22 @@ int mantis_stream_create_priority(int level, void** stream_out, int* levels_out)
 
 int mantis_stream_destroy(void* stream) { return hipStreamDestroy((hipStream_t)stream) == hipSuccess ? MANTIS_OK : MANTIS_ELAUNCH; }
 
+// out (+)= sum of n floats, one workgroup, fixed order (the tile partials of mantis_gemm_bf16_nt_sumsq): lane-strided partial sums, then the
+// block-wide reduction every kernel here uses.  n is small (~1e5 for an 8 B model).
+__global__ __launch_bounds__(1024) void sum_f32_kernel(const float* __restrict__ x, long n, float* __restrict__ out, int accumulate) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (long i = threadIdx.x; i < n; i += 1024) s += x[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[0] = accumulate ? out[0] + s : s;
+}
+
+int mantis_sum_f32(const float* x, int64_t n, float* out, int accumulate, void* stream) {
+    if (!x || !out || n < 0) return MANTIS_EINVAL;
+    MANTIS_LAUNCH(sum_f32_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, (long)n, out, accumulate);
+    return mantis_check_launch();
+}
+
 int mantis_sumsq_partials(int64_t n) { return SUMSQ_BLOCKS; }
 
 int mantis_sumsq(const void* x_bf16, int64_t n, float* partials_ws, float* out, int accumulate, void* stream) {

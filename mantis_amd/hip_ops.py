@@ -340,9 +340,44 @@ def linear_dx_swiglu(dy, w_down, gu, variant=0):
     return dgu
 
 
+# optim.FusedAdamW.begin_fold() installs a collector here for the backward of an accumulation boundary (single rank): every weight
+# gradient GEMM then also leaves the sum of squares of what it stored (mantis_gemm_bf16_nt_sumsq), and the optimizer's clip_grad_norm_
+# sums ~1e5 tile values instead of re-reading 16 GB of gradients
+DW_SUMSQ = None
+
+
 def linear_dw(dy, x, grad_w, accumulate):
     """grad_w[out, in] (+)= dy[M, out]^T @ x[M, in]: both activations are consumed K-major as stored."""
-    gemm_nt(dy[:, : grad_w.shape[0]], x, out=grad_w, accumulate=accumulate, a_kmajor=True, b_kmajor=True)
+    col = DW_SUMSQ
+    a = dy[:, : grad_w.shape[0]]
+    if col is not None and grad_w.is_contiguous():
+        Kd, M = a.shape
+        N = x.shape[1]
+        tiles = ((M + 255) // 256) * ((N + 255) // 256)
+        slot = col.take(grad_w, tiles)
+        if slot is not None:
+            prof = KERNEL_TIMER
+            if prof is not None:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+            wsp, wsn = _gemm_workspace()
+            rc = _L.mantis_gemm_bf16_nt_sumsq(_p(a), a.stride(0), _p(x), x.stride(0), _p(grad_w), grad_w.stride(0), M, N, Kd,
+                                              (32 if accumulate else 0) | 4096 | 8192, slot, wsp, wsn, _stream())
+            if rc == 0:
+                if prof is not None:
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record()
+                    prof.append(("gemm_nt_kernel", 2.0 * M * N * Kd, 2.0 * (M * Kd + N * Kd + M * N * (1 + bool(accumulate))), e0, e1,
+                                 (M, N, Kd, "TN", "sumsq" + ("+acc" if accumulate else "")), _stream()))
+                return
+            if rc != -2:
+                _lib.check(rc, f"gemm_sumsq M={M} N={N} K={Kd}")
+            col.give_back(grad_w, tiles)             # shape outside the fused kernel's conditions: plain GEMM, norm by the separate pass
+    gemm_nt(a, x, out=grad_w, accumulate=accumulate, a_kmajor=True, b_kmajor=True)
+
+
+def sum_f32(x, out, accumulate=False):
+    _lib.check(_L.mantis_sum_f32(_p(x), x.numel(), _p(out), int(accumulate), _stream()), "sum_f32")
 
 
 def colsum(x, grad, accumulate):

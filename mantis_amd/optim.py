@@ -169,6 +169,58 @@ class FusedAdamW(torch.optim.Optimizer):
         torch.cuda.current_stream().wait_stream(self._side)
         self._norm_ready = True
 
+    # ---- gradient norm folded into the weight-gradient GEMMs (single rank; the reference's clip_grad_norm_ is a separate pass over all
+    # gradients, HF:trainer.py:2535-2545).  On the backward of an accumulation boundary every dW GEMM also leaves the sum of squares of the
+    # tiles it stored (hip_ops.linear_dw -> mantis_gemm_bf16_nt_sumsq); end_fold() sums those ~1e5 floats and runs the ordinary
+    # sum-of-squares kernel only over what no such GEMM wrote (norm weights, biases, embedding, shapes outside the fused kernel's
+    # conditions).  Deterministic (fixed orders everywhere); differs from the separate pass only in summation order.  NOT for data
+    # parallel runs: there the norm is that of the REDUCED gradient, which exists only after the exchange.
+    class _Fold:
+        def __init__(self, opt):
+            self.opt, self.used, self.covered = opt, 0, []
+
+        def take(self, grad_w, tiles):
+            o = self.opt
+            base, n = o.model.grad_arena.data_ptr(), o.model.grad_arena.numel()
+            off = (grad_w.data_ptr() - base) // 2
+            if off < 0 or off + grad_w.numel() > n or self.used + tiles > o._fold_ws.numel():
+                return None
+            self.covered.append((off, grad_w.numel()))
+            ptr = o._fold_ws.data_ptr() + 4 * self.used
+            self.used += tiles
+            return ptr
+
+        def give_back(self, grad_w, tiles):
+            self.covered.pop()
+            self.used -= tiles
+
+    def begin_fold(self):
+        """-> collector for hip_ops.DW_SUMSQ (None when clipping is off).  Call right before the backward of an accumulation boundary."""
+        if self.max_grad_norm is None or self.max_grad_norm <= 0:
+            return None
+        if getattr(self, "_fold_ws", None) is None:
+            self._fold_ws = torch.empty(1 << 18, dtype=torch.float32, device=self.model.device)
+        self._fold = FusedAdamW._Fold(self)
+        return self._fold
+
+    def end_fold(self):
+        """The global sum of squares from the tile partials + a sum-of-squares pass over the gradient ranges no fused GEMM covered."""
+        f, self._fold = self._fold, None
+        m = self.model
+        n = m.grad_arena.numel()
+        if f.used:
+            K.sum_f32(self._fold_ws[:f.used], self._sumsq, accumulate=False)
+        first = f.used == 0
+        pos = 0
+        for off, cnt in sorted(f.covered) + [(n, 0)]:
+            lo, hi = pos, (off // 8) * 8                      # parameters start at multiples of 8 elements; pads are zero
+            if hi > lo:
+                K.grad_sumsq(m.grad_arena[lo:hi], self._sumsq, accumulate=not first)
+                first = False
+            pos = max(pos, -(-(off + cnt) // 8) * 8)
+        self._norm_ready = True
+        self.folded_tiles = f.used
+
     def clip_grad_norm(self, max_norm=None):
         """The fused `clip_grad_norm_`: global L2 norm of the (reduced) gradient arena and the clip coefficient min(1, max_norm / (norm
         + 1e-6)), both on the device; the coefficient is applied to the gradients INSIDE the next `step()` (one pass over the arena less

@@ -14,13 +14,17 @@ import torch
 
 
 class MantisHipTrainer:
-    def __init__(self, model=None, gradient_accumulation_steps=1, reducer=None, optimizer=None):
+    def __init__(self, model=None, gradient_accumulation_steps=1, reducer=None, optimizer=None, fold_norm_into=None):
         """optimizer (a `FusedAdamW`, optional): its gradient-norm pass is taken bucket by bucket on a side stream during the
-        backward of the boundary micro-batch instead of as a separate pass before the update."""
+        backward of the boundary micro-batch instead of as a separate pass before the update (measured slower, off in bench.py).
+        fold_norm_into (a `FusedAdamW`, optional): on the backward of an accumulation boundary, when NO gradient exchange is active
+        (single rank), the weight-gradient GEMMs also leave the sum of squares of what they store and the optimizer's clip_grad_norm_
+        needs no pass of its own over the gradients (`FusedAdamW.begin_fold`)."""
         self.model = model
         self.current_gradient_accumulation_steps = gradient_accumulation_steps
         self.reducer = reducer
         self.optimizer = optimizer
+        self.fold_norm_into = fold_norm_into
         self._micro = 0
 
     def _prepare_inputs(self, inputs):
@@ -90,8 +94,20 @@ class MantisHipTrainer:
             ev.record()
             model.engine.prefetch_vision(next_inputs, after_event=ev, stream=getattr(self, "prefetch_stream", None))
             next_inputs = None
-        out = model.engine.step_from_batch(batch, grad_scale=1.0 / ga, loss_scale=1.0 / ga, compute_grads=True,
-                                           overwrite_grads=overwrite, on_bucket_ready=hook, segment_ids=seg)
+        fold = None
+        if boundary and self.fold_norm_into is not None and not norm_now and (self.reducer is None or not self.reducer.active):
+            fold = self.fold_norm_into.begin_fold()
+        if fold is not None:
+            from . import hip_ops as _K
+            _K.DW_SUMSQ = fold
+        try:
+            out = model.engine.step_from_batch(batch, grad_scale=1.0 / ga, loss_scale=1.0 / ga, compute_grads=True,
+                                               overwrite_grads=overwrite, on_bucket_ready=hook, segment_ids=seg)
+        finally:
+            if fold is not None:
+                _K.DW_SUMSQ = None
+        if fold is not None:
+            self.fold_norm_into.end_fold()
         if reduce_now:
             self.reducer.finish()
         if norm_now:
@@ -158,6 +174,7 @@ def as_hf_trainer():
             if impl is None:
                 impl = self._mantis_impl = MantisHipTrainer(model, ga, getattr(self, "mantis_reducer", None))
             impl.current_gradient_accumulation_steps = ga
+            impl.fold_norm_into = self._fused() if getattr(self, "mantis_reducer", None) is None else None
             inner = model.module if hasattr(model, "module") else model
             # the loop's own notion of the accumulation boundary (set before every training_step call by HF's inner loop,
             # including the short window at the end of an epoch) -- never a private counter

@@ -588,6 +588,11 @@ def grad_sumsq(x, out, accumulate=False, ws=None):
     out[0] = out[0] + s if accumulate else s
 
 
+def sum_f32(x, out, accumulate=False):
+    s = x.float().sum()
+    out[0] = out[0] + s if accumulate else s
+
+
 def clip_scale(sumsq, max_norm):
     norm = sumsq.sqrt()
     return torch.clamp(max_norm / (norm + 1e-6), max=1.0).reshape(1), norm.reshape(1)

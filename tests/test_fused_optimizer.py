@@ -103,3 +103,37 @@ def test_hf_trainer_builds_the_fused_optimizer_and_routes_clipping(cpu_backend, 
     tr._save_optimizer_and_scheduler(str(tmp_path))
     sd = torch.load(str(tmp_path / "optimizer.pt"), weights_only=True)
     assert sd["format"] == "mantis_fused_adamw/1" and sd["step"] == 3
+
+
+def test_folded_norm_range_arithmetic_and_fallback(cpu_backend):
+    """FusedAdamW.begin_fold / end_fold: the global sum of squares = tile partials of the GEMM-covered gradient ranges + a plain
+    sum-of-squares pass over everything else.  (1) CPU backend: no GEMM folds anything -> the whole arena goes through the plain pass
+    and the norm equals the unfolded one; (2) coverage simulated for the largest weight gradients: same norm."""
+    from mantis_amd.optim import FusedAdamW
+    from mantis_amd.trainer import MantisHipTrainer
+    z = Hh.load_case("siglip_training_step_ga1")
+    model, _, _ = Hh.build_product_model("siglip", "cpu")
+    opt = FusedAdamW(model, lr=1e-3, max_grad_norm=1.0)
+    tr = MantisHipTrainer(model, 1, fold_norm_into=opt)
+    b = dict(input_ids=torch.from_numpy(z["mb0.input_ids"]), attention_mask=torch.from_numpy(z["mb0.attention_mask"]),
+             labels=torch.from_numpy(z["mb0.labels"]), pixel_values=Hh.pixels_list(z, "mb0."))
+    tr.training_step(model, b)
+    assert opt._norm_ready and opt.folded_tiles == 0
+    want = float(model.grad_arena.float().pow(2).sum().sqrt())
+    n1 = float(opt.clip_grad_norm(1.0))
+    assert abs(n1 - want) <= 1e-5 * want
+    # simulated coverage: pretend the fused GEMM produced the partials of every 2-D gradient (one "tile" each)
+    f = opt.begin_fold()
+    for name in opt._names:
+        g = model._param(name).grad
+        if g.dim() == 2:
+            ptr = f.take(g, 1)
+            assert ptr is not None
+            idx = (ptr - opt._fold_ws.data_ptr()) // 4
+            opt._fold_ws[idx] = g.float().pow(2).sum()
+    f.take(model._param(opt._names[0]).grad, 1)
+    f.give_back(model._param(opt._names[0]).grad, 1)          # a declined shape leaves no trace
+    opt.end_fold()
+    assert opt.folded_tiles == sum(1 for n in opt._names if model._param(n).dim() == 2)
+    n2 = float(opt.clip_grad_norm(1.0))
+    assert abs(n2 - want) <= 1e-5 * want
