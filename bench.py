@@ -7,15 +7,19 @@
 
 One step = one `MantisHipTrainer.training_step` (ViT forward, projector, packing, 32-layer Llama-3 forward + backward,
 gradient all-reduce over RCCL when N > 1) followed by the fused clip + AdamW update (`--no-optimizer` times the bare
-training_step boundary of the reference, transformers/trainer.py:1892-1963).  Weak scaling: 2 samples per GPU
+training_step boundary of the reference, transformers/trainer.py:1892-1963).  Defaults of round 4 (each with a switch): the frozen
+vision tower of the NEXT batch is queued at the start of the step on a lowest-priority stream (`--vision-prefetch early`; every
+timed step still computes exactly one tower forward), and on a single rank the gradient norm rides in the weight-gradient GEMMs'
+epilogues instead of a separate pass (`--no-norm-fold`).  Weak scaling: 2 samples per GPU
 (4 images 336x336 + 512 text tokens each -> merged length 2812), random-init weights, and a FRESH synthetic batch every step
 (the loss stays at ~ln V = 11.76, it cannot be memorised away, so the timed backward sees random-init operands).
 
 Prints ONE JSON line (rank 0) with the driver's fields plus
   ms_per_step_median / p10 / p90   per-step HIP-event durations over the K timed steps
-  roofline      dominant kernel (the bf16 MFMA GEMM family): algorithmic FLOPs / HIP-event time per launch, live in the timed
-                steps; `traffic` (memory-side bytes per launch) and `mfma_busy_pct` come from the tracked PMC summary
-                profiles/r03_pmc_step.json written by tools/pmc_step_report.py from rocprofv3 passes of this same command
+  roofline      dominant kernel (the bf16 MFMA GEMM family on the compute stream): algorithmic FLOPs / HIP-event time per launch,
+                live in the timed steps (`--gemm-table PATH` writes the per-shape table behind it); `traffic` and `mfma_busy_pct` need
+                PMC passes this run does not make and are null -- what the builder's own rocprofv3 passes of this command measured
+                (profiles/r04_pmc_step.json, tools/pmc_step_report.py) is carried under `pmc_static`
   cpu_baseline  the oracle's CPU restatement of the same training_step ("port"), timed on this host's cores on a bounded
                 sample (1 sample, 1 ViT + {1,2} LLM layers + lm_head) and extrapolated linearly in depth; fp32 is `value`,
                 the bf16 leg is reported beside it
@@ -33,7 +37,7 @@ sys.path.insert(0, ROOT)
 FLOP_PER_SAMPLE = 1.351e14      # SURVEY.md section 8d (ViT fwd x1, projector + LLM fwd+bwd x3, causal attention at 1/2)
 PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_FP8_TFLOPS = 5000.0        # MI355X dense fp8 MFMA (MX-scaled K = 64 / 128 forms; MI355X_MICROARCH.md)
-PMC_JSON = os.path.join(ROOT, "profiles", "r03_pmc_step.json")   # tools/pmc_step_report.py output (offline PMC passes, tracked)
+PMC_JSON = os.path.join(ROOT, "profiles", "r04_pmc_step.json")   # tools/pmc_step_report.py output (offline PMC passes, tracked)
 PMC_JSON_QWEN_FP8 = os.path.join(ROOT, "profiles", "r02_pmc_qwen2vl_fp8.json")   # same, for `--config qwen2_vl_7b --precision fp8`
 
 

@@ -1566,7 +1566,9 @@ static int ring_split(long ntiles, int nk, int cus) {
     int best = 1;
     double cost = nk + 5.0, cost1 = -1.0;    // cost1: best single-sub-round split
     int best1 = 1;
-    for (int S = 2; S <= 8; ++S) {
+    static int s_max = -1;                   // MANTIS_GEMM_SPLIT_MAX: cap on S (measurements)
+    if (s_max < 0) { const char* e = getenv("MANTIS_GEMM_SPLIT_MAX"); s_max = e && atoi(e) > 0 ? atoi(e) : 8; }
+    for (int S = 2; S <= s_max; ++S) {
         if (nk / S < 8) break;
         const int rounds = (S * rem + cus - 1) / cus;
         if (rounds > SK_MAX_ROUNDS) break;
