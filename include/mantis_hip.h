@@ -244,6 +244,9 @@ int mantis_adamw(void* param_bf16, const void* grad_bf16, float* master, float* 
                  const float* grad_scale_dev /*nullable: multiply grads by *grad_scale_dev (clip)*/, void* stream);
 /* out[0] (+)= sum of x[0 .. n): one workgroup, fixed summation order (the tile partials of mantis_gemm_bf16_nt_sumsq) */
 int mantis_sum_f32(const float* x, int64_t n, float* out, int accumulate, void* stream);
+/* partials[r] = sum of squares of the bf16 elements x[off_len[2r] .. off_len[2r] + off_len[2r+1]) for r < n_ranges (device array of
+ * int64 pairs, offsets and lengths multiples of 8), one workgroup per range: the many small gradient ranges no fused dW GEMM covers. */
+int mantis_sumsq_ranges(const void* x_bf16, const int64_t* off_len, int n_ranges, float* partials, void* stream);
 int mantis_sumsq_partials(int64_t n);
 int mantis_sumsq(const void* x_bf16, int64_t n, float* partials_ws, float* out /*[1], += */, int accumulate, void* stream);
 int mantis_clip_scale(const float* sumsq, float max_norm, float* scale_out, float* norm_out, void* stream);

@@ -62,6 +62,7 @@ SIGNATURES = {
     "mantis_navit_prepare": [P, P, I, I, I, I, I, I, P, I, P, P, P, P, P],
     "mantis_adamw": [P, P, P, P, P, L, F, F, F, F, F, F, F, P, P],
     "mantis_sum_f32": [P, L, P, I, P],
+    "mantis_sumsq_ranges": [P, P, I, P, P],
     "mantis_sumsq_partials": [L],
     "mantis_sumsq": [P, L, P, P, I, P],
     "mantis_clip_scale": [P, F, P, P, P],

@@ -62,6 +62,20 @@ __global__ void sumsq_finish_kernel(const float* __restrict__ partial, int P, fl
     s = block_sum(s, red);
     if (threadIdx.x == 0) out[0] = accumulate ? out[0] + s : s;
 }
+// partial[r] = sum of squares of x[off[r] .. off[r] + len[r]), one workgroup per range (the many small gradient ranges -- norm weights,
+// biases -- that no fused dW GEMM covers: one launch instead of one per range).  off / len in elements, multiples of 8.
+__global__ void sumsq_ranges_kernel(const bf16_t* __restrict__ x, const long* __restrict__ off_len, float* __restrict__ partial) {
+    __shared__ float red[16];
+    const long off = off_len[2 * blockIdx.x], n8 = off_len[2 * blockIdx.x + 1] >> 3;
+    float s = 0.f;
+    for (long i = threadIdx.x; i < n8; i += blockDim.x) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(x + off + i * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float a = bf2f_lo(v[e]), b = bf2f_hi(v[e]); s += a * a + b * b; }
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
 // scale = min(1, max_norm / (norm + 1e-6))   (torch.nn.utils.clip_grad_norm_)
 __global__ void clip_scale_kernel(const float* __restrict__ sumsq, float max_norm, float* __restrict__ scale, float* __restrict__ norm) {
     const float nrm = sqrtf(sumsq[0]);
@@ -134,6 +148,12 @@ __global__ __launch_bounds__(1024) void sum_f32_kernel(const float* __restrict__
 int mantis_sum_f32(const float* x, int64_t n, float* out, int accumulate, void* stream) {
     if (!x || !out || n < 0) return MANTIS_EINVAL;
     MANTIS_LAUNCH(sum_f32_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, (long)n, out, accumulate);
+    return mantis_check_launch();
+}
+
+int mantis_sumsq_ranges(const void* x_bf16, const int64_t* off_len, int n_ranges, float* partials, void* stream) {
+    if (!x_bf16 || !off_len || !partials || n_ranges <= 0) return MANTIS_EINVAL;
+    MANTIS_LAUNCH(sumsq_ranges_kernel, dim3(n_ranges), dim3(1024), 0, (hipStream_t)stream, (const bf16_t*)x_bf16, (const long*)off_len, partials);
     return mantis_check_launch();
 }
 

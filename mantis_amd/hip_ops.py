@@ -706,6 +706,11 @@ def grad_sumsq(x, out, accumulate=False, ws=None):
     _lib.check(_L.mantis_sumsq(_p(x), x.numel(), _p(ws), _p(out), int(accumulate), _stream()), "sumsq")
 
 
+def sumsq_ranges(x, off_len, partials):
+    """partials[r] = sum of squares of x[off .. off + len) for the int64 (off, len) pairs of `off_len` (device tensor [n, 2])"""
+    _lib.check(_L.mantis_sumsq_ranges(_p(x), _p(off_len), off_len.shape[0], _p(partials), _stream()), "sumsq_ranges")
+
+
 def clip_scale(sumsq, max_norm):
     scale = torch.empty((1,), dtype=torch.float32, device=sumsq.device)
     norm = torch.empty((1,), dtype=torch.float32, device=sumsq.device)

@@ -208,16 +208,31 @@ class FusedAdamW(torch.optim.Optimizer):
         f, self._fold = self._fold, None
         m = self.model
         n = m.grad_arena.numel()
-        if f.used:
-            K.sum_f32(self._fold_ws[:f.used], self._sumsq, accumulate=False)
-        first = f.used == 0
-        pos = 0
+        # uncovered ranges: the many small ones (norm weights, biases: one per layer) go through ONE multi-range launch whose partials land
+        # behind the tile partials; the few large ones (embedding, shapes the fused GEMM declined) through the ordinary kernel
+        gaps, pos = [], 0
         for off, cnt in sorted(f.covered) + [(n, 0)]:
             lo, hi = pos, (off // 8) * 8                      # parameters start at multiples of 8 elements; pads are zero
             if hi > lo:
-                K.grad_sumsq(m.grad_arena[lo:hi], self._sumsq, accumulate=not first)
-                first = False
+                gaps.append((lo, hi - lo))
             pos = max(pos, -(-(off + cnt) // 8) * 8)
+        small = [g for g in gaps if g[1] <= (1 << 20)]
+        used = f.used
+        if small and used + len(small) <= self._fold_ws.numel():
+            key = tuple(small)
+            if getattr(self, "_fold_small_key", None) != key:        # the layout is static: the table is uploaded once
+                self._fold_small = torch.tensor(small, dtype=torch.int64).to(m.device)
+                self._fold_small_key = key
+            K.sumsq_ranges(m.grad_arena, self._fold_small, self._fold_ws[used:used + len(small)])
+            used += len(small)
+            gaps = [g for g in gaps if g[1] > (1 << 20)]
+        first = True
+        if used:
+            K.sum_f32(self._fold_ws[:used], self._sumsq, accumulate=False)
+            first = False
+        for lo, cnt in gaps:
+            K.grad_sumsq(m.grad_arena[lo:lo + cnt], self._sumsq, accumulate=not first)
+            first = False
         self._norm_ready = True
         self.folded_tiles = f.used
 

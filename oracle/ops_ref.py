@@ -588,6 +588,11 @@ def grad_sumsq(x, out, accumulate=False, ws=None):
     out[0] = out[0] + s if accumulate else s
 
 
+def sumsq_ranges(x, off_len, partials):
+    for r, (o, n) in enumerate(off_len.tolist()):
+        partials[r] = _f(x[o:o + n]).pow(2).sum()
+
+
 def sum_f32(x, out, accumulate=False):
     s = x.float().sum()
     out[0] = out[0] + s if accumulate else s
