@@ -316,6 +316,29 @@ class Idefics2Engine:
         all_attended = bool((flags[2][real_h] != 0).all())        # every patch of every real image attended: the tower needs no key mask
         return pv, pos, (None if all_attended else pm), pm
 
+    def prefetch_vision(self, inputs, after_event=None, stream=None):
+        """Image preparation + the frozen tower of a FUTURE batch on `stream` (meant to be a lowest-priority stream: its workgroups take the
+        compute units the current step leaves idle; `MantisHipTrainer.prefetch_early`).  The tower is frozen and depends on nothing but
+        the pixels, so `after_event` is not needed for correctness; the preparation's three-ints-per-image readback waits only for this
+        stream's own upload and kernel.  Picked up by the step that is handed the SAME pixel_values object."""
+        pv = inputs.get("pixel_values")
+        if pv is None or not torch.cuda.is_available():
+            return
+        dev = self.m.device
+        if stream is None:
+            stream = getattr(self, "_side", None)
+            if stream is None:
+                stream = self._side = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(stream):
+            pix, pos_ids, vit_kmask, km_all = self._prepare_images(pv, inputs.get("pixel_attention_mask"))
+            feats, N = self.vision_forward(pix, pos_ids, vit_kmask)
+            done = torch.cuda.Event()
+            done.record(stream)
+        slots = self.__dict__.setdefault("_prefetched", {})
+        slots[id(pv)] = (pv, feats, N, pix.shape[0], km_all, done)
+        while len(slots) > 2:                               # a prefetched batch that never arrives must not pile up
+            slots.pop(next(iter(slots)))
+
     # ------------------------------------------------------------------ vision tower (frozen, forward only)
     def vision_forward(self, pix, pos_ids, kmask):
         m, vc = self.m, self.cfg.vision_config
@@ -439,9 +462,17 @@ class Idefics2Engine:
         n_rows = 0
         is_img = ids_cpu == IMG
         if pixel_values is not None:
-            pix, pos_ids, vit_kmask, km_all = self._prepare_images(pixel_values, pixel_attention_mask)
-            I = pix.shape[0]
-            feats, N = self.vision_forward(pix, pos_ids, vit_kmask)
+            pre = self.__dict__.get("_prefetched", {}).pop(id(pixel_values), None)
+            if pre is not None and pre[0] is pixel_values and record is None:
+                feats, N, I, km_all = pre[1], pre[2], pre[3], pre[4]        # computed ahead on another stream (prefetch_vision)
+                torch.cuda.current_stream().wait_event(pre[5])
+                for t in (feats, km_all):
+                    if t is not None:
+                        t.record_stream(torch.cuda.current_stream())
+            else:
+                pix, pos_ids, vit_kmask, km_all = self._prepare_images(pixel_values, pixel_attention_mask)
+                I = pix.shape[0]
+                feats, N = self.vision_forward(pix, pos_ids, vit_kmask)
             if record is not None:
                 record["vision_last_hidden_state"] = feats.view(I, N, -1)
             img, cctx = self.connector_forward(feats, I, N, km_all, record)

@@ -1357,6 +1357,34 @@ def check_llava_prefetch_cu_masked():
     return 0.0
 
 
+def check_idefics2_prefetch():
+    """Idefics2 engine: image preparation + frozen NaViT tower of the NEXT batch computed ahead on a lowest-priority stream (early mode of
+    MantisHipTrainer) give bit-identical loss and gradients to computing them in line -- on the variable-resolution case (pixel mask ->
+    patch key mask) and on the case with an all-zero padding image that the preparation removes."""
+    from mantis_amd.trainer import MantisHipTrainer
+    k = K()
+    for case in ("idefics2_b1_navit", "idefics2_b2_padimg_rightpad"):
+        z = Hh.load_case(case)
+        model = Hh.build_idefics2_product(DEV)
+        tr = MantisHipTrainer(model, gradient_accumulation_steps=1)
+        b1, b2 = Hh.idefics2_batch(z), Hh.idefics2_batch(z)
+        l_ref = tr.training_step(model, b1)
+        g_ref = model.grad_arena.clone()
+        for p in model.parameters():
+            p.grad = None
+        tr.prefetch_early = True
+        tr.prefetch_stream = k.priority_stream(1)
+        tr.training_step(model, b1, next_inputs=b2)           # queues b2's preparation + tower before this step's kernels
+        assert id(b2["pixel_values"]) in model.engine._prefetched
+        for p in model.parameters():
+            p.grad = None
+        l2 = tr.training_step(model, b2)
+        assert not model.engine._prefetched
+        torch.cuda.synchronize()
+        assert torch.equal(l2, l_ref) and torch.equal(model.grad_arena, g_ref), f"{case}: prefetched tower changed the result"
+    return 0.0
+
+
 def check_qwen2vl_prefetch():
     """The frozen tower computed ahead on the side stream (engine.prefetch_vision, driven by training_step(next_inputs=)) gives bit-identical
     loss and gradients to computing it in line; a prefetch for a different batch object is ignored."""
@@ -2192,6 +2220,7 @@ def all_checks():
     c["qwen2vl_packed_bf16"] = lambda: check_qwen2vl_packed("bf16")
     c["qwen2vl_packed_fp8"] = lambda: check_qwen2vl_packed("fp8")
     c["qwen2vl_prefetch_bit_identical"] = check_qwen2vl_prefetch
+    c["idefics2_prefetch_bit_identical"] = check_idefics2_prefetch
     c["llava_prefetch_cu_masked_bit_identical"] = check_llava_prefetch_cu_masked
     c["autograd_bridge_idefics2_qwen2vl"] = check_autograd_bridge_idefics2_qwen2vl
     c["rope_sections_cast_pad"] = check_rope_sections
