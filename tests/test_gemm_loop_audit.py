@@ -22,3 +22,12 @@ def test_ring_gemm_k_loops_are_clean():
     for name, what, _ in report:
         if "ring16" in name:
             assert what.endswith("64 MFMAs") or what.endswith("128 MFMAs"), (name, what)
+
+
+@pytest.mark.skipif(os.environ.get("MANTIS_SKIP_BUILD_AUDIT") == "1", reason="MANTIS_SKIP_BUILD_AUDIT=1")
+def test_fp8_ring_gemm_k_loops_are_clean():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gemm_loop_audit as A
+    asm = A.compile_asm(os.path.join(ROOT, "mantis_amd", "csrc", "gemm_fp8.hip"))
+    report, bad = A.audit(asm)
+    assert len(report) >= 4 and bad == 0, [(n, h[:4]) for n, _, h in report if h]
