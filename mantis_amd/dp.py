@@ -201,9 +201,11 @@ def hw_queue_probe(n_streams=7, busy_mib=512, passes=64):
     return sum(1 for e in done if start.elapsed_time(e) < 0.25 * total)
 
 
-def rccl_overlap_probe(pg=None, attempts=3, busy_mib=512, passes=64, op=None):
-    """Does a collective of process group `pg` execute WHILE the current (compute) stream is busy?  The compute stream runs ~15 ms of
-    elementwise passes; a tiny all-reduce is launched from a helper stream that only waits for the START of that work (so RCCL's stream
+def rccl_overlap_probe(pg=None, attempts=3, busy_mib=512, passes=256, op=None):
+    """Does a collective of process group `pg` execute WHILE the current (compute) stream is busy?  The compute stream runs ~50 ms of
+    elementwise passes (long against the few milliseconds by which the ranks' hosts may enter the probe apart: every attempt starts from
+    a rendezvous, and a collective counts as overlapped when it completed within HALF the busy time -- serialised, it cannot complete
+    before all of it); a tiny all-reduce is launched from a helper stream that only waits for the START of that work (so RCCL's stream
     has no dependency on the busy kernels -- in the step the bucket collectives likewise depend only on kernels already queued), and
     observer streams time its completion.  A helper or observer stream may itself land on the compute stream's hardware queue (streams
     are dealt round-robin onto the queues), hence `attempts` rounds with fresh streams: overlap seen in ANY round means RCCL's stream
@@ -220,6 +222,7 @@ def rccl_overlap_probe(pg=None, attempts=3, busy_mib=512, passes=64, op=None):
         for st in [launch] + obs:
             with torch.cuda.stream(st):
                 tiny.add_(0.0)                              # first launch on a stream creates its queue (milliseconds)
+        dist.all_reduce(tiny, op=op, group=pg)              # rendezvous: the ranks leave this point together
         torch.cuda.synchronize()
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         done = [torch.cuda.Event(enable_timing=True) for _ in obs]
@@ -236,7 +239,7 @@ def rccl_overlap_probe(pg=None, attempts=3, busy_mib=512, passes=64, op=None):
                 e.record()
         torch.cuda.synchronize()
         total = start.elapsed_time(end)
-        seen = seen or min(start.elapsed_time(e) for e in done) < 0.25 * total
+        seen = seen or min(start.elapsed_time(e) for e in done) < 0.5 * total
     return seen
 
 
