@@ -238,6 +238,25 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TN][TM], bf16_t* __r
 // every global instruction covers 8 whole 128-B lines.  Arithmetic and rounding order are those of gemm_epilogue (bit-identical).
 #define EPI_PITCH 272
 #define EPI_STRIP (64 * EPI_PITCH)
+// Streaming (`nt`) policy for epilogue traffic nobody reads soon: weight gradients (16 GB per step, next touched by the optimizer), the
+// [gate | up] pre-activations (kept for the backward), the dX outputs, residual / accumulate / gate|up operands that are read exactly
+// once.  They otherwise displace the operand panels of the running and the following GEMMs from L2 / Infinity Cache.  Measured per site
+// (profiles/r04_experiments.md 11): family -0.6 ... -1 %; the q|k|v + RoPE output (read by the attention kernel next) and the plain
+// forward store (lm_head logits, read by the loss next) measured slower with it and keep the default policy.  -DEPI_NO_STREAMING: off.
+template <bool NT>
+__device__ __forceinline__ void epi_st16(bf16_t* p, const u32x4& v) {
+#ifndef EPI_NO_STREAMING
+    if constexpr (NT) { __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p)); return; }
+#endif
+    *reinterpret_cast<u32x4*>(p) = v;
+}
+template <bool NT>
+__device__ __forceinline__ u32x4 epi_ld16(const bf16_t* p) {
+#ifndef EPI_NO_STREAMING
+    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+#endif
+    return *reinterpret_cast<const u32x4*>(p);
+}
 // Read-back half of the LDS-transposed epilogue, shared by both 256x256 kernels: a wave-private strip holds 64 rows x 64 fp32 columns
 // of the result (row pitch 272 B); lane (rr = lane >> 3, cc = lane & 7) takes 8 consecutive columns of row it*8 + rr, applies bias /
 // activation / residual / accumulate / the fused SwiGLU backward on 16-B vectors and stores 16 B: every global instruction covers 8
@@ -274,8 +293,8 @@ __device__ __forceinline__ void epi_readback64(const char* __restrict__ strip, b
             // SwiGLU backward fused behind dact = dY . W_down (transformers/models/llama/modeling_llama.py:163-176, autograd):
             // dgate = dact * up * silu'(gate), dup = dact * silu(gate); dact rounded to bf16 first, as the unfused path stores it
             if (full) {
-                const u32x4 g = *reinterpret_cast<const u32x4*>(res + (long)m * ldr + n);
-                const u32x4 u = *reinterpret_cast<const u32x4*>(res + (long)m * ldr + N + n);
+                const u32x4 g = epi_ld16<true>(res + (long)m * ldr + n);
+                const u32x4 u = epi_ld16<true>(res + (long)m * ldr + N + n);
                 u32x4 og, ou;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -293,8 +312,8 @@ __device__ __forceinline__ void epi_readback64(const char* __restrict__ strip, b
                     og[e] = pack_bf2(rg[0], rg[1]);
                     ou[e] = pack_bf2(ru[0], ru[1]);
                 }
-                *reinterpret_cast<u32x4*>(cp) = og;
-                *reinterpret_cast<u32x4*>(cp + N) = ou;
+                epi_st16<true>(cp, og);
+                epi_st16<true>(cp + N, ou);
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -313,7 +332,7 @@ __device__ __forceinline__ void epi_readback64(const char* __restrict__ strip, b
         if (SWIGLU) continue;
         if (full) {
             if (flags & EPI_RESIDUAL) {
-                const u32x4 rv = *reinterpret_cast<const u32x4*>(res + (long)m * ldr + n);
+                const u32x4 rv = epi_ld16<false>(res + (long)m * ldr + n);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     v[2 * e] = bf2f(f2bf(v[2 * e])) + bf2f_lo(rv[e]);
@@ -321,7 +340,7 @@ __device__ __forceinline__ void epi_readback64(const char* __restrict__ strip, b
                 }
             }
             if (flags & EPI_ACCUM) {
-                const u32x4 cv = *reinterpret_cast<const u32x4*>(cp);
+                const u32x4 cv = epi_ld16<false>(cp);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     v[2 * e] += bf2f_lo(cv[e]);
@@ -331,7 +350,7 @@ __device__ __forceinline__ void epi_readback64(const char* __restrict__ strip, b
             u32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
-            *reinterpret_cast<u32x4*>(cp) = o;
+            epi_st16<false>(cp, o);
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -370,16 +389,16 @@ __device__ __forceinline__ void epi_fast_prefetch(EpiPre<G>& p, const bf16_t* __
         for (int i = 0; i < G; ++i) {
             int m = m_base + (it0 + i) * 8 + rr;
             m = m < M ? m : M - 1;                          // rows past M: a harmless in-range address, the store is predicated
-            if constexpr (PRE == EPRE_RES) p.a[i] = *reinterpret_cast<const u32x4*>(res + (long)m * ldr + n);
-            if constexpr (PRE == EPRE_ACC) p.a[i] = *reinterpret_cast<const u32x4*>(C + (long)m * ldc + n);
+            if constexpr (PRE == EPRE_RES) p.a[i] = epi_ld16<true>(res + (long)m * ldr + n);
+            if constexpr (PRE == EPRE_ACC) p.a[i] = epi_ld16<true>(C + (long)m * ldc + n);
             if constexpr (PRE == EPRE_SWIGLU) {
-                p.a[i] = *reinterpret_cast<const u32x4*>(res + (long)m * ldr + n);
-                p.b[i] = *reinterpret_cast<const u32x4*>(res + (long)m * ldr + N + n);
+                p.a[i] = epi_ld16<true>(res + (long)m * ldr + n);
+                p.b[i] = epi_ld16<true>(res + (long)m * ldr + N + n);
             }
         }
     }
 }
-template <bool BIAS, int ACT, int PRE, int G, bool SS = false>
+template <bool BIAS, int ACT, int PRE, int G, bool SS = false, bool NTS = false>
 __device__ __forceinline__ void epi_fast_finish(const EpiPre<G>& p, const char* __restrict__ strip, bf16_t* __restrict__ C, int M, int N,
                                                 long ldc, const float (&bv)[8], int m_base, int it0, int n, int rr, int cc, float* ss = nullptr) {
 #pragma unroll
@@ -417,8 +436,8 @@ __device__ __forceinline__ void epi_fast_finish(const EpiPre<G>& p, const char* 
                 ou[e] = pack_bf2(ru[0], ru[1]);
             }
             if (m < M) {
-                *reinterpret_cast<u32x4*>(cp) = og;
-                *reinterpret_cast<u32x4*>(cp + N) = ou;
+                epi_st16<NTS>(cp, og);
+                epi_st16<NTS>(cp + N, ou);
             }
         } else {
             if constexpr (PRE == EPRE_RES) {
@@ -439,7 +458,7 @@ __device__ __forceinline__ void epi_fast_finish(const EpiPre<G>& p, const char* 
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
             if (m < M) {
-                *reinterpret_cast<u32x4*>(cp) = o;
+                epi_st16<NTS>(cp, o);
                 if constexpr (SS) {          // sum of squares of what was stored (the bf16 pairs): one v_dot2c_f32_bf16 per pair, fixed order
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -457,7 +476,7 @@ __device__ __forceinline__ void epi_fast_finish(const EpiPre<G>& p, const char* 
 // global operands travel in groups of G iterations, one group ahead of the arithmetic (G = 8, a whole pass, for residual / accumulate;
 // G = 4 for the SwiGLU backward, which holds two operand sets and whose exp-heavy arithmetic covers the loads of the next half pass --
 // requesting a whole pass up front and then computing measured 4 % slower on dX(down), HBM bursts instead of a stream).
-template <int NBN, int NBM, bool BIAS, int ACT, int PRE, bool SS = false>
+template <int NBN, int NBM, bool BIAS, int ACT, int PRE, bool SS = false, bool NTS = false>
 __device__ __forceinline__ void epi_fast_run(const f32x4 (&acc)[NBN][NBM], char* __restrict__ strip, bf16_t* __restrict__ C, int M, int N,
                                              long ldc, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res, long ldr, int mw0,
                                              int nw0, int lane, float* ss = nullptr) {
@@ -491,7 +510,7 @@ __device__ __forceinline__ void epi_fast_run(const f32x4 (&acc)[NBN][NBM], char*
                 for (int tn4 = 0; tn4 < 4; ++tn4)
                     *reinterpret_cast<f32x4*>(wr + tm4 * 16 * EPI_PITCH + tn4 * 16 * 4) = acc[pn * 4 + tn4][pm * 4 + tm4];
         }
-        epi_fast_finish<BIAS, ACT, PRE, G, SS>(cur, strip, C, M, N, ldc, bv, mw0 + pm * 64, sub * G, n, rr, cc, ss);
+        epi_fast_finish<BIAS, ACT, PRE, G, SS, NTS>(cur, strip, C, M, N, ldc, bv, mw0 + pm * 64, sub * G, n, rr, cc, ss);
         if constexpr (PRE != EPRE_NONE && g + 1 < NG) cur = nxt;
     });
 }
@@ -1427,7 +1446,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring16_kernel(
                         const float s0 = bf2f(f2bf(g0 * (1.f / (1.f + __expf(-g0))))), s1 = bf2f(f2bf(g1 * (1.f / (1.f + __expf(-g1)))));
                         oa[e] = pack_bf2(s0 * bf2f_lo(o2[e]), s1 * bf2f_hi(o2[e]));
                     }
-                    *reinterpret_cast<u32x4*>(aux0 + (long)m * aux_ld + col1) = oa;
+                    epi_st16<false>(aux0 + (long)m * aux_ld + col1, oa);      // read by the down projection next
                 } else {
                     const u32x4 vc = vcs[it], vs = vss[it];
 #pragma unroll
@@ -1451,8 +1470,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring16_kernel(
                         }
                     }
                 }
-                *reinterpret_cast<u32x4*>(C + (long)m * ldc + col1) = o1;
-                *reinterpret_cast<u32x4*>(C + (long)m * ldc + col2) = o2;
+                epi_st16<PAIR == PAIR_SWIGLU>(C + (long)m * ldc + col1, o1);      // [gate | up]: kept for the backward; q|k|v: read next
+                epi_st16<PAIR == PAIR_SWIGLU>(C + (long)m * ldc + col2, o2);
             }
         }
         return;
@@ -1464,15 +1483,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring16_kernel(
         const bool vec_ok = !(ldc & 7) && !((uintptr_t)C & 15) && (!needs_res || (!(ldr & 7) && !((uintptr_t)res & 15))) &&
                             (!(flags & EPI_BIAS) || !((uintptr_t)bias & 15)) && (!(flags & EPI_SWIGLU_BWD) || !(N & 7));
         if (vec_ok && nw0 + NBN * 16 <= N) {
-#define EPI_FAST(B_, A_, P_) epi_fast_run<NBN, NBM, B_, A_, P_>(acc, strip, C, M, N, ldc, bias, res, ldr, mw0, nw0, lane)
+#define EPI_FAST(B_, A_, P_, NT_) epi_fast_run<NBN, NBM, B_, A_, P_, false, NT_>(acc, strip, C, M, N, ldc, bias, res, ldr, mw0, nw0, lane)
             if constexpr (!SWIGLU && PAIR == PAIR_NONE) {
                 if (flags & EPI_SUMSQ) {
                     // weight-gradient launches of mantis_gemm_bf16_nt_sumsq: the squared norm of the stored tile rides along (the optimizer's
                     // global gradient norm then needs no pass of its own over these 16 GB).  Lane partials in a fixed order, DPP wave sum,
                     // waves summed in order by thread 0: deterministic.  The entry point guarantees the fast path for every wave.
                     float ss = 0.f;
-                    if (flags & EPI_ACCUM) epi_fast_run<NBN, NBM, false, 0, EPRE_ACC, true>(acc, strip, C, M, N, ldc, bias, res, ldr, mw0, nw0, lane, &ss);
-                    else epi_fast_run<NBN, NBM, false, 0, EPRE_NONE, true>(acc, strip, C, M, N, ldc, bias, res, ldr, mw0, nw0, lane, &ss);
+                    if (flags & EPI_ACCUM) epi_fast_run<NBN, NBM, false, 0, EPRE_ACC, true, true>(acc, strip, C, M, N, ldc, bias, res, ldr, mw0, nw0, lane, &ss);
+                    else epi_fast_run<NBN, NBM, false, 0, EPRE_NONE, true, true>(acc, strip, C, M, N, ldc, bias, res, ldr, mw0, nw0, lane, &ss);
                     ss = wave_sum(ss);
                     float* red = reinterpret_cast<float*>(smem + NW * EPI_STRIP);
                     if (lane == 0) red[wave] = ss;
@@ -1489,14 +1508,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring16_kernel(
             if constexpr (!SWIGLU) {      // the SwiGLU-backward read-back stays on the general path: its tile moves 512 KiB (gate, up in; dgate, dup
                                           // out) and is HBM-bound either way; requesting operands ahead measured 3 - 4 % SLOWER on dX(down) (bursts)
                 switch (flags & (EPI_BIAS | EPI_ACT_MASK | EPI_RESIDUAL | EPI_ACCUM)) {
-                    case 0: EPI_FAST(false, 0, EPRE_NONE); return;
-                    case EPI_RESIDUAL: EPI_FAST(false, 0, EPRE_RES); return;
-                    case EPI_ACCUM: EPI_FAST(false, 0, EPRE_ACC); return;
-                    case EPI_BIAS: EPI_FAST(true, 0, EPRE_NONE); return;
-                    case EPI_BIAS | EPI_RESIDUAL: EPI_FAST(true, 0, EPRE_RES); return;
-                    case EPI_BIAS | (1 << EPI_ACT_SHIFT): EPI_FAST(true, 1, EPRE_NONE); return;
-                    case EPI_BIAS | (2 << EPI_ACT_SHIFT): EPI_FAST(true, 2, EPRE_NONE); return;
-                    case EPI_BIAS | (3 << EPI_ACT_SHIFT): EPI_FAST(true, 3, EPRE_NONE); return;
+                    case 0: EPI_FAST(false, 0, EPRE_NONE, (AKM || BKM)); return;      // dX / dW stream out; a plain forward store is read next
+                    case EPI_RESIDUAL: EPI_FAST(false, 0, EPRE_RES, true); return;
+                    case EPI_ACCUM: EPI_FAST(false, 0, EPRE_ACC, true); return;
+                    case EPI_BIAS: EPI_FAST(true, 0, EPRE_NONE, false); return;
+                    case EPI_BIAS | EPI_RESIDUAL: EPI_FAST(true, 0, EPRE_RES, false); return;
+                    case EPI_BIAS | (1 << EPI_ACT_SHIFT): EPI_FAST(true, 1, EPRE_NONE, false); return;
+                    case EPI_BIAS | (2 << EPI_ACT_SHIFT): EPI_FAST(true, 2, EPRE_NONE, false); return;
+                    case EPI_BIAS | (3 << EPI_ACT_SHIFT): EPI_FAST(true, 3, EPRE_NONE, false); return;
                     default: break;
                 }
             }
