@@ -2,6 +2,8 @@
 gradient arena.  Fused projections (q|k|v, gate|up) are zero-copy views over adjacent parameters, data-parallel buckets are contiguous
 slices, the optimizer is one launch over the arena (mantis_amd/optim.py).  Parameter names are the reference's state_dict keys.
 Shared by the LLaVA path (modeling_llava.py) and the Idefics2 path (modeling_idefics2.py)."""
+import os
+
 import torch
 from torch import nn
 
@@ -13,18 +15,35 @@ def numel(shape):
     return n
 
 
+#: every parameter (and gradient) starts on a 256-byte boundary of its arena.  The GEMMs fetch their operands in 128-B row segments
+#: (row-major) or 256-B pieces (K-major); with 16-byte alignment only, the SigLIP biases (4304 elements) left every decoder weight of
+#: Mantis-8B 96 bytes into a cache line, each row segment straddled two lines, and every forward GEMM of the step ran 7 - 13 % slower
+#: than the same launch on separately allocated operands (profiles/r04_experiments.md 12).
+ARENA_ALIGN = int(os.environ.get("MANTIS_ARENA_ALIGN", "128"))       # elements (bf16); the variable exists for A/B measurements (8 = round 3's layout)
+
+
 class ArenaModule(nn.Module):
     #: name prefixes of parameters that are frozen on this path (no backward kernels exist for them)
     frozen_prefixes = ()
+    #: parameters that must directly follow their predecessor: the later members of a fused projection (`_flat` views: q|k|v, gate|up)
+    adjacent_suffixes = ("k_proj.weight", "v_proj.weight", "k_proj.bias", "v_proj.bias", "up_proj.weight")
+
+    def _place(self, items):
+        """[(name, numel)] in arena order -> ({name: offset}, total): sizes padded to 8 elements (zeros), starts aligned to ARENA_ALIGN
+        except inside a fused projection."""
+        offs, off = {}, 0
+        for name, n in items:
+            if off % ARENA_ALIGN and not name.endswith(self.adjacent_suffixes):
+                off = -(-off // ARENA_ALIGN) * ARENA_ALIGN
+            offs[name] = off
+            off += (n + 7) // 8 * 8
+        return offs, off
 
     def _init_arena(self, specs, device, dtype=torch.bfloat16):
         if dtype != torch.bfloat16:
             raise NotImplementedError("the gfx950 path computes in bf16 (fp32 accumulate); construct with dtype=torch.bfloat16")
         dev = torch.device(device) if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
-        offs, off = {}, 0
-        for name, shape in specs:
-            offs[name] = off
-            off += (numel(shape) + 7) // 8 * 8       # keep every parameter 16-byte aligned
+        offs, off = self._place([(name, numel(shape)) for name, shape in specs])
         self._specs, self._offs, self._arena_numel = specs, offs, off
         self.arena = torch.zeros(off, dtype=dtype, device=dev)
         for name, shape in specs:
@@ -85,10 +104,7 @@ class ArenaModule(nn.Module):
                                       f"requires_grad was switched on for {len(bad)} of its parameters")
         key = tuple(n for n, _ in trainable)
         if self.grad_arena is None or self._grad_key != key:
-            offs, off = {}, 0
-            for n, p in trainable:
-                offs[n] = off
-                off += (p.numel() + 7) // 8 * 8
+            offs, off = self._place([(n, p.numel()) for n, p in trainable])
             self.grad_arena = torch.zeros(off, dtype=self.arena.dtype, device=self.device)
             self._grad_offs, self._grad_key = offs, key
             self._grad_views = {n: self.grad_arena[offs[n]: offs[n] + p.numel()].view(p.shape) for n, p in trainable}
@@ -148,14 +164,15 @@ class ArenaModule(nn.Module):
         return self.grad_arena[a:b].view(rows, cols)
 
     def _bucket_span(self, pred):
-        """Contiguous slice of the gradient arena covering the trainable parameters selected by `pred` (None if none)."""
-        offs = self._grad_offs
-        sel = [n for n in self._grad_key if pred(n)]
-        if not sel:
+        """Contiguous slice of the gradient arena covering the trainable parameters selected by `pred` (None if none), up to the start
+        of the next parameter: alignment pads belong to the bucket before them, so consecutive buckets tile the arena."""
+        offs, key = self._grad_offs, self._grad_key
+        idx = [i for i, n in enumerate(key) if pred(n)]
+        if not idx:
             return None
-        a = min(offs[n] for n in sel)
-        b = max(offs[n] + (self._param(n).numel() + 7) // 8 * 8 for n in sel)
-        assert b - a == sum((self._param(n).numel() + 7) // 8 * 8 for n in sel), "bucket is not contiguous"
+        assert idx == list(range(idx[0], idx[-1] + 1)), "bucket is not contiguous"
+        a = offs[key[idx[0]]]
+        b = offs[key[idx[-1] + 1]] if idx[-1] + 1 < len(key) else self.grad_arena.numel()
         return self.grad_arena[a:b]
 
     def copy_state_dict(self, sd, rename=lambda k: k, ignorable=lambda k: False, strict=True):

@@ -19,7 +19,7 @@ import torch
 
 from . import hip_ops as K
 
-STATE_FORMAT = "mantis_fused_adamw/1"
+STATE_FORMAT = "mantis_fused_adamw/2"       # /2: arenas with 256-byte aligned parameters (round 4)
 
 
 class FusedAdamW(torch.optim.Optimizer):
@@ -67,17 +67,20 @@ class FusedAdamW(torch.optim.Optimizer):
         super().add_param_group(param_group)
 
     def _plan(self, names, no_decay):
-        """Maximal runs where the parameter arena and the gradient arena advance together and the weight-decay exemption does not change
+        """Maximal runs where the parameter arena and the gradient arena advance together (alignment pads included when both arenas
+        have the same one: pads are zeros in every array, AdamW leaves them zero) and the weight-decay exemption does not change
         -> (param_off, grad_off, numel, decays)."""
         m = self.model
         segs = []
         for n in names:
             cnt = (m._param(n).numel() + 7) // 8 * 8
             po, go, dec = m._offs[n], m._grad_offs[n], not no_decay(n)
-            if segs and segs[-1][0] + segs[-1][2] == po and segs[-1][1] + segs[-1][2] == go and segs[-1][3] == dec:
-                segs[-1] = (segs[-1][0], segs[-1][1], segs[-1][2] + cnt, dec)
-            else:
-                segs.append((po, go, cnt, dec))
+            if segs and segs[-1][3] == dec:
+                gap_p, gap_g = po - (segs[-1][0] + segs[-1][2]), go - (segs[-1][1] + segs[-1][2])
+                if gap_p == gap_g and 0 <= gap_p < 128:
+                    segs[-1] = (segs[-1][0], segs[-1][1], segs[-1][2] + gap_p + cnt, dec)
+                    continue
+            segs.append((po, go, cnt, dec))
         return segs
 
     def resync_master(self):

@@ -859,6 +859,14 @@ def check_hf_trainer_on_hip():
     return 0.0
 
 
+def _flat_like_grad_arena(model, tp, names):
+    """fp32 reference parameters laid out like the model's gradient arena (what FusedAdamW's flat state follows; pads are zero)."""
+    flat = torch.zeros(model.grad_arena.numel())
+    for n in names:
+        flat[model._grad_offs[n]: model._grad_offs[n] + tp[n].numel()] = tp[n].detach().reshape(-1)
+    return flat
+
+
 def check_optimizer_step_vs_torch():
     """Row f2 end to end on HIP: `FusedAdamW.step()` (sum-of-squares, clip coefficient, AdamW over the flat arenas) against
     `torch.nn.utils.clip_grad_norm_(1.0)` + `torch.optim.AdamW` on fp32 copies of the same parameters and the same bf16 gradients,
@@ -885,8 +893,8 @@ def check_optimizer_step_vs_torch():
         for n in names:
             got = model._param(n).detach().float().cpu()
             assert torch.equal(got, tp[n].detach().to(BF).float()) or rel(got, tp[n].detach()) < 4e-3, n
-        # the fp32 master copy is what torch holds (gradient-arena order, every parameter padded to 8 elements): compare it tightly
-        flat_ref = torch.cat([torch.nn.functional.pad(tp[n].detach().reshape(-1), (0, (-tp[n].numel()) % 8)) for n in names])
+        # the fp32 master copy is what torch holds (in the gradient arena's layout): compare it tightly
+        flat_ref = _flat_like_grad_arena(model, tp, names)
         worst = max(worst, close(opt.master.cpu(), flat_ref, 2e-5, f"fp32 master after step {i + 1}"))
     return worst
 
@@ -941,7 +949,7 @@ def check_hf_trainer_fused_optimizer():
         tr.lr_scheduler.step()
         tsch.step()
         model.zero_grad()
-        flat_ref = torch.cat([torch.nn.functional.pad(tp[n].detach().reshape(-1), (0, (-tp[n].numel()) % 8)) for n in names])
+        flat_ref = _flat_like_grad_arena(model, tp, names)
         worst = max(worst, close(tr.optimizer.master.cpu(), flat_ref, 2e-5, f"fp32 master after HF iteration {i + 1}"))
     assert tr.optimizer.step_count == 3
     return worst

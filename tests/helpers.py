@@ -165,7 +165,9 @@ def check_fused_optimizer_vs_torch(device, steps=5):
         sch.step()
         tsch.step()
         opt.zero_grad(set_to_none=True)
-        flat_ref = torch.cat([torch.nn.functional.pad(tp[n].detach().reshape(-1), (0, (-tp[n].numel()) % 8)) for n in names])
+        flat_ref = torch.zeros(model.grad_arena.numel())           # the optimizer's flat state follows the gradient arena's layout
+        for n in names:
+            flat_ref[model._grad_offs[n]: model._grad_offs[n] + tp[n].numel()] = tp[n].detach().reshape(-1)
         err = rel_l2(opt.master.cpu().numpy(), flat_ref.numpy())
         assert err < 2e-5, (i, err)
         worst = max(worst, err)

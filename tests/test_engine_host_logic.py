@@ -87,8 +87,9 @@ def test_projector_only_stage(cpu_backend, case):
         if "multi_modal_projector" not in n:
             p.requires_grad = False
     assert model._ensure_grad_arena()
-    n_proj = sum((p.numel() + 7) // 8 * 8 for n, p in model.named_parameters() if p.requires_grad)
-    assert model.grad_arena.numel() == n_proj
+    # the arena's placement rule: sizes padded to 8 elements, starts aligned to 256 bytes (mantis_amd/arena.py ARENA_ALIGN)
+    _, n_proj = model._place([(n, p.numel()) for n, p in model.named_parameters() if p.requires_grad])
+    assert model.grad_arena.numel() == n_proj and all(o % 128 == 0 for o in model._grad_offs.values())
     rec = {}
     out = model.engine.step(torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"]),
                             torch.from_numpy(z["labels"]), Hh.pixels_list(z), compute_grads=True, overwrite_grads=True,

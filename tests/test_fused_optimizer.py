@@ -102,7 +102,7 @@ def test_hf_trainer_builds_the_fused_optimizer_and_routes_clipping(cpu_backend, 
     assert n2.dim() == 0 and float(n2) > 0 and tr.optimizer._pending_scale is not None
     tr._save_optimizer_and_scheduler(str(tmp_path))
     sd = torch.load(str(tmp_path / "optimizer.pt"), weights_only=True)
-    assert sd["format"] == "mantis_fused_adamw/1" and sd["step"] == 3
+    assert sd["format"] == "mantis_fused_adamw/2" and sd["step"] == 3
 
 
 def test_folded_norm_range_arithmetic_and_fallback(cpu_backend):

@@ -30,6 +30,9 @@ def main():
     ap.add_argument("--table", default=None)
     ap.add_argument("--no-tower", action="store_true")
     ap.add_argument("--layers", type=int, default=32)
+    ap.add_argument("--keep-forward", action="store_true",
+                    help="keep every forward output alive until the end of the step, as the step does for its backward: the forward GEMMs "
+                         "then write 32 distinct sets of buffers (~22 GB) instead of the allocator's one hot block per shape")
     args = ap.parse_args()
     T, d, I, QKV, V, R = 5624, 4096, 14336, 6144, 128258, 512
     Vp = (V + 7) // 8 * 8
@@ -54,6 +57,8 @@ def main():
     xv, hv = rn(Mv, dv), rn(Mv, Iv8)
 
     def one_step():
+        keep = []
+        hold = keep.append if args.keep_forward else (lambda t: None)
         if not args.no_tower:
             for _ in range(26):
                 K.gemm_nt(xv, TW["qkv"], bias=TW["bq"])
@@ -64,10 +69,10 @@ def main():
             K.gemm_nt(h1, TW["p2"], bias=TW["pb2"])
         for l in range(args.layers):
             w, a = W[l % S], A[l % S]
-            K.linear_qkv_rope(a["n1"], w["qkv"], None, cos, sin, 40, 128)
-            K.gemm_nt(a["o"], w["o"], residual=a["x"])
-            K.linear_gu_swiglu(a["n2"], w["gu"])
-            K.gemm_nt(a["a"], w["down"], residual=a["x"])
+            hold(K.linear_qkv_rope(a["n1"], w["qkv"], None, cos, sin, 40, 128))
+            hold(K.gemm_nt(a["o"], w["o"], residual=a["x"]))
+            hold(K.linear_gu_swiglu(a["n2"], w["gu"]))
+            hold(K.gemm_nt(a["a"], w["down"], residual=a["x"]))
         K.gemm_nt(nf, head, ldc=Vp)
         K.linear_dw(dlog, nf, ghead, False)
         K.linear_dx(dlog, head, k=Vp)
