@@ -38,6 +38,18 @@ def main():
                 t = timeit(lambda: K.gemm_nt(a, b))
                 line += f"  padA={pa:2d} padB={pb:2d}: {1e3 * t:7.1f} us {2.0 * M * N * Kk / t / 1e9:5.0f} TF |"
         print(line, flush=True)
+        # the same GEMM with the weight (and, separately, the activation) starting 96 bytes into a 128-byte line, as every decoder weight
+        # of the 16-byte aligned parameter arena did (profiles/r04_experiments.md 12)
+        line = f"{name:12s} base offset:"
+        a0 = torch.randn(M * Kk + 64, device=dev, generator=g).to(torch.bfloat16)
+        b0 = (torch.randn(N * Kk + 64, device=dev, generator=g) * 0.05).to(torch.bfloat16)
+        for oa in (0, 48):
+            for ob in (0, 48):
+                a = a0[oa: oa + M * Kk].view(M, Kk)
+                b = b0[ob: ob + N * Kk].view(N, Kk)
+                t = timeit(lambda: K.gemm_nt(a, b))
+                line += f"  offA={2 * oa:2d}B offB={2 * ob:2d}B: {1e3 * t:7.1f} us |"
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

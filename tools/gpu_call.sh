@@ -1,0 +1,30 @@
+#!/bin/bash
+# Round-end evidence in ONE gpurun call: the three bench lines (with cpu_baseline), the in-step per-shape GEMM table, a kernel trace of
+# the headline step and the PMC passes (separate runs, --kernel-trace only beside --pmc).  Everything lands in gpurun_out/ev_*; copy what
+# is worth keeping into profiles/ (names per round).  Optional: SUITE=1 runs the GPU test suite first (~7.5 min).
+#   gpurun --timeout 2400 -- 'bash tools/gpu_call.sh'
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"; R=$PWD; O=gpurun_out; mkdir -p $O; export TMPDIR=/tmp
+python -m mantis_amd.build >/dev/null 2>&1
+if [ "${SUITE:-0}" = 1 ]; then timeout 1500 python -m pytest tests -m gpu -x -q > $O/ev_pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -1 $O/ev_pytest_gpu.log; fi
+timeout 600 python bench.py --gemm-table $O/ev_gemm_in_step.md > $O/ev_bench_headline.json 2>$O/ev_bench_headline.err; tail -c 400 $O/ev_bench_headline.json; echo
+timeout 600 python bench.py --config mantis_8b_idefics2 > $O/ev_bench_idefics2.json 2>$O/ev_bench_idefics2.err
+timeout 600 python bench.py --config qwen2_vl_7b --precision fp8 > $O/ev_bench_qwen2vl_fp8.json 2>$O/ev_bench_qwen2vl_fp8.err
+cd /tmp
+timeout 400 rocprofv3 --kernel-trace -d $R/$O/ev_prof -o p -- python $R/bench.py --steps 3 --warmup 2 --no-kernel-timer --no-cpu-baseline > /dev/null 2>&1
+cd $R; python tools/rocpd_stats.py $(find $O/ev_prof -name "p_results.db" | head -1) > $O/ev_kernel_stats.md 2>/dev/null; rm -rf $O/ev_prof
+cd /tmp; B="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timer"
+timeout 500 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/$O/pmc_fetch -o p -- $B > /dev/null 2>&1
+timeout 500 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/$O/pmc_write -o p -- $B > /dev/null 2>&1
+timeout 500 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $R/$O/pmc_sq -o p -- $B > /dev/null 2>&1
+cd $R; python tools/pmc_step_report.py --fetch $O/pmc_fetch --write $O/pmc_write --sq $O/pmc_sq --out $O/ev_pmc_step.json > $O/ev_pmc_step.txt 2>&1
+python tools/pmc_kernel.py $O/pmc_sq gemm > $O/ev_pmc_gemm.txt 2>&1; python tools/pmc_kernel.py $O/pmc_sq attn > $O/ev_pmc_attn.txt 2>&1
+rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_sq
+python - <<'PY'
+import json
+for n in ("headline", "idefics2", "qwen2vl_fp8"):
+    try:
+        d = [json.loads(l) for l in open(f"gpurun_out/ev_bench_{n}.json") if l.startswith("{")][-1]
+        print(n, d["ms_per_step"], d["value"], d["roofline"]["frac"], d.get("cpu_baseline", {}).get("value"))
+    except Exception as e:
+        print(n, "FAILED", e)
+PY
