@@ -52,6 +52,60 @@ __global__ __launch_bounds__(64 * NORM_WAVES) void rmsnorm_fwd_kernel(const bf16
     if (amax_parts) mantis_store_amax_part(umax, amax_parts);
 }
 
+// The same for d = NCH * 512 (4096: Llama-3 / Mistral, 3584: Qwen2-7B, ...) with the row held in registers: the generic kernel walks the
+// row twice in loops of run-time length, one 16-B load per lane and iteration, each waited for before the next is issued -- 2 x d / 512
+// memory round trips per row, 30 us for 5624 x 4096 (3 TB/s).  Here the NCH loads of a row are issued together, the sum of squares is
+// taken in the same order (bit-identical), and the output is produced from the registers: one round trip per row.
+template <int NCH>
+__global__ __launch_bounds__(64 * NORM_WAVES) void rmsnorm_fwd_regs_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                                           bf16_t* __restrict__ y, float* __restrict__ rstd_out,
+                                                                           long rows, float eps, float* __restrict__ amax_parts) {
+    constexpr int d = NCH * 512;
+    const int lane = threadIdx.x & 63;
+    unsigned int umax = 0;
+    const long wave = (long)blockIdx.x * NORM_WAVES + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * NORM_WAVES;
+    long r = wave;
+    if (r < rows) {
+        // first the row, then the weights (cache hits), one wait for both; a wave normally has ONE row
+        u32x4 v[NCH], g[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) v[k] = *reinterpret_cast<const u32x4*>(x + r * d + (lane + 64 * k) * 8);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) g[k] = *reinterpret_cast<const u32x4*>(w + (lane + 64 * k) * 8);
+        while (true) {
+            float ss = 0.f;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = bf2f_lo(v[k][e]), b = bf2f_hi(v[k][e]);
+                    ss += a * a + b * b;
+                }
+            ss = wave_sum(ss);
+            const float rstd = rsqrtf(ss / (float)d + eps);
+            if (lane == 0 && rstd_out) rstd_out[r] = rstd;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = bf2f(f2bf(bf2f_lo(v[k][e]) * rstd)) * bf2f_lo(g[k][e]);
+                    const float b = bf2f(f2bf(bf2f_hi(v[k][e]) * rstd)) * bf2f_hi(g[k][e]);
+                    o[e] = pack_bf2(a, b);
+                    umax = mantis_umax_bf2(umax, o[e]);
+                }
+                *reinterpret_cast<u32x4*>(y + r * d + (lane + 64 * k) * 8) = o;
+            }
+            r += nwaves;
+            if (r >= rows) break;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) v[k] = *reinterpret_cast<const u32x4*>(x + r * d + (lane + 64 * k) * 8);
+        }
+    }
+    if (amax_parts) mantis_store_amax_part(umax, amax_parts);
+}
+
 // dx = rstd * (g - xhat * mean(g * xhat)) [+ dres],  g = dy * w, xhat = x * rstd;   dW partial[workgroup] += dy * xhat
 // One wave per row, 8 waves per workgroup, 2 workgroups per CU (4 waves/SIMD: at 1 wave/SIMD the kernel was latency bound --
 // 75 us for 5624 x 4096 = 2.5 TB/s); the 8 waves' column sums are folded through one LDS row in wave order (deterministic), so
@@ -298,15 +352,28 @@ __global__ __launch_bounds__(64 * RMSQ_NQ * RMSQ_SLOTS, 4) void rmsnorm_bwd_d409
 }
 
 
-// grad[j] (+)= sum_p partial[p][j]   (fixed summation order -> deterministic).  64 columns x 16 row groups per workgroup.
-__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ partial, int P, int d,
-                                                               bf16_t* __restrict__ grad, int accumulate) {
-    __shared__ float red[16][64];
-    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + c;
+// grad[j] (+)= sum_p partial[p][j]   (fixed summation order -> deterministic): thread (column c, row group g) adds rows g, g + 16, ... in
+// that order, then the 16 group sums are added in order.  16 columns x 16 row groups per workgroup: d / 16 workgroups instead of the
+// d / 64 of round 3 (64 workgroups on 256 CUs: 10.7 us for 512 x 4096 partials), and the loads of eight rows are in flight before their
+// adds -- same order of additions, bit-identical.
+#define REDP_COLS 16
+__global__ __launch_bounds__(REDP_COLS * 16) void reduce_partials_kernel(const float* __restrict__ partial, int P, int d,
+                                                                         bf16_t* __restrict__ grad, int accumulate) {
+    __shared__ float red[16][REDP_COLS];
+    const int c = threadIdx.x % REDP_COLS, g = threadIdx.x / REDP_COLS;
+    const int j = blockIdx.x * REDP_COLS + c;
     float s = 0.f;
-    if (j < d)
-        for (int p = g; p < P; p += 16) s += partial[(long)p * d + j];
+    if (j < d) {
+        int p = g;
+        for (; p + 16 * 7 < P; p += 16 * 8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = partial[(long)(p + 16 * k) * d + j];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[k];
+        }
+        for (; p < P; p += 16) s += partial[(long)p * d + j];
+    }
     red[g][c] = s;
     __syncthreads();
     if (g == 0 && j < d) {
@@ -376,6 +443,19 @@ int mantis_rmsnorm_fwd(const void* x, const void* weight, void* y, float* rstd, 
                        void* stream) {
     if (d % 8 || d <= 0) return MANTIS_EUNSUPPORTED;
     if (rows == 0) return MANTIS_OK;
+    if (d % 512 == 0 && d / 512 >= 1 && d / 512 <= 16 && !((uintptr_t)x & 15) && !((uintptr_t)y & 15) && !((uintptr_t)weight & 15)) {
+        // one wave per row (no second trip through the row loop) up to the number of amax slots
+        long g = (rows + NORM_WAVES - 1) / NORM_WAVES;
+        g = g < 1 ? 1 : (g > MANTIS_AMAX_PARTS ? MANTIS_AMAX_PARTS : g);
+#define RMSF_LAUNCH(N_) case N_: MANTIS_LAUNCH(rmsnorm_fwd_regs_kernel<N_>, dim3((int)g), dim3(64 * NORM_WAVES), 0, (hipStream_t)stream, \
+                       (const bf16_t*)x, (const bf16_t*)weight, (bf16_t*)y, rstd, (long)rows, eps, amax_parts); return mantis_check_launch();
+        switch (d / 512) {
+            RMSF_LAUNCH(1) RMSF_LAUNCH(2) RMSF_LAUNCH(3) RMSF_LAUNCH(4) RMSF_LAUNCH(5) RMSF_LAUNCH(6) RMSF_LAUNCH(7) RMSF_LAUNCH(8)
+            RMSF_LAUNCH(10) RMSF_LAUNCH(12) RMSF_LAUNCH(16)
+            default: break;
+        }
+#undef RMSF_LAUNCH
+    }
     MANTIS_LAUNCH(rmsnorm_fwd_kernel, dim3(norm_grid(rows)), dim3(64 * NORM_WAVES), 0, (hipStream_t)stream,
                        (const bf16_t*)x, (const bf16_t*)weight, (bf16_t*)y, rstd, (long)rows, d, eps, amax_parts);
     return mantis_check_launch();
@@ -400,7 +480,7 @@ int mantis_rmsnorm_bwd(const void* dy, const void* x, const void* weight, const 
         else RMSQ_LAUNCH(false);
 #undef RMSQ_LAUNCH
         if (grad_weight)
-            MANTIS_LAUNCH(reduce_partials_kernel, dim3(cdiv(d, 64)), dim3(1024), 0, (hipStream_t)stream, workspace, P, d,
+            MANTIS_LAUNCH(reduce_partials_kernel, dim3(cdiv(d, REDP_COLS)), dim3(REDP_COLS * 16), 0, (hipStream_t)stream, workspace, P, d,
                           (bf16_t*)grad_weight, accumulate);
         return mantis_check_launch();
     }
@@ -412,7 +492,7 @@ int mantis_rmsnorm_bwd(const void* dy, const void* x, const void* weight, const 
     else RMSB_LAUNCH(NORM_MAXC);
 #undef RMSB_LAUNCH
     if (grad_weight)
-        MANTIS_LAUNCH(reduce_partials_kernel, dim3(cdiv(d, 64)), dim3(1024), 0, (hipStream_t)stream, workspace, P, d,
+        MANTIS_LAUNCH(reduce_partials_kernel, dim3(cdiv(d, REDP_COLS)), dim3(REDP_COLS * 16), 0, (hipStream_t)stream, workspace, P, d,
                            (bf16_t*)grad_weight, accumulate);
     return mantis_check_launch();
 }

@@ -45,7 +45,7 @@ class FusedAdamW(torch.optim.Optimizer):
                          dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         n = model.grad_arena.numel()
         dev = model.device
-        self.master = torch.empty(n, dtype=torch.float32, device=dev)
+        self.master = torch.zeros(n, dtype=torch.float32, device=dev)      # zeros: alignment pads between segments are never written
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.resync_master()
