@@ -726,8 +726,9 @@ __global__ __launch_bounds__(512) void gemm_nt_ring_kernel(
         part = lin / rem;
         tile_id = full + lin - part * rem;
     }
-    const int t0 = (bid < full) ? 0 : (int)((long)nk * part / S);
-    const int t1 = (bid < full) ? nk : (int)((long)nk * (part + 1) / S);
+    // 32-bit on purpose (nk <= 2^15, part < S <= 8): the 64-bit divisions cost the K-split units ~300 scalar instructions before their first DMA
+    const int t0 = (bid < full) ? 0 : (int)((unsigned)nk * (unsigned)part / (unsigned)S);
+    const int t1 = (bid < full) ? nk : (int)((unsigned)nk * (unsigned)(part + 1) / (unsigned)S);
     // tile id -> (m0, n0): groups of 8 tile rows, column-major inside a group
     const int GROUP = 8;
     const int per_group = GROUP * tiles_n;
@@ -1105,8 +1106,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring16_kernel(
         part = lin / rem;
         tile_id = full + lin - part * rem;
     }
-    const int t0 = (bid < full) ? 0 : (int)((long)nk * part / S);
-    const int t1 = (bid < full) ? nk : (int)((long)nk * (part + 1) / S);
+    // 32-bit on purpose (nk <= 2^15, part < S <= 8): the 64-bit divisions cost the K-split units ~300 scalar instructions before their first DMA
+    const int t0 = (bid < full) ? 0 : (int)((unsigned)nk * (unsigned)part / (unsigned)S);
+    const int t1 = (bid < full) ? nk : (int)((unsigned)nk * (unsigned)(part + 1) / (unsigned)S);
     const int GROUP = 8;
     const int per_group = GROUP * tiles_n;
     const int g = tile_id / per_group;
