@@ -1224,12 +1224,51 @@ static int launch_fwd(bool causal, dim3 grid, hipStream_t s, const bf16_t* Q, co
     return mantis_check_launch();
 }
 
+// attn_dq64.hip: the hd-128 dQ with 64 query rows per wave (one workgroup per CU, accumulators and Q / dO fragments in hand-owned AGPRs)
+int mantis_attn_dq64_launch(bool causal, int B, hipStream_t s, const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* dO,
+                            const float* LSE, float* Dsum, bf16_t* dQ, int L, int Lk, int H, int Hkv, long ldq, long ldk,
+                            long ldv, long ldo, long lddq, float scale, const bf16_t* Ofwd, long ldout, const int* kstart);
+
+// MANTIS_ATTN_DQ64 = 1 / 0 (read once): the 64-row dQ kernel for every length / never; default ATTN_DQ64_DEFAULT (2 = from 1024 query rows on)
+#ifndef ATTN_DQ64_DEFAULT
+#define ATTN_DQ64_DEFAULT 0
+#endif
+static int attn_dq64_mode() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MANTIS_ATTN_DQ64");
+        v = (e && e[0] == '0') ? 0 : (e && e[0] == '1') ? 1 : ATTN_DQ64_DEFAULT;
+    }
+    return v;
+}
+
+template <int HD>
+static void launch_dq(bool causal, hipStream_t s, const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* dO, const int* kmask,
+                      const float* LSE, float* Dsum, bf16_t* dQ, int B, int L, int Lk, int H, int Hkv, long ldq, long ldk, long ldv,
+                      long ldo, long lddq, float scale, const bf16_t* Ofwd, long ldout, const int* kstart) {
+    if constexpr (HD == 128) {
+        const int mode = attn_dq64_mode();
+        if (kmask == nullptr && (mode == 1 || (mode == 2 && L >= 1024))) {      // batches with a key-padding mask keep attn_bwd_dq_kernel
+            mantis_attn_dq64_launch(causal, B, s, Q, K, V, dO, LSE, Dsum, dQ, L, Lk, H, Hkv, ldq, ldk, ldv, ldo, lddq, scale, Ofwd, ldout,
+                                    kstart);
+            return;
+        }
+    }
+    const dim3 gq(cdiv(L, 128) * H * B);
+    if (causal)
+        MANTIS_LAUNCH((attn_bwd_dq_kernel<HD, true>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, L, Lk, H, Hkv, ldq, ldk, ldv,
+                           ldo, lddq, scale, Ofwd, ldout, kstart);
+    else
+        MANTIS_LAUNCH((attn_bwd_dq_kernel<HD, false>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, L, Lk, H, Hkv, ldq, ldk, ldv,
+                           ldo, lddq, scale, Ofwd, ldout, kstart);
+}
+
 template <int HD>
 static int launch_bwd(bool causal, hipStream_t s, const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* dO,
                       const int* kmask, const float* LSE, float* Dsum, bf16_t* dQ, bf16_t* dK, bf16_t* dV, bf16_t* ws, int B,
                       int L, int Lk, int H, int Hkv, long ldq, long ldk, long ldv, long ldo, long lddq, long lddk, long lddv, float scale,
                       const bf16_t* Ofwd, long ldout, const int* kstart, const int* qend) {
-    const dim3 gq(cdiv(L, 128) * H * B), gk(cdiv(Lk, DkvCfg<HD>::KEYS) * H * B);       // L queries, Lk keys per batch entry
+    const dim3 gk(cdiv(Lk, DkvCfg<HD>::KEYS) * H * B);       // Lk keys per batch entry
     const int G = H / Hkv;
     if constexpr (HD == 128) {
         // GQA-aware dK/dV (no HBM partials, no group reduce); dQ as before (it also publishes Dsum).  Its grid is one workgroup per
@@ -1239,12 +1278,7 @@ static int launch_bwd(bool causal, hipStream_t s, const bf16_t* Q, const bf16_t*
         const long nwg = (long)cdiv(L, 64) * Hkv * B;
         const int cus = attn_num_cus();
         if (Lk == L && attn_dkv_group_kernel_ok(G) && (G == 4 || nwg >= 2L * cus || nwg <= cus / 2 || ws == nullptr)) {
-            if (causal)
-                MANTIS_LAUNCH((attn_bwd_dq_kernel<HD, true>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, L, Lk, H, Hkv,
-                                   ldq, ldk, ldv, ldo, lddq, scale, Ofwd, ldout, kstart);
-            else
-                MANTIS_LAUNCH((attn_bwd_dq_kernel<HD, false>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, L, Lk, H, Hkv,
-                                   ldq, ldk, ldv, ldo, lddq, scale, Ofwd, ldout, kstart);
+            launch_dq<HD>(causal, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, B, L, Lk, H, Hkv, ldq, ldk, ldv, ldo, lddq, scale, Ofwd, ldout, kstart);
             const dim3 g4(cdiv(L, 64) * Hkv * B);
 #define DKV_G4(C_, S_) MANTIS_LAUNCH((attn_bwd_dkv_g4_kernel<C_, S_>), g4, dim3(256), 0, s, Q, K, V, dO, kmask, kstart, qend, LSE, \
                                           Dsum, dK, dV, L, H, Hkv, ldq, ldk, ldv, ldo, lddk, lddv, scale)
@@ -1259,14 +1293,11 @@ static int launch_bwd(bool causal, hipStream_t s, const bf16_t* Q, const bf16_t*
     bf16_t* pk = G == 1 ? dK : ws;
     bf16_t* pv = G == 1 ? dV : ws + rows * H * HD;
     const long ldpk = G == 1 ? lddk : (long)H * HD, ldpv = G == 1 ? lddv : (long)H * HD;
+    launch_dq<HD>(causal, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, B, L, Lk, H, Hkv, ldq, ldk, ldv, ldo, lddq, scale, Ofwd, ldout, kstart);
     if (causal) {
-        MANTIS_LAUNCH((attn_bwd_dq_kernel<HD, true>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, L, Lk, H, Hkv, ldq,
-                           ldk, ldv, ldo, lddq, scale, Ofwd, ldout, kstart);
         MANTIS_LAUNCH((attn_bwd_dkv_kernel<HD, true>), gk, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, pk, pv, L, Lk, H, Hkv,
                            ldq, ldk, ldv, ldo, ldpk, ldpv, scale, kstart, qend);
     } else {
-        MANTIS_LAUNCH((attn_bwd_dq_kernel<HD, false>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, L, Lk, H, Hkv, ldq,
-                           ldk, ldv, ldo, lddq, scale, Ofwd, ldout, kstart);
         MANTIS_LAUNCH((attn_bwd_dkv_kernel<HD, false>), gk, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, pk, pv, L, Lk, H, Hkv,
                            ldq, ldk, ldv, ldo, ldpk, ldpv, scale, kstart, qend);
     }
