@@ -88,6 +88,16 @@ __device__ __forceinline__ void lds_wait2(bf16x8& a, bf16x8& b) {
 
 }  // namespace
 
+#ifdef DQ64_STAMPS
+// timing probe (tools/build_probe_lib.sh attn_dq64 stamps -DDQ64_STAMPS; tools/attn_dq64_anatomy.py; never in the product build): wave 0
+// of every workgroup sums, over its unmasked tiles, the s_memtime intervals tile top -> MFMA 31 -> 63 -> 79 -> 95 -> behind the barrier,
+// and records entry / loop start / exit.  (s_memtime returns through lgkmcnt: every stamp also drains the LDS reads in flight.)
+__device__ unsigned long long g_dq64_stamps[4096 * 12];
+#define DQ64_STAMP(var) do { var = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DQ64_STAMP(var) do { } while (0)
+#endif
+
 template <bool CAUSAL>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                                const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
@@ -105,6 +115,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(const bf16_t* __r
     __shared__ __attribute__((aligned(16))) char smem[NB * BUF];
 
     asm volatile("" ::: DQ64_AGPR_ALL);      // declares the whole accumulator file as used: the kernel descriptor must allocate it
+#ifdef DQ64_STAMPS
+    unsigned long long st_entry, st_loop = 0, st_t0 = 0, st_a = 0, st_b = 0, st_c = 0, st_d = 0, st_e = 0;
+    unsigned long long sum_a = 0, sum_b = 0, sum_c = 0, sum_d = 0, sum_e = 0, n_plain = 0, n_masked = 0, n_skipped = 0;
+    DQ64_STAMP(st_entry);
+#endif
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hh = lane >> 5, lq = lane & 31;
     const int gx = (L + 255) >> 8;
     int bx, h, b;
@@ -204,6 +219,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(const bf16_t* __r
         const char* sV = sK + TILE;
         const float* sBias = reinterpret_cast<const float*>(sK + 2 * TILE);
         stage(t + 3);                  // into the buffer tile t - 1 has released (every wave is past the barrier that ended it)
+#ifdef DQ64_STAMPS
+        if (t == t_first) DQ64_STAMP(st_loop);
+        DQ64_STAMP(st_t0);
+        bool st_plain = false;
+#endif
         if (!(CAUSAL && key0 > q0 + 63)) {
             const bool need_mask = (CAUSAL && key0 + 63 > q0) || sBias[64] != 0.f || key0 < ks_hi;   // wave-uniform
             auto tile_body = [&](auto maskc) {
@@ -325,16 +345,35 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(const bf16_t* __r
                     // (r < 8 of both row blocks: stage 3 done in slot 73; r >= 8: slot 81)
                     if constexpr (i == 74) { pack(ic_<1>{}, ic_<0>{}, ic_<0>{}); pack(ic_<1>{}, ic_<0>{}, ic_<1>{}); }
                     if constexpr (i == 82) { pack(ic_<1>{}, ic_<1>{}, ic_<0>{}); pack(ic_<1>{}, ic_<1>{}, ic_<1>{}); }
+#ifdef DQ64_STAMPS
+                    if constexpr (i == 31) DQ64_STAMP(st_a);
+                    if constexpr (i == 63) DQ64_STAMP(st_b);
+                    if constexpr (i == 79) DQ64_STAMP(st_c);
+                    if constexpr (i == 95) DQ64_STAMP(st_d);
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 });
             };
             if (need_mask) tile_body(std::true_type{});
             else tile_body(std::false_type{});
+#ifdef DQ64_STAMPS
+            st_plain = !need_mask;
+            n_masked += need_mask ? 1 : 0;
+        } else {
+            n_skipped += 1;
+#endif
         }
         wait_two_stages_in_flight();       // tile t + 1 has landed (this wave's pieces; the barrier makes it everyone's)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this tile's LDS reads and the bias row's ds_write
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+#ifdef DQ64_STAMPS
+        DQ64_STAMP(st_e);
+        if (st_plain) {
+            sum_a += st_a - st_t0; sum_b += st_b - st_a; sum_c += st_c - st_b; sum_d += st_d - st_c; sum_e += st_e - st_d;
+            n_plain += 1;
+        }
+#endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the ring's last pieces must not outlive the workgroup's LDS
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");      // the last MFMAs' results -> v_accvgpr_read
@@ -353,6 +392,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(const bf16_t* __r
             });
         });
     });
+#ifdef DQ64_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {
+        unsigned long long* o = g_dq64_stamps + (size_t)blockIdx.x * 12;
+        unsigned long long st_exit;
+        DQ64_STAMP(st_exit);
+        o[0] = st_loop - st_entry; o[1] = st_exit - st_entry; o[2] = n_plain; o[3] = n_masked; o[4] = n_skipped;
+        o[5] = sum_a; o[6] = sum_b; o[7] = sum_c; o[8] = sum_d; o[9] = sum_e; o[10] = (unsigned long long)(ntiles - t_first); o[11] = (unsigned long long)qb;
+    }
+#endif
 }
 
 // (no key-padding mask: see the kernel)
@@ -368,3 +416,10 @@ int mantis_attn_dq64_launch(bool causal, int B, hipStream_t s, const bf16_t* Q, 
                       lddq, scale, Ofwd, ldout, kstart);
     return mantis_check_launch();
 }
+
+#ifdef DQ64_STAMPS
+// probe builds only: copy the stamps of the last launch (n workgroups x 12 u64) to host memory
+extern "C" int mantis_probe_dq64_stamps(void* host_dst, int n_wg) {
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_dq64_stamps), (size_t)n_wg * 96, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+}
+#endif
