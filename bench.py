@@ -176,7 +176,7 @@ def _pct(xs, q):
 
 def write_gemm_table(path, entries, steps, config, step_ms):
     """The in-step bf16 GEMM table: one row per (M, N, K, layout, epilogue) over the launches of the timed steps, from the HIP events
-    recorded around every launch on the launch stream (hip_ops.KERNEL_TIMER).  Layout: NT = x . W^T (forward), NN = dY . W (dX),
+    recorded around every launch on the launch stream (launch.LaunchContext.timer).  Layout: NT = x . W^T (forward), NN = dY . W (dX),
     TN = dY^T . X (dW).  Written as markdown; the last row is the family (= roofline.achieved)."""
     groups = {}
     for x in entries:
@@ -592,7 +592,7 @@ def main():
         reducer.collect_exposed_ms()
         reducer.stats.update(buckets=0, bytes=0, exposed_ms=[], steps=0)
     timer = None if (args.no_kernel_timer or host_only) else []
-    K.KERNEL_TIMER = timer
+    trainer.launch.timer = timer          # per-launch HIP events around every GEMM of THIS trainer's steps (launch.LaunchContext)
     sync()
     if world > 1:
         dist.barrier()
@@ -605,7 +605,7 @@ def main():
         dist.barrier()
     sync()
     elapsed = time.perf_counter() - t0
-    K.KERNEL_TIMER = None
+    trainer.launch.timer = None
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -107,6 +107,12 @@ int mantis_transpose(const void* in, void* out, int R, int C, int Rpad, int64_t 
  *        | 64 SwiGLU backward fused behind dact = A.B^T: residual = [gate | up][M, 2N], C = [dgate | dup][M, 2N]
  *        | bits 8-11 tile variant (0 = auto) | 4096 A is K-major ([K,M], row stride lda) | 8192 B is K-major ([K,N]):
  *        dX = dY.W uses B K-major (the weight as stored), dW = dY^T.X uses both K-major -- no transposed copies.
+ *        | bits 16-27 CU budget this launch is planned for (0 = default; see mantis_gemm_cu_budget)
+ *        | 16384 remainder tiles of a ring16 launch reduced by their last arriver inside the GEMM kernel instead of by the finishing
+ *          kernel (round-4 behaviour; same results bit for bit; tests / A-B measurements; process default: MANTIS_GEMM_SK_FINISH=0).
+ * Remainder rounds: tiles of an incomplete last round of 256x256 tiles are split along K (deterministic); the ring16 kernels' split
+ * units store fp32 partial slabs into the workspace and a second, small kernel on the same stream (gemm_ring16_finish_kernel) sums
+ * them and runs the epilogue on all compute units -- no tickets, no spinning, nothing that can deadlock under CU masks.
  * Tile variants: 1 = 128x128 generic kernel, 2 = 256x256 generic kernel, 12 = 256x256 ring kernel with 8 waves x (128 x 64) of
  * 32x32x16 MFMAs, 13 = 256x256 ring16 kernel with 4 waves x (128 x 128) of 16x16x32 MFMAs, 14 = 256x256 ring16 kernel with 8 waves x
  * (128 x 64) of 16x16x32 MFMAs.  Automatic choice (variant 0): a fitted cost model picks the 128x128 kernel or a ring kernel
@@ -122,12 +128,13 @@ int mantis_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, 
  * ring kernel's deterministic split-K remainder round uses it; every launch leaves it zeroed-for-reuse, so one buffer per stream
  * serves all stream-ordered launches).  M = N = K = 0: the largest requirement of any shape on the current device (~64 MB). */
 int mantis_gemm_workspace_bytes(int M, int N, int K);
-/* CU budget the GEMM tile scheduler plans for (rounds of tiles, the K split of an incomplete last round, the tile variant): cus > 0 sets
- * it (clamped to [8, #CU of the device]), cus < 0 resets it to the whole device, cus == 0 only queries; returns the budget in effect.
- * Default: the environment variable MANTIS_GEMM_CUS (read once), else the whole device.  For data-parallel runs: every RCCL channel is a
- * workgroup that cannot share a CU with a 160-KiB-LDS ring workgroup, so with C channels active plan for #CU - C.  Deterministic for a
- * given budget; a different budget changes which tiles are K-split, i.e. their fp32 summation order (results agree to bf16 rounding).
- * The split-K workspace size does not depend on it. */
+/* CU budget of the GEMM tile scheduler (rounds of tiles, the K split of an incomplete last round, the tile variant).  PER CALL since round 5:
+ * bits 16-27 of mantis_gemm_bf16_nt's / _sumsq's `flags` and of mantis_gemm_bf16_nt_fused's `variant` (0 = the default: the environment
+ * constant MANTIS_GEMM_CUS, read once, else the whole device) -- no process-wide state, two models / gradient reducers in one process do
+ * not interfere.  This entry is a pure query: the budget a launch asking for `cus` plans for (cus > 0: clamped to [8, #CU of the device];
+ * cus <= 0: the default).  For data-parallel runs: every RCCL channel is a workgroup that cannot share a CU with a 160-KiB-LDS ring
+ * workgroup, so with C channels active plan for #CU - C.  Deterministic for a given budget; a different budget changes which tiles are
+ * K-split, i.e. their fp32 summation order (results agree to bf16 rounding).  The split-K workspace size does not depend on it. */
 int mantis_gemm_cu_budget(int cus);
 /* Forward projections with a two-column epilogue fused in (16x16x32 ring kernels 13 / 14, NT layout).
  *   mode 1 (SwiGLU): B = [gate | up] weight [2 I, K], N = 2 I: C = A . B^T [M, 2 I] exactly as mantis_gemm_bf16_nt writes it AND
@@ -136,14 +143,15 @@ int mantis_gemm_cu_budget(int cus);
  *   mode 2 (RoPE):   q|k|v projection, heads of 128 columns, optional bias: columns [0, aux_n) leave with the rotary embedding applied
  *                    (aux0 = cos, aux1 = sin, bf16 [M, 64], row stride aux_ld), exactly as mantis_rope_apply(backward = 0) would
  *                    rotate them in a second pass (apply_rotary_pos_emb, modeling_llama.py:138-160)
- * variant 0 = per-shape choice, 13 / 14 forced.  MANTIS_EUNSUPPORTED for shapes outside the fused kernels' conditions (N % 256, I % 128,
+ * variant: bits 0-3 0 = per-shape choice, 13 / 14 forced | 64 = in-kernel remainder reduction (flag 16384 of mantis_gemm_bf16_nt) | bits
+ * 16-27 CU budget (as in mantis_gemm_bf16_nt's flags).  MANTIS_EUNSUPPORTED for shapes outside the fused kernels' conditions (N % 256, I % 128,
  * aux_n % 128, 16-B alignment, operands < 4 GiB): the caller then issues the two launches. */
 int mantis_gemm_bf16_nt_fused(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
                               const void* bias /*nullable*/, int mode, void* aux0, const void* aux1 /*mode 2*/, int64_t aux_ld, int aux_n,
                               int variant, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Weight-gradient GEMM that also leaves the squared norm of its result.  C (+)= A . B^T exactly as mantis_gemm_bf16_nt computes it
- * (flags: 32 accumulate | 4096 / 8192 K-major operands | bits 8-11 variant 13 / 14, or 0 = automatic) and, for every 256 x 256 output
+ * (flags: 32 accumulate | 4096 / 8192 K-major operands | bits 8-11 variant 13 / 14, or 0 = automatic | 16384 | bits 16-27 CU budget) and, for every 256 x 256 output
  * tile t (the kernel's tile order), tile_sumsq[t] = the sum of the squares of the bf16 values stored in that tile -- after the
  * accumulation when flag 32 is set.  tile_sumsq holds cdiv(M,256) * cdiv(N,256) floats; every entry is written exactly once.  Replaces,
  * for the weight gradients, the pass of clip_grad_norm_ (HF trainer.py:2535-2545) over the gradient: the optimizer sums the tile values
@@ -153,6 +161,8 @@ int mantis_gemm_bf16_nt_sumsq(const void* A, int64_t lda, const void* B, int64_t
                               float* tile_sumsq, void* workspace, int64_t workspace_bytes, void* stream);
 /* tile family the auto heuristic (flags bits 8-11 == 0) picks: 12 = a 256x256 ring kernel (which of 12 / 13 / 14: see above), 1 = the 128x128 generic kernel */
 int mantis_gemm_pick_variant(int M, int N, int K);
+/* the same for a launch planned for `cus` compute units (cus <= 0: the default budget) */
+int mantis_gemm_pick_variant_cus(int M, int N, int K, int cus);
 
 /* ---- fp8 linears (BASELINE configs[4] "fp8 MFMA"): an accelerated variant of the bf16 nn.Linear of the Qwen2
  * decoder (HF:models/qwen2_vl/modeling_qwen2_vl.py:453-466,501-504); the reference has no fp8, tolerance is stated against its bf16 /

@@ -27,9 +27,12 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
 def hw_queues_at_init():
-    """Hardware queues the HIP runtime was (or will be) created with, as far as this process can know: the value of
-    GPU_MAX_HW_QUEUES that was in the environment when HIP initialised -- ROCm's default of 4 if HIP was already up when this package
-    was imported and the variable was not set.  A value that does not parse counts as the default."""
+    """Hardware queues the HIP runtime was (or will be) created with -- BEST EFFORT: the value of GPU_MAX_HW_QUEUES that was in the
+    environment when HIP initialised, ROCm's default of 4 if HIP was already up when this package was imported and the variable was not
+    set.  "Already up" is taken from torch.cuda.is_initialized(), which stays False after torch.cuda.is_available() / device_count() --
+    calls that do bring the HIP runtime up (and make it read the variable): in that case this function reports 8 although the runtime
+    came up with 4 (round-4 advisor finding).  Nothing here can see that; only a probe of the streams themselves can
+    (`dp.hw_queue_probe`, `dp.rccl_overlap_probe`: what `GradReducer` relies on).  A value that does not parse counts as the default."""
     def parse(v, default):
         try:
             return int(str(v).strip())

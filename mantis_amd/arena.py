@@ -19,7 +19,21 @@ def numel(shape):
 #: (row-major) or 256-B pieces (K-major); with 16-byte alignment only, the SigLIP biases (4304 elements) left every decoder weight of
 #: Mantis-8B 96 bytes into a cache line, each row segment straddled two lines, and every forward GEMM of the step ran 7 - 13 % slower
 #: than the same launch on separately allocated operands (profiles/r04_experiments.md 12).
-ARENA_ALIGN = int(os.environ.get("MANTIS_ARENA_ALIGN", "128"))       # elements (bf16); the variable exists for A/B measurements (8 = round 3's layout)
+def _arena_align():
+    """MANTIS_ARENA_ALIGN in bf16 elements (the variable exists for A/B measurements; 8 = round 3's layout).  The GEMM, AdamW and
+    sum-of-squares kernels assume 16-byte aligned starts: a value below 8 or not a multiple of 8 is refused here, not as a
+    ZeroDivisionError in _place() or a misaligned access on the device."""
+    raw = os.environ.get("MANTIS_ARENA_ALIGN", "128")
+    try:
+        v = int(raw)
+    except ValueError:
+        raise ValueError(f"MANTIS_ARENA_ALIGN={raw!r}: expected a number of bf16 elements (a multiple of 8, >= 8)") from None
+    if v < 8 or v % 8:
+        raise ValueError(f"MANTIS_ARENA_ALIGN={v}: parameters must start on 16-byte boundaries -- a multiple of 8 elements, at least 8")
+    return v
+
+
+ARENA_ALIGN = _arena_align()
 
 
 class ArenaModule(nn.Module):

@@ -503,10 +503,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 #pragma unroll
                 for (int cp = 0; cp < 2; ++cp) {
                     const bf16x8 dsf = pack_frag(s, cp);
+                    if constexpr (kDqTrAsm && Y::DMA) {
+                        // hd 128: hand-issued K^T reads (the builtin's s_waitcnt vmcnt(0) would wait for the NEXT tile's DMA right here)
+                        bf16x8 kt[4];
+                        read_tr_frag4_sync(sK, sb * 32 + 16 * cp, lane, kt);
 #pragma unroll
-                    for (int d = 0; d < C::NDB; ++d) {
-                        const bf16x8 ktf = read_tr_frag<HD>(sK, sb * 32 + 16 * cp, d * 32, lane);
-                        acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf, acc[d], 0, 0, 0);
+                        for (int d = 0; d < 4; ++d) acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt[d], dsf, acc[d], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int d = 0; d < C::NDB; ++d) {
+                            const bf16x8 ktf = read_tr_frag<HD>(sK, sb * 32 + 16 * cp, d * 32, lane);
+                            acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf, acc[d], 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -763,6 +771,16 @@ __global__ void attn_group_reduce_kernel(const bf16_t* __restrict__ pk, const bf
 // imbalance is absorbed by the dispatch order (heaviest key block first) -- the reason the key block is 64 and not 128.
 // Optional segment bounds for packed samples: kstart[b, q] = first key position query q may attend (its sample's start),
 // qend[b, key] = one past the last query position that may attend key (its sample's end).
+#ifdef DKV_STAMPS
+// timing probe (tools/build_probe_lib.sh attn dkvstamps -DDKV_STAMPS; tools/attn_dkv_anatomy.py; never in the product build): wave 0 of every
+// workgroup sums, over the steps of its software-pipelined loop, the s_memtime intervals step top -> DMA of tile j + 3 issued, first fragments
+// requested -> MFMA 15 (S, dP of tile j + 2) -> MFMA 31 (dV, dK of tile j) -> behind the step's barrier; plus entry -> loop, entry -> exit.
+// (s_memtime returns through lgkmcnt: every stamp also drains the LDS reads in flight -- read the PROPORTIONS.)
+__device__ unsigned long long g_dkv_stamps[4096 * 8];
+#define DKV_STAMP(var) do { var = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define DKV_STAMP(var) do { } while (0)
+#endif
 template <bool CAUSAL, bool SEG>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_g4_kernel(
     const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V, const bf16_t* __restrict__ dO,
@@ -779,6 +797,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_g4_kernel(
     const int lane = threadIdx.x & 63, hh = lane >> 5, lk = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int kb = wave & 1, hp = wave >> 1;
+#ifdef DKV_STAMPS
+    unsigned long long st_entry, st_loop = 0, st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, sum_a = 0, sum_b = 0, sum_c = 0, sum_d = 0, n_steps = 0;
+    DKV_STAMP(st_entry);
+#endif
     // GQA group of G query heads per KV head, walked as two head streams (hp = 0, 1) of NH = ceil(G / 2) heads each.  Odd G: the last
     // head slot of stream 1 is a dummy (it re-reads the group's last head with lse = +inf, i.e. p = 0 and dS = 0: it adds exact zeros,
     // and keeps the two streams' barrier counts equal).  G = 4: Llama-3 / Mistral; G = 7: Qwen2-7B.
@@ -871,6 +893,31 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_g4_kernel(
         for (int j = 0; j < 4; ++j) {
             const int piece = kb * 4 + j;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lds_void_t*)(base + piece * 1024), 16, voQ[j] + soQ, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (lds_void_t*)(base + TILE + piece * 1024), 16, voD[j] + soD, 0, 0, 0);
+        }
+    };
+    // the same in two parts for the merged step (ATTN_DKV_MERGED): the words at the top of the step, the DMA pieces one per MFMA slot
+    auto stage_words = [&](int gi, int qt, float& vl, float& vs, int& ksv) {
+        const int q0 = qt * QT;
+        const int hl = hp * NH + gi;
+        const int h = hk * G + (hl < G ? hl : G - 1);
+        const unsigned soL = (unsigned)(((long)h * L + q0) * 4);
+        vl = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsL, (unsigned)lk * 4u + soL, 0, 0));
+        vs = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsS, (unsigned)lk * 4u + soL, 0, 0));
+        if constexpr (SEG) ksv = (int)__builtin_amdgcn_raw_buffer_load_b32(rsK, (unsigned)lk * 4u + (unsigned)q0 * 4u, 0, 0);
+    };
+    auto stage_piece = [&](auto qc, int gi, int qt, int slot) {       // piece q = 2 j + (0: Q rows, 1: dO rows) of the tile
+        constexpr int q = decltype(qc)::value, j = q >> 1;
+        const int q0 = qt * QT;
+        const int hl = hp * NH + gi;
+        const int h = hk * G + (hl < G ? hl : G - 1);
+        char* base = smem + slot * STAGE + hp * STREAM;
+        const int piece = kb * 4 + j;
+        if constexpr ((q & 1) == 0) {
+            const unsigned soQ = (unsigned)(((long)q0 * ldq + (long)h * HD) * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (lds_void_t*)(base + piece * 1024), 16, voQ[j] + soQ, 0, 0, 0);
+        } else {
+            const unsigned soD = (unsigned)(((long)q0 * ldo + (long)h * HD) * 2);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (lds_void_t*)(base + TILE + piece * 1024), 16, voD[j] + soD, 0, 0, 0);
         }
     };
@@ -1072,6 +1119,23 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_g4_kernel(
                         pk[0][1][cp][e] = pack_bf2(dv[0][8 * cp + 2 * e], dv[0][8 * cp + 2 * e + 1]);
                     }
             }
+            // this lane's transposing-read addresses (tr_issue): [ring slot pair][d-block], first read / the read eight rows further down; ring
+            // slot parity, the dO tile and the second 16-row half are immediate offsets
+            unsigned trA[2][4], trB[2][4];
+            if constexpr (kDkvTrAsm) {
+                const int s16 = lane & 15, g16 = (lane >> 4) & 1;
+                const int row = 4 * hh + (s16 >> 2);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int col = d * 32 + 16 * g16 + (s16 & 3) * 4;
+                    const int off = Y::chunk_off(row, col >> 3) + (col & 7) * 2;
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        trA[pr][d] = lds_addr_of(smem + pr * 2 * STAGE + hp * STREAM + off);
+                        trB[pr][d] = lds_addr_of(smem + pr * 2 * STAGE + hp * STREAM + ((off + 8 * 256) ^ 32));
+                    }
+                }
+            }
             auto step = [&](int j, auto kc) {
                 constexpr int k = decltype(kc)::value;                 // position inside the 12-step trip
                 constexpr int slot0 = k % 4, slot1 = (k + 1) % 4, slot2 = (k + 2) % 4, slot3 = (k + 3) % 4;
@@ -1080,54 +1144,133 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_g4_kernel(
                 constexpr int PF = 4;
                 const char* tq0 = smem + slot0 * STAGE + hp * STREAM;    // tile j: transposed fragments
                 const char* tq2 = smem + slot2 * STAGE + hp * STREAM;    // tile j + 2: row fragments
+                DKV_STAMP(st0);
                 const int gi3 = pg, qt3 = pq;                 // tile j + 3 (or the last tile again)
                 cursor_next();
                 float vl, vs;
                 int ksv = 0;
-                stage(gi3, qt3, slot3, vl, vs, ksv);       // slot3 held tile j-1: released by the barrier that ended step j-1
+                // slot3 held tile j-1: released by the barrier that ended step j-1.  Merged step: only the lse / rowsum words are requested
+                // here; the eight DMA pieces ride in the MFMA slots 1, 3, .. 15 (8 x ~60 cycles of issue with nothing else running cost the
+                // grouped step 655 of its 3087 cycles, profiles/r05_attn_anatomy.md) -- early enough to land before the step's barrier
+                if constexpr (kDkvMerged && kDkvDmaInSlots) stage_words(gi3, qt3, vl, vs, ksv);
+                else stage(gi3, qt3, slot3, vl, vs, ksv);
                 f32x4 lse4[4], dsm4[4];
                 load_words(slot1, lse4, dsm4);
                 bf16x8 fr[PF + 1];
 #pragma unroll
                 for (int g = 0; g < PF; ++g) fr[g] = rowfrag(tq2, g);
+                DKV_STAMP(st1);
                 FragU tf[4];
-                auto trfrag = [&](int g) -> bf16x8 {           // g = cp * 8 + d * 2 + which (0: dO^T for dV, 1: Q^T for dK)
-                    return read_tr_frag<HD>(tq0 + ((g & 1) ? 0 : TILE), 16 * (g >> 3), ((g >> 1) & 3) * 32, lane);
+                // transposed fragment g = cp * 8 + d * 2 + which (0: dO^T for dV, 1: Q^T for dK) of tile j.  Hand-issued (kDkvTrAsm): the builtin
+                // form put s_waitcnt vmcnt(0) in front of the step's first transposing read, i.e. the DMA of tile j + 3, issued at the top of
+                // this very step, was waited for in the MIDDLE of the step instead of at its end.  The reads' completion is then counted by
+                // hand: LDS operations retire in order, and behind the reads of fragment g only those of g + 1, g + 2 have been issued
+                auto tr_issue = [&](auto gc2, FragU& dst) {
+                    constexpr int g = decltype(gc2)::value, d = (g >> 1) & 3;
+                    if constexpr (kDkvTrAsm) {
+                        constexpr int imm = (slot0 & 1) * STAGE + ((g & 1) ? 0 : TILE) + (g >> 3) * 4096;
+                        const unsigned a0 = trA[slot0 >> 1][d], a1 = trB[slot0 >> 1][d];      // (named: asm operands alone do not capture)
+                        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst.h[0]) : "v"(a0), "i"(imm));
+                        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst.h[1]) : "v"(a1), "i"(imm));
+                    } else {
+                        dst.f = read_tr_frag<HD>(tq0 + ((g & 1) ? 0 : TILE), 16 * (g >> 3), d * 32, lane);
+                    }
                 };
-                // slots 0-15: MS(j+2)  ||  SM(j+1) elements 0-7  ||  cp = 1 packs of tile j (its elements 8-15 finished last step)
-                static_for<0, 16>([&](auto gc) {
-                    constexpr int g = decltype(gc)::value, ks = g >> 1;
-                    __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (g & 1) mfma_s(std::integral_constant<bool, ks == 0>{}, dv[r2], fr[g % (PF + 1)], vf[ks]);
-                    else mfma_s(std::integral_constant<bool, ks == 0>{}, sv[r2], fr[g % (PF + 1)], kf[ks]);
-                    if constexpr (g + PF < 16) fr[(g + PF) % (PF + 1)] = rowfrag(tq2, g + PF);
-                    if constexpr (g < 8) {
-                        constexpr int e = g & 3;
-                        if constexpr (g < 4) pk[par0][0][1][e] = pack_pinned(sv[r0][8 + 2 * e], sv[r0][8 + 2 * e + 1]);
-                        else pk[par0][1][1][e] = pack_pinned(dv[r0][8 + 2 * e], dv[r0][8 + 2 * e + 1]);
+                auto tr_wait = [&](auto gc2, FragU& f) {
+                    constexpr int g = decltype(gc2)::value;
+                    if constexpr (kDkvTrAsm) {
+                        if constexpr (g <= 13) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f.f));
+                        else if constexpr (g == 14) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(f.f));
+                        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.f));
                     }
-                    if constexpr (g & 1) sm_elem(std::integral_constant<int, (g >> 1)>{}, sv[r1], dv[r1], lse4, dsm4);
-                    if constexpr (g >= 13) tf[g - 13].f = trfrag(g - 13);
-                });
-                // slots 16-31: MA(j)  ||  SM(j+1) elements 8-15  ||  cp = 0 packs of tile j+1
-                static_for<0, 16>([&](auto gc) {
-                    constexpr int g = decltype(gc)::value, cp = g >> 3, d = (g >> 1) & 3;
-                    __builtin_amdgcn_sched_barrier(0);
-                    asm volatile("" ::: "memory");
-                    if constexpr (g & 1) dkacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[g & 3].f, as_bf16x8(pk[par0][1][cp]), dkacc[d], 0, 0, 0);
-                    else dvacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[g & 3].f, as_bf16x8(pk[par0][0][cp]), dvacc[d], 0, 0, 0);
-                    if constexpr (g + 3 < 16) tf[(g + 3) & 3].f = trfrag(g + 3);
-                    if constexpr (g & 1) sm_elem(std::integral_constant<int, 8 + (g >> 1)>{}, sv[r1], dv[r1], lse4, dsm4);
-                    if constexpr (g < 8) {
-                        constexpr int e = g & 3;
-                        if constexpr (g < 4) pk[par1][0][0][e] = pack_pinned(sv[r1][2 * e], sv[r1][2 * e + 1]);
-                        else pk[par1][1][0][e] = pack_pinned(dv[r1][2 * e], dv[r1][2 * e + 1]);
-                    }
-                });
+                };
+                if constexpr (kDkvMerged) {
+                    // MERGED order (round 5): the step's 32 MFMAs alternate between the two groups -- S(ks), dV, dP(ks), dK, S(ks + 1), ... -- so
+                    // that two MFMAs on the SAME accumulator are four instructions apart.  In the grouped order below the score chains
+                    // S(0) dP(0) S(1) dP(1) ... put every other MFMA behind its own predecessor's result (a 32x32x16 MFMA takes 16 passes;
+                    // with VALU / LDS work issued in between, a dependent pair costs ~110 cycles instead of 64): the in-kernel stamps showed
+                    // 1359 cycles for those 16 MFMAs against 775 for the 16 independent accumulation MFMAs (profiles/r05_attn_anatomy.md).
+                    // Even slot m: item g = m / 2 of MS(j+2); odd slot: item g = (m - 1) / 2 of MA(j).  The transposed fragments of items 0-2 are
+                    // requested at the top of the step (hand-issued: a builtin read would wait for the DMA issued just above), the cp = 0 packs
+                    // of tile j + 1 move behind the softmax-backward elements they read (odd items 3, 7, 11, 15).
+                    tr_issue(std::integral_constant<int, 0>{}, tf[0]);
+                    tr_issue(std::integral_constant<int, 1>{}, tf[1]);
+                    tr_issue(std::integral_constant<int, 2>{}, tf[2]);
+                    static_for<0, 32>([&](auto mc) {
+                        constexpr int m = decltype(mc)::value, g = m >> 1;
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr ((m & 1) == 0) {
+                            constexpr int ks = g >> 1;
+                            if constexpr (g & 1) mfma_s(std::integral_constant<bool, ks == 0>{}, dv[r2], fr[g % (PF + 1)], vf[ks]);
+                            else mfma_s(std::integral_constant<bool, ks == 0>{}, sv[r2], fr[g % (PF + 1)], kf[ks]);
+                            if constexpr (g + PF < 16) fr[(g + PF) % (PF + 1)] = rowfrag(tq2, g + PF);
+                            if constexpr (g < 8) {
+                                constexpr int e = g & 3;
+                                if constexpr (g < 4) pk[par0][0][1][e] = pack_pinned(sv[r0][8 + 2 * e], sv[r0][8 + 2 * e + 1]);
+                                else pk[par0][1][1][e] = pack_pinned(dv[r0][8 + 2 * e], dv[r0][8 + 2 * e + 1]);
+                            }
+                            if constexpr (g & 1) sm_elem(std::integral_constant<int, (g >> 1)>{}, sv[r1], dv[r1], lse4, dsm4);
+                        } else {
+                            constexpr int cp = g >> 3, d = (g >> 1) & 3;
+                            asm volatile("" ::: "memory");
+                            tr_wait(std::integral_constant<int, g>{}, tf[g & 3]);
+                            if constexpr (g & 1) dkacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[g & 3].f, as_bf16x8(pk[par0][1][cp]), dkacc[d], 0, 0, 0);
+                            else dvacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[g & 3].f, as_bf16x8(pk[par0][0][cp]), dvacc[d], 0, 0, 0);
+                            if constexpr (g + 3 < 16) tr_issue(std::integral_constant<int, g + 3>{}, tf[(g + 3) & 3]);
+                            if constexpr (kDkvDmaInSlots && g < 8) stage_piece(std::integral_constant<int, g>{}, gi3, qt3, slot3);
+                            if constexpr (g & 1) sm_elem(std::integral_constant<int, 8 + (g >> 1)>{}, sv[r1], dv[r1], lse4, dsm4);
+                            if constexpr ((g & 3) == 3) {       // elements 2 e, 2 e + 1 of tile j + 1 left the softmax backward in even item 4 e + 3
+                                constexpr int e = g >> 2;
+                                pk[par1][0][0][e] = pack_pinned(sv[r1][2 * e], sv[r1][2 * e + 1]);
+                                pk[par1][1][0][e] = pack_pinned(dv[r1][2 * e], dv[r1][2 * e + 1]);
+                            }
+                        }
+                    });
+                    DKV_STAMP(st2);
+                } else {
+                    // slots 0-15: MS(j+2)  ||  SM(j+1) elements 0-7  ||  cp = 1 packs of tile j (its elements 8-15 finished last step)
+                    static_for<0, 16>([&](auto gc) {
+                        constexpr int g = decltype(gc)::value, ks = g >> 1;
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (g & 1) mfma_s(std::integral_constant<bool, ks == 0>{}, dv[r2], fr[g % (PF + 1)], vf[ks]);
+                        else mfma_s(std::integral_constant<bool, ks == 0>{}, sv[r2], fr[g % (PF + 1)], kf[ks]);
+                        if constexpr (g + PF < 16) fr[(g + PF) % (PF + 1)] = rowfrag(tq2, g + PF);
+                        if constexpr (g < 8) {
+                            constexpr int e = g & 3;
+                            if constexpr (g < 4) pk[par0][0][1][e] = pack_pinned(sv[r0][8 + 2 * e], sv[r0][8 + 2 * e + 1]);
+                            else pk[par0][1][1][e] = pack_pinned(dv[r0][8 + 2 * e], dv[r0][8 + 2 * e + 1]);
+                        }
+                        if constexpr (g & 1) sm_elem(std::integral_constant<int, (g >> 1)>{}, sv[r1], dv[r1], lse4, dsm4);
+                        if constexpr (g >= 13) tr_issue(std::integral_constant<int, g - 13>{}, tf[g - 13]);
+                    });
+                    DKV_STAMP(st2);
+                    // slots 16-31: MA(j)  ||  SM(j+1) elements 8-15  ||  cp = 0 packs of tile j+1
+                    static_for<0, 16>([&](auto gc) {
+                        constexpr int g = decltype(gc)::value, cp = g >> 3, d = (g >> 1) & 3;
+                        __builtin_amdgcn_sched_barrier(0);
+                        asm volatile("" ::: "memory");
+                        tr_wait(gc, tf[g & 3]);
+                        if constexpr (g & 1) dkacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[g & 3].f, as_bf16x8(pk[par0][1][cp]), dkacc[d], 0, 0, 0);
+                        else dvacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tf[g & 3].f, as_bf16x8(pk[par0][0][cp]), dvacc[d], 0, 0, 0);
+                        if constexpr (g + 3 < 16) tr_issue(std::integral_constant<int, g + 3>{}, tf[(g + 3) & 3]);
+                        if constexpr (g & 1) sm_elem(std::integral_constant<int, 8 + (g >> 1)>{}, sv[r1], dv[r1], lse4, dsm4);
+                        if constexpr (g < 8) {
+                            constexpr int e = g & 3;
+                            if constexpr (g < 4) pk[par1][0][0][e] = pack_pinned(sv[r1][2 * e], sv[r1][2 * e + 1]);
+                            else pk[par1][1][0][e] = pack_pinned(dv[r1][2 * e], dv[r1][2 * e + 1]);
+                        }
+                    });
+                }
                 __builtin_amdgcn_sched_barrier(0);
+                DKV_STAMP(st3);
                 stage_finish(gi3, qt3, slot3, vl, vs, ksv);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile j+3 landed (this wave's pieces)
                 __syncthreads();
+#ifdef DKV_STAMPS
+                DKV_STAMP(st4);
+                if (st_loop == 0) st_loop = st0;
+                sum_a += st1 - st0; sum_b += st2 - st1; sum_c += st3 - st2; sum_d += st4 - st3; n_steps += 1;
+#endif
             };
             int j = 0;
             while (true) {
@@ -1172,7 +1315,23 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_g4_kernel(
                 }
         }
     }
+#ifdef DKV_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {
+        unsigned long long st_exit;
+        DKV_STAMP(st_exit);
+        unsigned long long* o = g_dkv_stamps + (size_t)blockIdx.x * 8;
+        o[0] = st_loop ? st_loop - st_entry : 0; o[1] = st_exit - st_entry; o[2] = n_steps; o[3] = sum_a; o[4] = sum_b; o[5] = sum_c; o[6] = sum_d;
+        o[7] = (unsigned long long)bx;
+    }
+#endif
 }
+
+#ifdef DKV_STAMPS
+// probe builds only: copy the stamps of the last attn_bwd_dkv_g4_kernel launch (n workgroups x 8 u64) to host memory
+extern "C" int mantis_probe_dkv_stamps(void* host_dst, int n_wg) {
+    return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_dkv_stamps), (size_t)n_wg * 64, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+}
+#endif
 
 static int attn_num_cus() {
     static int cached[64];

@@ -106,6 +106,57 @@ __device__ __forceinline__ bf16x8 read_tr_frag(const char* tile, int row0, int c
     return u.f;
 }
 
+// The builtin transposing read gets an `s_waitcnt vmcnt(0)` in front of it whenever LDS-DMA pieces are in flight (the compiler cannot tell its
+// address from the pieces' destinations): the prefetch of the NEXT K / V (Q / dO) tile is then waited for at the first transposing read of
+// the CURRENT tile (profiles/r04_experiments.md 14c).  Hand-issued reads are invisible to that pass; their own completion is waited for by hand.
+// Measured (round 5, profiles/r05_experiments.md): on the UNCHANGED instruction order they are 2 - 3 % SLOWER than the builtin (dQ 233 vs 228 us,
+// dK/dV 338 vs 328 us: the volatile statements cost the scheduler more than the mid-tile wait costs the DMA), so the dQ kernel keeps the
+// builtin; the dK/dV group kernel needs them for its merged MFMA order (ATTN_DKV_MERGED), which requests transposed fragments at the top of a
+// step, right behind that step's DMA issue.  Build flags for A/B probe builds: -DATTN_DQ_TR_ASM=1, -DATTN_DKV_TR_ASM=1, -DATTN_DKV_MERGED=0.
+#ifndef ATTN_DQ_TR_ASM
+#define ATTN_DQ_TR_ASM 0
+#endif
+#ifndef ATTN_DKV_MERGED
+#define ATTN_DKV_MERGED 1
+#endif
+#ifndef ATTN_DKV_TR_ASM
+#define ATTN_DKV_TR_ASM 0
+#endif
+constexpr bool kDqTrAsm = ATTN_DQ_TR_ASM != 0;
+constexpr bool kDkvMerged = ATTN_DKV_MERGED != 0;
+constexpr bool kDkvTrAsm = ATTN_DKV_TR_ASM != 0 || kDkvMerged;
+#ifndef ATTN_DKV_DMA_IN_SLOTS
+#define ATTN_DKV_DMA_IN_SLOTS 1
+#endif
+constexpr bool kDkvDmaInSlots = ATTN_DKV_DMA_IN_SLOTS != 0 && kDkvMerged;      // the merged step issues its DMA pieces one per MFMA slot
+
+__device__ __forceinline__ unsigned lds_addr_of(const char* p) {
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+// the four d-block fragments (columns d * 32 ..) of rows row0 .. row0 + 15 of an hd-128 tile: eight transposing reads behind ONE wait
+__device__ __forceinline__ void read_tr_frag4_sync(const char* tile, int row0, int lane, bf16x8 (&out)[4]) {
+    const int s = lane & 15, g16 = (lane >> 4) & 1, h = lane >> 5;
+    const int row = row0 + 4 * h + (s >> 2);
+    unsigned a[4], b[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const int col = d * 32 + 16 * g16 + (s & 3) * 4;
+        const int off = Lay<128>::chunk_off(row, col >> 3) + (col & 7) * 2;
+        a[d] = lds_addr_of(tile + off);
+        b[d] = lds_addr_of(tile + ((off + 8 * 256) ^ 32));       // row + 8: see read_tr_frag
+    }
+    union { s16x4 h2[2]; bf16x8 f; } u[4];
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %9\n\tds_read_b64_tr_b16 %2, %10\n\tds_read_b64_tr_b16 %3, %11\n\t"
+        "ds_read_b64_tr_b16 %4, %12\n\tds_read_b64_tr_b16 %5, %13\n\tds_read_b64_tr_b16 %6, %14\n\tds_read_b64_tr_b16 %7, %15\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(u[0].h2[0]), "=&v"(u[0].h2[1]), "=&v"(u[1].h2[0]), "=&v"(u[1].h2[1]), "=&v"(u[2].h2[0]), "=&v"(u[2].h2[1]), "=&v"(u[3].h2[0]),
+          "=&v"(u[3].h2[1])
+        : "v"(a[0]), "v"(b[0]), "v"(a[1]), "v"(b[1]), "v"(a[2]), "v"(b[2]), "v"(a[3]), "v"(b[3]));
+#pragma unroll
+    for (int d = 0; d < 4; ++d) out[d] = u[d].f;
+}
+
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) {

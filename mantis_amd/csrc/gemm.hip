@@ -42,6 +42,10 @@
 #define EPI_VARIANT_MASK (15 << EPI_VARIANT_SHIFT)
 #define EPI_A_KMAJOR 4096                   // A given as [K, M] (element (m,k) at A[k*lda + m])
 #define EPI_B_KMAJOR 8192                   // B given as [K, N]
+#define EPI_CUS_SHIFT 16                    // bits 16-27: CU budget this launch is planned for (0 = the default: MANTIS_GEMM_CUS or the whole device)
+#define EPI_CUS_MASK (0xFFF << EPI_CUS_SHIFT)
+#define EPI_SK_INKERNEL 16384                // ring16 kernels: remainder tiles reduced by their last arriver inside the GEMM kernel (round 4) instead of by
+                                            // gemm_ring16_finish_kernel -- same results bit for bit; tests and A/B measurements
 
 typedef __attribute__((address_space(3))) void lds_void;
 
@@ -480,7 +484,7 @@ template <int NBN, int NBM, bool BIAS, int ACT, int PRE, bool SS = false, bool N
 __device__ __forceinline__ void epi_fast_run(const f32x4 (&acc)[NBN][NBM], char* __restrict__ strip, bf16_t* __restrict__ C, int M, int N,
                                              long ldc, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res, long ldr, int mw0,
                                              int nw0, int lane, float* ss = nullptr) {
-    constexpr int PN = NBN / 4, NPASS = 2 * PN;
+    constexpr int PN = NBN / 4, NPASS = (NBM / 4) * PN;
     constexpr int G = PRE == EPRE_SWIGLU ? 4 : 8, GPP = 8 / G, NG = NPASS * GPP;
     const int rr = lane >> 3, cc = lane & 7;
     char* wr = strip + (lane & 15) * EPI_PITCH + (4 * (lane >> 4)) * 4;
@@ -1059,6 +1063,194 @@ __device__ unsigned long long g_ring16_stamps[8192 * 8];
 #define PAIR_NONE 0
 #define PAIR_SWIGLU 1
 #define PAIR_ROPE 2
+// Epilogue of a ring16 wave tile: all of it (NBM_ = 8, from the GEMM kernel) or one 64-row half of it (NBM_ = 4, from the K-split finishing
+// kernel).  acc[tn][tm] = 16 x 16 block (n block tn, m block tm) of the wave's 128 (64) x NBN*16 tile whose first row is mw0; wave_l / tid_l =
+// the wave's / thread's index inside its block (strip ownership, the sumsq reduction: that one needs all NW waves of the tile in the block);
+// KM: a K-major operand layout, i.e. a dX / dW launch whose plain result streams out.
+template <int NW, int NBM_, bool KM, bool SWIGLU, int PAIR, bool FIN>
+__device__ __forceinline__ void ring16_epilogue(const f32x4 (&acc)[NW == 4 ? 8 : 4][NBM_], char* __restrict__ smem, int wave_l, int tid_l, int lane,
+                                                int wn, bf16_t* __restrict__ C, int M, int N, long ldc, const bf16_t* __restrict__ bias,
+                                                const bf16_t* __restrict__ res, long ldr, int flags, int mw0, int n0, int tile_id,
+                                                bf16_t* __restrict__ aux0, const bf16_t* __restrict__ aux1, long aux_ld, int aux_n) {
+    // epilogue: the wave tile goes through the wave-private strip in 64 x 64 passes.  Block (tn, tm): lane l holds row tm*16 + (l & 15),
+    // columns tn*16 + 4*(l >> 4) .. + 3 -> one 16-B strip write per block (8 consecutive lanes = 8 rows of pitch 272 B: conflict-free)
+    constexpr int NBN = NW == 4 ? 8 : 4;
+    char* strip = smem + wave_l * EPI_STRIP;
+    const int nw0 = n0 + wn * (NBN * 16);
+    const int pair_dist = PAIR == PAIR_SWIGLU ? (N >> 1) : 64;
+    auto pair_first = [&](int phi) { return PAIR == PAIR_SWIGLU ? (n0 >> 1) + phi : n0 + (phi >> 6) * 128 + (phi & 63); };
+    if constexpr (PAIR != PAIR_NONE) {
+        // 4 waves: two strips per wave (8 x 17 KiB <= 160 KiB), A = the first columns, B = the second columns of the wave's 64 features; per
+        //          64-row pass, lane (rr = lane >> 3, cc = lane & 7) meets both columns of (row it*8 + rr, features cc*8 ..) at the same
+        //          position of the two strips
+        // 8 waves: one strip per wave (8 x 17 KiB): its 64 columns are [32 first | 32 second] -- the plain strip fill; per 64-row pass, lane
+        //          (r16 = lane >> 2, fg = lane & 3) reads the first columns at fg*8 and the second ones at 32 + fg*8 of row it*16 + r16
+        constexpr int G = NBN * 8;
+        char* sa = smem + (NW == 4 ? 2 * wave_l : wave_l) * EPI_STRIP;
+        char* sb = NW == 4 ? sa + EPI_STRIP : sa + 32 * 4;
+        const int phi0 = wn * G;
+        const int rr = NW == 4 ? lane >> 3 : lane >> 2, cc = NW == 4 ? lane & 7 : lane & 3;
+        constexpr int RPI = NW == 4 ? 8 : 16;              // rows per read-back iteration
+        const bool has_bias = flags & EPI_BIAS;
+#pragma unroll
+        for (int pass = 0; pass < NBM_ / 4; ++pass) {
+#pragma unroll
+            for (int tm4 = 0; tm4 < 4; ++tm4)
+#pragma unroll
+                for (int tn4 = 0; tn4 < 4; ++tn4) {
+                    const int off = (tm4 * 16 + (lane & 15)) * EPI_PITCH + (tn4 * 16 + 4 * (lane >> 4)) * 4;
+                    if constexpr (NW == 4) {
+                        *reinterpret_cast<f32x4*>(sa + off) = acc[tn4][pass * 4 + tm4];
+                        *reinterpret_cast<f32x4*>(sb + off) = acc[4 + tn4][pass * 4 + tm4];
+                    } else {
+                        *reinterpret_cast<f32x4*>(sa + off) = acc[tn4][pass * 4 + tm4];      // blocks 0,1 = first, 2,3 = second columns
+                    }
+                }
+            const int phi = phi0 + cc * 8;
+            const int col1 = pair_first(phi), col2 = col1 + pair_dist;
+            float b1[8], b2[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                b1[e] = has_bias ? bf2f(bias[col1 + e]) : 0.f;
+                b2[e] = has_bias ? bf2f(bias[col2 + e]) : 0.f;
+            }
+            // rotary tables of the whole pass requested up front (one memory round trip per pass instead of one per iteration)
+            u32x4 vcs[64 / RPI], vss[64 / RPI];
+            const bool rot = PAIR == PAIR_ROPE && col1 < aux_n;
+            if constexpr (PAIR == PAIR_ROPE) {
+                if (rot) {
+#pragma unroll
+                    for (int it = 0; it < 64 / RPI; ++it) {
+                        int m = mw0 + pass * 64 + it * RPI + rr;
+                        m = m < M ? m : M - 1;
+                        vcs[it] = *reinterpret_cast<const u32x4*>(aux0 + (long)m * aux_ld + (phi & 63));
+                        vss[it] = *reinterpret_cast<const u32x4*>(aux1 + (long)m * aux_ld + (phi & 63));
+                    }
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < 64 / RPI; ++it) {
+                const int row = it * RPI + rr;
+                const int m = mw0 + pass * 64 + row;
+                const f32x4 alo = *reinterpret_cast<const f32x4*>(sa + row * EPI_PITCH + cc * 32);
+                const f32x4 ahi = *reinterpret_cast<const f32x4*>(sa + row * EPI_PITCH + cc * 32 + 16);
+                const f32x4 blo = *reinterpret_cast<const f32x4*>(sb + row * EPI_PITCH + cc * 32);
+                const f32x4 bhi = *reinterpret_cast<const f32x4*>(sb + row * EPI_PITCH + cc * 32 + 16);
+                if (m >= M) continue;
+                float v1[8] = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+                float v2[8] = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
+                if (has_bias) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        v1[e] += b1[e];
+                        v2[e] += b2[e];
+                    }
+                }
+                u32x4 o1, o2;
+                if constexpr (PAIR == PAIR_SWIGLU) {
+                    // gate, up rounded to bf16 as the unfused GEMM stores them; a = bf16(bf16(silu(gate)) * up) as swiglu_fwd_kernel
+                    u32x4 oa;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o1[e] = pack_bf2(v1[2 * e], v1[2 * e + 1]);
+                        o2[e] = pack_bf2(v2[2 * e], v2[2 * e + 1]);
+                        const float g0 = bf2f_lo(o1[e]), g1 = bf2f_hi(o1[e]);
+                        const float s0 = bf2f(f2bf(g0 * (1.f / (1.f + __expf(-g0))))), s1 = bf2f(f2bf(g1 * (1.f / (1.f + __expf(-g1)))));
+                        oa[e] = pack_bf2(s0 * bf2f_lo(o2[e]), s1 * bf2f_hi(o2[e]));
+                    }
+                    epi_st16<false>(aux0 + (long)m * aux_ld + col1, oa);      // read by the down projection next
+                } else {
+                    const u32x4 vc = vcs[it], vs = vss[it];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned w1 = pack_bf2(v1[2 * e], v1[2 * e + 1]);
+                        const unsigned w2 = pack_bf2(v2[2 * e], v2[2 * e + 1]);
+                        if (rot) {
+                            const float x1[2] = {bf2f_lo(w1), bf2f_hi(w1)}, x2[2] = {bf2f_lo(w2), bf2f_hi(w2)};
+                            const float cs[2] = {bf2f_lo(vc[e]), bf2f_hi(vc[e])}, sn[2] = {bf2f_lo(vs[e]), bf2f_hi(vs[e])};
+                            float r1[2], r2[2];
+#pragma unroll
+                            for (int h2 = 0; h2 < 2; ++h2) {
+                                r1[h2] = bf2f(f2bf(x1[h2] * cs[h2])) - bf2f(f2bf(x2[h2] * sn[h2]));
+                                r2[h2] = bf2f(f2bf(x2[h2] * cs[h2])) + bf2f(f2bf(x1[h2] * sn[h2]));
+                            }
+                            o1[e] = pack_bf2(r1[0], r1[1]);
+                            o2[e] = pack_bf2(r2[0], r2[1]);
+                        } else {
+                            o1[e] = w1;
+                            o2[e] = w2;
+                        }
+                    }
+                }
+                epi_st16<PAIR == PAIR_SWIGLU>(C + (long)m * ldc + col1, o1);      // [gate | up]: kept for the backward; q|k|v: read next
+                epi_st16<PAIR == PAIR_SWIGLU>(C + (long)m * ldc + col2, o2);
+            }
+        }
+        return;
+    }
+    {
+        // fast read-back (see epi_fast_run) when every column of this wave's tile is inside N and the operands are 16-B vectors; the
+        // epilogue kinds of the step are compile-time variants, anything else takes the general path below
+        const bool needs_res = flags & (EPI_RESIDUAL | EPI_SWIGLU_BWD);
+        const bool vec_ok = !(ldc & 7) && !((uintptr_t)C & 15) && (!needs_res || (!(ldr & 7) && !((uintptr_t)res & 15))) &&
+                            (!(flags & EPI_BIAS) || !((uintptr_t)bias & 15)) && (!(flags & EPI_SWIGLU_BWD) || !(N & 7));
+        if (vec_ok && nw0 + NBN * 16 <= N) {
+#define EPI_FAST(B_, A_, P_, NT_) epi_fast_run<NBN, NBM_, B_, A_, P_, false, NT_>(acc, strip, C, M, N, ldc, bias, res, ldr, mw0, nw0, lane)
+            if constexpr (!SWIGLU && PAIR == PAIR_NONE) {
+                if (flags & EPI_SUMSQ) {
+                    // weight-gradient launches of mantis_gemm_bf16_nt_sumsq: the squared norm of the stored tile rides along (the optimizer's
+                    // global gradient norm then needs no pass of its own over these 16 GB).  Lane partials in a fixed order, DPP wave sum,
+                    // waves summed in order by thread 0: deterministic.  The entry point guarantees the fast path for every wave.
+                    float ss = 0.f;
+                    if (flags & EPI_ACCUM) epi_fast_run<NBN, NBM_, false, 0, EPRE_ACC, true, true>(acc, strip, C, M, N, ldc, bias, res, ldr, mw0, nw0, lane, &ss);
+                    else epi_fast_run<NBN, NBM_, false, 0, EPRE_NONE, true, true>(acc, strip, C, M, N, ldc, bias, res, ldr, mw0, nw0, lane, &ss);
+                    ss = wave_sum(ss);
+                    float* red = reinterpret_cast<float*>(smem + NW * EPI_STRIP);
+                    if (lane == 0) red[wave_l] = ss;
+                    __syncthreads();
+                    if (tid_l == 0) {
+                        float t = 0.f;
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) t += red[w];
+                        // finishing kernel: the tile's two 64-row halves are two workgroups -- two addends on a slot the GEMM kernel zeroed:
+                        // a + b == b + a bit for bit, so the atomic adds are deterministic
+                        if constexpr (FIN) __hip_atomic_fetch_add(reinterpret_cast<float*>(aux0) + tile_id, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        else reinterpret_cast<float*>(aux0)[tile_id] = t;
+                    }
+                    return;
+                }
+            }
+            if constexpr (!SWIGLU) {      // the SwiGLU-backward read-back stays on the general path: its tile moves 512 KiB (gate, up in; dgate, dup
+                                          // out) and is HBM-bound either way; requesting operands ahead measured 3 - 4 % SLOWER on dX(down) (bursts)
+                switch (flags & (EPI_BIAS | EPI_ACT_MASK | EPI_RESIDUAL | EPI_ACCUM)) {
+                    case 0: EPI_FAST(false, 0, EPRE_NONE, KM); return;      // dX / dW stream out; a plain forward store is read next
+                    case EPI_RESIDUAL: EPI_FAST(false, 0, EPRE_RES, true); return;
+                    case EPI_ACCUM: EPI_FAST(false, 0, EPRE_ACC, true); return;
+                    case EPI_BIAS: EPI_FAST(true, 0, EPRE_NONE, false); return;
+                    case EPI_BIAS | EPI_RESIDUAL: EPI_FAST(true, 0, EPRE_RES, false); return;
+                    case EPI_BIAS | (1 << EPI_ACT_SHIFT): EPI_FAST(true, 1, EPRE_NONE, false); return;
+                    case EPI_BIAS | (2 << EPI_ACT_SHIFT): EPI_FAST(true, 2, EPRE_NONE, false); return;
+                    case EPI_BIAS | (3 << EPI_ACT_SHIFT): EPI_FAST(true, 3, EPRE_NONE, false); return;
+                    default: break;
+                }
+            }
+#undef EPI_FAST
+        }
+    }
+#pragma unroll
+    for (int pm = 0; pm < NBM_ / 4; ++pm)
+#pragma unroll
+        for (int pn = 0; pn < NBN / 4; ++pn) {
+#pragma unroll
+            for (int tm4 = 0; tm4 < 4; ++tm4)
+#pragma unroll
+                for (int tn4 = 0; tn4 < 4; ++tn4)
+                    *reinterpret_cast<f32x4*>(strip + (tm4 * 16 + (lane & 15)) * EPI_PITCH + (tn4 * 16 + 4 * (lane >> 4)) * 4) =
+                        acc[pn * 4 + tn4][pm * 4 + tm4];
+            epi_readback64<SWIGLU>(strip, C, M, N, ldc, bias, res, ldr, flags, mw0 + pm * 64, nw0 + pn * 64, lane);
+        }
+}
+
 template <int NW, bool AKM, bool BKM, bool SWIGLU = false, int PAIR = PAIR_NONE>
 __global__ __launch_bounds__(NW * 64) void gemm_nt_ring16_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C, int M, int N, int K, long lda, long ldb,
@@ -1339,6 +1531,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring16_kernel(
         const int rt = tile_id - full;
         float* slabs = sk_slabs + (size_t)rt * S * SK_SLAB_FLOATS;
         sk_store16<NBN, NBM, NW * 64>(acc, slabs + (size_t)part * SK_SLAB_FLOATS, tid);
+        if (sk_cnt == nullptr) {
+            // finishing-kernel mode (launch_gemm_ring): no ticket, no reduction here -- gemm_ring16_finish_kernel, launched behind this
+            // kernel on the same stream, sums the S slabs of every remainder tile on ALL compute units and runs the epilogue (the kernel
+            // boundary publishes the slabs).  A sumsq launch zeroes the tile's slot for the finishing halves' two atomic adds.
+            if constexpr (!SWIGLU && PAIR == PAIR_NONE) {
+                if ((flags & EPI_SUMSQ) && part == 0 && tid == 0) reinterpret_cast<float*>(aux0)[tile_id] = 0.f;
+            }
+            return;
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
@@ -1365,177 +1566,75 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring16_kernel(
             for (int p = 0; p < S; ++p) sk_add16<NBN, NBM, NW * 64>(acc, slabs + (size_t)p * SK_SLAB_FLOATS, tid);
         }
     }
-    // epilogue: the wave tile goes through the wave-private strip in 64 x 64 passes.  Block (tn, tm): lane l holds row tm*16 + (l & 15),
-    // columns tn*16 + 4*(l >> 4) .. + 3 -> one 16-B strip write per block (8 consecutive lanes = 8 rows of pitch 272 B: conflict-free)
-    char* strip = smem + wave * EPI_STRIP;
-    const int mw0 = m0 + wm * 128, nw0 = n0 + wn * (NBN * 16);
-    if constexpr (PAIR != PAIR_NONE) {
-        // 4 waves: two strips per wave (8 x 17 KiB <= 160 KiB), A = the first columns, B = the second columns of the wave's 64 features; per
-        //          64-row pass, lane (rr = lane >> 3, cc = lane & 7) meets both columns of (row it*8 + rr, features cc*8 ..) at the same
-        //          position of the two strips
-        // 8 waves: one strip per wave (8 x 17 KiB): its 64 columns are [32 first | 32 second] -- the plain strip fill; per 64-row pass, lane
-        //          (r16 = lane >> 2, fg = lane & 3) reads the first columns at fg*8 and the second ones at 32 + fg*8 of row it*16 + r16
-        constexpr int G = NBN * 8;
-        char* sa = smem + (NW == 4 ? 2 * wave : wave) * EPI_STRIP;
-        char* sb = NW == 4 ? sa + EPI_STRIP : sa + 32 * 4;
-        const int phi0 = wn * G;
-        const int rr = NW == 4 ? lane >> 3 : lane >> 2, cc = NW == 4 ? lane & 7 : lane & 3;
-        constexpr int RPI = NW == 4 ? 8 : 16;              // rows per read-back iteration
-        const bool has_bias = flags & EPI_BIAS;
+    ring16_epilogue<NW, NBM, (AKM || BKM), SWIGLU, PAIR, false>(acc, smem, wave, tid, lane, wn, C, M, N, ldc, bias, res, ldr, flags, m0 + wm * 128, n0,
+                                                                 tile_id, aux0, aux1, aux_ld, aux_n);
+}
+
+// K-split finishing pass of the ring16 kernels (round 5).  Until round 4 the LAST ARRIVER of a remainder tile summed the tile's S slabs and ran
+// the epilogue: S x 256 KiB through ONE compute unit's memory pipeline while most of the chip idled -- 38 - 49 us behind the K loop of every
+// launch with an incomplete last round (S = 2), 47 - 95 us at S = 8 (profiles/r04_gemm_anatomy.md).  Now the split units only store their slabs and
+// this kernel, launched behind the GEMM on the same stream, spreads the reduction over the whole device: workgroup = (remainder tile, 64-row
+// half pm of every wave tile, group of `blockDim.x / 64` of the tile's NW waves); a thread takes exactly the accumulator elements thread
+// (wave, lane) of the GEMM kernel held for that half -- slab element ((tn * 8 + pm * 4 + tm) * NW * 64 + wave * 64 + lane) -- summed over the
+// slabs in the order the last arriver used (S = 2: slab 0 + slab 1; S > 2: 0 + slab 0 + slab 1 + ...: bit-identical results), and runs
+// ring16_epilogue on them.  One-wave workgroups for every epilogue but the sum of squares (whose fixed-order reduction wants the tile's NW
+// waves in one block).  No tickets, no fences, no spinning: nothing here can deadlock under CU masks or a shared GPU.
+template <int NW, bool KM, bool SWIGLU, int PAIR, int WPB>
+__global__ __launch_bounds__(WPB * 64) void gemm_ring16_finish_kernel(
+    bf16_t* __restrict__ C, int M, int N, long ldc, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res, long ldr, int flags,
+    int tiles_m, int tiles_n, int full, int S, const float* __restrict__ sk_slabs, bf16_t* __restrict__ aux0, const bf16_t* __restrict__ aux1,
+    long aux_ld, int aux_n) {
+    constexpr int NBN = NW == 4 ? 8 : 4, NT = NW * 64;
+    static_assert(WPB == 1 || WPB == NW, "one wave per workgroup, or all waves of the tile (sum of squares)");
+    __shared__ __attribute__((aligned(16))) char fin_smem[(PAIR != PAIR_NONE && NW == 4 ? 2 * WPB : WPB) * EPI_STRIP + 64];
+    const int tid_l = threadIdx.x, lane = tid_l & 63;
+    const int wave_l = __builtin_amdgcn_readfirstlane(tid_l >> 6);
+    constexpr int wpb = WPB, groups = NW / WPB;
+    const int bid = blockIdx.x;
+    const int grp = bid % groups, pm = (bid / groups) & 1, rt = bid / (2 * groups);
+    const int wave = grp * wpb + wave_l;
+    const int wm = NW == 4 ? wave >> 1 : wave >> 2, wn = NW == 4 ? wave & 1 : wave & 3;
+    const int tile_id = full + rt;
+    const int GROUP = 8;
+    const int per_group = GROUP * tiles_n;
+    const int g = tile_id / per_group;
+    const int first_m = g * GROUP;
+    const int gsz = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+    const int in_g = tile_id - g * per_group;
+    const int m0 = (first_m + in_g % gsz) * 256, n0 = (in_g / gsz) * 256;
+    const f32x4* slab = reinterpret_cast<const f32x4*>(sk_slabs + (size_t)rt * S * SK_SLAB_FLOATS) + wave * 64 + lane;
+    constexpr int SLAB4 = SK_SLAB_FLOATS / 4;
+    f32x4 acc[NBN][4];
+    auto load_part = [&](int p, f32x4 (&v)[NBN][4]) {
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
+        for (int i = 0; i < NBN; ++i)
 #pragma unroll
-            for (int tm4 = 0; tm4 < 4; ++tm4)
+            for (int j = 0; j < 4; ++j) v[i][j] = __builtin_nontemporal_load(slab + (size_t)p * SLAB4 + (i * 8 + pm * 4 + j) * NT);
+    };
+    if (S == 2) {
+        f32x4 o[NBN][4];
+        load_part(0, acc);
+        load_part(1, o);
 #pragma unroll
-                for (int tn4 = 0; tn4 < 4; ++tn4) {
-                    const int off = (tm4 * 16 + (lane & 15)) * EPI_PITCH + (tn4 * 16 + 4 * (lane >> 4)) * 4;
-                    if constexpr (NW == 4) {
-                        *reinterpret_cast<f32x4*>(sa + off) = acc[tn4][pass * 4 + tm4];
-                        *reinterpret_cast<f32x4*>(sb + off) = acc[4 + tn4][pass * 4 + tm4];
-                    } else {
-                        *reinterpret_cast<f32x4*>(sa + off) = acc[tn4][pass * 4 + tm4];      // blocks 0,1 = first, 2,3 = second columns
-                    }
-                }
-            const int phi = phi0 + cc * 8;
-            const int col1 = pair_first(phi), col2 = col1 + pair_dist;
-            float b1[8], b2[8];
+        for (int i = 0; i < NBN; ++i)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                b1[e] = has_bias ? bf2f(bias[col1 + e]) : 0.f;
-                b2[e] = has_bias ? bf2f(bias[col2 + e]) : 0.f;
-            }
-            // rotary tables of the whole pass requested up front (one memory round trip per pass instead of one per iteration)
-            u32x4 vcs[64 / RPI], vss[64 / RPI];
-            const bool rot = PAIR == PAIR_ROPE && col1 < aux_n;
-            if constexpr (PAIR == PAIR_ROPE) {
-                if (rot) {
+            for (int j = 0; j < 4; ++j) acc[i][j] += o[i][j];
+    } else {
 #pragma unroll
-                    for (int it = 0; it < 64 / RPI; ++it) {
-                        int m = mw0 + pass * 64 + it * RPI + rr;
-                        m = m < M ? m : M - 1;
-                        vcs[it] = *reinterpret_cast<const u32x4*>(aux0 + (long)m * aux_ld + (phi & 63));
-                        vss[it] = *reinterpret_cast<const u32x4*>(aux1 + (long)m * aux_ld + (phi & 63));
-                    }
-                }
-            }
+        for (int i = 0; i < NBN; ++i)
 #pragma unroll
-            for (int it = 0; it < 64 / RPI; ++it) {
-                const int row = it * RPI + rr;
-                const int m = mw0 + pass * 64 + row;
-                const f32x4 alo = *reinterpret_cast<const f32x4*>(sa + row * EPI_PITCH + cc * 32);
-                const f32x4 ahi = *reinterpret_cast<const f32x4*>(sa + row * EPI_PITCH + cc * 32 + 16);
-                const f32x4 blo = *reinterpret_cast<const f32x4*>(sb + row * EPI_PITCH + cc * 32);
-                const f32x4 bhi = *reinterpret_cast<const f32x4*>(sb + row * EPI_PITCH + cc * 32 + 16);
-                if (m >= M) continue;
-                float v1[8] = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
-                float v2[8] = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
-                if (has_bias) {
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int p = 0; p < S; ++p) {
+            f32x4 o[NBN][4];
+            load_part(p, o);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        v1[e] += b1[e];
-                        v2[e] += b2[e];
-                    }
-                }
-                u32x4 o1, o2;
-                if constexpr (PAIR == PAIR_SWIGLU) {
-                    // gate, up rounded to bf16 as the unfused GEMM stores them; a = bf16(bf16(silu(gate)) * up) as swiglu_fwd_kernel
-                    u32x4 oa;
+            for (int i = 0; i < NBN; ++i)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        o1[e] = pack_bf2(v1[2 * e], v1[2 * e + 1]);
-                        o2[e] = pack_bf2(v2[2 * e], v2[2 * e + 1]);
-                        const float g0 = bf2f_lo(o1[e]), g1 = bf2f_hi(o1[e]);
-                        const float s0 = bf2f(f2bf(g0 * (1.f / (1.f + __expf(-g0))))), s1 = bf2f(f2bf(g1 * (1.f / (1.f + __expf(-g1)))));
-                        oa[e] = pack_bf2(s0 * bf2f_lo(o2[e]), s1 * bf2f_hi(o2[e]));
-                    }
-                    epi_st16<false>(aux0 + (long)m * aux_ld + col1, oa);      // read by the down projection next
-                } else {
-                    const u32x4 vc = vcs[it], vs = vss[it];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const unsigned w1 = pack_bf2(v1[2 * e], v1[2 * e + 1]);
-                        const unsigned w2 = pack_bf2(v2[2 * e], v2[2 * e + 1]);
-                        if (rot) {
-                            const float x1[2] = {bf2f_lo(w1), bf2f_hi(w1)}, x2[2] = {bf2f_lo(w2), bf2f_hi(w2)};
-                            const float cs[2] = {bf2f_lo(vc[e]), bf2f_hi(vc[e])}, sn[2] = {bf2f_lo(vs[e]), bf2f_hi(vs[e])};
-                            float r1[2], r2[2];
-#pragma unroll
-                            for (int h2 = 0; h2 < 2; ++h2) {
-                                r1[h2] = bf2f(f2bf(x1[h2] * cs[h2])) - bf2f(f2bf(x2[h2] * sn[h2]));
-                                r2[h2] = bf2f(f2bf(x2[h2] * cs[h2])) + bf2f(f2bf(x1[h2] * sn[h2]));
-                            }
-                            o1[e] = pack_bf2(r1[0], r1[1]);
-                            o2[e] = pack_bf2(r2[0], r2[1]);
-                        } else {
-                            o1[e] = w1;
-                            o2[e] = w2;
-                        }
-                    }
-                }
-                epi_st16<PAIR == PAIR_SWIGLU>(C + (long)m * ldc + col1, o1);      // [gate | up]: kept for the backward; q|k|v: read next
-                epi_st16<PAIR == PAIR_SWIGLU>(C + (long)m * ldc + col2, o2);
-            }
-        }
-        return;
-    }
-    {
-        // fast read-back (see epi_fast_run) when every column of this wave's tile is inside N and the operands are 16-B vectors; the
-        // epilogue kinds of the step are compile-time variants, anything else takes the general path below
-        const bool needs_res = flags & (EPI_RESIDUAL | EPI_SWIGLU_BWD);
-        const bool vec_ok = !(ldc & 7) && !((uintptr_t)C & 15) && (!needs_res || (!(ldr & 7) && !((uintptr_t)res & 15))) &&
-                            (!(flags & EPI_BIAS) || !((uintptr_t)bias & 15)) && (!(flags & EPI_SWIGLU_BWD) || !(N & 7));
-        if (vec_ok && nw0 + NBN * 16 <= N) {
-#define EPI_FAST(B_, A_, P_, NT_) epi_fast_run<NBN, NBM, B_, A_, P_, false, NT_>(acc, strip, C, M, N, ldc, bias, res, ldr, mw0, nw0, lane)
-            if constexpr (!SWIGLU && PAIR == PAIR_NONE) {
-                if (flags & EPI_SUMSQ) {
-                    // weight-gradient launches of mantis_gemm_bf16_nt_sumsq: the squared norm of the stored tile rides along (the optimizer's
-                    // global gradient norm then needs no pass of its own over these 16 GB).  Lane partials in a fixed order, DPP wave sum,
-                    // waves summed in order by thread 0: deterministic.  The entry point guarantees the fast path for every wave.
-                    float ss = 0.f;
-                    if (flags & EPI_ACCUM) epi_fast_run<NBN, NBM, false, 0, EPRE_ACC, true, true>(acc, strip, C, M, N, ldc, bias, res, ldr, mw0, nw0, lane, &ss);
-                    else epi_fast_run<NBN, NBM, false, 0, EPRE_NONE, true, true>(acc, strip, C, M, N, ldc, bias, res, ldr, mw0, nw0, lane, &ss);
-                    ss = wave_sum(ss);
-                    float* red = reinterpret_cast<float*>(smem + NW * EPI_STRIP);
-                    if (lane == 0) red[wave] = ss;
-                    __syncthreads();
-                    if (tid == 0) {
-                        float t = 0.f;
-#pragma unroll
-                        for (int w = 0; w < NW; ++w) t += red[w];
-                        reinterpret_cast<float*>(aux0)[tile_id] = t;
-                    }
-                    return;
-                }
-            }
-            if constexpr (!SWIGLU) {      // the SwiGLU-backward read-back stays on the general path: its tile moves 512 KiB (gate, up in; dgate, dup
-                                          // out) and is HBM-bound either way; requesting operands ahead measured 3 - 4 % SLOWER on dX(down) (bursts)
-                switch (flags & (EPI_BIAS | EPI_ACT_MASK | EPI_RESIDUAL | EPI_ACCUM)) {
-                    case 0: EPI_FAST(false, 0, EPRE_NONE, (AKM || BKM)); return;      // dX / dW stream out; a plain forward store is read next
-                    case EPI_RESIDUAL: EPI_FAST(false, 0, EPRE_RES, true); return;
-                    case EPI_ACCUM: EPI_FAST(false, 0, EPRE_ACC, true); return;
-                    case EPI_BIAS: EPI_FAST(true, 0, EPRE_NONE, false); return;
-                    case EPI_BIAS | EPI_RESIDUAL: EPI_FAST(true, 0, EPRE_RES, false); return;
-                    case EPI_BIAS | (1 << EPI_ACT_SHIFT): EPI_FAST(true, 1, EPRE_NONE, false); return;
-                    case EPI_BIAS | (2 << EPI_ACT_SHIFT): EPI_FAST(true, 2, EPRE_NONE, false); return;
-                    case EPI_BIAS | (3 << EPI_ACT_SHIFT): EPI_FAST(true, 3, EPRE_NONE, false); return;
-                    default: break;
-                }
-            }
-#undef EPI_FAST
+                for (int j = 0; j < 4; ++j) acc[i][j] += o[i][j];
         }
     }
-#pragma unroll
-    for (int pm = 0; pm < 2; ++pm)
-#pragma unroll
-        for (int pn = 0; pn < NBN / 4; ++pn) {
-#pragma unroll
-            for (int tm4 = 0; tm4 < 4; ++tm4)
-#pragma unroll
-                for (int tn4 = 0; tn4 < 4; ++tn4)
-                    *reinterpret_cast<f32x4*>(strip + (tm4 * 16 + (lane & 15)) * EPI_PITCH + (tn4 * 16 + 4 * (lane >> 4)) * 4) =
-                        acc[pn * 4 + tn4][pm * 4 + tm4];
-            epi_readback64<SWIGLU>(strip, C, M, N, ldc, bias, res, ldr, flags, mw0 + pm * 64, nw0 + pn * 64, lane);
-        }
+    ring16_epilogue<NW, 4, KM, SWIGLU, PAIR, true>(acc, fin_smem, wave_l, tid_l, lane, wn, C, M, N, ldc, bias, res, ldr, flags,
+                                                   m0 + wm * 128 + pm * 64, n0, tile_id, aux0, aux1, aux_ld, aux_n);
 }
 
 // split-K workspace (caller-owned, see mantis_gemm_workspace_bytes): [ticket counters: (#CU + 1) u32, padded to 256 B][#CU fp32
@@ -1556,23 +1655,29 @@ static int num_cus() {
     return g_num_cu[dev];
 }
 
-// CU budget of the tile scheduler.  Rounds, the K split of an incomplete last round and the kernel choice are planned for plan_cus()
+// CU budget of the tile scheduler.  Rounds, the K split of an incomplete last round and the kernel choice are planned for plan_cus(req)
 // compute units: all of the device by default; fewer when something else holds CUs for the length of a GEMM -- every RCCL channel is a
 // workgroup that cannot share a CU with a ring workgroup (160 KiB of LDS each), so with C channels busy a launch planned for 256 CUs
-// runs its "one round" as two.  MANTIS_GEMM_CUS (read once) or mantis_gemm_cu_budget() sets it; the split-K workspace is always sized
-// for the whole device, so any budget fits it.  Results are deterministic for a given budget; across budgets the K-split of the
-// remainder tiles differs, i.e. the fp32 summation order of those tiles (bf16 results agree to rounding, not bit for bit).
-static int g_cu_budget = -1;          // -1: not decided yet (environment), 0: the whole device, > 0: that many
-static int plan_cus() {
+// runs its "one round" as two.  The budget is a PER-CALL argument (bits 16-27 of `flags`; round 5 -- until round 4 a process-wide
+// variable, which let two models / reducers of one process interfere); 0 = the default, MANTIS_GEMM_CUS (an environment constant,
+// read once) or the whole device.  The split-K workspace is always sized for the whole device, so any budget fits it.  Results are
+// deterministic for a given budget; across budgets the K-split of the remainder tiles differs, i.e. the fp32 summation order of those
+// tiles (bf16 results agree to rounding, not bit for bit).
+static int plan_cus(int req) {
     const int dev = num_cus();
-    if (g_cu_budget < 0) {
-        const char* e = getenv("MANTIS_GEMM_CUS");
-        const int v = e ? atoi(e) : 0;
-        g_cu_budget = v > 0 ? v : 0;
+    if (req <= 0) {
+        static int env = -1;              // the process' configuration constant, never written after the first read
+        if (env < 0) {
+            const char* e = getenv("MANTIS_GEMM_CUS");
+            const int v = e ? atoi(e) : 0;
+            env = v > 0 ? v : 0;
+        }
+        req = env;
     }
-    if (g_cu_budget == 0) return dev;
-    return g_cu_budget < 8 ? 8 : (g_cu_budget > dev ? dev : g_cu_budget);
+    if (req == 0) return dev;
+    return req < 8 ? 8 : (req > dev ? dev : req);
 }
+static inline int flags_cus(int flags) { return (flags & EPI_CUS_MASK) >> EPI_CUS_SHIFT; }
 
 // K parts for the tiles of the ring kernel's incomplete last round: minimise K-steps per part + the measured reduction cost
 // (slab write, publish, S slab reads by the last arriver ~ 8 + 1.7 S K-step equivalents; sc1 write-through slabs instead of the
@@ -1606,11 +1711,11 @@ static int ring_split(long ntiles, int nk, int cus) {
 // tile variant by a cost model fitted to measurements (profiles/r01_gemm_experiments.md), in microseconds:
 //   ring 256x256, 1 workgroup/CU: 1.45 per K-step + 5 K-step equivalents per round (prologue, epilogue, launch)
 //   generic 128x128, 2 workgroups/CU: 1.05 per K-step per round of 2 x #CU tiles + 5.2 equivalents
-static int gemm_pick_variant(int M, int N, int K) {
+static int gemm_pick_variant(int M, int N, int K, int cus_req = 0) {
     // below two tile rows / columns the cost model decides too (M = 504 label rows of the lm_head used to fall to the 128x128 kernel
     // -- and, on the dX side, to a transposed weight copy: 2.3 ms instead of 0.58 ms); only genuinely small operands skip it
     if (M < 384 || N < 384) return 1;
-    const int cus = plan_cus(), nk = cdiv(K, BK);
+    const int cus = plan_cus(cus_req), nk = cdiv(K, BK);
     const long t256 = (long)cdiv(M, 256) * cdiv(N, 256), t128 = (long)cdiv(M, 128) * cdiv(N, 128);
     const int S = ring_split(t256, nk, cus);
     const long rem = t256 % cus;
@@ -1625,20 +1730,25 @@ static int gemm_pick_variant(int M, int N, int K) {
 // the 32x32x16 one (12) on twelve of them and within 3 % on the rest; the 4-wave kernel (13) is faster still -- 4-5 % over 14 -- where the
 // main loop is all there is: row-major operands (NT) and a long per-CU K walk (rounds x K-steps), and slower everywhere else (its
 // prologue, epilogue and K-split reduction run on half the waves)
-static int ring_variant_for(int M, int N, int K, bool akm, bool bkm) {
+static int ring_variant_for(int M, int N, int K, bool akm, bool bkm, int cus_req = 0) {
     if (akm || bkm) return 14;
     const long tiles = (long)cdiv(M, 256) * cdiv(N, 256);
-    const long rounds = (tiles + plan_cus() - 1) / plan_cus();
+    const long rounds = (tiles + plan_cus(cus_req) - 1) / plan_cus(cus_req);
     return rounds * cdiv(K, BK) >= 400 ? 13 : 14;
 }
 
+static bool sk_finish_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MANTIS_GEMM_SK_FINISH"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v != 0;
+}
 template <bool AKM, bool BKM, bool SWIGLU = false, int R16 = 0, int PAIR = PAIR_NONE>       // R16: 0 = the 32x32x16 kernel, 4 / 8 = ring16 waves
 static int launch_gemm_ring(hipStream_t s, const bf16_t* A, const bf16_t* B, bf16_t* C, int M, int N, int K, long lda, long ldb,
                             long ldc, const bf16_t* bias, const bf16_t* res, long ldr, int flags, void* ws, long ws_bytes,
                             bf16_t* aux0 = nullptr, const bf16_t* aux1 = nullptr, long aux_ld = 0, int aux_n = 0) {
     const int tiles_m = cdiv(M, 256), tiles_n = cdiv(N, 256), nk = cdiv(K, BK);
     const long ntiles = (long)tiles_m * tiles_n;
-    const int cus = plan_cus();
+    const int cus = plan_cus(flags_cus(flags));
     const int rem = (int)(ntiles % cus);
     const int S = ring_split(ntiles, nk, cus);
     const int full = S > 1 ? (int)(ntiles - rem) : (int)ntiles;
@@ -1652,8 +1762,25 @@ static int launch_gemm_ring(hipStream_t s, const bf16_t* A, const bf16_t* B, bf1
         slabs = (float*)((char*)ws + sk_cnt_bytes(dev_cus));
     }
     if constexpr (R16 != 0) {
+        // remainder tiles: the split units leave their slabs and gemm_ring16_finish_kernel reduces them on all CUs (cnt = nullptr tells the GEMM
+        // kernel); MANTIS_GEMM_SK_FINISH=0 keeps the round-4 in-kernel reduction by the last arriver (A/B measurements)
+        const bool finish = S > 1 && !(flags & EPI_SK_INKERNEL) && sk_finish_enabled();
         MANTIS_LAUNCH((gemm_nt_ring16_kernel<R16, AKM, BKM, SWIGLU, PAIR>), dim3(grid), dim3(R16 * 64), 0, s, A, B, C, M, N, K, lda, ldb, ldc,
-                           bias, res, ldr, flags, tiles_m, tiles_n, full, S, slabs, cnt, aux0, aux1, aux_ld, aux_n);
+                           bias, res, ldr, flags, tiles_m, tiles_n, full, S, slabs, finish ? nullptr : cnt, aux0, aux1, aux_ld, aux_n);
+        if (finish) {
+            // one wave per workgroup, except for the sum of squares (all R16 waves of a tile half in one block: fixed-order reduction)
+#define FIN_ARGS 0, s, C, M, N, ldc, bias, res, ldr, flags, tiles_m, tiles_n, full, S, slabs, aux0, aux1, aux_ld, aux_n
+            bool done = false;
+            if constexpr (!SWIGLU && PAIR == PAIR_NONE) {
+                if (flags & EPI_SUMSQ) {
+                    MANTIS_LAUNCH((gemm_ring16_finish_kernel<R16, (AKM || BKM), false, PAIR_NONE, R16>), dim3(rem * 2), dim3(R16 * 64), FIN_ARGS);
+                    done = true;
+                }
+            }
+            if (!done)
+                MANTIS_LAUNCH((gemm_ring16_finish_kernel<R16, (AKM || BKM), SWIGLU, PAIR, 1>), dim3(rem * 2 * R16), dim3(64), FIN_ARGS);
+#undef FIN_ARGS
+        }
     } else {
         MANTIS_LAUNCH((gemm_nt_ring_kernel<AKM, BKM, SWIGLU>), dim3(grid), dim3(512), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias, res, ldr, flags,
                            tiles_m, tiles_n, full, S, slabs, cnt);
@@ -1683,6 +1810,8 @@ int mantis_probe_ring16_stamps(void* host_dst, int n_wg) {
 
 // tile variant the auto heuristic picks for C[M,N] over K (12 = 256x256 ring kernel, 1 = 128x128 generic kernel)
 int mantis_gemm_pick_variant(int M, int N, int K) { return gemm_pick_variant(M, N, K); }
+// the same for a launch planned for `cus` compute units (bits 16-27 of its flags); cus <= 0: the default budget
+int mantis_gemm_pick_variant_cus(int M, int N, int K, int cus) { return gemm_pick_variant(M, N, K, cus > 0 ? cus : 0); }
 
 // C[M,N] (bf16, row stride ldc) = epilogue(A[M,K] . B[N,K]^T); A,B,C 16-B aligned, lda/ldb % 8 == 0, K % 8 == 0.
 // flags: bit0 bias[n] add | bits1-3 activation (1 gelu-erf, 2 gelu-tanh, 3 quick-gelu) | bit4 + residual[m,n] (stride ldr)
@@ -1695,17 +1824,12 @@ int mantis_gemm_workspace_bytes(int M, int N, int K) {
     if (M <= 0 && N <= 0 && K <= 0) return (int)sk_ws_bytes(cus);
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const long t256 = (long)cdiv(M, 256) * cdiv(N, 256);
-    return ring_split(t256, cdiv(K, BK), plan_cus()) > 1 ? (int)sk_ws_bytes(cus) : 0;
+    return ring_split(t256, cdiv(K, BK), plan_cus(0)) > 1 ? (int)sk_ws_bytes(cus) : 0;
 }
 
-// CU budget of the GEMM tile scheduler (see plan_cus): cus > 0 sets it (clamped to [8, #CU]), cus < 0 resets it to the whole device,
-// cus == 0 only queries.  Returns the budget now in effect.  Process-wide, like MANTIS_GEMM_CUS, which it overrides; meant to be set once,
-// before the step loop, by whoever knows how many CUs the concurrent collectives hold (dp.GradReducer: MANTIS_GEMM_CUS).
-int mantis_gemm_cu_budget(int cus) {
-    if (cus > 0) g_cu_budget = cus;
-    else if (cus < 0) g_cu_budget = 0;
-    return plan_cus();
-}
+// CU budget a launch plans for when it asks for `cus` (bits 16-27 of its flags): cus > 0 -> clamped to [8, #CU]; cus <= 0 -> the default
+// (MANTIS_GEMM_CUS, else the whole device).  A pure query: there is no process-wide budget to set any more (round 5).
+int mantis_gemm_cu_budget(int cus) { return plan_cus(cus > 0 ? cus : 0); }
 
 int mantis_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
                         const void* bias, const void* residual, int64_t ldr, int flags, void* workspace, int64_t workspace_bytes,
@@ -1730,8 +1854,8 @@ int mantis_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, 
     // variant 12 = the 8-wave ring kernel (32x32x16 MFMA), 13 / 14 = the ring16 kernel (16x16x32 MFMA) with 4 / 8 waves: same tile, same
     // work split, same results up to the accumulation order inside a K-step
     if (variant == 0) {
-        variant = (flags & EPI_SWIGLU_BWD) ? 12 : gemm_pick_variant(M, N, K);
-        if (variant == 12) variant = default_ring_variant() ? default_ring_variant() : ring_variant_for(M, N, K, akm, bkm);
+        variant = (flags & EPI_SWIGLU_BWD) ? 12 : gemm_pick_variant(M, N, K, flags_cus(flags));
+        if (variant == 12) variant = default_ring_variant() ? default_ring_variant() : ring_variant_for(M, N, K, akm, bkm, flags_cus(flags));
     }
     const bool ring = variant >= 12 && variant <= 14, big = variant == 2;
     if ((flags & EPI_SWIGLU_BWD) && (!ring || akm || !bkm)) return MANTIS_EUNSUPPORTED;
@@ -1783,7 +1907,7 @@ int mantis_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, 
 int mantis_gemm_bf16_nt_sumsq(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K, int flags,
                               float* tile_sumsq, void* workspace, int64_t workspace_bytes, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || !tile_sumsq) return MANTIS_EINVAL;
-    if (flags & ~(EPI_ACCUM | EPI_A_KMAJOR | EPI_B_KMAJOR | EPI_VARIANT_MASK)) return MANTIS_EUNSUPPORTED;
+    if (flags & ~(EPI_ACCUM | EPI_A_KMAJOR | EPI_B_KMAJOR | EPI_VARIANT_MASK | EPI_SK_INKERNEL | EPI_CUS_MASK)) return MANTIS_EUNSUPPORTED;
     const bool akm = flags & EPI_A_KMAJOR, bkm = flags & EPI_B_KMAJOR;
     if (N % 256 || ldc % 8 || ldc < N || lda % 8 || ldb % 8 || (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15)) return MANTIS_EUNSUPPORTED;
     const int K8 = (K + 7) / 8 * 8;
@@ -1792,8 +1916,8 @@ int mantis_gemm_bf16_nt_sumsq(const void* A, int64_t lda, const void* B, int64_t
     if (a_bytes >= lim || b_bytes >= lim) return MANTIS_EUNSUPPORTED;
     int variant = (flags & EPI_VARIANT_MASK) >> EPI_VARIANT_SHIFT;
     if (variant == 0) {
-        if (gemm_pick_variant(M, N, K) != 12) return MANTIS_EUNSUPPORTED;
-        variant = default_ring_variant() >= 13 ? default_ring_variant() : ring_variant_for(M, N, K, akm, bkm);
+        if (gemm_pick_variant(M, N, K, flags_cus(flags)) != 12) return MANTIS_EUNSUPPORTED;
+        variant = default_ring_variant() >= 13 ? default_ring_variant() : ring_variant_for(M, N, K, akm, bkm, flags_cus(flags));
     }
     if (variant != 13 && variant != 14) return MANTIS_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
@@ -1828,10 +1952,13 @@ int mantis_gemm_bf16_nt_fused(const void* A, int64_t lda, const void* B, int64_t
         return MANTIS_EUNSUPPORTED;
     const long lim = (1L << 32) - (1L << 16);
     if ((long)M * lda * 2 >= lim || (long)N * ldb * 2 >= lim) return MANTIS_EUNSUPPORTED;
-    if (variant == 0) variant = default_ring_variant() >= 13 ? default_ring_variant() : ring_variant_for(M, N, K, false, false);
+    const bool inkernel = variant & 64;          // bit 6 of `variant`: see EPI_SK_INKERNEL
+    const int cus_bits = variant & EPI_CUS_MASK; // bits 16-27 of `variant`: the CU budget, as in mantis_gemm_bf16_nt's flags
+    variant &= 15;
+    if (variant == 0) variant = default_ring_variant() >= 13 ? default_ring_variant() : ring_variant_for(M, N, K, false, false, cus_bits >> EPI_CUS_SHIFT);
     if (variant != 13 && variant != 14) return MANTIS_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    const int flags = bias ? EPI_BIAS : 0;
+    const int flags = (bias ? EPI_BIAS : 0) | (inkernel ? EPI_SK_INKERNEL : 0) | cus_bits;
 #define PAIR_ARGS s, (const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C, M, N, K, (long)lda, (long)ldb, (long)ldc, (const bf16_t*)bias, \
                   (const bf16_t*)nullptr, 0L, flags, workspace, (long)workspace_bytes, (bf16_t*)aux0, (const bf16_t*)aux1, (long)aux_ld, aux_n
     if (mode == PAIR_SWIGLU)

@@ -35,9 +35,13 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, model, process_group=None, algo=None):
+    def __init__(self, model, process_group=None, algo=None, gemm_cus=0):
+        """gemm_cus: compute units the GEMM tile scheduler should plan for while this reducer's collectives run (every RCCL channel is a
+        workgroup holding a CU): handed to the kernels PER LAUNCH through the trainer's `LaunchContext` (0 = the library's default,
+        MANTIS_GEMM_CUS or the whole device) -- a property of this reducer, not of the process."""
         self.model = model
         self.pg = process_group
+        self.gemm_cus = int(gemm_cus)
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self._handles = []
@@ -60,41 +64,52 @@ class GradReducer:
         the compute stream's queue exactly when 8 streams were created before it, with the default 4 queues also when none was), so
         neither the environment nor a count settles it -- the thing itself is tested: on a GPU with RCCL, a tiny all-reduce of the
         process group is launched while the compute stream is busy for ~15 ms and must complete long before the compute stream does
-        (`rccl_overlap_probe`; collective, every rank runs it at construction and the ranks agree on the verdict).  On a collision a
-        NEW process group over the same ranks is created -- its RCCL stream takes the next queue -- and probed, up to three times;
-        if none overlaps, that is an ERROR (a silently serialised exchange costs ~the whole all-reduce time per step;
-        MANTIS_DP_ALLOW_SHARED_QUEUE=1: warn only).  Fewer than 8 queues at HIP initialisation (mantis_amd.hw_queues_at_init: what the
-        runtime saw, not what os.environ says after the package's own setdefault) only warns: the probe decides."""
+        (`rccl_overlap_probe`; collective, every rank of the group runs it at construction and the ranks agree on the verdict).
+
+        Remediation, only where it is safe (round-4 advisor finding): a NEW process group over the same ranks -- its RCCL stream takes
+        the next queue -- is created and probed, up to three times, ONLY when this reducer's group is the default (world) group:
+        `dist.new_group` must be entered by every rank of the default group, and the ranks outside a sub-group never reach this line (they
+        would deadlock the job).  A sub-group is probed and reported, never re-created.  Process groups this reducer created and then
+        abandoned are destroyed again.
+
+        The verdict is a wall-clock heuristic on a possibly noisy node, so by default a collision is a WARNING and training goes on
+        (MANTIS_DP_REQUIRE_OVERLAP=1: RuntimeError -- for benchmark runs that must not silently serialise the exchange).  Fewer than 8
+        queues at HIP initialisation (mantis_amd.hw_queues_at_init: best effort, see there) only warns: the probe decides."""
         import warnings
         import mantis_amd
         q = mantis_amd.hw_queues_at_init()
         overlapped, regrouped = None, 0
         if torch.cuda.is_available() and dist.is_initialized() and dist.get_backend(self.pg) == "nccl":
+            world_ranks = list(range(dist.get_world_size()))
+            ranks = dist.get_process_group_ranks(self.pg if self.pg is not None else dist.group.WORLD)
+            may_regroup = list(ranks) == world_ranks            # every rank of the default group is here: new_group cannot strand anyone
+            mine = None                                         # a process group created here (to be destroyed if it is abandoned)
             for attempt in range(4):
                 ok = rccl_overlap_probe(self.pg)
                 flag = torch.tensor([1 if ok else 0], device=f"cuda:{torch.cuda.current_device()}", dtype=torch.int32)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.pg)          # one verdict for all ranks
                 overlapped = bool(int(flag.item()))
-                if overlapped or attempt == 3:
+                if overlapped or attempt == 3 or not may_regroup:
                     break
-                ranks = dist.get_process_group_ranks(self.pg if self.pg is not None else dist.group.WORLD)
-                self.pg = dist.new_group(ranks=ranks, backend="nccl")               # a new communicator: its stream takes the next queue
+                fresh = dist.new_group(ranks=ranks, backend="nccl")                 # a new communicator: its stream takes the next queue
+                if mine is not None:
+                    dist.destroy_process_group(mine)                               # the previous attempt's group: nobody else holds it
+                self.pg = mine = fresh
                 regrouped += 1
         self.hw_queues = (q, overlapped, regrouped)
         if q < 8:
-            warnings.warn(f"GPU_MAX_HW_QUEUES was {q} when HIP initialised: with so few hardware queues the side streams of the step (RCCL, "
-                          "gradient norm, prefetch) share queues with the compute stream more often.  Export GPU_MAX_HW_QUEUES=8 (or `import "
-                          "mantis_amd`) BEFORE the first GPU call of the process.")
+            warnings.warn(f"GPU_MAX_HW_QUEUES was (as far as this process can tell) {q} when HIP initialised: with so few hardware queues the "
+                          "side streams of the step (RCCL, gradient norm, prefetch) share queues with the compute stream more often.  Export "
+                          "GPU_MAX_HW_QUEUES=8 (or `import mantis_amd`) BEFORE the first GPU call of the process.")
         if overlapped is not False:
             return
         msg = (f"RCCL's stream shares a hardware queue with the compute stream (GPU_MAX_HW_QUEUES at HIP initialisation: {q}; a probe "
                f"all-reduce did not run beside a busy compute stream, also not on {regrouped} freshly created process group(s)): the "
                "bucket collectives would be serialised with the backward's kernels instead of overlapping them "
                "(profiles/r03_dp_world1.md, profiles/r04_rccl_queue_probe.md).")
-        if os.environ.get("MANTIS_DP_ALLOW_SHARED_QUEUE") == "1":
-            warnings.warn(msg)
-        else:
-            raise RuntimeError(msg + "  (MANTIS_DP_ALLOW_SHARED_QUEUE=1 downgrades this to a warning.)")
+        if os.environ.get("MANTIS_DP_REQUIRE_OVERLAP") == "1":
+            raise RuntimeError(msg + "  (MANTIS_DP_REQUIRE_OVERLAP=1 makes this an error; unset it to train on with a warning.)")
+        warnings.warn(msg + "  Training continues; MANTIS_DP_REQUIRE_OVERLAP=1 turns this into an error.")
 
     @property
     def active(self):
@@ -198,6 +213,7 @@ def hw_queue_probe(n_streams=7, busy_mib=512, passes=64):
             e.record()
     torch.cuda.synchronize()
     total = start.elapsed_time(end)
+    del busy                                                # 512 MiB back to the caching allocator
     return sum(1 for e in done if start.elapsed_time(e) < 0.25 * total)
 
 
@@ -240,6 +256,7 @@ def rccl_overlap_probe(pg=None, attempts=3, busy_mib=512, passes=256, op=None):
         torch.cuda.synchronize()
         total = start.elapsed_time(end)
         seen = seen or min(start.elapsed_time(e) for e in done) < 0.5 * total
+    del busy                                                # the 512 MiB scratch goes back to the caching allocator (not kept for the run)
     return seen
 
 

@@ -19,6 +19,7 @@ import torch
 from . import decoder as D
 from . import decoder_fp8 as D8
 from . import hip_ops as K   # the ONLY compute backend; tests may monkeypatch `engine.K` with the oracle to test host logic
+from .launch import launch_context
 
 
 _DEBUG_SYNC = os.environ.get("MANTIS_DEBUG_SYNC") == "1"
@@ -69,9 +70,11 @@ class LlavaEngine:
                              f"(torch.nn.CrossEntropyLoss: 'Target out of bounds')")
         self._verified = True
 
-    def step_from_batch(self, inputs, **kw):
-        """The batch dict of the Mantis collator -> step()."""
-        return self.step(inputs["input_ids"], inputs["attention_mask"], inputs.get("labels"), inputs.get("pixel_values"), **kw)
+    def step_from_batch(self, inputs, launch=None, **kw):
+        """The batch dict of the Mantis collator -> step().  launch: the caller's `launch.LaunchContext` (per-launch timers, the optimizer's
+        sum-of-squares collector, the GEMM CU budget), in force for exactly this call."""
+        with launch_context(launch):
+            return self.step(inputs["input_ids"], inputs["attention_mask"], inputs.get("labels"), inputs.get("pixel_values"), **kw)
 
     # ------------------------------------------------------------------------------------------------ vision tower (frozen)
     def vision_forward(self, pixels, record=None):
@@ -120,7 +123,7 @@ class LlavaEngine:
             pixel_values = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
         return pixel_values.to(dev, non_blocking=True).to(torch.float32).contiguous()
 
-    def prefetch_vision(self, inputs, after_event=None, stream=None):
+    def prefetch_vision(self, inputs, after_event=None, stream=None, launch=None):
         """Enqueue the frozen tower's forward of a FUTURE batch on `stream` (default: a plain side stream) behind `after_event` of the
         compute stream.  The tower is frozen, so its output does not depend on the optimizer step in between: with `stream` confined to
         a share of the compute units (hip_ops.cu_masked_stream) and the optimizer pass on the complementary share, the MFMA-bound tower of
@@ -136,7 +139,7 @@ class LlavaEngine:
                 stream = self._side = torch.cuda.Stream(device=dev)
         if after_event is not None:
             stream.wait_event(after_event)
-        with torch.cuda.stream(stream):
+        with torch.cuda.stream(stream), launch_context(launch):
             feats, N = self.vision_forward(self._pixels_to_device(pv, dev))
             done = torch.cuda.Event()
             done.record(stream)

@@ -7,13 +7,16 @@ import math
 import torch
 
 from . import _lib
+from .launch import LaunchContext, current as _launch, launch_context      # noqa: F401  (re-exported: K.LaunchContext, K.launch_context)
 
 _L = _lib.load()
 BF16 = torch.bfloat16
 ACT_KIND = {"gelu": 0, "gelu_pytorch_tanh": 1, "quick_gelu": 2, "silu": 3}
 GEMM_ACT = {None: 0, "gelu": 1, "gelu_pytorch_tanh": 2, "quick_gelu": 3}
-# bench.py sets this to a list to collect (kernel, algorithmic flops, algorithmic bytes, start event, end event) per GEMM launch
-KERNEL_TIMER = None
+# Launch options (per-launch HIP events for bench.py, the optimizer's sum-of-squares collector, the GEMM scheduler's CU budget) come from
+# the caller's LaunchContext (mantis_amd/launch.py), installed by the engine for the duration of one step -- no module-level switches.
+CUS_SHIFT = 16               # bits 16-27 of the GEMM entry points' flags: the CU budget of that launch (include/mantis_hip.h)
+SK_INKERNEL = 16384          # flag: K-split remainder tiles reduced inside the GEMM kernel (round 4) instead of by the finishing kernel
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -64,9 +67,10 @@ def _gemm_workspace():
 
 # ----------------------------------------------------------------------------------------------------------- GEMM family
 def gemm_nt(a, b, bias=None, act=None, residual=None, out=None, accumulate=False, n_valid=None, k=None, ldc=None, variant=0,
-            a_kmajor=False, b_kmajor=False):
+            a_kmajor=False, b_kmajor=False, cus=None, sk_inkernel=False):
     """out[M,N] = epi(A . B^T) with A = a[M,K] (or a[K,M] if a_kmajor), B = b[N,K] (or b[K,N] if b_kmajor).
-    `k` overrides the contraction length (zero-padded operands)."""
+    `k` overrides the contraction length (zero-padded operands).  cus: CU budget of this launch (None = the LaunchContext's);
+    sk_inkernel: round 4's in-kernel reduction of K-split remainder tiles (tests: bit-identical to the finishing kernel)."""
     _chk2d(a, "a"), _chk2d(b, "b")
     if a_kmajor:
         K, M = a.shape
@@ -83,9 +87,11 @@ def gemm_nt(a, b, bias=None, act=None, residual=None, out=None, accumulate=False
     else:
         _chk2d(out, "out")
     C = out
+    ctx = _launch()
     flags = (1 if bias is not None else 0) | (GEMM_ACT[act] << 1) | (16 if residual is not None else 0) | (32 if accumulate else 0) \
-        | (variant << 8) | (4096 if a_kmajor else 0) | (8192 if b_kmajor else 0)
-    prof = KERNEL_TIMER
+        | (variant << 8) | (4096 if a_kmajor else 0) | (8192 if b_kmajor else 0) | ((ctx.gemm_cus if cus is None else cus) << CUS_SHIFT) \
+        | (SK_INKERNEL if sk_inkernel else 0)
+    prof = ctx.timer
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()          # torch's current stream == the stream handed to the kernel below
@@ -183,7 +189,7 @@ def gemm_fp8_nt(a8, a_dequant, b8, b_dequant, fmt_a=FP8_E4M3, bias=None, residua
         raise ValueError("gemm_fp8_nt: per-tensor dequant factors are fp32[1]; pass rowwise=True for vectors")
     flags = ((1 if bias is not None else 0) | (16 if residual is not None else 0) | (32 if accumulate else 0) | (128 if rowwise else 0) |
              (variant << 8))
-    prof = KERNEL_TIMER
+    prof = _launch().timer
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -207,7 +213,7 @@ def gemm_fp8_dx_swiglu(dy8, dy_dequant, wt8, w_dequant, gu, fmt_a=FP8_E5M2):
         raise ValueError(f"gemm_fp8_dx_swiglu: dy8 {tuple(dy8.shape)} wt8 {tuple(wt8.shape)} gu {tuple(gu.shape)}")
     dgu = torch.empty_like(gu)
     amax = torch.empty(1, dtype=torch.float32, device=gu.device)
-    prof = KERNEL_TIMER
+    prof = _launch().timer
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -249,8 +255,9 @@ def linear_fwd(x, w, bias=None, act=None, residual=None):
 
 
 def _prefers_256(M, N, K):
-    """True when the library's tile heuristic (csrc/gemm.hip, gemm_pick_variant) takes the 256x256 ring kernel."""
-    return _L.mantis_gemm_pick_variant(M, N, K) == 12
+    """True when the library's tile heuristic (csrc/gemm.hip, gemm_pick_variant) takes the 256x256 ring kernel (for the CU budget the
+    launch will carry)."""
+    return _L.mantis_gemm_pick_variant_cus(M, N, K, _launch().gemm_cus) == 12
 
 
 def linear_dx(dy, w, k=None):
@@ -270,13 +277,13 @@ def _gemm_fused(a, b, out, mode, aux0, aux1, aux_ld, aux_n, bias, variant, extra
     """mantis_gemm_bf16_nt_fused; returns False when the library declines the shape (the caller runs the unfused launches)."""
     M, K = a.shape
     N = b.shape[0]
-    prof = KERNEL_TIMER
+    prof = _launch().timer
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
     wsp, wsn = _gemm_workspace()
     rc = _L.mantis_gemm_bf16_nt_fused(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, _p(bias), mode, _p(aux0),
-                                      _p(aux1), aux_ld, aux_n, variant, wsp, wsn, _stream())
+                                      _p(aux1), aux_ld, aux_n, variant | (_launch().gemm_cus << CUS_SHIFT), wsp, wsn, _stream())
     if rc == -2:
         return False
     _lib.check(rc, f"gemm_fused mode={mode} M={M} N={N} K={K}")
@@ -316,7 +323,7 @@ def linear_qkv_rope(x, w_qkv, bias, cos, sin, n_rope_heads, hd, variant=0):
     return rope_apply_(qkv, cos, sin, n_rope_heads, hd)
 
 
-def linear_dx_swiglu(dy, w_down, gu, variant=0):
+def linear_dx_swiglu(dy, w_down, gu, variant=0, sk_inkernel=False):
     """dgu[M, 2I] = swiglu_bwd(dy[M, d] @ w_down[d, I], gu[M, 2I]) in one launch: the SwiGLU backward runs in the GEMM epilogue
     (the [M, I] activation gradient never goes to HBM)."""
     _chk2d(dy, "dy"), _chk2d(w_down, "w_down"), _chk2d(gu, "gu")
@@ -325,13 +332,14 @@ def linear_dx_swiglu(dy, w_down, gu, variant=0):
     if gu.shape != (M, 2 * I) or w_down.shape[0] != d:
         raise ValueError(f"linear_dx_swiglu: dy {tuple(dy.shape)} w_down {tuple(w_down.shape)} gu {tuple(gu.shape)}")
     dgu = torch.empty_like(gu)
-    prof = KERNEL_TIMER
+    prof = _launch().timer
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
     wsp, wsn = _gemm_workspace()
     rc = _L.mantis_gemm_bf16_nt(_p(dy), dy.stride(0), _p(w_down), w_down.stride(0), _p(dgu), dgu.stride(0), M, I, d, None, _p(gu),
-                                gu.stride(0), 64 | 8192 | (variant << 8), wsp, wsn, _stream())
+                                gu.stride(0), 64 | 8192 | (variant << 8) | (_launch().gemm_cus << CUS_SHIFT) | (SK_INKERNEL if sk_inkernel else 0), wsp, wsn,
+                                _stream())
     _lib.check(rc, f"gemm+swiglu_bwd M={M} I={I} d={d}")
     if prof is not None:
         e1 = torch.cuda.Event(enable_timing=True)
@@ -340,15 +348,13 @@ def linear_dx_swiglu(dy, w_down, gu, variant=0):
     return dgu
 
 
-# optim.FusedAdamW.begin_fold() installs a collector here for the backward of an accumulation boundary (single rank): every weight
-# gradient GEMM then also leaves the sum of squares of what it stored (mantis_gemm_bf16_nt_sumsq), and the optimizer's clip_grad_norm_
-# sums ~1e5 tile values instead of re-reading 16 GB of gradients
-DW_SUMSQ = None
-
-
 def linear_dw(dy, x, grad_w, accumulate):
-    """grad_w[out, in] (+)= dy[M, out]^T @ x[M, in]: both activations are consumed K-major as stored."""
-    col = DW_SUMSQ
+    """grad_w[out, in] (+)= dy[M, out]^T @ x[M, in]: both activations are consumed K-major as stored.
+    With a collector in the LaunchContext (`dw_sumsq` = optim.FusedAdamW.begin_fold(), the backward of an accumulation boundary on a single
+    rank) the GEMM also leaves the sum of squares of what it stored (mantis_gemm_bf16_nt_sumsq), and the optimizer's clip_grad_norm_ sums
+    ~1e5 tile values instead of re-reading 16 GB of gradients."""
+    ctx = _launch()
+    col = ctx.dw_sumsq
     a = dy[:, : grad_w.shape[0]]
     if col is not None and grad_w.is_contiguous():
         Kd, M = a.shape
@@ -356,13 +362,13 @@ def linear_dw(dy, x, grad_w, accumulate):
         tiles = ((M + 255) // 256) * ((N + 255) // 256)
         slot = col.take(grad_w, tiles)
         if slot is not None:
-            prof = KERNEL_TIMER
+            prof = ctx.timer
             if prof is not None:
                 e0 = torch.cuda.Event(enable_timing=True)
                 e0.record()
             wsp, wsn = _gemm_workspace()
             rc = _L.mantis_gemm_bf16_nt_sumsq(_p(a), a.stride(0), _p(x), x.stride(0), _p(grad_w), grad_w.stride(0), M, N, Kd,
-                                              (32 if accumulate else 0) | 4096 | 8192, slot, wsp, wsn, _stream())
+                                              (32 if accumulate else 0) | 4096 | 8192 | (ctx.gemm_cus << CUS_SHIFT), slot, wsp, wsn, _stream())
             if rc == 0:
                 if prof is not None:
                     e1 = torch.cuda.Event(enable_timing=True)

@@ -15,6 +15,7 @@ from . import decoder as D
 from . import decoder_fp8 as D8
 from . import hip_ops as K   # tests may monkeypatch `modeling_idefics2.K` with the oracle's operators to test the host logic
 from .arena import ArenaModule
+from .launch import launch_context
 from .configuration_idefics2 import Idefics2Config
 
 
@@ -261,11 +262,13 @@ class Idefics2Engine:
         self.w8 = None                       # decoder_fp8.Fp8Weights after model.set_precision("fp8")
         self.weights_unchanged = False       # set by MantisHipTrainer on the 2nd.. micro-batch of an accumulation window
 
-    def step_from_batch(self, inputs, **kw):
+    def step_from_batch(self, inputs, launch=None, **kw):
+        """launch: the caller's `launch.LaunchContext`, in force for exactly this call (see engine.LlavaEngine.step_from_batch)"""
         if kw.get("segment_ids") is None and inputs.get("segment_ids") is not None:
             kw["segment_ids"] = inputs["segment_ids"]
-        return self.step(inputs["input_ids"], inputs["attention_mask"], inputs.get("labels"), inputs.get("pixel_values"),
-                         inputs.get("pixel_attention_mask"), **kw)
+        with launch_context(launch):
+            return self.step(inputs["input_ids"], inputs["attention_mask"], inputs.get("labels"), inputs.get("pixel_values"),
+                             inputs.get("pixel_attention_mask"), **kw)
 
     # ------------------------------------------------------------------ NaViT image preparation (device kernel + one tiny readback)
     def _bucket_table(self, tab_n, dev):
@@ -316,21 +319,33 @@ class Idefics2Engine:
         all_attended = bool((flags[2][real_h] != 0).all())        # every patch of every real image attended: the tower needs no key mask
         return pv, pos, (None if all_attended else pm), pm
 
-    def prefetch_vision(self, inputs, after_event=None, stream=None):
-        """Image preparation + the frozen tower of a FUTURE batch on `stream` (meant to be a lowest-priority stream: its workgroups take the
-        compute units the current step leaves idle; `MantisHipTrainer.prefetch_early`).  The tower is frozen and depends on nothing but
-        the pixels, so `after_event` is not needed for correctness; the preparation's three-ints-per-image readback waits only for this
-        stream's own upload and kernel.  Picked up by the step that is handed the SAME pixel_values object."""
+    def prefetch_vision(self, inputs, after_event=None, stream=None, launch=None):
+        """Image preparation + the frozen tower of a FUTURE batch.  The TOWER goes to `stream` (meant to be a lowest-priority stream: its
+        workgroups take the compute units the current step leaves idle; `MantisHipTrainer.prefetch_early`); the image PREPARATION -- one
+        small kernel whose three ints per image the host reads back, because the shapes downstream depend on the number of real images --
+        runs on a plain default-priority side stream: on the lowest-priority queue that kernel would be dispatched behind everything
+        already queued on the compute stream and the host would sit in its readback before it could enqueue the current step (round-4
+        advisor finding).  The tower is frozen and depends on nothing but the pixels, so `after_event` is not needed for correctness.
+        Picked up by the step that is handed the SAME pixel_values object."""
         pv = inputs.get("pixel_values")
         if pv is None or not torch.cuda.is_available():
             return
         dev = self.m.device
+        prep = getattr(self, "_side", None)
+        if prep is None:
+            prep = self._side = torch.cuda.Stream(device=dev)
         if stream is None:
-            stream = getattr(self, "_side", None)
-            if stream is None:
-                stream = self._side = torch.cuda.Stream(device=dev)
-        with torch.cuda.stream(stream):
+            stream = prep
+        with torch.cuda.stream(prep):
             pix, pos_ids, vit_kmask, km_all = self._prepare_images(pv, inputs.get("pixel_attention_mask"))
+            prepared = torch.cuda.Event()
+            prepared.record(prep)
+        if stream is not prep:
+            stream.wait_event(prepared)
+            for t in (pix, pos_ids, vit_kmask, km_all):          # allocated on `prep`, consumed on `stream`
+                if t is not None:
+                    t.record_stream(stream)
+        with torch.cuda.stream(stream), launch_context(launch):
             feats, N = self.vision_forward(pix, pos_ids, vit_kmask)
             done = torch.cuda.Event()
             done.record(stream)

@@ -19,6 +19,7 @@ from . import decoder as D
 from . import decoder_fp8 as D8
 from . import hip_ops as K   # tests may monkeypatch `modeling_qwen2_vl.K` with the oracle's operators to test the host logic
 from .arena import ArenaModule
+from .launch import launch_context
 from .configuration_qwen2_vl import Qwen2VLConfig
 
 
@@ -302,7 +303,7 @@ class Qwen2VLEngine:
         self._prefetched = {}                # id(pixel_values object) -> (pixel_values object, image rows, done event)
 
     # ------------------------------------------------------------------ software pipelining of the frozen tower
-    def prefetch_vision(self, inputs, after_event=None, stream=None):
+    def prefetch_vision(self, inputs, after_event=None, stream=None, launch=None):
         """Enqueue the tower + merger forward of a FUTURE batch on a side stream (behind `after_event` of the compute stream).  `visual`
         is frozen, so its output does not depend on the optimizer step in between: MantisHipTrainer calls this at the end of an
         accumulation window so the MFMA-bound tower of batch i+1 runs beside the HBM-bound clip + AdamW of step i.  The result is
@@ -318,7 +319,7 @@ class Qwen2VLEngine:
         grids = [tuple(int(v) for v in g) for g in torch.as_tensor(inputs["image_grid_thw"]).tolist()]
         if after_event is not None:
             stream.wait_event(after_event)
-        with torch.cuda.stream(stream):
+        with torch.cuda.stream(stream), launch_context(launch):
             pix = torch.as_tensor(pv).to(dev, non_blocking=True).to(torch.float32).contiguous()
             img = self.vision_forward(pix, grids)
             done = torch.cuda.Event()
@@ -327,11 +328,13 @@ class Qwen2VLEngine:
         while len(self._prefetched) > 2:                   # a prefetched batch that never arrives must not pile up
             self._prefetched.pop(next(iter(self._prefetched)))
 
-    def step_from_batch(self, inputs, **kw):
+    def step_from_batch(self, inputs, launch=None, **kw):
+        """launch: the caller's `launch.LaunchContext`, in force for exactly this call (see engine.LlavaEngine.step_from_batch)"""
         if kw.get("segment_ids") is None and inputs.get("segment_ids") is not None:
             kw["segment_ids"] = inputs["segment_ids"]
-        return self.step(inputs["input_ids"], inputs["attention_mask"], inputs.get("labels"), inputs.get("pixel_values"),
-                         inputs.get("image_grid_thw"), **kw)
+        with launch_context(launch):
+            return self.step(inputs["input_ids"], inputs["attention_mask"], inputs.get("labels"), inputs.get("pixel_values"),
+                             inputs.get("image_grid_thw"), **kw)
 
     # ------------------------------------------------------------------ vision tower + patch merger (frozen, forward only)
     def vision_forward(self, pix, grids, record=None):

@@ -18,6 +18,7 @@ over the whole trainable arena; the clip coefficient stays on the device (no hos
 import torch
 
 from . import hip_ops as K
+from .arena import ARENA_ALIGN
 
 STATE_FORMAT = "mantis_fused_adamw/2"       # /2: arenas with 256-byte aligned parameters (round 4)
 
@@ -77,7 +78,7 @@ class FusedAdamW(torch.optim.Optimizer):
             po, go, dec = m._offs[n], m._grad_offs[n], not no_decay(n)
             if segs and segs[-1][3] == dec:
                 gap_p, gap_g = po - (segs[-1][0] + segs[-1][2]), go - (segs[-1][1] + segs[-1][2])
-                if gap_p == gap_g and 0 <= gap_p < 128:
+                if gap_p == gap_g and 0 <= gap_p < ARENA_ALIGN:
                     segs[-1] = (segs[-1][0], segs[-1][1], segs[-1][2] + gap_p + cnt, dec)
                     continue
             segs.append((po, go, cnt, dec))
@@ -103,8 +104,8 @@ class FusedAdamW(torch.optim.Optimizer):
         g = self.param_groups[0]
         group = {k: (list(v) if isinstance(v, tuple) else v) for k, v in g.items() if k != "params"}
         group["params"] = list(range(len(g["params"])))
-        return {"format": STATE_FORMAT, "step": int(self.step_count), "layout": self._layout(), "master": self.master,
-                "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "param_groups": [group]}
+        return {"format": STATE_FORMAT, "step": int(self.step_count), "layout": self._layout(), "arena_align": ARENA_ALIGN,
+                "master": self.master, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "param_groups": [group]}
 
     def load_state_dict(self, state_dict):
         """Resume: step count, fp32 master weights and Adam moments, hyper-parameters (as torch: the checkpoint's lr / betas / eps /
@@ -115,6 +116,10 @@ class FusedAdamW(torch.optim.Optimizer):
         if sd.get("format") != STATE_FORMAT:
             raise ValueError(f"not a FusedAdamW state (format {sd.get('format')!r}, expected {STATE_FORMAT!r}); a torch.optim.AdamW state "
                              "holds per-parameter tensors and cannot be mapped onto the flat arenas")
+        if int(sd.get("arena_align", 128)) != ARENA_ALIGN:
+            raise ValueError(f"FusedAdamW.load_state_dict: the checkpoint's flat state was laid out with parameters aligned to "
+                             f"{sd.get('arena_align', 128)} elements, this process places them on {ARENA_ALIGN}-element boundaries "
+                             "(MANTIS_ARENA_ALIGN): the offsets inside master / exp_avg / exp_avg_sq differ")
         if [list(x) for x in sd["layout"]] != self._layout():
             raise ValueError("FusedAdamW.load_state_dict: the checkpoint's parameter layout (names / sizes of the trainable parameters, in "
                              "arena order) differs from this model's")
@@ -181,6 +186,8 @@ class FusedAdamW(torch.optim.Optimizer):
     class _Fold:
         def __init__(self, opt):
             self.opt, self.used, self.covered = opt, 0, []
+            self.stale = []              # ranges whose tile partials must NOT be counted (written again after a fused launch): see take()
+            self.slots = {}              # covered range start -> (first tile slot, tiles)
 
         def take(self, grad_w, tiles):
             o = self.opt
@@ -188,17 +195,30 @@ class FusedAdamW(torch.optim.Optimizer):
             off = (grad_w.data_ptr() - base) // 2
             if off < 0 or off + grad_w.numel() > n or self.used + tiles > o._fold_ws.numel():
                 return None
+            # a gradient written twice in one backward (a shared / tied weight, a per-chunk loop with accumulate=True): the second
+            # launch's tile sums cover the accumulated values and the first launch's partials are still in the workspace -- the norm
+            # would count that range twice.  Decline: the caller runs the plain GEMM, and end_fold() takes the range from the separate
+            # pass only if no fused launch covered it; the already-covered range keeps the FIRST launch's partials, which are then stale,
+            # so the whole range is handed back to the separate pass (round-4 advisor finding)
+            for i, (o2, n2) in enumerate(self.covered):
+                if off < o2 + n2 and o2 < off + grad_w.numel():
+                    self.stale.append(self.covered.pop(i))          # end_fold() zeroes its tile partials
+                    return None
+            if any(off < o2 + n2 and o2 < off + grad_w.numel() for o2, n2 in self.stale):
+                return None
             self.covered.append((off, grad_w.numel()))
+            self.slots[off] = (self.used, tiles)
             ptr = o._fold_ws.data_ptr() + 4 * self.used
             self.used += tiles
             return ptr
 
         def give_back(self, grad_w, tiles):
-            self.covered.pop()
+            off, _ = self.covered.pop()
+            self.slots.pop(off, None)
             self.used -= tiles
 
     def begin_fold(self):
-        """-> collector for hip_ops.DW_SUMSQ (None when clipping is off).  Call right before the backward of an accumulation boundary."""
+        """-> collector for the step's `LaunchContext.dw_sumsq` (None when clipping is off).  Call right before the backward of an accumulation boundary."""
         if self.max_grad_norm is None or self.max_grad_norm <= 0:
             return None
         if getattr(self, "_fold_ws", None) is None:
@@ -211,6 +231,9 @@ class FusedAdamW(torch.optim.Optimizer):
         f, self._fold = self._fold, None
         m = self.model
         n = m.grad_arena.numel()
+        for off, _ in f.stale:                               # ranges written again after their fused launch: their partials do not count
+            a, t = f.slots[off]
+            self._fold_ws[a:a + t].zero_()
         # uncovered ranges: the many small ones (norm weights, biases: one per layer) go through ONE multi-range launch whose partials land
         # behind the tile partials; the few large ones (embedding, shapes the fused GEMM declined) through the ordinary kernel
         gaps, pos = [], 0
@@ -292,7 +315,10 @@ class FusedAdamW(torch.optim.Optimizer):
                          wd if decays else 0.0, self.step_count, grad_scale=scale)
 
     def zero_grad(self, set_to_none=True):
-        """model.zero_grad() of the HF loop: dropping the .grad views lets the next backward overwrite instead of accumulate."""
+        """model.zero_grad() of the HF loop: dropping the .grad views lets the next backward overwrite instead of accumulate.  A gradient
+        norm that was taken for a step which then never happened (an exception, a skipped optimizer step) dies with the gradients."""
+        self._norm_ready = False
+        self._pending_scale = None
         for p in self.model.parameters():
             if p.requires_grad:
                 if set_to_none:

@@ -12,6 +12,8 @@ launched from inside the backward as each bucket's gradients complete.
 same way in train_intern_vl_25.py:104-122)."""
 import torch
 
+from .launch import LaunchContext
+
 
 class MantisHipTrainer:
     def __init__(self, model=None, gradient_accumulation_steps=1, reducer=None, optimizer=None, fold_norm_into=None):
@@ -26,6 +28,10 @@ class MantisHipTrainer:
         self.optimizer = optimizer
         self.fold_norm_into = fold_norm_into
         self._micro = 0
+        # launch options of THIS trainer's steps (per-launch timers: bench.py sets `launch.timer`; the folded gradient norm's collector;
+        # the GEMM scheduler's CU budget = what the reducer's RCCL channels leave): handed to the engine with every call, never a
+        # process-wide switch -- two trainers / models in one process do not see each other's
+        self.launch = LaunchContext(gemm_cus=getattr(reducer, "gemm_cus", 0) or 0)
 
     def _prepare_inputs(self, inputs):
         # HF:trainer.py:2203-2235 moves tensors to the device; here the engine does the H2D itself (non_blocking) because
@@ -92,20 +98,17 @@ class MantisHipTrainer:
             # leave idle (incomplete tile rounds, epilogues) during the whole forward + backward
             ev = torch.cuda.Event()
             ev.record()
-            model.engine.prefetch_vision(next_inputs, after_event=ev, stream=getattr(self, "prefetch_stream", None))
+            model.engine.prefetch_vision(next_inputs, after_event=ev, stream=getattr(self, "prefetch_stream", None), launch=self.launch)
             next_inputs = None
         fold = None
         if boundary and self.fold_norm_into is not None and not norm_now and (self.reducer is None or not self.reducer.active):
             fold = self.fold_norm_into.begin_fold()
-        if fold is not None:
-            from . import hip_ops as _K
-            _K.DW_SUMSQ = fold
+        self.launch.dw_sumsq = fold
         try:
-            out = model.engine.step_from_batch(batch, grad_scale=1.0 / ga, loss_scale=1.0 / ga, compute_grads=True,
+            out = model.engine.step_from_batch(batch, launch=self.launch, grad_scale=1.0 / ga, loss_scale=1.0 / ga, compute_grads=True,
                                                overwrite_grads=overwrite, on_bucket_ready=hook, segment_ids=seg)
         finally:
-            if fold is not None:
-                _K.DW_SUMSQ = None
+            self.launch.dw_sumsq = None
         if fold is not None:
             self.fold_norm_into.end_fold()
         if reduce_now:
@@ -115,7 +118,7 @@ class MantisHipTrainer:
         if next_inputs is not None and boundary and hasattr(model.engine, "prefetch_vision"):
             ev = torch.cuda.Event()
             ev.record()                       # end of this window's backward (and gradient reduction) on the compute stream
-            model.engine.prefetch_vision(next_inputs, after_event=ev, stream=getattr(self, "prefetch_stream", None))
+            model.engine.prefetch_vision(next_inputs, after_event=ev, stream=getattr(self, "prefetch_stream", None), launch=self.launch)
         return out["loss"].reshape(()).detach()
 
 

@@ -1946,36 +1946,121 @@ def check_gemm_fullsize_down_fwd():
 
 
 def check_gemm_cu_budget():
-    """mantis_gemm_cu_budget (MANTIS_GEMM_CUS): planning the tile rounds / K splits for fewer CUs than the device has (RCCL channels hold
-    the others).  For every budget the result is reproducible bit for bit and within the bf16 bar of the oracle; the split-K workspace
-    requirement does not grow; resetting restores the default plan (bit-identical to the first run)."""
+    """The GEMM scheduler's CU budget, PER CALL since round 5 (bits 16-27 of the flags; `LaunchContext.gemm_cus` / `gemm_nt(cus=)`): planning
+    the tile rounds / K splits for fewer CUs than the device has (RCCL channels hold the others).  For every budget the result is
+    reproducible bit for bit and within the bf16 bar of the oracle; the split-K workspace requirement does not grow; a launch without a
+    budget right after one with a budget is bit-identical to the first run (no state left behind); two contexts with different budgets
+    interleave without seeing each other; mantis_gemm_cu_budget is a pure query."""
     k = K()
     L = k._L
-    dev_cus = L.mantis_gemm_cu_budget(-1)
-    assert dev_cus == k.num_cus()
+    dev_cus = L.mantis_gemm_cu_budget(0)
+    assert dev_cus == k.num_cus() == L.mantis_gemm_cu_budget(-1)
     worst = 0.0
-    try:
-        for (M, N, K_, akm, bkm) in [(5624, 4096, 4096, False, False), (5624, 4096, 6144, False, True), (6144, 4096, 5624, True, True)]:
-            a, b = rnd(M, K_, seed=71), rnd(N, K_, seed=72, scale=0.05)
-            ref = a.float() @ b.float().t()
+    for (M, N, K_, akm, bkm) in [(5624, 4096, 4096, False, False), (5624, 4096, 6144, False, True), (6144, 4096, 5624, True, True)]:
+        a, b = rnd(M, K_, seed=71), rnd(N, K_, seed=72, scale=0.05)
+        ref = a.float() @ b.float().t()
+        ad = (a.t().contiguous() if akm else a).to(DEV)
+        bd = (b.t().contiguous() if bkm else b).to(DEV)
+        base = k.gemm_nt(ad, bd, a_kmajor=akm, b_kmajor=bkm)
+        ws0 = L.mantis_gemm_workspace_bytes(0, 0, 0)
+        per_budget = {}
+        for budget in (dev_cus - 16, dev_cus - 32, 200, 97, 8):
+            assert L.mantis_gemm_cu_budget(budget) == max(8, min(budget, dev_cus))
+            assert L.mantis_gemm_cu_budget(0) == dev_cus                        # the query changed nothing
+            assert L.mantis_gemm_workspace_bytes(0, 0, 0) == ws0
+            o1 = k.gemm_nt(ad, bd, a_kmajor=akm, b_kmajor=bkm, cus=budget)
+            with k.launch_context(k.LaunchContext(gemm_cus=budget)):            # the same budget through the caller's context
+                o2 = k.gemm_nt(ad, bd, a_kmajor=akm, b_kmajor=bkm)
+            assert torch.equal(o1, o2), (M, N, K_, budget)
+            worst = max(worst, close(o1, ref, 1e-2, f"gemm {M}x{N}x{K_} planned for {budget} CUs"))
+            err = (o1.float().cpu() - ref).norm(dim=1) / (ref.norm(dim=1) + 1e-30)
+            assert float(err.max()) < 2e-2, (budget, float(err.max()))
+            assert torch.equal(k.gemm_nt(ad, bd, a_kmajor=akm, b_kmajor=bkm), base), "a budgeted launch left state behind"
+            per_budget[budget] = o1
+        # two callers with different budgets, interleaved: each gets exactly its own plan
+        c200, c97 = k.LaunchContext(gemm_cus=200), k.LaunchContext(gemm_cus=97)
+        with k.launch_context(c200):
+            x200 = k.gemm_nt(ad, bd, a_kmajor=akm, b_kmajor=bkm)
+            with k.launch_context(c97):
+                x97 = k.gemm_nt(ad, bd, a_kmajor=akm, b_kmajor=bkm)
+            y200 = k.gemm_nt(ad, bd, a_kmajor=akm, b_kmajor=bkm)
+        assert torch.equal(x200, per_budget[200]) and torch.equal(y200, per_budget[200]) and torch.equal(x97, per_budget[97])
+    return worst
+
+
+def check_gemm_sk_finish():
+    """Round 5: the K-split remainder tiles of the ring16 kernels are reduced by gemm_ring16_finish_kernel on all compute units instead of by
+    their last arriver inside the GEMM kernel.  Same summation order -> BIT-IDENTICAL to the in-kernel reduction (flag 16384 / variant bit
+    64), for every epilogue kind of the step, S = 2 and S > 2, both ring16 geometries, ragged M; reproducible; within the bf16 bar."""
+    import ctypes
+    k = K()
+    L = k._L
+    worst = 0.0
+    M = 5624
+    for v in (14, 13):
+        # (M, N, K, A K-major, B K-major, epilogue): 352 / 384 tiles on 256 CUs -> S = 2; 8 x 9 = 72 tiles -> S = 3 (and a ragged N: general read-back)
+        for (Mm, Nn, K_, akm, bkm, epi) in [(M, 4096, 4096, False, False, "plain"), (M, 4096, 4096, False, False, "res"),
+                                            (M, 4096, 2048, False, False, "bias+tanh"), (M, 4096, 6144, False, True, "plain"),
+                                            (6144, 4096, 2048, True, True, "acc"), (2000, 2100, 2048, False, False, "bias")]:
+            a, b = rnd(Mm, K_, seed=91), rnd(Nn, K_, seed=92, scale=0.05)
             ad = (a.t().contiguous() if akm else a).to(DEV)
             bd = (b.t().contiguous() if bkm else b).to(DEV)
-            L.mantis_gemm_cu_budget(-1)
-            base = k.gemm_nt(ad, bd, a_kmajor=akm, b_kmajor=bkm)
-            ws0 = L.mantis_gemm_workspace_bytes(0, 0, 0)
-            for budget in (dev_cus - 16, dev_cus - 32, 200, 97, 8):
-                assert L.mantis_gemm_cu_budget(budget) == max(8, min(budget, dev_cus))
-                assert L.mantis_gemm_workspace_bytes(0, 0, 0) == ws0
-                o1 = k.gemm_nt(ad, bd, a_kmajor=akm, b_kmajor=bkm)
-                o2 = k.gemm_nt(ad, bd, a_kmajor=akm, b_kmajor=bkm)
-                assert torch.equal(o1, o2), (M, N, K_, budget)
-                worst = max(worst, close(o1, ref, 1e-2, f"gemm {M}x{N}x{K_} planned for {budget} CUs"))
-                err = (o1.float().cpu() - ref).norm(dim=1) / (ref.norm(dim=1) + 1e-30)
-                assert float(err.max()) < 2e-2, (budget, float(err.max()))
-            L.mantis_gemm_cu_budget(-1)
-            assert torch.equal(k.gemm_nt(ad, bd, a_kmajor=akm, b_kmajor=bkm), base)
-    finally:
-        L.mantis_gemm_cu_budget(-1)
+            bias = rnd(Nn, seed=93).to(DEV) if "bias" in epi else None
+            res = rnd(Mm, Nn, seed=94).to(DEV) if epi == "res" else None
+            act = "gelu_pytorch_tanh" if "tanh" in epi else None
+            c0 = rnd(Mm, Nn, seed=95).to(DEV) if epi == "acc" else None
+            outs = []
+            for ink in (False, True, False):
+                out = None if c0 is None else c0.clone()
+                outs.append(k.gemm_nt(ad, bd, bias=bias, act=act, residual=res, out=out, accumulate=c0 is not None, a_kmajor=akm, b_kmajor=bkm,
+                                      variant=v, sk_inkernel=ink))
+            assert L.mantis_gemm_workspace_bytes(Mm, Nn, K_) > 0, f"{Mm}x{Nn}x{K_} has no K-split remainder round"
+            assert torch.equal(outs[0], outs[1]), f"finishing kernel != in-kernel reduction: {Mm}x{Nn}x{K_} v{v} {epi}"
+            assert torch.equal(outs[0], outs[2]), f"finishing kernel not reproducible: {Mm}x{Nn}x{K_} v{v} {epi}"
+            ref = R.gemm_nt(a, b, bias=None if bias is None else bias.cpu(), act=act, residual=None if res is None else res.cpu())
+            if c0 is not None:
+                ref = ref.float() + c0.cpu().float()
+            worst = max(worst, close(outs[0], ref, 1e-2, f"gemm + finishing kernel {Mm}x{Nn}x{K_} v{v} {epi}"))
+        # fused forward epilogues (two columns per lane): q|k|v + RoPE at the step's shape (16 remainder tiles, S = 8), gate|up + SwiGLU
+        x = rnd(M, 4096, seed=96).to(DEV)
+        wq = rnd(6144, 4096, seed=97, scale=0.02).to(DEV)
+        pos = torch.arange(M, dtype=torch.int64, device=DEV) % 2812
+        from mantis_amd.decoder import inv_freq
+        cos, sin = k.rope_table(pos, inv_freq(128, 5e5).to(DEV))
+        q1 = k.linear_qkv_rope(x, wq, None, cos, sin, 40, 128, variant=v)
+        q2 = k.linear_qkv_rope(x, wq, None, cos, sin, 40, 128, variant=v | 64)
+        assert torch.equal(q1, q2), f"q|k|v + RoPE: finishing kernel != in-kernel reduction (v{v})"
+        wg = rnd(2 * 1920, 4096, seed=98, scale=0.02).to(DEV)           # N = 3840: 22 x 15 = 330 tiles -> 74 remainder tiles, S = 3
+        g1, a1 = k.linear_gu_swiglu(x, wg, variant=v)
+        g2, a2 = k.linear_gu_swiglu(x, wg, variant=v | 64)
+        assert torch.equal(g1, g2) and torch.equal(a1, a2), f"gate|up + SwiGLU: finishing kernel != in-kernel reduction (v{v})"
+    # the SwiGLU backward fused behind dX(down) (general read-back) with a remainder round: I = 3840 -> 22 x 15 = 330 tiles
+    dy, wd = rnd(M, 4096, seed=99).to(DEV), rnd(4096, 3840, seed=100, scale=0.02).to(DEV)
+    gu = rnd(M, 2 * 3840, seed=101).to(DEV)
+    d1 = k.linear_dx_swiglu(dy, wd, gu)
+    d2 = k.linear_dx_swiglu(dy, wd, gu, sk_inkernel=True)
+    assert torch.equal(d1, d2), "dX(down) + SwiGLU backward: finishing kernel != in-kernel reduction"
+    # the sum-of-squares epilogue: C identical, the tile partials agree with the stored values (two atomic addends per remainder tile)
+    for (Mm, Nn, K_, v) in [(6144, 4096, 5624, 14), (6144, 4096, 5624, 13)]:
+        a, b = rnd(K_, Mm, seed=102, scale=0.5).to(DEV), rnd(K_, Nn, seed=103, scale=0.5).to(DEV)
+        tiles = ((Mm + 255) // 256) * ((Nn + 255) // 256)
+        got = []
+        for ink in (0, 16384, 0):
+            c = torch.empty(Mm, Nn, dtype=BF, device=DEV)
+            ts = torch.full((tiles,), float("nan"), dtype=torch.float32, device=DEV)
+            wsp, wsn = k._gemm_workspace()
+            rc = L.mantis_gemm_bf16_nt_sumsq(ctypes.c_void_p(a.data_ptr()), a.stride(0), ctypes.c_void_p(b.data_ptr()), b.stride(0),
+                                             ctypes.c_void_p(c.data_ptr()), c.stride(0), Mm, Nn, K_, 4096 | 8192 | (v << 8) | ink,
+                                             ctypes.c_void_p(ts.data_ptr()), wsp, wsn, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+            assert rc == 0
+            torch.cuda.synchronize()
+            assert torch.isfinite(ts).all()
+            got.append((c, ts))
+        assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][0], got[2][0])
+        assert torch.equal(got[0][1], got[2][1]), "sumsq tile partials of the finishing kernel not reproducible"
+        want = float(got[0][0].double().pow(2).sum())
+        for c, ts in got:
+            assert abs(float(ts.double().sum()) - want) <= 1e-5 * want
     return worst
 
 
@@ -2255,6 +2340,7 @@ def all_checks():
     c["norm_fold_step"] = check_norm_fold_step
     c["fullsize_gemm_down_fwd_residual_v13"] = check_gemm_fullsize_down_fwd
     c["gemm_cu_budget"] = check_gemm_cu_budget
+    c["gemm_sk_finish"] = check_gemm_sk_finish
     # BASELINE configs[3] / [4] shapes against the oracle (round-2 verdict: the cfg4 / cfg5 analogue of the cfg2 fullsize_* checks)
     c["fullsize_attn_cfg5_decoder_b2"] = lambda: check_attn_cfg5_decoder(2, False)
     c["fullsize_attn_cfg5_decoder_b1_perhead"] = lambda: check_attn_cfg5_decoder(1, False)

@@ -131,12 +131,36 @@ def test_folded_norm_range_arithmetic_and_fallback(cpu_backend):
             assert ptr is not None
             idx = (ptr - opt._fold_ws.data_ptr()) // 4
             opt._fold_ws[idx] = g.float().pow(2).sum()
-    f.take(model._param(opt._names[0]).grad, 1)
-    f.give_back(model._param(opt._names[0]).grad, 1)          # a declined shape leaves no trace
+    one_d = next(model._param(n).grad for n in opt._names if model._param(n).dim() == 1)
+    assert f.take(one_d, 1) is not None
+    f.give_back(one_d, 1)                                     # a declined shape leaves no trace
     opt.end_fold()
     assert opt.folded_tiles == sum(1 for n in opt._names if model._param(n).dim() == 2)
     n2 = float(opt.clip_grad_norm(1.0))
     assert abs(n2 - want) <= 1e-5 * want
+    # a gradient written TWICE in one backward (a tied / shared weight, a chunked dW loop): the second fused launch is declined, the first
+    # launch's partials -- now stale -- do not count, and the range goes through the separate pass (round-4 advisor finding)
+    f = opt.begin_fold()
+    twice = None
+    for name in opt._names:
+        g = model._param(name).grad
+        if g.dim() == 2:
+            ptr = f.take(g, 1)
+            idx = (ptr - opt._fold_ws.data_ptr()) // 4
+            opt._fold_ws[idx] = g.float().pow(2).sum()
+            if twice is None:
+                twice = g
+                opt._fold_ws[idx] = 12345.0                   # what a first, partial write would have left: must not reach the norm
+    assert f.take(twice, 1) is None and f.take(twice, 1) is None
+    opt.end_fold()
+    n3 = float(opt.clip_grad_norm(1.0))
+    assert abs(n3 - want) <= 1e-5 * want
+    # ... and a norm taken for a step that never happens dies with the gradients
+    opt.begin_fold()
+    opt.end_fold()
+    assert opt._norm_ready
+    opt.zero_grad(set_to_none=False)
+    assert not opt._norm_ready
 
 
 def test_flat_state_is_defined_in_the_alignment_pads(cpu_backend, monkeypatch):

@@ -91,14 +91,13 @@ def main():
         one_step()
     torch.cuda.synchronize()
     timer = []
-    K.KERNEL_TIMER = timer
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(args.steps):
-        one_step()
-    e1.record()
+    with K.launch_context(K.LaunchContext(timer=timer)):
+        e0.record()
+        for _ in range(args.steps):
+            one_step()
+        e1.record()
     torch.cuda.synchronize()
-    K.KERNEL_TIMER = None
     wall = e0.elapsed_time(e1) / args.steps
     fam_ms = sum(x[3].elapsed_time(x[4]) for x in timer) / args.steps
     fam_fl = sum(x[1] for x in timer) / args.steps
