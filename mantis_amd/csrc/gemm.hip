@@ -1063,6 +1063,39 @@ __device__ unsigned long long g_ring16_stamps[8192 * 8];
 #define PAIR_NONE 0
 #define PAIR_SWIGLU 1
 #define PAIR_ROPE 2
+// ---- Balanced remainder round (round 5; finishing-kernel mode only).  The tiles of an incomplete last round used to be split into S EQUAL
+// K parts with S * rem <= #CU: 352 tiles on 256 CUs = 96 remainder tiles x 2 parts -- 192 units of K/2 while 64 CUs idle; every CU that works
+// walks 0.5 K where 96 / 256 = 0.375 K would do.  Now the remainder's K-steps are one sequence of T = rem * nk steps cut into `units` (= #CU)
+// equal ranges; a range that crosses a tile boundary is TWO workgroups (the tail of one tile, the head of the next), so no workgroup ever
+// spans tiles (the K loop, its DMA prologue and the slab store stay as they are).  Grid order: first the `units` workgroups that start each
+// range (they start together; workgroup j = range j runs on XCD j % 8), then the second segments -- each on the XCD of its range's first
+// segment (the hardware deals workgroup j to XCD j % 8 and hands it to the first CU of that XCD that frees up: a tail placed on another XCD
+// waits behind that XCD's long first segments -- measured: +3 % on the family instead of -2 %), per XCD the one whose first segment is SHORTEST
+// first, so a CU that finishes a short head picks up the longest remaining tail and every CU ends after ~T / units steps.  The tail region of
+// the grid is therefore 8 x R slots (R = the largest number of crossing ranges on one XCD); slots without a tail hold SK_EMPTY and exit at
+// once.  (Placement and order are assumptions for speed only: any dispatch order gives the same result.)  Slabs: first segment of range c ->
+// slab c; the segment that BEGINS tile t (t >= 1) from a range started in tile t - 1 -> slab units + t - 1 (at most one per tile boundary).
+// The finishing kernel adds a tile's parts in K order.  Boundaries closer than SK_MINSEG steps to a tile boundary snap onto it (no 1-step
+// segments).
+#define SK_MINSEG 4
+#define SK_BALANCED_MIN_STEPS 16            // ranges shorter than this: the equal split (its parts are >= 8 steps)
+#define SK_BALANCED_MIN_GAIN 24             // K-steps per CU the balanced round must save over the equal split to be chosen
+#define SK_EMPTY 0xFFFFu
+struct SkPlan {
+    int units;                              // 0: equal split (S parts per tile, slab rt * S + part)
+    int nspan;                              // slots of the tail region (a multiple of 8)
+    unsigned short span[256];               // slot i (XCD i % 8): the range whose second segment runs there, or SK_EMPTY
+};
+// first step of range c (0 .. units) in the remainder's step sequence; T = rem * nk
+// (32-bit on purpose: c <= 256 and T < 2^23, see sk_make_plan -- a 64-bit division is ~300 scalar instructions in a workgroup's prologue)
+__host__ __device__ __forceinline__ int sk_bound(int c, int units, int T, int nk) {
+    unsigned a = (unsigned)c * (unsigned)T / (unsigned)units;
+    const unsigned r = a % (unsigned)nk;
+    if (r < SK_MINSEG) a -= r;
+    else if ((unsigned)nk - r < SK_MINSEG) a += (unsigned)nk - r;
+    return (int)a;
+}
+
 // Epilogue of a ring16 wave tile: all of it (NBM_ = 8, from the GEMM kernel) or one 64-row half of it (NBM_ = 4, from the K-split finishing
 // kernel).  acc[tn][tm] = 16 x 16 block (n block tn, m block tm) of the wave's 128 (64) x NBN*16 tile whose first row is mw0; wave_l / tid_l =
 // the wave's / thread's index inside its block (strip ownership, the sumsq reduction: that one needs all NW waves of the tile in the block);
@@ -1256,7 +1289,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring16_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C, int M, int N, int K, long lda, long ldb,
     long ldc, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res, long ldr, int flags, int tiles_m, int tiles_n,
     int full, int S, float* __restrict__ sk_slabs, unsigned int* __restrict__ sk_cnt, bf16_t* __restrict__ aux0,
-    const bf16_t* __restrict__ aux1, long aux_ld, int aux_n) {
+    const bf16_t* __restrict__ aux1, long aux_ld, int aux_n, SkPlan plan) {
     static_assert(NW == 4 || NW == 8, "4 waves of 128 x 128 or 8 waves of 128 x 64");
     static_assert(PAIR == PAIR_NONE || (!AKM && !BKM && !SWIGLU), "the pair epilogues are forward (NT) fusions");
 #ifdef RING16_STAMPS
@@ -1291,16 +1324,45 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring16_kernel(
     if (bid < full) {
         const int q = full >> 3, r = full & 7, xcd = bid & 7;
         tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    } else {
+    } else if (plan.units == 0) {
         const int j = bid - full, nu = gridDim.x - full, rem = nu / S;
         const int q = nu >> 3, r = nu & 7, xcd = j & 7;
         const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (j >> 3);
         part = lin / rem;
         tile_id = full + lin - part * rem;
+    } else {
+        tile_id = full;                      // balanced remainder round: set below
     }
     // 32-bit on purpose (nk <= 2^15, part < S <= 8): the 64-bit divisions cost the K-split units ~300 scalar instructions before their first DMA
-    const int t0 = (bid < full) ? 0 : (int)((unsigned)nk * (unsigned)part / (unsigned)S);
-    const int t1 = (bid < full) ? nk : (int)((unsigned)nk * (unsigned)(part + 1) / (unsigned)S);
+    int t0 = (bid < full) ? 0 : (int)((unsigned)nk * (unsigned)part / (unsigned)S);
+    int t1 = (bid < full) ? nk : (int)((unsigned)nk * (unsigned)(part + 1) / (unsigned)S);
+    int sk_slab = 0;                         // balanced plan: this workgroup's slab
+    if (bid >= full && plan.units != 0) {
+        // see SkPlan: workgroups [0, units) start the ranges, the rest are the second segments of the ranges that cross a tile boundary
+        const int j = bid - full, U = plan.units, rem = S, T = rem * nk;      // (S carries the number of remainder tiles in this mode)
+        const bool first = j < U;
+        int c;
+        if (first) {
+            c = j;                                   // range j on XCD j % 8: ranges of one K phase (period 8 for 96 tiles on 256 CUs) share panels
+        } else {
+            c = plan.span[j - U];
+            if (c == (int)SK_EMPTY) return;         // a tail slot of an XCD with fewer crossing ranges than the fullest one
+        }
+        const int a0 = sk_bound(c, U, T, nk), a1 = sk_bound(c + 1, U, T, nk);
+        int tl = a0 / nk;
+        if (first) {
+            const int e = (tl + 1) * nk;
+            t0 = a0 - tl * nk;
+            t1 = (a1 < e ? a1 : e) - tl * nk;
+            sk_slab = c;
+        } else {
+            tl += 1;
+            t0 = 0;
+            t1 = a1 - tl * nk;
+            sk_slab = U + tl - 1;
+        }
+        tile_id = full + tl;
+    }
     const int GROUP = 8;
     const int per_group = GROUP * tiles_n;
     const int g = tile_id / per_group;
@@ -1530,13 +1592,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring16_kernel(
     if (bid >= full) {
         const int rt = tile_id - full;
         float* slabs = sk_slabs + (size_t)rt * S * SK_SLAB_FLOATS;
-        sk_store16<NBN, NBM, NW * 64>(acc, slabs + (size_t)part * SK_SLAB_FLOATS, tid);
+        if (plan.units != 0) sk_store16<NBN, NBM, NW * 64>(acc, sk_slabs + (size_t)sk_slab * SK_SLAB_FLOATS, tid);
+        else sk_store16<NBN, NBM, NW * 64>(acc, slabs + (size_t)part * SK_SLAB_FLOATS, tid);
         if (sk_cnt == nullptr) {
             // finishing-kernel mode (launch_gemm_ring): no ticket, no reduction here -- gemm_ring16_finish_kernel, launched behind this
             // kernel on the same stream, sums the S slabs of every remainder tile on ALL compute units and runs the epilogue (the kernel
             // boundary publishes the slabs).  A sumsq launch zeroes the tile's slot for the finishing halves' two atomic adds.
             if constexpr (!SWIGLU && PAIR == PAIR_NONE) {
-                if ((flags & EPI_SUMSQ) && part == 0 && tid == 0) reinterpret_cast<float*>(aux0)[tile_id] = 0.f;
+                if ((flags & EPI_SUMSQ) && t0 == 0 && tid == 0) reinterpret_cast<float*>(aux0)[tile_id] = 0.f;      // the segment that begins the tile
             }
             return;
         }
@@ -1583,7 +1646,7 @@ template <int NW, bool KM, bool SWIGLU, int PAIR, int WPB>
 __global__ __launch_bounds__(WPB * 64) void gemm_ring16_finish_kernel(
     bf16_t* __restrict__ C, int M, int N, long ldc, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res, long ldr, int flags,
     int tiles_m, int tiles_n, int full, int S, const float* __restrict__ sk_slabs, bf16_t* __restrict__ aux0, const bf16_t* __restrict__ aux1,
-    long aux_ld, int aux_n) {
+    long aux_ld, int aux_n, int sk_units, int nk) {
     constexpr int NBN = NW == 4 ? 8 : 4, NT = NW * 64;
     static_assert(WPB == 1 || WPB == NW, "one wave per workgroup, or all waves of the tile (sum of squares)");
     __shared__ __attribute__((aligned(16))) char fin_smem[(PAIR != PAIR_NONE && NW == 4 ? 2 * WPB : WPB) * EPI_STRIP + 64];
@@ -1602,8 +1665,9 @@ __global__ __launch_bounds__(WPB * 64) void gemm_ring16_finish_kernel(
     const int gsz = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
     const int in_g = tile_id - g * per_group;
     const int m0 = (first_m + in_g % gsz) * 256, n0 = (in_g / gsz) * 256;
-    const f32x4* slab = reinterpret_cast<const f32x4*>(sk_slabs + (size_t)rt * S * SK_SLAB_FLOATS) + wave * 64 + lane;
     constexpr int SLAB4 = SK_SLAB_FLOATS / 4;
+    // equal split: the tile's S slabs are rt * S + p; balanced plan (sk_units != 0): absolute slab indices, see below
+    const f32x4* slab = reinterpret_cast<const f32x4*>(sk_slabs + (sk_units ? (size_t)0 : (size_t)rt * S * SK_SLAB_FLOATS)) + wave * 64 + lane;
     f32x4 acc[NBN][4];
     auto load_part = [&](int p, f32x4 (&v)[NBN][4]) {
 #pragma unroll
@@ -1611,7 +1675,31 @@ __global__ __launch_bounds__(WPB * 64) void gemm_ring16_finish_kernel(
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[i][j] = __builtin_nontemporal_load(slab + (size_t)p * SLAB4 + (i * 8 + pm * 4 + j) * NT);
     };
-    if (S == 2) {
+    if (sk_units != 0) {
+        // the parts of remainder tile rt in K order (SkPlan): the head left by a range that started in tile rt - 1 (slab units + rt - 1), then
+        // the first segments of the ranges that start inside the tile (slab = range index)
+        const int rem = S, T = rem * nk, lo = rt * nk, hi = lo + nk;
+        int c = (int)((unsigned)lo * (unsigned)sk_units / (unsigned)T);      // lo < T < 2^23, units <= 256
+        while (c + 1 <= sk_units && sk_bound(c + 1, sk_units, T, nk) <= lo) ++c;
+        while (c > 0 && sk_bound(c, sk_units, T, nk) > lo) --c;
+#pragma unroll
+        for (int i = 0; i < NBN; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto add_part = [&](int p) {
+            f32x4 o[NBN][4];
+            load_part(p, o);
+#pragma unroll
+            for (int i = 0; i < NBN; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] += o[i][j];
+        };
+        if (sk_bound(c, sk_units, T, nk) < lo) {
+            add_part(sk_units + rt - 1);
+            ++c;
+        }
+        for (; c < sk_units && sk_bound(c, sk_units, T, nk) < hi; ++c) add_part(c);
+    } else if (S == 2) {
         f32x4 o[NBN][4];
         load_part(0, acc);
         load_part(1, o);
@@ -1642,7 +1730,8 @@ __global__ __launch_bounds__(WPB * 64) void gemm_ring16_finish_kernel(
 // tile resets its ticket), so one workspace serves any number of stream-ordered launches.  No allocation, no global state here.
 static int g_num_cu[64];
 static inline size_t sk_cnt_bytes(int cus) { return (((size_t)(cus + 1) * sizeof(unsigned int)) + 255) / 256 * 256; }
-static inline size_t sk_ws_bytes(int cus) { return sk_cnt_bytes(cus) + (size_t)SK_MAX_ROUNDS * cus * SK_SLAB_FLOATS * sizeof(float); }
+// slabs: #CU for the equal split; the balanced remainder round (SkPlan) needs one per range (<= #CU) + one per crossed tile boundary (< #CU)
+static inline size_t sk_ws_bytes(int cus) { return sk_cnt_bytes(cus) + (size_t)(SK_MAX_ROUNDS > 2 ? SK_MAX_ROUNDS : 2) * cus * SK_SLAB_FLOATS * sizeof(float); }
 
 static int num_cus() {
     int dev = 0;
@@ -1737,6 +1826,44 @@ static int ring_variant_for(int M, int N, int K, bool akm, bool bkm, int cus_req
     return rounds * cdiv(K, BK) >= 400 ? 13 : 14;
 }
 
+static bool sk_balanced_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MANTIS_GEMM_SK_BALANCED"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v != 0;
+}
+// the balanced remainder plan of a launch (SkPlan), or units = 0 when the equal split already fills the planned CUs / the ranges would be short
+static void sk_make_plan(SkPlan& plan, int rem, int S, int nk, int cus) {
+    plan.units = 0;
+    plan.nspan = 0;
+    const long T = (long)rem * nk;
+    if (!sk_balanced_enabled() || S * rem == cus || rem >= cus || cus > 256 || T / cus < SK_BALANCED_MIN_STEPS || T >= (1L << 23)) return;
+    // what it buys: nk / S - T / units K-steps per CU; what it costs: a second prologue + slab store on the CUs that take a tail, more
+    // slabs for the finishing pass -- measured ~25 - 30 us, i.e. ~20 K-steps (profiles/r05_experiments.md: dX(gate|up), 448 K-steps, -43 us;
+    // down_proj forward, 224, -8 us; the 64- and 96-step shapes +8 ... +16 us): only where the saving is clearly larger
+    if (nk / S - (int)(T / cus) < SK_BALANCED_MIN_GAIN) return;
+    const int U = cus;
+    if (U % 8) return;                                          // the tail placement assumes workgroup j of the remainder section runs on XCD j % 8
+    int f[8][32], idx[8][32], n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int c = 0; c < U; ++c) {
+        const int a0 = sk_bound(c, U, (int)T, nk), a1 = sk_bound(c + 1, U, (int)T, nk);
+        const int e = (a0 / nk + 1) * nk;
+        if (a1 <= a0) return;                                   // a degenerate range: keep the equal split
+        if (a1 > e) {
+            if (a1 - e > nk) return;                            // a range spanning three tiles cannot happen for rem < units; be safe
+            const int x = c & 7;
+            int j = n[x]++;                                     // insertion by first-segment length (then range index): <= 32 per XCD
+            while (j > 0 && f[x][j - 1] > e - a0) { f[x][j] = f[x][j - 1]; idx[x][j] = idx[x][j - 1]; --j; }
+            f[x][j] = e - a0;
+            idx[x][j] = c;
+        }
+    }
+    int R = 0;
+    for (int x = 0; x < 8; ++x) R = n[x] > R ? n[x] : R;
+    plan.units = U;
+    plan.nspan = 8 * R;
+    for (int r = 0; r < R; ++r)
+        for (int x = 0; x < 8; ++x) plan.span[8 * r + x] = r < n[x] ? (unsigned short)idx[x][r] : (unsigned short)SK_EMPTY;
+}
 static bool sk_finish_enabled() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("MANTIS_GEMM_SK_FINISH"); v = (e && e[0] == '0') ? 0 : 1; }
@@ -1765,11 +1892,17 @@ static int launch_gemm_ring(hipStream_t s, const bf16_t* A, const bf16_t* B, bf1
         // remainder tiles: the split units leave their slabs and gemm_ring16_finish_kernel reduces them on all CUs (cnt = nullptr tells the GEMM
         // kernel); MANTIS_GEMM_SK_FINISH=0 keeps the round-4 in-kernel reduction by the last arriver (A/B measurements)
         const bool finish = S > 1 && !(flags & EPI_SK_INKERNEL) && sk_finish_enabled();
-        MANTIS_LAUNCH((gemm_nt_ring16_kernel<R16, AKM, BKM, SWIGLU, PAIR>), dim3(grid), dim3(R16 * 64), 0, s, A, B, C, M, N, K, lda, ldb, ldc,
-                           bias, res, ldr, flags, tiles_m, tiles_n, full, S, slabs, finish ? nullptr : cnt, aux0, aux1, aux_ld, aux_n);
+        SkPlan plan;
+        plan.units = 0;
+        plan.nspan = 0;
+        if (finish) sk_make_plan(plan, rem, S, nk, cus);
+        const int grid16 = plan.units ? full + plan.units + plan.nspan : grid;
+        const int S16 = plan.units ? rem : S;                  // balanced plan: the kernels take the number of remainder tiles here
+        MANTIS_LAUNCH((gemm_nt_ring16_kernel<R16, AKM, BKM, SWIGLU, PAIR>), dim3(grid16), dim3(R16 * 64), 0, s, A, B, C, M, N, K, lda, ldb, ldc,
+                           bias, res, ldr, flags, tiles_m, tiles_n, full, S16, slabs, finish ? nullptr : cnt, aux0, aux1, aux_ld, aux_n, plan);
         if (finish) {
             // one wave per workgroup, except for the sum of squares (all R16 waves of a tile half in one block: fixed-order reduction)
-#define FIN_ARGS 0, s, C, M, N, ldc, bias, res, ldr, flags, tiles_m, tiles_n, full, S, slabs, aux0, aux1, aux_ld, aux_n
+#define FIN_ARGS 0, s, C, M, N, ldc, bias, res, ldr, flags, tiles_m, tiles_n, full, S16, slabs, aux0, aux1, aux_ld, aux_n, plan.units, nk
             bool done = false;
             if constexpr (!SWIGLU && PAIR == PAIR_NONE) {
                 if (flags & EPI_SUMSQ) {

@@ -1181,6 +1181,117 @@ def check_idefics2_full_width():
     return close(model.grad_arena, 2 * g1.float(), 5e-3, "accumulated gradients = 2x")
 
 
+def check_llava_full_width_vs_oracle():
+    """BASELINE configs[1] (the HEADLINE) at FULL WIDTH in the mode bench.py times (round-4 verdict, weak 1): SigLIP-so400m geometry (1152 x 16
+    heads x 72, MLP 4304, 576 patches per 336^2 image) at depth 3 (hidden_states[-2]: two layers run), Llama-3-8B geometry (4096, 32:8 x 128, MLP 14336, V = 128258) with 2
+    layers; `bench.synthetic_batch(cfg, 2, 512, 4, 336)` -> merged length 2812 x 2 samples; ONE `MantisHipTrainer.training_step` whose tower
+    was prefetched by the previous step on a lowest-priority stream (`prefetch_early`), with the gradient norm folded into the dW GEMMs
+    (`fold_norm_into`), followed by ONE `FusedAdamW.step()` -- against `LlavaRef` (fp32, CPU) on the same bf16-rounded weights:
+      merged attention mask / labels / position ids exact; loss; EVERY gradient (cosine, rel-L2; the per-tensor table goes to
+      $MANTIS_CHECK_REPORT_DIR/llava_full_width_grads.md when that is set); the gradient norm clip_grad_norm_ returns;
+      the optimizer arithmetic: fp32 masters after the step == torch.optim.AdamW on fp32 copies fed the SAME bf16 gradients (2e-5);
+      and end to end: the parameter UPDATE against torch.optim.AdamW + clip_grad_norm_ fed the oracle's own gradients (cosine)."""
+    from mantis_amd import configuration_llava as C
+    from mantis_amd.modeling_llava import LlavaForConditionalGeneration
+    from mantis_amd.trainer import MantisHipTrainer
+    from mantis_amd.optim import FusedAdamW
+    from oracle.llava_ref import LlavaRef
+    import bench
+    k = K()
+    cfg = C.mantis_8b_siglip_llama3()
+    cfg.vision_config.num_hidden_layers = 3                     # hidden_states[-2]: the first two layers are computed
+    cfg.text_config.num_hidden_layers = 2
+    model = LlavaForConditionalGeneration(cfg, device=DEV, seed=0)
+    meta = dict(vision=cfg.vision_config.to_dict(), text=cfg.text_config.to_dict(), image_token_index=cfg.image_token_index,
+                pad_token_id=cfg.pad_token_id, vision_feature_select_strategy=cfg.vision_feature_select_strategy,
+                vision_feature_layer=cfg.vision_feature_layer, projector_hidden_act=cfg.projector_hidden_act)
+    oracle = LlavaRef({n: p.detach().float().cpu() for n, p in model.named_parameters()}, meta)
+    lr = 1e-3
+    opt = FusedAdamW(model, lr=lr, weight_decay=0.0, max_grad_norm=1.0)
+    tr = MantisHipTrainer(model, 1, fold_norm_into=opt)
+    tr.prefetch_early = True
+    tr.prefetch_stream = k.priority_stream(1)
+    b0 = bench.synthetic_batch(cfg, 2, 512, 4, cfg.vision_config.image_size, 0, 0)
+    b1 = bench.synthetic_batch(cfg, 2, 512, 4, cfg.vision_config.image_size, 0, 1)
+    # step on b0 queues b1's frozen tower on the priority stream; its own gradients are dropped again
+    tr.training_step(model, b0, next_inputs=b1)
+    opt.zero_grad(set_to_none=True)
+    assert id(b1["pixel_values"]) in model.engine._prefetched, "the next batch's tower was not prefetched"
+    # merged integers of b1 (a forward-only pass on a copy of the dict whose pixel list is another object: the prefetch slot stays untouched)
+    rec = {}
+    model.engine.step_from_batch(dict(b1, pixel_values=list(b1["pixel_values"])), compute_grads=False, record=rec)
+    assert id(b1["pixel_values"]) in model.engine._prefetched
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    before = {n: model._param(n).detach().float().cpu().clone() for n in names}
+    loss = tr.training_step(model, b1)
+    assert id(b1["pixel_values"]) not in model.engine._prefetched, "the step did not pick the prefetched tower up"
+    assert opt._norm_ready and opt.folded_tiles > 1000, "the gradient norm was not folded into the dW GEMMs"
+    torch.cuda.synchronize()
+    # ---- oracle: forward + backward on the same batch
+    orec = {}
+    oracle.zero_grad()
+    oloss, _ = oracle.forward(b1["input_ids"].numpy(), b1["pixel_values"], b1["attention_mask"].numpy(), b1["labels"].numpy(), record=orec)
+    oloss.backward()
+    for key in ("merged_attention_mask", "merged_labels", "merged_position_ids"):
+        assert np.array_equal(rec[key].cpu().numpy(), orec[key].numpy()), key
+    assert abs(float(loss) - float(oloss)) <= 5e-3 * abs(float(oloss)), (float(loss), float(oloss))
+    rows, worst_c, worst_r = [], 1.0, 0.0
+    grads = {}
+    for n in names:
+        g = model._param(n).grad.detach().float().cpu()
+        og = oracle.w[n].grad
+        grads[n] = g
+        c, r = Hh.cosine(g.numpy(), og.numpy()), Hh.rel_l2(g.numpy(), og.numpy())
+        rows.append((n, tuple(g.shape), c, r, float(og.norm())))
+        worst_c, worst_r = min(worst_c, c), max(worst_r, r)
+    Hh._note_report({n: (c, r) for n, _, c, r, _ in rows})
+    rep_dir = os.environ.get("MANTIS_CHECK_REPORT_DIR")
+    if rep_dir:
+        with open(os.path.join(rep_dir, "llava_full_width_grads.md"), "w") as fh:
+            fh.write("# llava_full_width_vs_oracle: every gradient of the headline geometry (3 tower / 2 decoder layers, B 2, L 2812) in the benched mode "
+                     "(prefetched tower, folded norm) vs LlavaRef fp32\n\n| parameter | shape | cosine | rel-L2 | oracle norm |\n|---|---|---|---|---|\n")
+            for n, sh, c, r, on in rows:
+                fh.write(f"| {n} | {'x'.join(map(str, sh))} | {c:.6f} | {r:.4f} | {on:.3e} |\n")
+            fh.write(f"\nloss {float(loss):.5f} vs oracle {float(oloss):.5f}; worst cosine {worst_c:.6f}, worst rel-L2 {worst_r:.4f}\n")
+    for n, sh, c, r, on in rows:
+        assert c >= 0.999 and r <= 0.04, (n, c, r)          # measured: worst 0.99968 / 0.026 (q and k projections of layer 1); SURVEY 8c's 2e-2 holds for all others
+    # ---- the clip norm and the optimizer step
+    tp = {n: torch.nn.Parameter(before[n].clone()) for n in names}
+    for n in names:
+        tp[n].grad = grads[n].clone()
+    # clip_grad_norm_ restated with float64 norms: torch's own fp32 reduction on the CPU loses 0.3 % of the squared norm of a 525 M-element
+    # gradient (lm_head) -- the addends fall below half an ulp of the running sum -- which is more than the bar below
+    def clip64(params, max_norm):
+        tot = float(sum(float(p.grad.double().pow(2).sum()) for p in params)) ** 0.5
+        coef = min(1.0, max_norm / (tot + 1e-6))               # torch.nn.utils.clip_grad_norm_: clip_coef clamped to 1
+        for p in params:
+            p.grad.mul_(coef)
+        return tot
+    total = clip64(list(tp.values()), 1.0)
+    ototal = clip64([oracle.w[n] for n in names], 1.0)
+    topt = torch.optim.AdamW(list(tp.values()), lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    topt.step()
+    oopt = torch.optim.AdamW([oracle.w[n] for n in names], lr=lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    oopt.step()
+    opt.step()
+    torch.cuda.synchronize()
+    norm = float(opt.last_grad_norm)
+    assert abs(norm - total) <= 1e-3 * total, ("folded norm vs torch norm of the stored gradients", norm, total, ototal)
+    assert abs(norm - ototal) <= 2e-2 * ototal, ("folded norm vs the oracle's gradient norm", norm, total, ototal)
+    flat_ref = _flat_like_grad_arena(model, tp, names)
+    close(opt.master.cpu(), flat_ref, 2e-5, "fp32 masters after FusedAdamW.step() at full width (torch AdamW on the same gradients)")
+    # end to end: the UPDATE (a first Adam step is lr * g / (|g| + eps'): mostly the gradient's sign) against the oracle's own step
+    upd_c = 1.0
+    for n in names:
+        mine = opt.master[model._grad_offs[n]: model._grad_offs[n] + before[n].numel()].cpu().reshape(before[n].shape) - before[n]
+        theirs = oracle.w[n].detach() - before[n]
+        upd_c = min(upd_c, Hh.cosine(mine.numpy(), theirs.numpy()))
+    assert upd_c >= 0.9, upd_c
+    print(f"    llava full width vs oracle: loss {float(loss):.4f} / {float(oloss):.4f}, worst gradient cosine {worst_c:.5f}, worst rel {worst_r:.4f}, "
+          f"norm {norm:.4f} / {total:.4f} / {ototal:.4f}, worst update cosine {upd_c:.4f}", flush=True)
+    return 1.0 - worst_c
+
+
 def check_idefics2_full_width_vs_oracle():
     """BASELINE configs[3] at FULL WIDTH, depth 2 (SigLIP-so400m NaViT at 448^2 -> 1024 patches per image, perceiver 16/4 x 96 with its
     cross attention over 1088 keys, Mistral width 4096 / 14336, V = 32003; two images, 512 tokens), the whole step against the Idefics2
@@ -1205,7 +1316,7 @@ def check_idefics2_full_width_vs_oracle():
     rec = {}
     out = model.engine.step_from_batch(batch, compute_grads=True, overwrite_grads=True, need_logits=True, record=rec)
     torch.cuda.synchronize()
-    rep = Hh.check_idefics2_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-3, grad_cos=0.997, grad_rel=0.08)     # measured 0.99926 / 0.040
+    rep = Hh.check_idefics2_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-3, grad_cos=0.999, grad_rel=0.05)     # measured 0.99931 / 0.037 (round 5; rounds 3 - 4: bars 0.997 / 0.08)
     worst = min(c for c, _ in rep.values())
     print(f"    idefics2 full width vs oracle: worst gradient cosine {worst:.5f}, worst rel {max(r for _, r in rep.values()):.4f}", flush=True)
     return 1.0 - worst
@@ -1233,7 +1344,7 @@ def check_qwen2vl_full_width_vs_oracle():
     rec = {}
     out = model.engine.step_from_batch(batch, compute_grads=True, overwrite_grads=True, need_logits=True, record=rec)
     torch.cuda.synchronize()
-    rep = Hh.check_qwen2vl_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-3, grad_cos=0.997, grad_rel=0.08)      # measured 0.99959 / 0.029
+    rep = Hh.check_qwen2vl_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-3, grad_cos=0.999, grad_rel=0.04)      # measured 0.99959 / 0.029 (round 5; rounds 3 - 4: bars 0.997 / 0.08)
     worst = min(c for c, _ in rep.values())
     print(f"    qwen2-vl full width vs oracle: worst gradient cosine {worst:.5f}, worst rel {max(r for _, r in rep.values()):.4f}", flush=True)
     return 1.0 - worst
@@ -1990,38 +2101,58 @@ def check_gemm_cu_budget():
 
 def check_gemm_sk_finish():
     """Round 5: the K-split remainder tiles of the ring16 kernels are reduced by gemm_ring16_finish_kernel on all compute units instead of by
-    their last arriver inside the GEMM kernel.  Same summation order -> BIT-IDENTICAL to the in-kernel reduction (flag 16384 / variant bit
-    64), for every epilogue kind of the step, S = 2 and S > 2, both ring16 geometries, ragged M; reproducible; within the bf16 bar."""
+    their last arriver inside the GEMM kernel, and the remainder round is BALANCED (SkPlan: ranges of T / #CU K-steps, a range that crosses a
+    tile boundary is two workgroups) where the equal split would leave CUs idle.
+      (1) where both paths use the same partition (384 tiles on 256 CUs: 128 remainder tiles x 2 parts; 528 tiles: 16 x 8 parts) the finishing
+          kernel is BIT-IDENTICAL to the in-kernel reduction (flag 16384 / variant bit 64): every epilogue kind, both ring16 geometries;
+      (2) the balanced plan (352 / 330 / 72 tiles): reproducible bit for bit, every row within the bf16 bar of the oracle, and within 2e-3 of
+          the equal-split result (same products, another fp32 summation order); fused epilogues and the sum of squares included."""
     import ctypes
     k = K()
     L = k._L
     worst = 0.0
     M = 5624
+
+    def run(Mm, Nn, K_, akm, bkm, epi, v, ink):
+        a, b = rnd(Mm, K_, seed=91), rnd(Nn, K_, seed=92, scale=0.05)
+        ad = (a.t().contiguous() if akm else a).to(DEV)
+        bd = (b.t().contiguous() if bkm else b).to(DEV)
+        bias = rnd(Nn, seed=93).to(DEV) if "bias" in epi else None
+        res = rnd(Mm, Nn, seed=94).to(DEV) if epi == "res" else None
+        act = "gelu_pytorch_tanh" if "tanh" in epi else None
+        c0 = rnd(Mm, Nn, seed=95).to(DEV) if epi == "acc" else None
+        out = k.gemm_nt(ad, bd, bias=bias, act=act, residual=res, out=None if c0 is None else c0.clone(), accumulate=c0 is not None,
+                        a_kmajor=akm, b_kmajor=bkm, variant=v, sk_inkernel=ink)
+        ref = R.gemm_nt(a, b, bias=None if bias is None else bias.cpu(), act=act, residual=None if res is None else res.cpu())
+        if c0 is not None:
+            ref = ref.float() + c0.cpu().float()
+        return out, ref
     for v in (14, 13):
-        # (M, N, K, A K-major, B K-major, epilogue): 352 / 384 tiles on 256 CUs -> S = 2; 8 x 9 = 72 tiles -> S = 3 (and a ragged N: general read-back)
+        # (1) same partition: 24 x 16 = 384 tiles
+        for (Mm, Nn, K_, akm, bkm, epi) in [(6144, 4096, 2048, False, False, "plain"), (6144, 4096, 2048, False, False, "res"),
+                                            (6144, 4096, 2048, False, False, "bias+tanh"), (6144, 4096, 2048, False, True, "plain"),
+                                            (6144, 4096, 2048, True, True, "acc")]:
+            assert L.mantis_gemm_workspace_bytes(Mm, Nn, K_) > 0, f"{Mm}x{Nn}x{K_} has no K-split remainder round"
+            o_fin, ref = run(Mm, Nn, K_, akm, bkm, epi, v, False)
+            o_ink, _ = run(Mm, Nn, K_, akm, bkm, epi, v, True)
+            assert torch.equal(o_fin, o_ink), f"finishing kernel != in-kernel reduction: {Mm}x{Nn}x{K_} v{v} {epi}"
+            worst = max(worst, close(o_fin, ref, 1e-2, f"gemm + finishing kernel {Mm}x{Nn}x{K_} v{v} {epi}"))
+        # (2) balanced remainder round: 352 tiles (96 remainder tiles -> 256 ranges + 64 heads), 72 tiles (ragged N: general read-back)
         for (Mm, Nn, K_, akm, bkm, epi) in [(M, 4096, 4096, False, False, "plain"), (M, 4096, 4096, False, False, "res"),
                                             (M, 4096, 2048, False, False, "bias+tanh"), (M, 4096, 6144, False, True, "plain"),
-                                            (6144, 4096, 2048, True, True, "acc"), (2000, 2100, 2048, False, False, "bias")]:
-            a, b = rnd(Mm, K_, seed=91), rnd(Nn, K_, seed=92, scale=0.05)
-            ad = (a.t().contiguous() if akm else a).to(DEV)
-            bd = (b.t().contiguous() if bkm else b).to(DEV)
-            bias = rnd(Nn, seed=93).to(DEV) if "bias" in epi else None
-            res = rnd(Mm, Nn, seed=94).to(DEV) if epi == "res" else None
-            act = "gelu_pytorch_tanh" if "tanh" in epi else None
-            c0 = rnd(Mm, Nn, seed=95).to(DEV) if epi == "acc" else None
-            outs = []
-            for ink in (False, True, False):
-                out = None if c0 is None else c0.clone()
-                outs.append(k.gemm_nt(ad, bd, bias=bias, act=act, residual=res, out=out, accumulate=c0 is not None, a_kmajor=akm, b_kmajor=bkm,
-                                      variant=v, sk_inkernel=ink))
+                                            (5632, 4096, 2048, True, True, "acc"), (2000, 2100, 2048, False, False, "bias"),
+                                            (M, 4096, 14336, False, False, "res")]:
             assert L.mantis_gemm_workspace_bytes(Mm, Nn, K_) > 0, f"{Mm}x{Nn}x{K_} has no K-split remainder round"
-            assert torch.equal(outs[0], outs[1]), f"finishing kernel != in-kernel reduction: {Mm}x{Nn}x{K_} v{v} {epi}"
-            assert torch.equal(outs[0], outs[2]), f"finishing kernel not reproducible: {Mm}x{Nn}x{K_} v{v} {epi}"
-            ref = R.gemm_nt(a, b, bias=None if bias is None else bias.cpu(), act=act, residual=None if res is None else res.cpu())
-            if c0 is not None:
-                ref = ref.float() + c0.cpu().float()
-            worst = max(worst, close(outs[0], ref, 1e-2, f"gemm + finishing kernel {Mm}x{Nn}x{K_} v{v} {epi}"))
-        # fused forward epilogues (two columns per lane): q|k|v + RoPE at the step's shape (16 remainder tiles, S = 8), gate|up + SwiGLU
+            o1, ref = run(Mm, Nn, K_, akm, bkm, epi, v, False)
+            o2, _ = run(Mm, Nn, K_, akm, bkm, epi, v, False)
+            o_ink, _ = run(Mm, Nn, K_, akm, bkm, epi, v, True)
+            assert torch.equal(o1, o2), f"balanced remainder round not reproducible: {Mm}x{Nn}x{K_} v{v} {epi}"
+            close(o1, o_ink, 2e-3, f"balanced vs equal split {Mm}x{Nn}x{K_} v{v} {epi}")
+            worst = max(worst, close(o1, ref, 1e-2, f"gemm, balanced remainder round {Mm}x{Nn}x{K_} v{v} {epi}"))
+            err = (o1.float().cpu() - ref.float()).norm(dim=1) / (ref.float().norm(dim=1) + 1e-30)
+            assert float(err.max()) < 2e-2, (Mm, Nn, K_, v, epi, float(err.max()), int(err.argmax()))
+        # fused forward epilogues (two columns per lane): q|k|v + RoPE at the step's shape (16 remainder tiles x 8 equal parts: bit-identical),
+        # gate|up + SwiGLU with 74 remainder tiles (balanced)
         x = rnd(M, 4096, seed=96).to(DEV)
         wq = rnd(6144, 4096, seed=97, scale=0.02).to(DEV)
         pos = torch.arange(M, dtype=torch.int64, device=DEV) % 2812
@@ -2030,18 +2161,22 @@ def check_gemm_sk_finish():
         q1 = k.linear_qkv_rope(x, wq, None, cos, sin, 40, 128, variant=v)
         q2 = k.linear_qkv_rope(x, wq, None, cos, sin, 40, 128, variant=v | 64)
         assert torch.equal(q1, q2), f"q|k|v + RoPE: finishing kernel != in-kernel reduction (v{v})"
-        wg = rnd(2 * 1920, 4096, seed=98, scale=0.02).to(DEV)           # N = 3840: 22 x 15 = 330 tiles -> 74 remainder tiles, S = 3
+        wg = rnd(2 * 1920, 4096, seed=98, scale=0.02).to(DEV)           # N = 3840: 22 x 15 = 330 tiles -> 74 remainder tiles
         g1, a1 = k.linear_gu_swiglu(x, wg, variant=v)
+        g1b, a1b = k.linear_gu_swiglu(x, wg, variant=v)
         g2, a2 = k.linear_gu_swiglu(x, wg, variant=v | 64)
-        assert torch.equal(g1, g2) and torch.equal(a1, a2), f"gate|up + SwiGLU: finishing kernel != in-kernel reduction (v{v})"
+        assert torch.equal(g1, g1b) and torch.equal(a1, a1b)
+        close(g1, g2, 2e-3, f"gate|up + SwiGLU, balanced vs equal split (v{v})")
+        close(a1, a2, 4e-3, f"silu(gate) * up, balanced vs equal split (v{v})")
+        assert torch.equal(a1, k.swiglu_fwd(g1)), "fused SwiGLU output differs from swiglu_fwd of the stored gate|up"
     # the SwiGLU backward fused behind dX(down) (general read-back) with a remainder round: I = 3840 -> 22 x 15 = 330 tiles
     dy, wd = rnd(M, 4096, seed=99).to(DEV), rnd(4096, 3840, seed=100, scale=0.02).to(DEV)
     gu = rnd(M, 2 * 3840, seed=101).to(DEV)
     d1 = k.linear_dx_swiglu(dy, wd, gu)
-    d2 = k.linear_dx_swiglu(dy, wd, gu, sk_inkernel=True)
-    assert torch.equal(d1, d2), "dX(down) + SwiGLU backward: finishing kernel != in-kernel reduction"
-    # the sum-of-squares epilogue: C identical, the tile partials agree with the stored values (two atomic addends per remainder tile)
-    for (Mm, Nn, K_, v) in [(6144, 4096, 5624, 14), (6144, 4096, 5624, 13)]:
+    assert torch.equal(d1, k.linear_dx_swiglu(dy, wd, gu))
+    close(d1, k.linear_dx_swiglu(dy, wd, gu, sk_inkernel=True), 4e-3, "dX(down) + SwiGLU backward, balanced vs equal split")
+    # the sum-of-squares epilogue: equal partition (384 tiles) bit-identical to the in-kernel path, balanced (352 tiles) consistent with what it stored
+    for (Mm, Nn, K_, v, same) in [(6144, 4096, 5624, 14, True), (6144, 4096, 5624, 13, True), (5632, 4096, 2048, 14, False), (5632, 4096, 2048, 13, False)]:
         a, b = rnd(K_, Mm, seed=102, scale=0.5).to(DEV), rnd(K_, Nn, seed=103, scale=0.5).to(DEV)
         tiles = ((Mm + 255) // 256) * ((Nn + 255) // 256)
         got = []
@@ -2056,11 +2191,12 @@ def check_gemm_sk_finish():
             torch.cuda.synchronize()
             assert torch.isfinite(ts).all()
             got.append((c, ts))
-        assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][0], got[2][0])
-        assert torch.equal(got[0][1], got[2][1]), "sumsq tile partials of the finishing kernel not reproducible"
-        want = float(got[0][0].double().pow(2).sum())
+        assert torch.equal(got[0][0], got[2][0]) and torch.equal(got[0][1], got[2][1]), "sumsq launch with a finishing pass not reproducible"
+        if same:
+            assert torch.equal(got[0][0], got[1][0])
         for c, ts in got:
-            assert abs(float(ts.double().sum()) - want) <= 1e-5 * want
+            want = float(c.double().pow(2).sum())
+            assert abs(float(ts.double().sum()) - want) <= 1e-5 * want, (Mm, Nn, K_, v)
     return worst
 
 
@@ -2355,6 +2491,7 @@ def all_checks():
         c["attn_cross_" + "_".join(map(str, a))] = (lambda a=a: check_attn_cross(*a))
     c["dw_side_stream_bitwise"] = check_dw_side_stream
     c["navit_prepare"] = check_navit_prepare
+    c["llava_full_width_vs_oracle"] = check_llava_full_width_vs_oracle
     c["idefics2_full_width_vs_oracle"] = check_idefics2_full_width_vs_oracle
     c["qwen2vl_full_width_vs_oracle"] = check_qwen2vl_full_width_vs_oracle
     c["fullsize_linear_gu_swiglu_fused"] = lambda: check_linear_gu_swiglu_fused(CFG2["M"], CFG2["d"], CFG2["I"], 0)

@@ -53,7 +53,41 @@ def cosine(a, b):
     return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
 
 
-def check_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-3, grad_cos=0.995, grad_rel=6e-2):
+#: (case name, {parameter: (cosine, rel-L2)}) of every whole-step comparison run in this process (tools/gpu_selftest.py sets CURRENT_CASE and
+#: writes the per-tensor table: which gradients sit where against SURVEY 8c's proposed 0.999 / 2e-2)
+GRAD_REPORTS = []
+CURRENT_CASE = None
+
+
+def _note_report(report):
+    GRAD_REPORTS.append((CURRENT_CASE, dict(report)))
+
+
+def write_grad_parity(path):
+    """Every whole-step comparison of this process against SURVEY 8c's proposed bars, one row per case (tools/gpu_selftest.py; the -m gpu
+    suite writes it at session end when MANTIS_CHECK_REPORT_DIR is set)."""
+    with open(path, "w") as f:
+        f.write("# whole-step gradient parity (bf16 HIP path vs fp32 oracle on the same bf16-rounded weights), per case: worst cosine / worst rel-L2 "
+                "over the trainable parameters, and every parameter outside SURVEY 8c's proposed bars (cosine >= 0.999, rel-L2 <= 2e-2)\n\n"
+                "| case | tensors | worst cosine | worst rel-L2 | outside 0.999 / 2e-2 |\n|---|---|---|---|---|\n")
+        for case, rep in GRAD_REPORTS:
+            if not rep:
+                continue
+            wc = min(c for c, _ in rep.values())
+            wr = max(r for _, r in rep.values())
+            out = [f"{n} ({c:.5f}, {r:.4f})" for n, (c, r) in rep.items() if c < 0.999 or r > 2e-2]
+            f.write(f"| {case} | {len(rep)} | {wc:.6f} | {wr:.4f} | {'; '.join(out) if out else '-'} |\n")
+
+
+# Whole-step gradient bars (bf16 product vs fp32 oracle on the same bf16-rounded weights): SURVEY.md 8c's proposal, cosine >= 0.999 and
+# rel-L2 <= 2e-2 per tensor, since round 5 (rounds 1 - 4 ran 0.995 / 6e-2).  Measured on the MI355X over every golden case
+# (profiles/r05_grad_parity.md): LLaVA worst 0.99993 / 0.012, Idefics2 0.99986 / 0.017; the exceptions are stated where they apply -- the Qwen2-VL
+# key bias (a near-cancelling sum: up to 0.9990 / 0.045) and the q / k projections of the FULL-WIDTH steps (4096-wide contractions over 2812 -
+# 4096 positions: 0.9993 / 0.037), which carry their own bars at the call sites.
+GRAD_COS, GRAD_REL = 0.999, 2e-2
+
+
+def check_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-3, grad_cos=GRAD_COS, grad_rel=GRAD_REL):
     """bf16 product path vs fp32 oracle on identical (bf16-rounded) weights.  Tolerances: SURVEY.md section 8c."""
     orec = {}
     oracle.zero_grad()
@@ -89,6 +123,7 @@ def check_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-3, grad_c
             assert np.linalg.norm(g) < 1e-6, name
             continue
         assert c >= grad_cos and r <= grad_rel, (name, c, r)
+    _note_report(report)
     return report
 
 
@@ -263,7 +298,7 @@ def idefics2_batch(z):
     return b
 
 
-def check_idefics2_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-3, grad_cos=0.995, grad_rel=6e-2):
+def check_idefics2_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-3, grad_cos=GRAD_COS, grad_rel=GRAD_REL):
     """bf16 product path vs the fp32 Idefics2 oracle on identical (bf16-rounded) weights."""
     orec = {}
     oracle.zero_grad()
@@ -296,6 +331,7 @@ def check_idefics2_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-
             assert np.linalg.norm(g) < 1e-6, name
             continue
         assert c >= grad_cos and r <= grad_rel, (name, c, r)
+    _note_report(report)
     return report
 
 
@@ -323,11 +359,12 @@ def qwen2vl_batch(z):
     return b
 
 
-def check_qwen2vl_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-3, grad_cos=0.995, grad_rel=6e-2, act_rel=3e-2,
-                                      grad_cos_1d=None, grad_rel_1d=None):
+def check_qwen2vl_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-3, grad_cos=GRAD_COS, grad_rel=GRAD_REL, act_rel=3e-2,
+                                      grad_cos_1d=None, grad_rel_1d=None, kbias_cos=0.998, kbias_rel=6e-2):
     """bf16 product path vs the fp32 Qwen2-VL oracle on identical (bf16-rounded) weights.  grad_cos_1d / grad_rel_1d: separate bar for
-    the 1-D parameters (biases, norm weights) -- the fp8 variant needs it for the key bias, whose gradient is a near-cancelling sum
-    (a constant added to every key only shifts the scores of a query uniformly, up to RoPE) and therefore mostly quantisation noise."""
+    the 1-D parameters (biases, norm weights; default: the matrices' bar); kbias_cos / kbias_rel: the KEY bias, whose gradient is a
+    near-cancelling sum (a constant added to every key only shifts the scores of a query uniformly, up to RoPE) and therefore mostly rounding
+    noise of dS -- bf16 measured 0.99898 / 0.045 at worst (profiles/r05_grad_parity.md); with an fp8 1-D bar given, FP8_COS_KBIAS applies."""
     orec = {}
     oracle.zero_grad()
     pv = z["pixel_values"] if "pixel_values" in z.files else None
@@ -361,10 +398,13 @@ def check_qwen2vl_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-3
         if np.linalg.norm(og.numpy()) < 1e-12:
             assert np.linalg.norm(g) < 1e-6, name
             continue
-        one_d = p.dim() == 1 and grad_cos_1d is not None
-        kbias = one_d and name.endswith("k_proj.bias")            # fp8 variant: the near-cancelling key-bias gradient (FP8_COS_KBIAS)
-        assert c >= ((min(grad_cos_1d, FP8_COS_KBIAS) if kbias else grad_cos_1d) if one_d else grad_cos) and \
-            r <= (grad_rel_1d if one_d else grad_rel), (name, c, r)
+        one_d = p.dim() == 1
+        cbar, rbar = (grad_cos if grad_cos_1d is None else grad_cos_1d, grad_rel if grad_rel_1d is None else grad_rel_1d) if one_d else (grad_cos, grad_rel)
+        if one_d and name.endswith("k_proj.bias"):                 # the near-cancelling key-bias gradient
+            cbar = min(kbias_cos, FP8_COS_KBIAS) if grad_cos_1d is not None else kbias_cos
+            rbar = max(rbar, kbias_rel)
+        assert c >= cbar and r <= rbar, (name, c, r, cbar, rbar)
+    _note_report(report)
     return report
 
 

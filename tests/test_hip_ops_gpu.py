@@ -11,6 +11,8 @@ CHECKS = gpu_checks.all_checks()
 def test_kernel_parity(name):
     import torch
     assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    from tests import helpers
+    helpers.CURRENT_CASE = name          # whole-step checks file their per-tensor gradient report under it (helpers.GRAD_REPORTS)
     CHECKS[name]()
 
 

@@ -1,12 +1,13 @@
 #!/bin/bash
-# Round-end evidence in ONE gpurun call: the three bench lines (with cpu_baseline), the in-step per-shape GEMM table, a kernel trace of
+# Round-end evidence in ONE gpurun call: the three bench lines (with cpu_baseline) + the headline through the HF loop, the in-step per-shape GEMM table, a kernel trace of
 # the headline step and the PMC passes (separate runs, --kernel-trace only beside --pmc).  Everything lands in gpurun_out/ev_*; copy what
 # is worth keeping into profiles/ (names per round).  Optional: SUITE=1 runs the GPU test suite first (~7.5 min).
 #   gpurun --timeout 2400 -- 'bash tools/gpu_call.sh'
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"; R=$PWD; O=gpurun_out; mkdir -p $O; export TMPDIR=/tmp
 python -m mantis_amd.build >/dev/null 2>&1
-if [ "${SUITE:-0}" = 1 ]; then timeout 1500 python -m pytest tests -m gpu -x -q > $O/ev_pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -1 $O/ev_pytest_gpu.log; fi
+if [ "${SUITE:-0}" = 1 ]; then MANTIS_CHECK_REPORT_DIR=$R/$O timeout 1800 python -m pytest tests -m gpu -x -q > $O/ev_pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -1 $O/ev_pytest_gpu.log; fi
 timeout 600 python bench.py --gemm-table $O/ev_gemm_in_step.md > $O/ev_bench_headline.json 2>$O/ev_bench_headline.err; tail -c 400 $O/ev_bench_headline.json; echo
+timeout 600 python bench.py --loop hf --steps 8 --warmup 3 --no-cpu-baseline > $O/ev_bench_hf_loop.json 2>$O/ev_bench_hf_loop.err      # the same workload through transformers.Trainer.train()
 timeout 600 python bench.py --config mantis_8b_idefics2 > $O/ev_bench_idefics2.json 2>$O/ev_bench_idefics2.err
 timeout 600 python bench.py --config qwen2_vl_7b --precision fp8 > $O/ev_bench_qwen2vl_fp8.json 2>$O/ev_bench_qwen2vl_fp8.err
 cd /tmp
@@ -21,10 +22,10 @@ python tools/pmc_kernel.py $O/pmc_sq gemm > $O/ev_pmc_gemm.txt 2>&1; python tool
 rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_sq
 python - <<'PY'
 import json
-for n in ("headline", "idefics2", "qwen2vl_fp8"):
+for n in ("headline", "hf_loop", "idefics2", "qwen2vl_fp8"):
     try:
-        d = [json.loads(l) for l in open(f"gpurun_out/ev_bench_{n}.json") if l.startswith("{")][-1]
-        print(n, d["ms_per_step"], d["value"], d["roofline"]["frac"], d.get("cpu_baseline", {}).get("value"))
+        d = [json.loads(l) for l in open(f"gpurun_out/ev_bench_{n}.json") if l.startswith('{"')][-1]
+        print(n, d["ms_per_step"], d["ms_training_step"], d["value"], d["roofline"]["frac"], (d.get("cpu_baseline") or {}).get("value"), d.get("native_loop"))
     except Exception as e:
         print(n, "FAILED", e)
 PY

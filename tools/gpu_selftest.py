@@ -13,6 +13,7 @@ sys.path.insert(0, ROOT)
 def main():
     import torch
     from tests import gpu_checks
+    from tests import helpers as Hh
     only = sys.argv[1:]
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     res = {}
@@ -21,6 +22,7 @@ def main():
         if only and not any(o in name for o in only):
             continue
         t0 = time.time()
+        Hh.CURRENT_CASE = name
         try:
             v = fn()
             torch.cuda.synchronize()
@@ -37,6 +39,8 @@ def main():
                 break
         with open(os.path.join(ROOT, "gpurun_out", "selftest.json"), "w") as f:
             json.dump(res, f, indent=1)
+    if Hh.GRAD_REPORTS:
+        Hh.write_grad_parity(os.path.join(ROOT, "gpurun_out", "grad_parity.md"))
     nfail = sum(1 for r in res.values() if not r["ok"])
     print(f"{len(res) - nfail}/{len(res)} passed", flush=True)
     return 1 if nfail else 0
