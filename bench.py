@@ -19,7 +19,7 @@ Prints ONE JSON line (rank 0) with the driver's fields plus
   roofline      dominant kernel (the bf16 MFMA GEMM family on the compute stream): algorithmic FLOPs / HIP-event time per launch,
                 live in the timed steps (`--gemm-table PATH` writes the per-shape table behind it); `traffic` and `mfma_busy_pct` need
                 PMC passes this run does not make and are null -- what the builder's own rocprofv3 passes of this command measured
-                (profiles/r04_pmc_step.json, tools/pmc_step_report.py) is carried under `pmc_static`
+                (profiles/r05_pmc_step.json, tools/pmc_step_report.py) is carried under `pmc_static`
   cpu_baseline  the oracle's CPU restatement of the same training_step ("port"), timed on this host's cores on a bounded
                 sample (1 sample, 1 ViT + {1,2} LLM layers + lm_head) and extrapolated linearly in depth; fp32 is `value`,
                 the bf16 leg is reported beside it
@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 FLOP_PER_SAMPLE = 1.351e14      # SURVEY.md section 8d (ViT fwd x1, projector + LLM fwd+bwd x3, causal attention at 1/2)
 PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_FP8_TFLOPS = 5000.0        # MI355X dense fp8 MFMA (MX-scaled K = 64 / 128 forms; MI355X_MICROARCH.md)
-PMC_JSON = os.path.join(ROOT, "profiles", "r04_pmc_step.json")   # tools/pmc_step_report.py output (offline PMC passes, tracked)
+PMC_JSON = os.path.join(ROOT, "profiles", "r05_pmc_step.json")   # tools/pmc_step_report.py output (offline PMC passes, tracked)
 PMC_JSON_QWEN_FP8 = os.path.join(ROOT, "profiles", "r02_pmc_qwen2vl_fp8.json")   # same, for `--config qwen2_vl_7b --precision fp8`
 
 
@@ -782,7 +782,7 @@ def main():
                             source=os.path.relpath(pmc_path, os.path.dirname(os.path.abspath(__file__))),
                             note="NOT measured by this run: rocprofv3 PMC passes of this command on the builder's box, summarised by "
                                  "tools/pmc_step_report.py; bytes/launch on the L2 memory side (Infinity-Cache hits included)",
-                            traffic_bytes_per_launch=gf.get("traffic_bytes_per_launch"),
+                            traffic_bytes_per_launch=gf.get("traffic_bytes_per_launch_incl_finish") or gf.get("traffic_bytes_per_launch"),
                             mfma_busy_pct=((pmc or {}).get("step") or {}).get("mfma_busy_pct")),
                         prefetch_stream_gemms=None if not side_gemms else dict(
                             note="GEMM launches of the next batch's frozen tower on the lowest-priority prefetch stream (--vision-prefetch "

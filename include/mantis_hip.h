@@ -163,6 +163,12 @@ int mantis_gemm_bf16_nt_sumsq(const void* A, int64_t lda, const void* B, int64_t
 int mantis_gemm_pick_variant(int M, int N, int K);
 /* the same for a launch planned for `cus` compute units (cus <= 0: the default budget) */
 int mantis_gemm_pick_variant_cus(int M, int N, int K, int cus);
+/* The remainder-round plan of a ring16 launch of C[M,N] over K planned for `cus` compute units (<= 0: default), for tests and tools (no device
+ * work).  out[0..7] = {tiles, full tiles, remainder tiles, S of the equal split (1 = none), balanced units (0 = equal split), tail slots,
+ * remainder workgroups, K-steps}; then 4 ints per remainder workgroup in grid order, while they fit `cap`: {remainder tile (-1 = empty tail
+ * slot), first K-step, end K-step, slab}.  Returns the number of ints of the full description (tests/test_gemm_remainder_plan.py checks
+ * that every K-step of every remainder tile is covered exactly once, slabs are unique and tails sit on their range's XCD). */
+int mantis_gemm_remainder_plan(int M, int N, int K, int cus, int32_t* out, int cap);
 
 /* ---- fp8 linears (BASELINE configs[4] "fp8 MFMA"): an accelerated variant of the bf16 nn.Linear of the Qwen2
  * decoder (HF:models/qwen2_vl/modeling_qwen2_vl.py:453-466,501-504); the reference has no fp8, tolerance is stated against its bf16 /

@@ -1946,6 +1946,60 @@ int mantis_gemm_pick_variant(int M, int N, int K) { return gemm_pick_variant(M, 
 // the same for a launch planned for `cus` compute units (bits 16-27 of its flags); cus <= 0: the default budget
 int mantis_gemm_pick_variant_cus(int M, int N, int K, int cus) { return gemm_pick_variant(M, N, K, cus > 0 ? cus : 0); }
 
+// The remainder-round plan of a ring16 launch of C[M,N] over K planned for `cus` compute units (<= 0: the default budget), as the launcher and
+// the kernels compute it -- for tests and tools, no device work.  out[0..7] = {tiles, full, remainder tiles, S (equal split; 1 = no split),
+// balanced units (0 = equal split), tail slots, remainder workgroups in the grid, K-steps}; then, while they fit `cap` ints, one record of 4
+// ints per remainder workgroup in grid order: {remainder tile (-1: an empty tail slot), first K-step, end K-step, slab}.  Returns the number of
+// ints the full description has.  (The records restate the kernel's own arithmetic, gemm_nt_ring16_kernel: the same sk_bound.)
+int mantis_gemm_remainder_plan(int M, int N, int K, int cus_req, int* out, int cap) {
+    if (M <= 0 || N <= 0 || K <= 0 || !out || cap < 8) return MANTIS_EINVAL;
+    const int tiles_m = cdiv(M, 256), tiles_n = cdiv(N, 256), nk = cdiv(K, BK);
+    const long ntiles = (long)tiles_m * tiles_n;
+    const int cus = plan_cus(cus_req > 0 ? cus_req : 0);
+    const int rem = (int)(ntiles % cus);
+    const int S = ring_split(ntiles, nk, cus);
+    const int full = S > 1 ? (int)(ntiles - rem) : (int)ntiles;
+    SkPlan plan;
+    plan.units = 0;
+    plan.nspan = 0;
+    if (S > 1 && sk_finish_enabled()) sk_make_plan(plan, rem, S, nk, cus);
+    const int nwg = S > 1 ? (plan.units ? plan.units + plan.nspan : S * rem) : 0;
+    const int head[8] = {(int)ntiles, full, S > 1 ? rem : 0, S, plan.units, plan.nspan, nwg, nk};
+    for (int i = 0; i < 8; ++i) out[i] = head[i];
+    int n = 8;
+    for (int j = 0; j < nwg; ++j, n += 4) {
+        int rec[4];
+        if (plan.units == 0) {
+            const int nu = nwg, q = nu >> 3, r = nu & 7, xcd = j & 7;
+            const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (j >> 3);
+            const int part = lin / rem, tl = lin - part * rem;
+            rec[0] = tl;
+            rec[1] = (int)((unsigned)nk * (unsigned)part / (unsigned)S);
+            rec[2] = (int)((unsigned)nk * (unsigned)(part + 1) / (unsigned)S);
+            rec[3] = tl * S + part;
+        } else {
+            const int U = plan.units, T = rem * nk;
+            const bool first = j < U;
+            const int c = first ? j : (int)plan.span[j - U];
+            if (c == (int)SK_EMPTY) {
+                rec[0] = -1; rec[1] = rec[2] = rec[3] = 0;
+            } else {
+                const int a0 = sk_bound(c, U, T, nk), a1 = sk_bound(c + 1, U, T, nk);
+                int tl = a0 / nk;
+                if (first) {
+                    const int e = (tl + 1) * nk;
+                    rec[0] = tl; rec[1] = a0 - tl * nk; rec[2] = (a1 < e ? a1 : e) - tl * nk; rec[3] = c;
+                } else {
+                    tl += 1;
+                    rec[0] = tl; rec[1] = 0; rec[2] = a1 - tl * nk; rec[3] = U + tl - 1;
+                }
+            }
+        }
+        if (n + 4 <= cap) for (int i = 0; i < 4; ++i) out[n + i] = rec[i];
+    }
+    return n;
+}
+
 // C[M,N] (bf16, row stride ldc) = epilogue(A[M,K] . B[N,K]^T); A,B,C 16-B aligned, lda/ldb % 8 == 0, K % 8 == 0.
 // flags: bit0 bias[n] add | bits1-3 activation (1 gelu-erf, 2 gelu-tanh, 3 quick-gelu) | bit4 + residual[m,n] (stride ldr)
 //        | bit5 accumulate into C (C += result, used for gradient accumulation) | bits8-11 tile variant (0 = auto)

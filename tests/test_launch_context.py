@@ -1,0 +1,87 @@
+"""CPU: `mantis_amd.launch` -- the per-caller launch options that replaced the process-wide switches of round 4 (hip_ops.KERNEL_TIMER,
+hip_ops.DW_SUMSQ, mantis_gemm_cu_budget).  Two trainers / models in one process must not see each other's options."""
+import threading
+
+import pytest
+import torch
+
+from tests import helpers as Hh
+
+
+def test_context_is_scoped_nested_and_restored_on_exceptions():
+    from mantis_amd.launch import LaunchContext, current, launch_context
+    base = current()
+    assert base.timer is None and base.dw_sumsq is None and base.gemm_cus == 0
+    a, b = LaunchContext(timer=[], gemm_cus=200), LaunchContext(gemm_cus=97)
+    with launch_context(a):
+        assert current() is a
+        with launch_context(b):
+            assert current() is b
+        assert current() is a
+        with launch_context(None):                 # None leaves the caller's context in force
+            assert current() is a
+        with pytest.raises(RuntimeError):
+            with launch_context(b):
+                raise RuntimeError("step failed")
+        assert current() is a
+    assert current() is base
+
+
+def test_context_is_per_thread():
+    from mantis_amd.launch import LaunchContext, current, launch_context
+    seen = {}
+
+    def worker():
+        seen["inside"] = current().gemm_cus
+    with launch_context(LaunchContext(gemm_cus=123)):
+        t = threading.Thread(target=worker)
+        t.start()
+        t.join()
+        assert current().gemm_cus == 123
+    assert seen["inside"] == 0
+
+
+def test_two_trainers_keep_their_own_options(monkeypatch):
+    """Each MantisHipTrainer owns a LaunchContext; the engine installs it for exactly one call.  With the oracle operators in place of the HIP
+    backend, a spy on one operator records the context it runs under: trainer A's timer / CU budget never shows up in trainer B's step."""
+    import mantis_amd.engine as eng
+    from oracle import ops_ref
+    from mantis_amd.launch import current
+    from mantis_amd.trainer import MantisHipTrainer
+    monkeypatch.setattr(eng, "K", ops_ref)
+    z = Hh.load_case("siglip_training_step_ga1")
+    batch = dict(input_ids=torch.from_numpy(z["mb0.input_ids"]), attention_mask=torch.from_numpy(z["mb0.attention_mask"]),
+                 labels=torch.from_numpy(z["mb0.labels"]), pixel_values=Hh.pixels_list(z, "mb0."))
+    seen = []
+    real = ops_ref.rmsnorm_fwd
+
+    def spy(*a, **k):
+        seen.append(current())
+        return real(*a, **k)
+    monkeypatch.setattr(ops_ref, "rmsnorm_fwd", spy)
+    m1, _, _ = Hh.build_product_model("siglip", "cpu")
+    m2, _, _ = Hh.build_product_model("siglip", "cpu")
+
+    class Red:                                   # an inactive reducer (world size 1) that carries a CU budget
+        active, gemm_cus = False, 200
+
+        def begin(self):
+            pass
+
+        def bucket_ready(self, key):
+            return ()
+
+        def finish(self):
+            pass
+    t1, t2 = MantisHipTrainer(m1, 1, reducer=Red()), MantisHipTrainer(m2, 1)
+    t1.launch.timer = []
+    assert t1.launch.gemm_cus == 200 and t2.launch.gemm_cus == 0
+    t1.training_step(m1, batch)
+    n1 = len(seen)
+    t2.training_step(m2, batch)
+    assert n1 > 0 and all(c is t1.launch for c in seen[:n1]) and all(c is t2.launch for c in seen[n1:])
+    assert current() is not t1.launch and current() is not t2.launch and current().timer is None
+    # a direct engine call (model(**batch), tests) runs without any caller context
+    seen.clear()
+    m1.engine.step_from_batch(batch, compute_grads=False)
+    assert seen and all(c.timer is None and c.gemm_cus == 0 for c in seen)

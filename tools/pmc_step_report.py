@@ -26,6 +26,7 @@ import re
 from collections import defaultdict
 
 GEMM_FAMILY = ("gemm_nt_ring_kernel", "gemm_nt_ring16_kernel", "gemm_nt_kernel")
+GEMM_FINISH = ("gemm_ring16_finish_kernel",)       # round 5: K-split finishing pass -- its bytes belong to the family, its launches do not count
 ATTN_FAMILY = ("attn_fwd_kernel", "attn_fwd64_kernel", "attn_bwd")
 
 
@@ -90,6 +91,13 @@ def main():
         if n and n2:
             out[fam] = dict(launches=int(n), fetch_bytes_per_launch=fb * 2048 / n, write_bytes_per_launch=wb * 1024 / n2,
                             traffic_bytes_per_launch=fb * 2048 / n + wb * 1024 / n2)
+            if fam == "gemm_family":
+                _, ffb = family(f, GEMM_FINISH, "FETCH_SIZE")
+                _, fwb = family(w, GEMM_FINISH, "WRITE_SIZE")
+                fin = ffb * 2048 / n + fwb * 1024 / n2
+                out[fam].update(finish_kernel_bytes_per_launch=fin, traffic_bytes_per_launch_incl_finish=out[fam]["traffic_bytes_per_launch"] + fin,
+                                note="launches = GEMM kernel launches; the K-split finishing kernels' traffic (slab reads + the remainder tiles' epilogue) "
+                                     "is carried separately and added in traffic_bytes_per_launch_incl_finish")
     ad = [k for k in f if k.startswith("adamw_kernel")]
     if ad:
         out["calibration"] = dict(kernel=ad[0], fetch_bytes_per_launch=out["per_kernel"][ad[0]]["fetch_bytes_per_launch"],
