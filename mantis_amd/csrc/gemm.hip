@@ -1014,7 +1014,7 @@ __device__ __forceinline__ void sk_store16(const f32x4 (&acc)[NBN][NBM], float* 
 #pragma unroll
     for (int i = 0; i < NBN; ++i)
 #pragma unroll
-        for (int j = 0; j < NBM; ++j) reinterpret_cast<f32x4*>(slab)[(i * NBM + j) * NT + tid] = acc[i][j];
+        for (int j = 0; j < NBM; ++j) reinterpret_cast<f32x4*>(slab)[(i * NBM + j) * NT + tid] = acc[i][j];      // (nt stores: measured equal, round 5)
 }
 // acc += slab, eight 16-B loads in flight per lane.  The accumulators live in AGPRs and the compiler's scheduler, minimising register
 // pressure, turned `acc += slab[...]` into load -> s_waitcnt vmcnt(0) -> add, one memory round trip per 16 bytes: 32 - 64 round trips per
@@ -1375,11 +1375,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring16_kernel(
     const int pair_dist = PAIR == PAIR_SWIGLU ? (N >> 1) : 64;
     auto pair_first = [&](int phi) { return PAIR == PAIR_SWIGLU ? (n0 >> 1) + phi : n0 + (phi >> 6) * 128 + (phi & 63); };
 
-    f32x4 acc[NBN][NBM];       // acc[tn][tm]: block (n block tn, m block tm)
-#pragma unroll
-    for (int i = 0; i < NBN; ++i)
-#pragma unroll
-        for (int j = 0; j < NBM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[NBN][NBM];       // acc[tn][tm]: block (n block tn, m block tm); zeroed BEHIND the prologue's DMA issue (below)
 
     // DMA pieces: slab (t, p) = 16 pieces of 1 KiB, pieces PPW*w .. PPW*w + PPW - 1 belong to wave w (descriptor + fixed lane offset +
     // scalar K-step offset)
@@ -1478,6 +1474,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring16_kernel(
     }
 
     STAMP(1);
+#ifndef RING16_ZERO_FIRST
+    // the accumulators are cleared while the first K-steps are in flight (128 / 256 v_accvgpr_write: in front of the DMA issue they delayed the
+    // first byte by as many issue slots; -DRING16_ZERO_FIRST: the round-4 order, for A/B builds)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+    for (int i = 0; i < NBN; ++i)
+#pragma unroll
+        for (int j = 0; j < NBM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // fragment addresses.  Row-major image: lane (r, kg) reads 16 B of row blk*16 + r at chunk kh*4 + kg, swizzled with (r >> 1) & 7
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const unsigned r16 = (unsigned)lane & 15u, kg = (unsigned)lane >> 4;
