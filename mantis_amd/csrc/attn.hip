@@ -1071,19 +1071,38 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_g4_kernel(
             // softmax backward of ONE element r (in place) with the lse / dsum words of its tile
             auto sm_elem = [&](auto rc, f32x16& sx, f32x16& dx, const f32x4 (&lse4)[4], const f32x4 (&dsm4)[4]) {
                 constexpr int r = decltype(rc)::value;
-                float l = lse4[r >> 2][r & 3];
-                asm volatile("" : "+v"(l));            // pins the element's arithmetic behind the slot's (volatile asm) MFMA
-                float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sx[r], c, -l));
-                float ds = p * (dx[r] - dsm4[r >> 2][r & 3]);
-                asm volatile("" : "+v"(p), "+v"(ds));  // ... and in front of the next one (IR sinking would move it to its user's block)
-                sx[r] = p;
-                dx[r] = ds;
+                if constexpr (kDkvAsmElems) {
+                    // the element's four instructions as ONE statement: placed where the slot puts them (a volatile asm neither sinks to its
+                    // user's block nor moves across the slot's MFMA), and without the two empty pinning statements of the C++ form, each of
+                    // which the hazard recognizer pads with an s_nop (33 - 44 s_nop per 32-MFMA step, profiles/r05_attn_anatomy.md).  Same
+                    // arithmetic: p = exp2(s * c - lse), dS = p * (dP - D); the v_sub between v_exp and its use covers the trans-use hazard
+                    float p, ds;
+                    asm volatile("v_fma_f32 %0, %2, %3, -%4\n\tv_exp_f32 %0, %0\n\tv_sub_f32 %1, %5, %6\n\tv_mul_f32 %1, %1, %0"
+                                 : "=&v"(p), "=&v"(ds)
+                                 : "v"(sx[r]), "v"(c), "v"(lse4[r >> 2][r & 3]), "v"(dx[r]), "v"(dsm4[r >> 2][r & 3]));
+                    sx[r] = p;
+                    dx[r] = ds;
+                } else {
+                    float l = lse4[r >> 2][r & 3];
+                    asm volatile("" : "+v"(l));            // pins the element's arithmetic behind the slot's (volatile asm) MFMA
+                    float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sx[r], c, -l));
+                    float ds = p * (dx[r] - dsm4[r >> 2][r & 3]);
+                    asm volatile("" : "+v"(p), "+v"(ds));  // ... and in front of the next one (IR sinking would move it to its user's block)
+                    sx[r] = p;
+                    dx[r] = ds;
+                }
             };
             auto pack_pinned = [&](float a, float b2) -> unsigned {
-                asm volatile("" : "+v"(a));
-                unsigned u = pack_bf2(a, b2);
-                asm volatile("" : "+v"(u));
-                return u;
+                if constexpr (kDkvAsmElems) {
+                    unsigned u;
+                    asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u) : "v"(a), "v"(b2));      // == pack_bf2 (round to nearest even), pinned
+                    return u;
+                } else {
+                    asm volatile("" : "+v"(a));
+                    unsigned u = pack_bf2(a, b2);
+                    asm volatile("" : "+v"(u));
+                    return u;
+                }
             };
             auto load_words = [&](int slot, f32x4 (&lse4)[4], f32x4 (&dsm4)[4]) {
                 const float* sLse = reinterpret_cast<const float*>(smem + slot * STAGE + hp * STREAM + 2 * TILE) + 4 * hh;

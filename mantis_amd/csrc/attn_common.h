@@ -129,6 +129,10 @@ constexpr bool kDkvTrAsm = ATTN_DKV_TR_ASM != 0 || kDkvMerged;
 #define ATTN_DKV_DMA_IN_SLOTS 1
 #endif
 constexpr bool kDkvDmaInSlots = ATTN_DKV_DMA_IN_SLOTS != 0 && kDkvMerged;      // the merged step issues its DMA pieces one per MFMA slot
+#ifndef ATTN_DKV_ASM_ELEMS
+#define ATTN_DKV_ASM_ELEMS 1
+#endif
+constexpr bool kDkvAsmElems = ATTN_DKV_ASM_ELEMS != 0;      // softmax-backward elements and packs of the pipelined dK/dV step as single asm statements
 
 __device__ __forceinline__ unsigned lds_addr_of(const char* p) {
     return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
