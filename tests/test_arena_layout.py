@@ -113,3 +113,38 @@ def test_optimizer_segments_cover_every_trainable_parameter_once(model):
     for n in opt._names:
         ref[model._grad_offs[n]: model._grad_offs[n] + model._param(n).numel()] = model._param(n).detach().float().reshape(-1)
     assert torch.equal(opt.master.cpu(), ref)
+
+
+def test_arena_alignment_variable_is_validated(monkeypatch):
+    """MANTIS_ARENA_ALIGN (round-4 advisor finding): 0 used to end in a ZeroDivisionError in _place(), a value that is not a multiple of 8
+    broke the 16-byte alignment the GEMM / AdamW / sum-of-squares kernels assume."""
+    import pytest
+    from mantis_amd import arena
+    for bad in ("0", "4", "12", "-8", "lots"):
+        monkeypatch.setenv("MANTIS_ARENA_ALIGN", bad)
+        with pytest.raises(ValueError):
+            arena._arena_align()
+    for good, want in (("8", 8), ("128", 128), ("256", 256)):
+        monkeypatch.setenv("MANTIS_ARENA_ALIGN", good)
+        assert arena._arena_align() == want
+    monkeypatch.delenv("MANTIS_ARENA_ALIGN")
+    assert arena._arena_align() == 128
+
+
+def test_optimizer_state_records_the_alignment_it_was_laid_out_with(monkeypatch):
+    """A FusedAdamW checkpoint belongs to the arena layout it was written under: the alignment is part of the state and a mismatch is
+    reported as such (it used to surface as a tensor-shape mismatch)."""
+    import pytest
+    import mantis_amd.engine as eng
+    import mantis_amd.optim as opt
+    from oracle import ops_ref
+    from tests import helpers as Hh
+    monkeypatch.setattr(eng, "K", ops_ref)
+    monkeypatch.setattr(opt, "K", ops_ref)
+    model, _, _ = Hh.build_product_model("siglip", "cpu")
+    o = opt.FusedAdamW(model, lr=1e-3)
+    sd = o.state_dict()
+    assert sd["arena_align"] == opt.ARENA_ALIGN
+    o.load_state_dict(sd)                                       # round trip
+    with pytest.raises(ValueError, match="aligned to 8 elements"):
+        o.load_state_dict(dict(sd, arena_align=8))
