@@ -258,6 +258,19 @@ int mantis_navit_prepare(const float* pixels, const uint8_t* pixel_mask, int n_i
 int mantis_adamw(void* param_bf16, const void* grad_bf16, float* master, float* exp_avg, float* exp_avg_sq, int64_t n,
                  float lr, float beta1, float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2,
                  const float* grad_scale_dev /*nullable: multiply grads by *grad_scale_dev (clip)*/, void* stream);
+/* The same step with the fp32 master stored SPLIT: its round-to-nearest-even upper half is the bf16 parameter itself (param_bf16, read AND
+ * written), master_lo (uint16 [n]) holds its low 16 bits, and the sign bit of exp_avg_sq (a value that is never negative) records the one case
+ * those 32 bits leave open -- an exact tie that rounded UP to the even neighbour.  26 instead of 28 bytes of HBM traffic and 2 instead of 4
+ * bytes of state per parameter; bit-identical to mantis_adamw on the joined master (DeepSpeed's fp32 master weights,
+ * HF:trainer.py:1785-1796).  exp_avg_sq as stored: |x| is Adam's second moment. */
+int mantis_adamw_split(void* param_bf16, const void* grad_bf16, void* master_lo, float* exp_avg, float* exp_avg_sq, int64_t n,
+                       float lr, float beta1, float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2,
+                       const float* grad_scale_dev, void* stream);
+/* master_out[i] = the fp32 master of element i, from (param_bf16, master_lo, sign of exp_avg_sq): checkpoints, tests */
+int mantis_master_join(const void* param_bf16, const void* master_lo, const float* exp_avg_sq, float* master_out, int64_t n, void* stream);
+/* the inverse (resume from a checkpoint that holds fp32 masters): param_bf16 = bf16(master), master_lo = its low half, tie bit -> sign of
+ * exp_avg_sq (its magnitude is kept) */
+int mantis_master_split(const float* master, void* param_bf16, void* master_lo, float* exp_avg_sq, int64_t n, void* stream);
 /* out[0] (+)= sum of x[0 .. n): one workgroup, fixed summation order (the tile partials of mantis_gemm_bf16_nt_sumsq) */
 int mantis_sum_f32(const float* x, int64_t n, float* out, int accumulate, void* stream);
 /* partials[r] = sum of squares of the bf16 elements x[off_len[2r] .. off_len[2r] + off_len[2r+1]) for r < n_ranges (device array of

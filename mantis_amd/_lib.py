@@ -63,6 +63,9 @@ SIGNATURES = {
     "mantis_drop_cls": [P, P, I, I, I, P],
     "mantis_navit_prepare": [P, P, I, I, I, I, I, I, P, I, P, P, P, P, P],
     "mantis_adamw": [P, P, P, P, P, L, F, F, F, F, F, F, F, P, P],
+    "mantis_adamw_split": [P, P, P, P, P, L, F, F, F, F, F, F, F, P, P],
+    "mantis_master_join": [P, P, P, P, L, P],
+    "mantis_master_split": [P, P, P, P, L, P],
     "mantis_sum_f32": [P, L, P, I, P],
     "mantis_sumsq_ranges": [P, P, I, P, P],
     "mantis_sumsq_partials": [L],

@@ -706,6 +706,28 @@ def adamw_flat(param, grad, master, m, v, lr, beta1, beta2, eps, wd, step, grad_
     _lib.check(rc, "adamw")
 
 
+def adamw_split_flat(param, grad, master_lo, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=None):
+    """AdamW with the fp32 master stored as (bf16 parameter, low 16 bits `master_lo` int16, tie bit in the sign of `v`): 26 B / parameter."""
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    rc = _L.mantis_adamw_split(_p(param), _p(grad), _p(master_lo), _p(m), _p(v), param.numel(), lr, beta1, beta2, eps, wd, bc1, bc2,
+                               _p(grad_scale), _stream())
+    _lib.check(rc, "adamw_split")
+
+
+def master_join(param, master_lo, v, out=None):
+    """fp32 masters of a split-master range (a new tensor unless `out`)."""
+    if out is None:
+        out = torch.empty(param.numel(), dtype=torch.float32, device=param.device)
+    _lib.check(_L.mantis_master_join(_p(param), _p(master_lo), _p(v), _p(out), param.numel(), _stream()), "master_join")
+    return out
+
+
+def master_split(master, param, master_lo, v):
+    """param <- bf16(master), master_lo <- its low 16 bits, the tie bit into the sign of v (|v| kept)."""
+    _lib.check(_L.mantis_master_split(_p(master), _p(param), _p(master_lo), _p(v), master.numel(), _stream()), "master_split")
+
+
 def grad_sumsq(x, out, accumulate=False, ws=None):
     if ws is None:
         ws = torch.empty((_L.mantis_sumsq_partials(x.numel()),), dtype=torch.float32, device=x.device)

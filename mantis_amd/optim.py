@@ -10,17 +10,24 @@ over the whole trainable arena; the clip coefficient stays on the device (no hos
 `FusedAdamW` IS a `torch.optim.Optimizer` (round 4), so the reference's own loop can drive it:
   * one `param_group` over the trainable parameters whose `lr` (and betas / eps / weight_decay) is read on EVERY step -- an HF / torch LR
     scheduler (`get_cosine_schedule_with_warmup`, `LambdaLR`) steers it like any optimizer;
-  * `state_dict()` / `load_state_dict()` carry the step count and the flat fp32 master / exp_avg / exp_avg_sq arenas (the 97 GB of a
-    Mantis-8B run) plus the layout they belong to: `Trainer._save_optimizer_and_scheduler` / `_load_optimizer_and_scheduler`
+  * `state_dict()` / `load_state_dict()` carry the step count and the flat fp32 master (as its two halves, below) / exp_avg / exp_avg_sq
+    arenas (the 96 GB of a Mantis-8B run) plus the layout they belong to: `Trainer._save_optimizer_and_scheduler` / `_load_optimizer_and_scheduler`
     (torch.save / torch.load(weights_only=True)) work unchanged;
   * `clip_grad_norm(max_norm)` is the fused `clip_grad_norm_`: norm and clip coefficient on the device, applied inside the next `step()`;
-    `trainer.as_hf_trainer()` builds this optimizer in `create_optimizer` and routes the loop's clipping call here."""
+    `trainer.as_hf_trainer()` builds this optimizer in `create_optimizer` and routes the loop's clipping call here.
+
+The fp32 master weights are stored SPLIT (round 5): the upper half of a master, rounded to nearest even, IS the bf16 parameter in the model's
+arena (the GEMM operand that exists anyway); `master_lo` holds the low 16 bits, and the sign bit of `exp_avg_sq` (never negative) the one
+case those 32 bits leave open (an exact tie that rounded up).  The step then moves 26 instead of 28 bytes per parameter and the optimizer
+state shrinks by 2 bytes per parameter (16 GB for Mantis-8B), on the bit-identical fp32 trajectory (csrc/optim.hip: adamw_split_kernel;
+GPU check `adamw_split_bitwise`).  `opt.master` joins the halves on demand."""
 import torch
 
 from . import hip_ops as K
 from .arena import ARENA_ALIGN
 
-STATE_FORMAT = "mantis_fused_adamw/2"       # /2: arenas with 256-byte aligned parameters (round 4)
+STATE_FORMAT = "mantis_fused_adamw/3"       # /3: fp32 master split into master_hi (bf16) + master_lo (int16) + the sign of exp_avg_sq
+FP32_MASTER_FORMAT = "mantis_fused_adamw/2"  # /2 (round 4): one flat fp32 `master`; still loadable
 
 
 class FusedAdamW(torch.optim.Optimizer):
@@ -46,7 +53,7 @@ class FusedAdamW(torch.optim.Optimizer):
                          dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         n = model.grad_arena.numel()
         dev = model.device
-        self.master = torch.zeros(n, dtype=torch.float32, device=dev)      # zeros: alignment pads between segments are never written
+        self.master_lo = torch.zeros(n, dtype=torch.int16, device=dev)     # zeros: alignment pads between segments are never written
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.resync_master()
@@ -85,14 +92,29 @@ class FusedAdamW(torch.optim.Optimizer):
         return segs
 
     def resync_master(self):
-        """Re-snapshot the fp32 master weights from the bf16 parameter arena.  Needed whenever parameter values are replaced
-        behind the optimizer's back (`load_reference_state_dict`, `reset_parameters`): `step()` writes bf16(master) over
-        the parameters, so a stale master would silently undo the load.  `step()` calls this itself when the model's
-        `_param_version` moved; Adam moments are kept."""
+        """Make the fp32 master weights equal to the bf16 parameters (low halves and tie bits cleared).  Needed whenever parameter values
+        are replaced behind the optimizer's back (`load_reference_state_dict`, `reset_parameters`): the low half of the OLD master under a
+        NEW parameter would be noise.  `step()` calls this itself when the model's `_param_version` moved; Adam moments are kept."""
         m = self.model
         for p_off, g_off, cnt, _ in self._segments:
-            self.master[g_off:g_off + cnt].copy_(m.arena[p_off:p_off + cnt])
+            self.master_lo[g_off:g_off + cnt].zero_()
+            self.exp_avg_sq[g_off:g_off + cnt].abs_()
         self._seen_version = getattr(m, "_param_version", 0)
+
+    @property
+    def master(self):
+        """The fp32 master weights in the gradient arena's layout (zeros in the alignment pads): a NEW tensor, joined from the bf16
+        parameters, `master_lo` and the tie bits (tests, exports; the step never materialises it)."""
+        m = self.model
+        out = torch.zeros(self.master_lo.numel(), dtype=torch.float32, device=self.master_lo.device)
+        for p_off, g_off, cnt, _ in self._segments:
+            K.master_join(m.arena[p_off:p_off + cnt], self.master_lo[g_off:g_off + cnt], self.exp_avg_sq[g_off:g_off + cnt],
+                          out=out[g_off:g_off + cnt])
+        return out
+
+    def second_moment(self):
+        """Adam's exp_avg_sq proper (|stored|: the stored array carries the masters' tie bits in its sign)."""
+        return self.exp_avg_sq.abs()
 
     # ---- checkpoint / resume (train_mllava.py:281-294 resumes from the newest checkpoint-*; HF saves optimizer.state_dict() with torch.save)
     def _layout(self):
@@ -100,22 +122,31 @@ class FusedAdamW(torch.optim.Optimizer):
         return [[n, int(m._param(n).numel())] for n in self._names]
 
     def state_dict(self):
-        """References (no copies) to the flat fp32 state + the step count + the hyper-parameters + the layout the arenas belong to."""
+        """The flat state (references, no copies, except `master_hi`) + the step count + the hyper-parameters + the layout the arenas
+        belong to.  master_hi: the bf16 parameters in the gradient arena's layout (a copy: the checkpoint is self-contained);
+        master_lo: the masters' low 16 bits; exp_avg_sq AS STORED: its sign bit is a master's tie bit, its magnitude Adam's second moment."""
         g = self.param_groups[0]
         group = {k: (list(v) if isinstance(v, tuple) else v) for k, v in g.items() if k != "params"}
         group["params"] = list(range(len(g["params"])))
+        m = self.model
+        hi = torch.zeros(self.master_lo.numel(), dtype=m.arena.dtype, device=self.master_lo.device)
+        for p_off, g_off, cnt, _ in self._segments:
+            hi[g_off:g_off + cnt].copy_(m.arena[p_off:p_off + cnt])
         return {"format": STATE_FORMAT, "step": int(self.step_count), "layout": self._layout(), "arena_align": ARENA_ALIGN,
-                "master": self.master, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "param_groups": [group]}
+                "master_hi": hi, "master_lo": self.master_lo, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
+                "param_groups": [group]}
 
     def load_state_dict(self, state_dict):
         """Resume: step count, fp32 master weights and Adam moments, hyper-parameters (as torch: the checkpoint's lr / betas / eps /
         weight_decay replace the constructor's; an LR scheduler restores its own state separately).  The masters of the checkpoint are
-        kept as they are -- NOT re-derived from the bf16 parameters, which hold only their rounding -- so a resumed run continues the
-        fp32 trajectory exactly; load the model weights BEFORE the optimizer state (the HF loop does), or call `resync_master()`."""
+        restored bit for bit -- including their upper halves, i.e. the trainable bf16 parameters are written too (= bf16(master), what the
+        model checkpoint of the same step holds) -- so a resumed run continues the fp32 trajectory exactly.  Load the model weights BEFORE
+        the optimizer state (the HF loop does).  Also accepts a round-4 state (`mantis_fused_adamw/2`, one fp32 `master` array)."""
         sd = state_dict
-        if sd.get("format") != STATE_FORMAT:
+        if sd.get("format") not in (STATE_FORMAT, FP32_MASTER_FORMAT):
             raise ValueError(f"not a FusedAdamW state (format {sd.get('format')!r}, expected {STATE_FORMAT!r}); a torch.optim.AdamW state "
                              "holds per-parameter tensors and cannot be mapped onto the flat arenas")
+        split = sd["format"] == STATE_FORMAT
         if int(sd.get("arena_align", 128)) != ARENA_ALIGN:
             raise ValueError(f"FusedAdamW.load_state_dict: the checkpoint's flat state was laid out with parameters aligned to "
                              f"{sd.get('arena_align', 128)} elements, this process places them on {ARENA_ALIGN}-element boundaries "
@@ -123,11 +154,22 @@ class FusedAdamW(torch.optim.Optimizer):
         if [list(x) for x in sd["layout"]] != self._layout():
             raise ValueError("FusedAdamW.load_state_dict: the checkpoint's parameter layout (names / sizes of the trainable parameters, in "
                              "arena order) differs from this model's")
-        for k in ("master", "exp_avg", "exp_avg_sq"):
-            src = sd[k]
-            if tuple(src.shape) != tuple(getattr(self, k).shape):
-                raise ValueError(f"FusedAdamW.load_state_dict: {k} has {tuple(src.shape)}, expected {tuple(getattr(self, k).shape)}")
-            getattr(self, k).copy_(src)
+        keys = ("master_hi", "master_lo", "exp_avg", "exp_avg_sq") if split else ("master", "exp_avg", "exp_avg_sq")
+        for k in keys:
+            if tuple(sd[k].shape) != tuple(self.exp_avg.shape):
+                raise ValueError(f"FusedAdamW.load_state_dict: {k} has {tuple(sd[k].shape)}, expected {tuple(self.exp_avg.shape)}")
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        m = self.model
+        if split:
+            self.master_lo.copy_(sd["master_lo"])
+            for p_off, g_off, cnt, _ in self._segments:      # the upper halves ARE the parameters
+                m.arena[p_off:p_off + cnt].copy_(sd["master_hi"][g_off:g_off + cnt])
+        else:                                                # a round-4 checkpoint: split its fp32 masters
+            self.exp_avg_sq.abs_()
+            for p_off, g_off, cnt, _ in self._segments:
+                src = sd["master"][g_off:g_off + cnt].to(device=self.exp_avg.device, dtype=torch.float32).contiguous()
+                K.master_split(src, m.arena[p_off:p_off + cnt], self.master_lo[g_off:g_off + cnt], self.exp_avg_sq[g_off:g_off + cnt])
         self.step_count = int(sd["step"])
         g = self.param_groups[0]
         for k, v in sd["param_groups"][0].items():
@@ -310,9 +352,9 @@ class FusedAdamW(torch.optim.Optimizer):
         g = self.param_groups[0]                            # read every step: an LR scheduler writes g["lr"]
         lr, (b1, b2), eps, wd = float(g["lr"]), g["betas"], float(g["eps"]), float(g["weight_decay"])
         for p_off, g_off, cnt, decays in self._segments:
-            K.adamw_flat(m.arena[p_off:p_off + cnt], m.grad_arena[g_off:g_off + cnt], self.master[g_off:g_off + cnt],
-                         self.exp_avg[g_off:g_off + cnt], self.exp_avg_sq[g_off:g_off + cnt], lr, float(b1), float(b2), eps,
-                         wd if decays else 0.0, self.step_count, grad_scale=scale)
+            K.adamw_split_flat(m.arena[p_off:p_off + cnt], m.grad_arena[g_off:g_off + cnt], self.master_lo[g_off:g_off + cnt],
+                               self.exp_avg[g_off:g_off + cnt], self.exp_avg_sq[g_off:g_off + cnt], lr, float(b1), float(b2), eps,
+                               wd if decays else 0.0, self.step_count, grad_scale=scale)
 
     def zero_grad(self, set_to_none=True):
         """model.zero_grad() of the HF loop: dropping the .grad views lets the next backward overwrite instead of accumulate.  A gradient

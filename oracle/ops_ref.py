@@ -583,6 +583,45 @@ def adamw_flat(param, grad, master, m, v, lr, beta1, beta2, eps, wd, step, grad_
     param.copy_(master.to(param.dtype))
 
 
+def _u16(x):
+    return x.view(torch.int16).to(torch.int32) & 0xFFFF
+
+
+def master_join(param, master_lo, v, out=None):
+    """fp32 master <- (bf16 parameter = its round-to-nearest-even upper half, low 16 bits, tie bit in the sign of v): the storage of
+    mantis_adamw_split (include/mantis_hip.h), restated with integer tensor arithmetic."""
+    p, lo = _u16(param), _u16(master_lo)
+    tie = v.view(torch.int32) < 0
+    up = (lo > 0x8000) | ((lo == 0x8000) & tie)
+    hi = (p - up.to(torch.int32)) & 0xFFFF
+    bits = (hi.to(torch.int64) << 16) | lo.to(torch.int64)
+    bits = torch.where(bits >= 2 ** 31, bits - 2 ** 32, bits).to(torch.int32)
+    res = bits.view(torch.float32)
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
+
+
+def master_split(master, param, master_lo, v):
+    bits = master.contiguous().view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    lo, hi = bits & 0xFFFF, bits >> 16
+    param.copy_(master.to(param.dtype))
+    lo16 = torch.where(lo >= 2 ** 15, lo - 2 ** 16, lo).to(torch.int16)
+    master_lo.copy_(lo16.view(master_lo.dtype) if master_lo.dtype != torch.int16 else lo16)
+    tie = (lo == 0x8000) & ((hi & 1) == 1)
+    vb = v.view(torch.int32)
+    vb.copy_(torch.where(tie, vb | -2 ** 31, vb & 0x7FFFFFFF))
+
+
+def adamw_split_flat(param, grad, master_lo, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=None):
+    """AdamW on the split master: join, the fp32 update of adamw_flat, split."""
+    master = master_join(param, master_lo, v).clone()
+    v.copy_(v.abs())
+    adamw_flat(param, grad, master, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=grad_scale)
+    master_split(master, param, master_lo, v)
+
+
 def grad_sumsq(x, out, accumulate=False, ws=None):
     s = _f(x).pow(2).sum()
     out[0] = out[0] + s if accumulate else s

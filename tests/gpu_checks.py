@@ -685,6 +685,61 @@ def check_optim():
     return r
 
 
+def check_adamw_split_bitwise():
+    """The split-master AdamW (26 B / parameter: bf16 parameter + low 16 bits + tie bit in the sign of exp_avg_sq, csrc/optim.hip) against
+    the fp32-master kernel on the same gradients, 6 steps with and without weight decay and clipping: parameters, both moments and the
+    joined masters BIT FOR BIT; ties (low half exactly 0x8000, both parities of the upper half) injected at the start and re-injected
+    through a gradient that lands masters on ties is not controllable -- so the join / split pair is also checked on its own over every
+    low-half pattern around the tie, against the oracle's integer restatement, incl. +-0, denormals, the largest finite value and inf."""
+    k = K()
+    n = 8 * 40000
+    gen = torch.Generator().manual_seed(11)
+    master = torch.randn(n, generator=gen) * 0.05
+    b = master.view(torch.int32)
+    b[:65536] = (b[:65536] & ~0xFFFF) | torch.arange(65536, dtype=torch.int32).roll(1234)      # every low half once
+    b[65536:65536 + 8192] = (b[65536:65536 + 8192] & ~0xFFFF) | 0x8000                      # ties, both parities
+    master[70000:70008] = torch.tensor([0.0, -0.0, 1e-42, -1e-42, 3.3895e38, -3.3895e38, float("inf"), 1.0])
+    # join / split alone
+    pd, lod, vd = torch.zeros(n, dtype=BF, device=DEV), torch.zeros(n, dtype=torch.int16, device=DEV), torch.rand(n, generator=gen).to(DEV)
+    v_mag = vd.clone()
+    k.master_split(master.to(DEV), pd, lod, vd)
+    pr, lor, vr = torch.zeros(n, dtype=BF), torch.zeros(n, dtype=torch.int16), v_mag.cpu().clone()
+    R.master_split(master, pr, lor, vr)
+    assert torch.equal(pd.cpu().view(torch.int16), pr.view(torch.int16)) and torch.equal(pd.cpu().view(torch.int16), master.to(BF).view(torch.int16))
+    assert torch.equal(lod.cpu(), lor) and torch.equal(vd.cpu().view(torch.int32), vr.view(torch.int32))
+    assert torch.equal(vd.abs(), v_mag)
+    assert int((vd.view(torch.int32) < 0).sum()) > 1000, "expected tie bits"
+    back = k.master_join(pd, lod, vd).cpu()
+    assert torch.equal(back.view(torch.int32), master.view(torch.int32)), "join(split(x)) != x"
+    assert torch.equal(R.master_join(pr, lor, vr).view(torch.int32), master.view(torch.int32))
+    # the step: fp32-master kernel vs split kernel
+    worst_ties = 0
+    for wd, clip in ((0.0, False), (0.01, True)):
+        m1, v1 = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        m2, v2 = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        mast = master.clone()
+        mast[70006] = 2.0                                   # no inf in the trajectory
+        mast = mast.to(DEV)
+        p1 = mast.to(BF)
+        p2, lo2 = torch.zeros(n, dtype=BF, device=DEV), torch.zeros(n, dtype=torch.int16, device=DEV)
+        k.master_split(mast, p2, lo2, v2)
+        assert torch.equal(p1.view(torch.int16), p2.view(torch.int16))
+        scale = torch.tensor([0.37], device=DEV) if clip else None
+        for step in range(1, 7):
+            g = (torch.randn(n, generator=gen) * (0.02 if step % 2 else 1e-4)).to(BF).to(DEV)
+            if step == 3:
+                g[:4096] = 0                              # zero gradients: the master moves by the momentum term only
+            k.adamw_flat(p1, g, mast, m1, v1, 1e-3, 0.9, 0.999, 1e-8, wd, step, grad_scale=scale)
+            k.adamw_split_flat(p2, g, lo2, m2, v2, 1e-3, 0.9, 0.999, 1e-8, wd, step, grad_scale=scale)
+            assert torch.equal(p1.view(torch.int16), p2.view(torch.int16)), f"bf16 parameters differ at step {step}"
+            assert torch.equal(m1.view(torch.int32), m2.view(torch.int32)), f"exp_avg differs at step {step}"
+            assert torch.equal(v1.view(torch.int32), v2.abs().view(torch.int32)), f"exp_avg_sq differs at step {step}"
+            joined = k.master_join(p2, lo2, v2)
+            assert torch.equal(joined.view(torch.int32), mast.view(torch.int32)), f"fp32 masters differ at step {step}"
+            worst_ties = max(worst_ties, int((v2.view(torch.int32) < 0).sum()))
+    return float(worst_ties)
+
+
 # ------------------------------------------------------------------------------------------------------------- whole step
 MODEL_CASES = ["siglip_b1_img1", "siglip_b1_img4", "siglip_b2_equal_rightpad", "siglip_b2_unequal_quirk", "siglip_b1_text_only",
                "clip_b2_equal_rightpad"]
@@ -2409,6 +2464,7 @@ def all_checks():
     c["ce_32002"] = lambda: check_ce(40, 32002, 0.5)
     c["vit_front"] = check_vit_front
     c["optim"] = check_optim
+    c["adamw_split_bitwise"] = check_adamw_split_bitwise
     for case in MODEL_CASES:
         c["model_step_" + case] = (lambda case=case: check_model_step(case))
     c["model_step_fix_unequal_counts_right"] = lambda: check_model_step_fixed_counts("right")

@@ -248,7 +248,7 @@ def check_fused_optimizer_resume(device, tmpdir):
     assert o_c.step_count == 2 and o_c.param_groups[0]["lr"] == o_b.param_groups[0]["lr"]
     run(m_c, o_c, s_c, t_c, batches[2:])
     assert torch.equal(m_c.arena, m_a.arena), "parameters after resume differ from the uninterrupted run"
-    for k in ("master", "exp_avg", "exp_avg_sq"):
+    for k in ("master_lo", "exp_avg", "exp_avg_sq", "master"):     # the stored halves AND the joined fp32 masters
         assert torch.equal(getattr(o_c, k), getattr(o_a, k)), k
     assert o_c.step_count == 4 and o_c.param_groups[0]["lr"] == o_a.param_groups[0]["lr"]
     return 0.0

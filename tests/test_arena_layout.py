@@ -83,16 +83,12 @@ def test_gradient_buckets_tile_the_gradient_arena(model):
     assert all(o % 128 == 0 or n.endswith(model.adjacent_suffixes) for n, o in model._grad_offs.items())
 
 
-def test_optimizer_segments_cover_every_trainable_parameter_once(model):
+def test_optimizer_segments_cover_every_trainable_parameter_once(model, monkeypatch):
     from mantis_amd.optim import FusedAdamW
     import mantis_amd.optim as opt_mod
     from oracle import ops_ref
-    saved = opt_mod.K
-    opt_mod.K = ops_ref
-    try:
-        opt = FusedAdamW(model, lr=1e-3, weight_decay=0.1, no_decay=lambda n: model._param(n).dim() <= 1)
-    finally:
-        opt_mod.K = saved
+    monkeypatch.setattr(opt_mod, "K", ops_ref)      # construction and `opt.master` (joined on demand) run on the oracle's operators
+    opt = FusedAdamW(model, lr=1e-3, weight_decay=0.1, no_decay=lambda n: model._param(n).dim() <= 1)
     cover_p = torch.zeros(model.arena.numel(), dtype=torch.int32)
     cover_g = torch.zeros(model.grad_arena.numel(), dtype=torch.int32)
     for p_off, g_off, cnt, _ in opt._segments:

@@ -102,7 +102,7 @@ def test_hf_trainer_builds_the_fused_optimizer_and_routes_clipping(cpu_backend, 
     assert n2.dim() == 0 and float(n2) > 0 and tr.optimizer._pending_scale is not None
     tr._save_optimizer_and_scheduler(str(tmp_path))
     sd = torch.load(str(tmp_path / "optimizer.pt"), weights_only=True)
-    assert sd["format"] == "mantis_fused_adamw/2" and sd["step"] == 3
+    assert sd["format"] == "mantis_fused_adamw/3" and sd["step"] == 3
 
 
 def test_folded_norm_range_arithmetic_and_fallback(cpu_backend):
@@ -181,6 +181,78 @@ def test_flat_state_is_defined_in_the_alignment_pads(cpu_backend, monkeypatch):
     for _, g_off, cnt, _ in opt._segments:
         covered[g_off:g_off + cnt] = True
     assert not bool(covered.all()), "this model is expected to have pads between segments"
-    for name in ("master", "exp_avg", "exp_avg_sq"):
-        t = getattr(opt, name)
+    for name in ("master", "master_lo", "exp_avg", "exp_avg_sq"):
+        t = getattr(opt, name).float()
         assert bool(torch.isfinite(t).all()) and float(t[~covered].abs().sum()) == 0.0, name
+    assert float(opt.state_dict()["master_hi"].float()[~covered].abs().sum()) == 0.0
+
+
+def test_split_master_restatement_round_trips_every_low_half():
+    """The storage of the round-5 optimizer (include/mantis_hip.h: mantis_adamw_split): fp32 master = (bf16 parameter, low 16 bits, tie
+    bit in the sign of exp_avg_sq).  The oracle's integer restatement of join / split, over every low-half pattern, ties of both
+    parities, signed zeros, denormals and the largest finite value: split gives bf16(master) exactly, join gives the master back bit for
+    bit, and WITHOUT the tie bit exactly the ties that rounded up come back wrong (why 32 stored bits are not enough)."""
+    from oracle import ops_ref as R
+    n = 1 << 17
+    master = torch.randn(n, generator=torch.Generator().manual_seed(0)) * 0.05
+    b = master.view(torch.int32)
+    b[:65536] = (b[:65536] & ~0xFFFF) | torch.arange(65536, dtype=torch.int32)
+    b[65536:69632] = (b[65536:69632] & ~0xFFFF) | 0x8000
+    master[70000:70006] = torch.tensor([0.0, -0.0, 1e-42, -1e-42, 3.3895e38, -3.3895e38])
+    p, lo, v = torch.zeros(n, dtype=torch.bfloat16), torch.zeros(n, dtype=torch.int16), torch.rand(n)
+    v0 = v.clone()
+    R.master_split(master, p, lo, v)
+    assert torch.equal(p.view(torch.int16), master.to(torch.bfloat16).view(torch.int16))
+    assert torch.equal(v.abs(), v0)
+    ties = v.view(torch.int32) < 0
+    up_ties = ((b & 0xFFFF) == 0x8000) & (((b >> 16) & 1) == 1)
+    assert torch.equal(ties, up_ties) and int(ties.sum()) > 1000
+    assert torch.equal(R.master_join(p, lo, v).view(torch.int32), b)
+    wrong = R.master_join(p, lo, v.abs()).view(torch.int32) != b
+    assert torch.equal(wrong, up_ties)
+
+
+def test_split_master_step_equals_the_fp32_master_step():
+    """adamw_split_flat == adamw_flat on the joined master, bit for bit, over 5 steps with weight decay (oracle operators; the HIP twin is
+    the GPU check `adamw_split_bitwise`)."""
+    from oracle import ops_ref as R
+    n = 1 << 14
+    gen = torch.Generator().manual_seed(3)
+    master = torch.randn(n, generator=gen) * 0.05
+    m1, v1, mast, p1 = torch.zeros(n), torch.zeros(n), master.clone(), master.to(torch.bfloat16)
+    m2, v2, p2, lo2 = torch.zeros(n), torch.zeros(n), torch.zeros(n, dtype=torch.bfloat16), torch.zeros(n, dtype=torch.int16)
+    R.master_split(master, p2, lo2, v2)
+    for step in range(1, 6):
+        g = (torch.randn(n, generator=gen) * 0.01).to(torch.bfloat16)
+        R.adamw_flat(p1, g, mast, m1, v1, 1e-3, 0.9, 0.999, 1e-8, 0.01, step)
+        R.adamw_split_flat(p2, g, lo2, m2, v2, 1e-3, 0.9, 0.999, 1e-8, 0.01, step)
+        assert torch.equal(p1, p2) and torch.equal(m1, m2) and torch.equal(v1, v2.abs())
+        assert torch.equal(R.master_join(p2, lo2, v2).view(torch.int32), mast.view(torch.int32))
+
+
+def test_round4_checkpoint_with_fp32_masters_still_loads(cpu_backend):
+    """A `mantis_fused_adamw/2` state (one flat fp32 `master` array) resumes on the split-master optimizer: same parameters, same joined
+    masters, same moments as the optimizer it was exported from, and the same next step."""
+    from mantis_amd.optim import FusedAdamW, FP32_MASTER_FORMAT
+
+    def fresh():
+        model, _, _ = Hh.build_product_model("siglip", "cpu")
+        return model, FusedAdamW(model, lr=1e-2, weight_decay=0.05, max_grad_norm=None)
+    gen = torch.Generator().manual_seed(5)
+    m_a, o_a = fresh()
+    grads = [(torch.randn(m_a.grad_arena.numel(), generator=gen) * 0.02).to(torch.bfloat16) for _ in range(3)]
+    for g in grads[:2]:
+        m_a.grad_arena.copy_(g)
+        o_a.step()
+    sd = o_a.state_dict()
+    old = {"format": FP32_MASTER_FORMAT, "step": sd["step"], "layout": sd["layout"], "arena_align": sd["arena_align"],
+           "master": o_a.master.clone(), "exp_avg": sd["exp_avg"].clone(), "exp_avg_sq": o_a.second_moment(), "param_groups": sd["param_groups"]}
+    m_b, o_b = fresh()
+    o_b.load_state_dict(old)
+    assert torch.equal(m_b.arena, m_a.arena)
+    for k in ("master_lo", "exp_avg", "exp_avg_sq", "master"):
+        assert torch.equal(getattr(o_b, k), getattr(o_a, k)), k
+    for m, o in ((m_a, o_a), (m_b, o_b)):
+        m.grad_arena.copy_(grads[2])
+        o.step()
+    assert torch.equal(m_b.arena, m_a.arena) and torch.equal(o_b.master, o_a.master) and o_b.step_count == 3

@@ -11,6 +11,7 @@ sys.path.insert(0, ROOT)
 
 
 def main():
+    import mantis_amd  # noqa: F401  (before the first GPU call: exports GPU_MAX_HW_QUEUES=8, as the pytest run does through conftest)
     import torch
     from tests import gpu_checks
     from tests import helpers as Hh
