@@ -136,6 +136,14 @@ class FusedAdamW(torch.optim.Optimizer):
                 "master_hi": hi, "master_lo": self.master_lo, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
                 "param_groups": [group]}
 
+    def export_fp32_state(self):
+        """The state as plain fp32 arrays -- `master` (joined), `exp_avg`, `exp_avg_sq` (magnitudes) -- in the round-4 format
+        `mantis_fused_adamw/2`: for consumers that want DeepSpeed-style fp32 masters (16 B of new tensors per parameter; `state_dict()`
+        itself stays copy-free).  `load_state_dict` accepts it and continues the same trajectory bit for bit."""
+        sd = self.state_dict()
+        return {"format": FP32_MASTER_FORMAT, "step": sd["step"], "layout": sd["layout"], "arena_align": sd["arena_align"],
+                "master": self.master, "exp_avg": self.exp_avg, "exp_avg_sq": self.second_moment(), "param_groups": sd["param_groups"]}
+
     def load_state_dict(self, state_dict):
         """Resume: step count, fp32 master weights and Adam moments, hyper-parameters (as torch: the checkpoint's lr / betas / eps /
         weight_decay replace the constructor's; an LR scheduler restores its own state separately).  The masters of the checkpoint are

@@ -244,9 +244,9 @@ def test_round4_checkpoint_with_fp32_masters_still_loads(cpu_backend):
     for g in grads[:2]:
         m_a.grad_arena.copy_(g)
         o_a.step()
-    sd = o_a.state_dict()
-    old = {"format": FP32_MASTER_FORMAT, "step": sd["step"], "layout": sd["layout"], "arena_align": sd["arena_align"],
-           "master": o_a.master.clone(), "exp_avg": sd["exp_avg"].clone(), "exp_avg_sq": o_a.second_moment(), "param_groups": sd["param_groups"]}
+    old = o_a.export_fp32_state()            # plain fp32 master / exp_avg / exp_avg_sq arrays, the round-4 layout
+    assert old["format"] == FP32_MASTER_FORMAT and old["master"].dtype == torch.float32 and float(old["exp_avg_sq"].min()) >= 0.0
+    old = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in old.items()}
     m_b, o_b = fresh()
     o_b.load_state_dict(old)
     assert torch.equal(m_b.arena, m_a.arena)
