@@ -479,6 +479,10 @@ def main():
     ap.add_argument("--prefetch-early", action="store_true", help="alias of --vision-prefetch early")
     ap.add_argument("--adam-cus", type=int, default=192, help="with --prefetch: compute units given to the optimizer pass")
     ap.add_argument("--no-optimizer", action="store_true")
+    ap.add_argument("--gradient-checkpointing", action="store_true",
+                    help="activation checkpointing per decoder layer (the reference launches with --gradient_checkpointing True, "
+                         "train_mllava.sh:168): one kept tensor per layer, the layer forward runs again in the backward -- same results, "
+                         "less memory, more time; NOT the default line (288 GB hold the activations of every configuration)")
     ap.add_argument("--no-norm-fold", action="store_true",
                     help="keep clip_grad_norm_'s separate pass over the gradients also on a single rank (default there: the sum of squares rides "
                          "in the weight-gradient GEMMs' epilogues)")
@@ -572,6 +576,8 @@ def main():
         if not hasattr(model, "set_precision"):
             raise SystemExit(f"--precision {precision} needs a module with set_precision (config {args.config})")
         model.set_precision(precision)
+    if args.gradient_checkpointing:
+        model.gradient_checkpointing_enable()
     if args.stage == "pretrain":
         for n, p in model.named_parameters():
             if "multi_modal_projector" not in n and "model.connector." not in n:
@@ -868,6 +874,7 @@ def main():
                    ms_training_step_p10=round(_pct(ts_ms, 0.1), 2), ms_training_step_p90=round(_pct(ts_ms, 0.9), 2),
                    ms_optimizer=round(_pct([e[1].elapsed_time(e[2]) for e in split], 0.5), 2) if opt is not None else None,
                    samples_per_s_training_step_only=round(world * B / (1e-3 * _pct(ts_ms, 0.5)), 4),
+                   peak_hbm_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1) if on_gpu else None,      # torch's allocator, this rank, whole run
                    higher_is_better=True, scaling="weak", vs_baseline=None,
                    dtype="bf16" if precision == "bf16" else "fp8 (e4m3 activations/weights, e5m2 gradients in the decoder linears" +
                          (", per-row / per-column scales" if precision == "fp8_rowwise" else "") + "; bf16 elsewhere)",
@@ -883,7 +890,8 @@ def main():
                                flop_per_sample=flop_per_sample,
                                parallelism=f"dp{world}", optimizer=not args.no_optimizer, stage=args.stage,
                                packed=bool(idefics and not args.no_pack),
-                               vision_prefetch=vmode, grad_norm_folded_into_dw=bool(fold)),
+                               vision_prefetch=vmode, grad_norm_folded_into_dw=bool(fold),
+                               gradient_checkpointing=bool(args.gradient_checkpointing)),
                    loop=("transformers.Trainer.train() over as_hf_trainer() (HF dataloader / get_batch_samples / create_optimizer -> FusedAdamW / "
                          "scheduler / clip call / zero_grad)" if args.loop == "hf" else "native (MantisHipTrainer + FusedAdamW)"),
                    native_loop=None if native_loop is None else dict(

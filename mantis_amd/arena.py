@@ -42,6 +42,24 @@ class ArenaModule(nn.Module):
     #: parameters that must directly follow their predecessor: the later members of a fused projection (`_flat` views: q|k|v, gate|up)
     adjacent_suffixes = ("k_proj.weight", "v_proj.weight", "k_proj.bias", "v_proj.bias", "up_proj.weight")
 
+    # ---- activation checkpointing, with HF's names (PreTrainedModel.gradient_checkpointing_enable / _disable / is_gradient_checkpointing:
+    # transformers.Trainer calls the first when TrainingArguments.gradient_checkpointing is set, as the reference's launch script does,
+    # /root/reference/mantis/train/scripts/train_mllava.sh:168).  The engines read the flag on every step.
+    gradient_checkpointing = False
+
+    def gradient_checkpointing_enable(self, gradient_checkpointing_kwargs=None):
+        """Keep only every decoder layer's input in the forward and re-run the layer in the backward (same kernels, same bits; ~0.75 GB
+        less per Llama-3-8B layer at 5624 rows, one more layer forward of time).  `gradient_checkpointing_kwargs` (use_reentrant ...)
+        concern torch.utils.checkpoint and are accepted and ignored: nothing here goes through autograd."""
+        self.gradient_checkpointing = True
+
+    def gradient_checkpointing_disable(self):
+        self.gradient_checkpointing = False
+
+    @property
+    def is_gradient_checkpointing(self):
+        return bool(self.gradient_checkpointing)
+
     def _place(self, items):
         """[(name, numel)] in arena order -> ({name: offset}, total): sizes padded to 8 elements (zeros), starts aligned to ARENA_ALIGN
         except inside a fused projection."""

@@ -16,28 +16,39 @@ def inv_freq(head_dim, theta):
     return 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
 
 
-def decoder_forward(K, lm, tc, x, B, L, position_ids, kmask, kstart=None, compute_grads=True, record=None, rope=None):
-    """x [B*L, d] merged input embeddings -> (hidden states before the final norm, ctx for decoder_backward).
-    `rope` = (cos, sin) tables [B*L, hd/2] built by the caller (Qwen2-VL's multimodal RoPE); default: 1-D RoPE of position_ids.
-    A layer dict may carry `qkv_b`, the fused q|k|v bias (Qwen2: HF:models/qwen2_vl/modeling_qwen2_vl.py:501-503)."""
+def layer_forward(K, lw, tc, x, B, L, cos, sin, kmask, kstart, scale):
+    """One decoder block: x [B*L, d] -> (x_out, what its backward reads).  Deterministic (fixed summation orders everywhere): running it
+    again on the same x gives the same bits, which is what activation checkpointing relies on."""
     H, Hkv, hd = tc.num_attention_heads, tc.num_key_value_heads, tc.head_dim
     eps = tc.rms_norm_eps
+    n1, rstd1 = K.rmsnorm_fwd(x, lw["ln1"], eps)
+    qkv = K.linear_qkv_rope(n1, lw["qkv"], lw.get("qkv_b"), cos, sin, H + Hkv, hd)      # RoPE in the projection's epilogue (hd 128)
+    o, lse = K.attn_fwd(qkv, B, L, H, Hkv, hd, kmask, scale, True, kstart=kstart)
+    x_mid = K.gemm_nt(o, lw["o"], residual=x)
+    n2, rstd2 = K.rmsnorm_fwd(x_mid, lw["ln2"], eps)
+    gu, a = K.linear_gu_swiglu(n2, lw["gu"])                                            # SwiGLU in the projection's epilogue
+    x_out = K.gemm_nt(a, lw["down"], residual=x_mid)
+    return x_out, (x, rstd1, qkv, o, lse, x_mid, rstd2, gu, n1, n2, a)
+
+
+def decoder_forward(K, lm, tc, x, B, L, position_ids, kmask, kstart=None, compute_grads=True, record=None, rope=None, checkpoint=False):
+    """x [B*L, d] merged input embeddings -> (hidden states before the final norm, ctx for decoder_backward).
+    `rope` = (cos, sin) tables [B*L, hd/2] built by the caller (Qwen2-VL's multimodal RoPE); default: 1-D RoPE of position_ids.
+    A layer dict may carry `qkv_b`, the fused q|k|v bias (Qwen2: HF:models/qwen2_vl/modeling_qwen2_vl.py:501-503).
+    checkpoint: activation checkpointing per decoder layer (`--gradient_checkpointing True`,
+    /root/reference/mantis/train/scripts/train_mllava.sh:168; HF wraps every LlamaDecoderLayer in torch.utils.checkpoint,
+    transformers/models/llama/modeling_llama.py:284-325): keep only each layer's INPUT and run the layer's forward again in the backward."""
+    hd = tc.head_dim
     scale = hd ** -0.5
     cos, sin = rope if rope is not None else K.rope_table(position_ids.reshape(-1), inv_freq(hd, tc.rope_theta).to(x.device))
     saved = []
     for i in range(tc.num_hidden_layers):
-        lw = lm["layers"][i]
-        n1, rstd1 = K.rmsnorm_fwd(x, lw["ln1"], eps)
-        qkv = K.linear_qkv_rope(n1, lw["qkv"], lw.get("qkv_b"), cos, sin, H + Hkv, hd)      # RoPE in the projection's epilogue (hd 128)
-        o, lse = K.attn_fwd(qkv, B, L, H, Hkv, hd, kmask, scale, True, kstart=kstart)
-        x_mid = K.gemm_nt(o, lw["o"], residual=x)
-        n2, rstd2 = K.rmsnorm_fwd(x_mid, lw["ln2"], eps)
-        gu, a = K.linear_gu_swiglu(n2, lw["gu"])                                            # SwiGLU in the projection's epilogue
-        x_out = K.gemm_nt(a, lw["down"], residual=x_mid)
+        x_out, keep = layer_forward(K, lm["layers"][i], tc, x, B, L, cos, sin, kmask, kstart, scale)
         if compute_grads:
-            # 288 GB of HBM: keep the cheap-to-recompute tensors too (n1, n2, a: +370 MB per layer) instead of re-running
-            # RMSNorm / SwiGLU in the backward
-            saved.append((x, rstd1, qkv, o, lse, x_mid, rstd2, gu, n1, n2, a))
+            # 288 GB of HBM: by default keep the cheap-to-recompute tensors too (n1, n2, a: +370 MB per layer) instead of re-running
+            # RMSNorm / SwiGLU in the backward; with `checkpoint` only the layer input stays
+            saved.append((x,) if checkpoint else keep)
+        del keep
         x = x_out
         if record is not None:
             record[f"llm_layer{i}_out"] = x.view(B, L, -1)
@@ -150,7 +161,11 @@ def decoder_backward(K, lm, grads, grads_layers, tc, ctx, hctx, plan, B, L, kmas
     for i in reversed(range(tc.num_hidden_layers)):
         lw = lm["layers"][i]
         lg_ = grads_layers[i]
-        x_in, rstd1, qkv, o, lse, x_mid, rstd2, gu, n1, n2, a = saved.pop()
+        entry = saved.pop()
+        if len(entry) == 1:          # activation checkpointing: only the layer input was kept -- run the layer's forward again
+            _, entry = layer_forward(K, lw, tc, entry[0], B, L, cos, sin, kmask, kstart, scale)
+        x_in, rstd1, qkv, o, lse, x_mid, rstd2, gu, n1, n2, a = entry
+        del entry
         if lg_["down"] is not None:
             off_path(lambda dx=dx, a=a: K.linear_dw(dx, a, lg_["down"], acc), dx, a)
         bucket(("layer", i, "down"))

@@ -157,13 +157,16 @@ def decoder_backward(K, lm, w8, grads, grads_layers, tc, ctx, hctx, plan, B, L, 
 
 
 # ---------------------------------------------------------------------------------------------------------------- engine-side dispatch
-def forward(K, eng, lm, tc, x, B, L, position_ids, kmask, kstart, compute_grads, record, rope=None):
+def forward(K, eng, lm, tc, x, B, L, position_ids, kmask, kstart, compute_grads, record, rope=None, checkpoint=False):
     """Decoder forward on the engine's precision: `eng.w8` (Fp8Weights, set by ArenaModule.set_precision("fp8")) selects the fp8
     layer loop, None the bf16 one of decoder.py.  The e4m3 weight copies are re-made unless the trainer flagged this micro-batch as
     following another one of the same accumulation window (`eng.weights_unchanged`)."""
     w8 = getattr(eng, "w8", None)
     if w8 is None:
-        return D.decoder_forward(K, lm, tc, x, B, L, position_ids, kmask, kstart, compute_grads, record, rope=rope)
+        return D.decoder_forward(K, lm, tc, x, B, L, position_ids, kmask, kstart, compute_grads, record, rope=rope, checkpoint=checkpoint)
+    if checkpoint and compute_grads:
+        raise NotImplementedError("activation checkpointing is implemented for the bf16 decoder loop (decoder.py); the fp8 loop keeps its "
+                                  "quantised activations -- switch one of the two off (gradient_checkpointing_disable() / set_precision('bf16'))")
     if not getattr(eng, "weights_unchanged", False):
         w8.refresh()
     eng.weights_unchanged = False

@@ -239,7 +239,8 @@ class LlavaEngine:
         # a batch without a single pad position needs no key mask (decided on the host copy of the batch: no device sync): the attention
         # kernels then skip the per-tile mask words altogether
         kmask = None if D.no_padding(am_cpu, grown, L) else plan.kmask
-        x, dctx = D8.forward(K, self, m.lm, tc, x, B, L, plan.position_ids, kmask, kstart, compute_grads, record)
+        x, dctx = D8.forward(K, self, m.lm, tc, x, B, L, plan.position_ids, kmask, kstart, compute_grads, record,
+                             checkpoint=m.is_gradient_checkpointing)
         loss, count, logits_full, hctx = D.head_and_loss(K, m.lm, tc, x, plan, B, L, labels is not None, grad_scale, loss_scale,
                                                          compute_grads, need_logits, record)
         if count is not None and (not self._verified or _DEBUG_SYNC):

@@ -80,7 +80,7 @@ def _param_specs(cfg: Idefics2Config):
 
 class Idefics2ForConditionalGeneration(ArenaModule):
     config_class = Idefics2Config
-    supports_gradient_checkpointing = False
+    supports_gradient_checkpointing = True       # per decoder layer (decoder.decoder_forward(checkpoint=True)); the frozen tower saves nothing anyway
     frozen_prefixes = ("model.vision_model.",)
 
     def __init__(self, config: Idefics2Config, device=None, dtype=torch.bfloat16, init="normal", seed=0):
@@ -519,7 +519,8 @@ class Idefics2Engine:
         if record is not None and img is not None:
             record["merged_embeds"] = x.view(B, T, -1)
         kmask = None if D.no_padding(am_cpu, 0, T) else plan.kmask      # no pad position in the batch: no key mask (host-side decision)
-        x, dctx = D8.forward(K, self, m.lm, tc, x, B, T, plan.position_ids, kmask, kstart, compute_grads, record)
+        x, dctx = D8.forward(K, self, m.lm, tc, x, B, T, plan.position_ids, kmask, kstart, compute_grads, record,
+                             checkpoint=m.is_gradient_checkpointing)
         loss, count, logits_full, hctx = D.head_and_loss(K, m.lm, tc, x, plan, B, T, labels is not None, grad_scale, loss_scale,
                                                          compute_grads, need_logits, record)
         if count is not None and not self._verified:

@@ -90,7 +90,7 @@ def _param_specs(cfg: LlavaConfig):
 
 class LlavaForConditionalGeneration(ArenaModule):
     config_class = LlavaConfig
-    supports_gradient_checkpointing = False
+    supports_gradient_checkpointing = True       # per decoder layer (decoder.decoder_forward(checkpoint=True)); the frozen tower saves nothing anyway
     frozen_prefixes = ("vision_tower.",)      # train_mllava.py:240-242
 
     def __init__(self, config: LlavaConfig, device=None, dtype=torch.bfloat16, init="normal", seed=0):

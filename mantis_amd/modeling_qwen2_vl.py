@@ -84,7 +84,7 @@ def _rename_hf4(k):
 
 class Qwen2VLForConditionalGeneration(ArenaModule):
     config_class = Qwen2VLConfig
-    supports_gradient_checkpointing = False
+    supports_gradient_checkpointing = True       # per decoder layer (decoder.decoder_forward(checkpoint=True)); the frozen tower saves nothing anyway
     frozen_prefixes = ("model.visual.",)                     # train_qwen2_vl.py:209-212
 
     def __init__(self, config: Qwen2VLConfig, device=None, dtype=torch.bfloat16, init="normal", seed=0):
@@ -453,7 +453,8 @@ class Qwen2VLEngine:
         sec = torch.repeat_interleave(torch.arange(3, dtype=torch.int32), torch.tensor(tc.rope_parameters["mrope_section"])).to(dev)
         rope = K.rope_table_sections(pos3.reshape(3, B * T).to(dev), D.inv_freq(tc.head_dim, tc.rope_theta).to(dev), sec)
         kmask = None if D.no_padding(am_cpu, 0, T) else plan.kmask      # no pad position in the batch: no key mask (host-side decision)
-        x, dctx = D8.forward(K, self, m.lm, tc, x, B, T, None, kmask, kstart, compute_grads, record, rope=rope)
+        x, dctx = D8.forward(K, self, m.lm, tc, x, B, T, None, kmask, kstart, compute_grads, record, rope=rope,
+                             checkpoint=m.is_gradient_checkpointing)
         loss, count, logits_full, hctx = D.head_and_loss(K, m.lm, tc, x, plan, B, T, labels is not None, grad_scale, loss_scale,
                                                          compute_grads, need_logits, record)
         if count is not None and not self._verified:

@@ -357,3 +357,47 @@ def test_hf_train_loop_hands_training_step_the_next_batch(cpu_backend, tmp_path,
     assert [s[2] for s in seen] == [False, True, False, True]              # the loop's own accumulation boundaries
     from mantis_amd.optim import FusedAdamW
     assert isinstance(tr._fused(), FusedAdamW) and tr._fused().step_count == 2
+
+
+def test_hf_training_arguments_switch_activation_checkpointing_on(cpu_backend, tmp_path, monkeypatch):
+    """The reference launches with `--gradient_checkpointing True` (/root/reference/mantis/train/scripts/train_mllava.sh:168): the stock
+    `Trainer.train()` then calls `model.gradient_checkpointing_enable(gradient_checkpointing_kwargs=...)`.  Under `as_hf_trainer()` that
+    reaches the engine (one kept tensor per decoder layer) and two optimizer steps end on the same parameters as without it."""
+    transformers = pytest.importorskip("transformers")
+    import mantis_amd.decoder as D
+    import mantis_amd.trainer as T
+    z = Hh.load_case("siglip_training_step_ga4")
+    batches = [_batch(z, f"mb{i}.") for i in range(4)]
+
+    class Items(torch.utils.data.Dataset):
+        def __len__(self):
+            return len(batches)
+
+        def __getitem__(self, i):
+            return i
+    monkeypatch.setattr(T, "_on_gpu", lambda: False, raising=False)
+    kept = []
+    real_forward = D.decoder_forward
+
+    def spy(*a, **kw):
+        x, ctx = real_forward(*a, **kw)
+        kept.append({len(e) for e in ctx["saved"]})
+        return x, ctx
+    monkeypatch.setattr(D, "decoder_forward", spy)
+
+    class Tr(T.as_hf_trainer()):
+        def _get_train_sampler(self, *a, **k):
+            return torch.utils.data.SequentialSampler(self.train_dataset)
+    finals = []
+    for gc in (False, True):
+        model, _, _ = Hh.build_product_model("siglip", "cpu")
+        args = transformers.TrainingArguments(output_dir=str(tmp_path / str(gc)), use_cpu=True, report_to=[], remove_unused_columns=False,
+                                              per_device_train_batch_size=1, gradient_accumulation_steps=2, max_steps=2, learning_rate=1e-3,
+                                              max_grad_norm=1.0, save_strategy="no", logging_strategy="no", logging_nan_inf_filter=False,
+                                              disable_tqdm=True, dataloader_pin_memory=False, gradient_checkpointing=gc)
+        kept.clear()
+        Tr(model=model, args=args, train_dataset=Items(), data_collator=lambda idx: batches[idx[0]]).train()
+        assert model.is_gradient_checkpointing == gc
+        assert len(kept) == 4 and all(k == ({1} if gc else {11}) for k in kept), kept
+        finals.append(model.arena.clone())
+    assert torch.equal(finals[0], finals[1])

@@ -246,3 +246,48 @@ def test_packed_step_equals_the_separate_samples(cpu_backend, case, rows):
                    labels=packed["labels"], pixel_values=packed["pixel_values"])
     l2 = MantisHipTrainer(m2, 1).training_step(m2, ref_fmt)
     assert abs(float(l2) - float(out["loss"])) < 1e-6
+
+
+@pytest.mark.parametrize("case", ["siglip_b2_equal_rightpad", "siglip_b1_img4"])
+def test_activation_checkpointing_changes_memory_not_results(cpu_backend, case, monkeypatch):
+    """`--gradient_checkpointing True` of the reference's launch script (/root/reference/mantis/train/scripts/train_mllava.sh:168; HF
+    re-runs every LlamaDecoderLayer in the backward).  Here: `model.gradient_checkpointing_enable()` keeps ONE tensor per decoder layer (its
+    input) instead of eleven and runs `decoder.layer_forward` again in the backward -- loss and every gradient must come out identical,
+    bit for bit, and the forward must indeed have kept less."""
+    import mantis_amd.decoder as D
+    z = Hh.load_case(case)
+    args = (torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"]), torch.from_numpy(z["labels"]), Hh.pixels_list(z))
+    kept = []
+    real_forward = D.decoder_forward
+
+    def spy(*a, **kw):
+        x, ctx = real_forward(*a, **kw)
+        kept.append([len(e) for e in ctx["saved"]])
+        return x, ctx
+    monkeypatch.setattr(D, "decoder_forward", spy)
+    res = []
+    for on in (False, True):
+        model, _, _ = Hh.build_product_model("siglip", "cpu")
+        assert type(model).supports_gradient_checkpointing and not model.is_gradient_checkpointing
+        if on:
+            model.gradient_checkpointing_enable(gradient_checkpointing_kwargs={"use_reentrant": False})      # HF's call (trainer.py)
+            assert model.is_gradient_checkpointing
+        model._ensure_grad_arena()
+        out = model.engine.step(*args, compute_grads=True, overwrite_grads=True)
+        res.append((float(out["loss"]), model.grad_arena.clone()))
+        model.gradient_checkpointing_disable()
+        assert not model.is_gradient_checkpointing
+    n_layers = len(kept[0])
+    assert kept[0] == [11] * n_layers and kept[1] == [1] * n_layers, kept
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1]) and float(res[0][1].float().abs().sum()) > 0
+
+
+def test_activation_checkpointing_is_skipped_without_a_backward(cpu_backend):
+    """An evaluation forward (compute_grads=False) keeps nothing either way."""
+    z = Hh.load_case("siglip_b1_img1")
+    model, _, _ = Hh.build_product_model("siglip", "cpu")
+    model.gradient_checkpointing_enable()
+    out = model.engine.step(torch.from_numpy(z["input_ids"]), torch.from_numpy(z["attention_mask"]), torch.from_numpy(z["labels"]),
+                            Hh.pixels_list(z), compute_grads=False)
+    assert out["loss"] is not None

@@ -189,3 +189,17 @@ def test_bucket_table_reproduces_the_reference_position_ids():
             got = torch.zeros(big * big, dtype=torch.int64)
             got[pm[0].reshape(-1)] = (tab[nh][k // nw].long() * side + tab[nw][k % nw].long())
             assert torch.equal(got, ref), (nh, nw)
+
+
+def test_activation_checkpointing_is_bit_identical(cpu_backend):
+    """gradient_checkpointing_enable() on the Idefics2 path (Mistral decoder through the shared decoder.py loop): same loss, same gradients."""
+    z = Hh.load_case(CASES[0])
+    res = []
+    for on in (False, True):
+        model = Hh.build_idefics2_product("cpu")
+        if on:
+            model.gradient_checkpointing_enable()
+        model._ensure_grad_arena()
+        out = model.engine.step_from_batch(Hh.idefics2_batch(z), compute_grads=True, overwrite_grads=True)
+        res.append((float(out["loss"]), model.grad_arena.clone()))
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
