@@ -161,3 +161,53 @@ def test_clip_flavour_full_width_step_runs_and_is_reproducible():
     assert math.isfinite(float(l1)) and 10.0 < float(l1) < 13.5
     out = model.engine.step(batch["input_ids"], batch["attention_mask"], batch["labels"], batch["pixel_values"], compute_grads=False)
     assert out["plan"].L == 2812
+
+
+def test_adamw_split_master_equals_fp32_master_beyond_2_32_elements():
+    """The optimizer pass of the headline covers 8.03e9 parameters in a few launches -- element indices beyond 2^32, which no model-sized
+    parity check reaches (the full-width checks hold ~1.5e9 parameters).  Size-independent property: the split-master kernel (26 B / parameter,
+    fp32 master = bf16 parameter + low 16 bits + tie bit in the sign of exp_avg_sq) and the fp32-master kernel agree BIT FOR BIT on the same
+    gradients over 3 steps at n = 2^32 + 98760 elements -- bf16 parameters, exp_avg, |exp_avg_sq| and the joined masters, compared in full
+    (integer views, chunked) -- and the join / split helpers round-trip at that size."""
+    k = _k()
+    n = 2 ** 32 + 98760
+    free, _ = torch.cuda.mem_get_info()
+    if free < 150 * 2 ** 30:
+        pytest.skip("needs ~130 GB of free HBM")
+    gen = torch.Generator(device=DEV).manual_seed(7)
+    blk = 1 << 26
+
+    def fill(t, scale):                                  # pseudo-random values without a 17-GB temporary per call
+        for o in range(0, n, blk):
+            e = min(n, o + blk)
+            t[o:e] = (torch.randn(e - o, generator=gen, device=DEV) * scale).to(t.dtype)
+    master = torch.empty(n, dtype=torch.float32, device=DEV)
+    fill(master, 0.05)
+    mb = master.view(torch.int32)
+    mb[-65536:] = (mb[-65536:] & ~0xFFFF) | 0x8000       # ties of both parities in the LAST elements
+    p1 = torch.empty(n, dtype=BF, device=DEV)
+    p2, lo2 = torch.empty(n, dtype=BF, device=DEV), torch.empty(n, dtype=torch.int16, device=DEV)
+    m1, v1, m2, v2 = (torch.zeros(n, dtype=torch.float32, device=DEV) for _ in range(4))
+    for o in range(0, n, blk):
+        p1[o:o + blk] = master[o:o + blk].to(BF)
+    k.master_split(master, p2, lo2, v2)
+    assert int((v2[-65536:].view(torch.int32) < 0).sum()) > 10000            # tie bits were set at the far end
+
+    def same(a, b, what):
+        for o in range(0, n, blk):
+            assert torch.equal(a[o:o + blk], b[o:o + blk]), f"{what} differ in elements [{o}, {o + blk})"
+    same(p1.view(torch.int16), p2.view(torch.int16), "split parameters / bf16(master)")
+    joined = k.master_join(p2, lo2, v2)
+    same(joined.view(torch.int32), mb, "join(split(master)) / master")
+    del joined
+    g = torch.empty(n, dtype=BF, device=DEV)
+    for step in (1, 2, 3):
+        fill(g, 0.02)
+        k.adamw_flat(p1, g, master, m1, v1, 1e-3, 0.9, 0.999, 1e-8, 0.01, step)
+        k.adamw_split_flat(p2, g, lo2, m2, v2, 1e-3, 0.9, 0.999, 1e-8, 0.01, step)
+    same(p1.view(torch.int16), p2.view(torch.int16), "bf16 parameters")
+    same(m1.view(torch.int32), m2.view(torch.int32), "exp_avg")
+    for o in range(0, n, blk):
+        assert torch.equal(v1[o:o + blk].view(torch.int32), v2[o:o + blk].abs().view(torch.int32)), f"exp_avg_sq differs at {o}"
+    joined = k.master_join(p2, lo2, v2)
+    same(joined.view(torch.int32), master.view(torch.int32), "fp32 masters")
