@@ -53,40 +53,52 @@ def _lin(K, xq, wq, bias=None, residual=None):
     return K.gemm_fp8_nt(xq.q, xq.dequant, wq.q, wq.dequant, E4M3, bias=bias, residual=residual, rowwise=xq.rowwise)
 
 
-def decoder_forward(K, lm, w8, tc, x, B, L, kmask, compute_grads=True, record=None, rope=None, kstart=None):
-    """Same contract as decoder.decoder_forward (rope tables given by the caller)."""
+def layer_forward(K, lw, w8, i, tc, x, B, L, cos, sin, kmask, kstart, scale, parts, keep):
+    """One fp8 decoder block: x -> (x_out, what its backward reads).  `keep`: make the transposed quantised copies the weight-gradient GEMMs
+    read.  Deterministic (amax is a maximum, the GEMMs' K-split order is fixed): a second run on the same x reproduces the first bit for
+    bit -- what activation checkpointing relies on."""
     H, Hkv, hd = tc.num_attention_heads, tc.num_key_value_heads, tc.head_dim
     eps = tc.rms_norm_eps
+    rw = w8.rowwise
+    n1, rstd1 = K.rmsnorm_fwd(x, lw["ln1"], eps, amax_parts=parts)
+    n1q = _quant(K, n1, E4M3, keep, parts, rw)
+    qkv = _lin(K, n1q, w8.get(K, i, "qkv"), bias=lw.get("qkv_b"))
+    K.rope_apply_(qkv, cos, sin, H + Hkv, hd)
+    o, lse = K.attn_fwd(qkv, B, L, H, Hkv, hd, kmask, scale, True, kstart=kstart)
+    oq = _quant(K, o, E4M3, keep, None, rw)
+    x_mid = _lin(K, oq, w8.get(K, i, "o"), residual=x)
+    n2, rstd2 = K.rmsnorm_fwd(x_mid, lw["ln2"], eps, amax_parts=parts)
+    n2q = _quant(K, n2, E4M3, keep, parts, rw)
+    gu = _lin(K, n2q, w8.get(K, i, "gu"))
+    a = K.swiglu_fwd(gu, amax_parts=parts)
+    aq = _quant(K, a, E4M3, keep, parts, rw)
+    x_out = _lin(K, aq, w8.get(K, i, "down"), residual=x_mid)
+    if keep:
+        for t in (n1q, oq, n2q, aq):
+            t.q = None                                  # the backward reads only the transposed copies
+    return x_out, (x, rstd1, qkv, o, lse, x_mid, rstd2, gu, n1q, oq, n2q, aq)
+
+
+def decoder_forward(K, lm, w8, tc, x, B, L, kmask, compute_grads=True, record=None, rope=None, kstart=None, checkpoint=False):
+    """Same contract as decoder.decoder_forward (rope tables given by the caller; `checkpoint`: keep only every layer's input and run
+    `layer_forward` again in the backward)."""
+    hd = tc.head_dim
     scale = hd ** -0.5
     cos, sin = rope
     saved = []
     # producer-side amax: RMSNorm and SwiGLU take the maximum |value| of what they write, so the quantiser that follows skips its own
     # pass over the tensor (one scratch buffer, reused: producer and consumer are adjacent on the stream)
-    rw = w8.rowwise
-    parts = K.amax_parts_buffer(x.device) if PRODUCER_AMAX and not rw else None
+    parts = K.amax_parts_buffer(x.device) if PRODUCER_AMAX and not w8.rowwise else None
     for i in range(tc.num_hidden_layers):
-        lw = lm["layers"][i]
-        n1, rstd1 = K.rmsnorm_fwd(x, lw["ln1"], eps, amax_parts=parts)
-        n1q = _quant(K, n1, E4M3, compute_grads, parts, rw)
-        qkv = _lin(K, n1q, w8.get(K, i, "qkv"), bias=lw.get("qkv_b"))
-        K.rope_apply_(qkv, cos, sin, H + Hkv, hd)
-        o, lse = K.attn_fwd(qkv, B, L, H, Hkv, hd, kmask, scale, True, kstart=kstart)
-        oq = _quant(K, o, E4M3, compute_grads, None, rw)
-        x_mid = _lin(K, oq, w8.get(K, i, "o"), residual=x)
-        n2, rstd2 = K.rmsnorm_fwd(x_mid, lw["ln2"], eps, amax_parts=parts)
-        n2q = _quant(K, n2, E4M3, compute_grads, parts, rw)
-        gu = _lin(K, n2q, w8.get(K, i, "gu"))
-        a = K.swiglu_fwd(gu, amax_parts=parts)
-        aq = _quant(K, a, E4M3, compute_grads, parts, rw)
-        x_out = _lin(K, aq, w8.get(K, i, "down"), residual=x_mid)
+        keep_copies = compute_grads and not checkpoint
+        x_out, keep = layer_forward(K, lm["layers"][i], w8, i, tc, x, B, L, cos, sin, kmask, kstart, scale, parts, keep_copies)
         if compute_grads:
-            for t in (n1q, oq, n2q, aq):
-                t.q = None                                  # the backward reads only the transposed copies
-            saved.append((x, rstd1, qkv, o, lse, x_mid, rstd2, gu, n1q, oq, n2q, aq))
+            saved.append((x,) if checkpoint else keep)
+        del keep
         x = x_out
         if record is not None:
             record[f"llm_layer{i}_out"] = x.view(B, L, -1)
-    return x, dict(saved=saved, cos=cos, sin=sin, scale=scale)
+    return x, dict(saved=saved, cos=cos, sin=sin, scale=scale, parts=parts)
 
 
 def _dw(K, dyq, xq, grad, acc):
@@ -113,7 +125,11 @@ def decoder_backward(K, lm, w8, grads, grads_layers, tc, ctx, hctx, plan, B, L, 
     for i in reversed(range(tc.num_hidden_layers)):
         lw = lm["layers"][i]
         lg_ = grads_layers[i]
-        x_in, rstd1, qkv, o, lse, x_mid, rstd2, gu, n1q, oq, n2q, aq = saved.pop()
+        entry = saved.pop()
+        if len(entry) == 1:          # activation checkpointing: only the layer input was kept -- run the layer's forward again
+            _, entry = layer_forward(K, lw, w8, i, tc, entry[0], B, L, cos, sin, kmask, kstart, scale, ctx.get("parts"), True)
+        x_in, rstd1, qkv, o, lse, x_mid, rstd2, gu, n1q, oq, n2q, aq = entry
+        del entry
         dxq = _quant(K, dx, E5M2, lg_["down"] is not None, dx_amax, rw)
         _dw(K, dxq, aq, lg_["down"], acc)
         if on_bucket_ready is not None:
@@ -164,15 +180,12 @@ def forward(K, eng, lm, tc, x, B, L, position_ids, kmask, kstart, compute_grads,
     w8 = getattr(eng, "w8", None)
     if w8 is None:
         return D.decoder_forward(K, lm, tc, x, B, L, position_ids, kmask, kstart, compute_grads, record, rope=rope, checkpoint=checkpoint)
-    if checkpoint and compute_grads:
-        raise NotImplementedError("activation checkpointing is implemented for the bf16 decoder loop (decoder.py); the fp8 loop keeps its "
-                                  "quantised activations -- switch one of the two off (gradient_checkpointing_disable() / set_precision('bf16'))")
     if not getattr(eng, "weights_unchanged", False):
         w8.refresh()
     eng.weights_unchanged = False
     if rope is None:
         rope = K.rope_table(position_ids.reshape(-1), D.inv_freq(tc.head_dim, tc.rope_theta).to(x.device))
-    return decoder_forward(K, lm, w8, tc, x, B, L, kmask, compute_grads, record, rope=rope, kstart=kstart)
+    return decoder_forward(K, lm, w8, tc, x, B, L, kmask, compute_grads, record, rope=rope, kstart=kstart, checkpoint=checkpoint)
 
 
 def backward(K, eng, lm, grads, grads_layers, tc, ctx, hctx, plan, B, L, kmask, kstart, qend, accumulate, on_bucket_ready):

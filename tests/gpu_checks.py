@@ -1275,6 +1275,34 @@ def check_activation_checkpointing_bitwise():
     return saved
 
 
+def check_activation_checkpointing_paths(precision):
+    """gradient_checkpointing_enable() on the other two paths' golden batches, HIP kernels: Idefics2 (bf16) and Qwen2-VL with bf16 / fp8 /
+    fp8_rowwise decoder linears (the fp8 loop re-runs its quantisations in the backward: amax is a maximum, the scales come out the same) --
+    loss and gradient arena bit-identical to the run that keeps every activation."""
+    worst = 0.0
+    jobs = [("qwen2vl_b2_rightpad", Hh.build_qwen2vl_product, Hh.qwen2vl_batch)]
+    if precision == "bf16":
+        jobs.append(("idefics2_b2_padimg_rightpad", Hh.build_idefics2_product, Hh.idefics2_batch))
+    for case, build, batch in jobs:
+        z = Hh.load_case(case)
+        res = []
+        for on in (False, True):
+            model = build(DEV)
+            if precision != "bf16":
+                model.set_precision(precision)
+            if on:
+                model.gradient_checkpointing_enable()
+            model._ensure_grad_arena()
+            out = model.engine.step_from_batch(batch(z), compute_grads=True, overwrite_grads=True)
+            torch.cuda.synchronize()
+            res.append((float(out["loss"].cpu()), model.grad_arena.clone()))
+        assert res[0][0] == res[1][0], (case, res[0][0], res[1][0])
+        assert torch.equal(res[0][1], res[1][1]), f"{case} ({precision}): gradients differ with activation checkpointing"
+        worst = max(worst, float(res[0][1].float().abs().max()))
+    assert worst > 0
+    return 0.0
+
+
 def k_clip(opt):
     """(clip coefficient, gradient norm) the optimizer would apply now (folded norm when it is ready, else a pass over the arena)."""
     k = K()
@@ -2513,6 +2541,8 @@ def all_checks():
     c["optim"] = check_optim
     c["adamw_split_bitwise"] = check_adamw_split_bitwise
     c["activation_checkpointing_bitwise"] = check_activation_checkpointing_bitwise
+    for prec in ("bf16", "fp8", "fp8_rowwise"):
+        c["activation_checkpointing_paths_" + prec] = (lambda prec=prec: check_activation_checkpointing_paths(prec))
     for case in MODEL_CASES:
         c["model_step_" + case] = (lambda case=case: check_model_step(case))
     c["model_step_fix_unequal_counts_right"] = lambda: check_model_step_fixed_counts("right")
