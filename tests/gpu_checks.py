@@ -67,7 +67,40 @@ def check_gemm_accumulate_padded():
     return close(c[:, :N], ref[:, :N], 1e-2, "gemm accumulate, ldc > N, N % 4 != 0")
 
 
-def check_gemm_operand_over_2gib(ring=12):
+def check_gemm_ring176_accumulate():
+    """C += A . B^T (EPI_ACCUM, the gradient-accumulation epilogue) on the 176-row kernel, ldc > N, both B layouts."""
+    k = K()
+    worst = 0.0
+    for (M, N, K_, bkm) in [(700, 512, 136, False), (530, 768, 200, True)]:
+        a, b = rnd(M, K_, seed=5), rnd(N, K_, seed=6, scale=0.1)
+        c0 = rnd(M, N + 8, seed=7)
+        ref = c0.clone()
+        R.gemm_nt(a, b, out=ref[:, :N], accumulate=True)
+        c = c0.to(DEV)
+        bd = (b.t().contiguous() if bkm else b).to(DEV)
+        k.gemm_nt(a.to(DEV), bd, out=c[:, :N], accumulate=True, b_kmajor=bkm, variant=15)
+        assert torch.equal(c[:, N:].cpu(), c0[:, N:]), "gemm wrote outside its N columns"
+        worst = max(worst, close(c[:, :N], ref[:, :N], 1e-2, f"ring176 accumulate {M}x{N}x{K_} bkm={bkm}"))
+    return worst
+
+
+def check_gemm_ring176_planner():
+    """The automatic choice takes the 176-row tile exactly where it turns the grid into whole rounds on this device (the M = 5624 forward / dX
+    shapes with N = 4096 / 6144) and the result of the automatic launch is then bit-identical to the forced variant 15; shapes whose 256-row
+    grid is already whole (M = 4096) never take it."""
+    k = K()
+    a, b = rnd(5624, 512, seed=1), rnd(4096, 512, seed=2, scale=0.1)
+    ad, bd = a.to(DEV), b.to(DEV)
+    auto, forced = k.gemm_nt(ad, bd), k.gemm_nt(ad, bd, variant=15)
+    r = close(forced, R.gemm_nt(a, b), 1e-2, "ring176 5624x4096x512")
+    if k.num_cus() == 256 and os.environ.get("MANTIS_GEMM_176", "1") == "1" and not os.environ.get("MANTIS_GEMM_RING"):
+        assert torch.equal(auto, forced), "the planner did not take the 176-row tile for 5624 x 4096"
+        a2 = ad[:4096]
+        assert torch.equal(k.gemm_nt(a2, bd), k.gemm_nt(a2, bd, variant=14)) or torch.equal(k.gemm_nt(a2, bd), k.gemm_nt(a2, bd, variant=13))
+    return r
+
+
+def check_gemm_operand_over_2gib(ring=12, kmajor_a=True):
     """Ring kernel with an operand between 2 and 4 GiB (32-bit unsigned buffer offsets): row-major A of 2.2 GB, and the same data read
     K-major, against the generic kernel's 64-bit addressing -- in particular the rows / k-rows that lie beyond the 2 GiB mark."""
     k = K()
@@ -80,6 +113,12 @@ def check_gemm_operand_over_2gib(ring=12):
     out = k.gemm_nt(a, b, variant=ring)
     r1 = close(out, ref, 5e-3, f"ring v{ring} vs generic, A row-major > 2 GiB")
     close(out[-300:], ref[-300:], 5e-3, "rows beyond the 2 GiB mark")
+    if not kmajor_a:                                     # the 176-row kernel reads A row-major only; its K-major side is B
+        b2 = a[:, :512]                                  # [K' = 8448, N = 512] K-major, row stride 131072: the last k-rows lie > 2 GiB in
+        w2 = (torch.randn(600, M, device=DEV, generator=g, dtype=torch.float32) * 0.05).to(BF)         # A2 [600, K' = 8448]
+        ref2 = k.gemm_nt(w2, b2, b_kmajor=True, variant=1)
+        out2 = k.gemm_nt(w2, b2, b_kmajor=True, variant=ring)
+        return max(r1, close(out2, ref2, 5e-3, f"ring v{ring} vs generic, B K-major spanning > 2 GiB"))
     # the same buffer as a K-major operand: C2[Kk-part, N2] = a^T-view . w ; take A = a as [K'=M, M'=Kk] K-major with a narrow M' window
     a2 = a[:, :1024]                                     # [K' = 8448, M' = 1024], row stride 131072: the window's last rows lie > 2 GiB in
     w = (torch.randn(N, M, device=DEV, generator=g, dtype=torch.float32) * 0.05).to(BF)      # [N, K']
@@ -139,7 +178,7 @@ def check_linear_dx_swiglu(M, d, I):
     # so each fused form is compared with the unfused launch of the SAME variant); the automatic choice must be one of them
     gud, dyd, wd = gu.to(DEV), dy.to(DEV), w.to(DEV)
     same = []
-    for v in (12, 13, 14):
+    for v in (12, 13, 14, 15):
         f_v = k.linear_dx_swiglu(dyd, wd, gud, variant=v)
         unfused = k.swiglu_bwd(k.gemm_nt(dyd, wd, b_kmajor=True, variant=v), gud)
         assert torch.equal(f_v, unfused), f"fused SwiGLU-backward epilogue (ring variant {v}) differs from GEMM + swiglu_bwd"
@@ -2508,6 +2547,22 @@ def all_checks():
             c[f"gemm_ring16_v{v}_epi_{f}"] = (lambda f=f, v=v: check_gemm(300, 200, 72, f, v))
         c[f"gemm_ring16_v{v}_ksplit_deterministic"] = lambda v=v: check_gemm_ksplit_deterministic(v)
         c[f"gemm_ring16_v{v}_operand_over_2gib"] = lambda v=v: check_gemm_operand_over_2gib(v)
+    # the 176 x 256 kernel (variant 15; A row-major: forward and dX layouts): tile-row seams at 176 / 352, the short third epilogue pass (rows
+    # 128 - 175 of a tile), ragged M / N / K, one and two K-steps, every epilogue, accumulate, operands beyond 2 GiB
+    for (M, N, K_, bkm) in [(1000, 1152, 4304, True), (520, 600, 1000, False), (300, 200, 72, True), (77, 40, 8, False), (257, 388, 1152, False),
+                            (1024, 302, 256, False), (176, 256, 64, False), (352, 512, 128, True), (353, 300, 200, False), (529, 776, 136, True),
+                            (2816, 2304, 1152, False), (1409, 1032, 520, True)]:
+        c[f"gemm_ring176_{M}x{N}x{K_}_0{int(bkm)}"] = (lambda M=M, N=N, K_=K_, bkm=bkm: check_gemm_kmajor(M, N, K_, False, bkm, 15))
+    for f in ("bias", "bias+gelu", "bias+tanh", "bias+quick", "res", "bias+res"):
+        c[f"gemm_ring176_epi_{f}"] = (lambda f=f: check_gemm(300, 200, 72, f, 15))
+        c[f"gemm_ring176_epi_{f}_700x512"] = (lambda f=f: check_gemm(700, 512, 136, f, 15))
+    c["gemm_ring176_accumulate"] = check_gemm_ring176_accumulate
+    c["gemm_ring176_operand_over_2gib"] = lambda: check_gemm_operand_over_2gib(15, kmajor_a=False)
+    c["gemm_ring176_planner"] = check_gemm_ring176_planner
+    for (M, d, I) in [(333, 64, 128), (700, 768, 3072), (520, 256, 1152)]:
+        c[f"linear_gu_swiglu_fused_v15_{M}x{d}x{I}"] = (lambda M=M, d=d, I=I: check_linear_gu_swiglu_fused(M, d, I, 15))
+    for (M, d, H, Hkv, bias) in [(333, 64, 2, 1, False), (700, 512, 4, 2, True), (1000, 256, 6, 1, True)]:
+        c[f"linear_qkv_rope_fused_v15_{M}x{d}_{H}_{Hkv}_{int(bias)}"] = (lambda M=M, d=d, H=H, Hkv=Hkv, bias=bias: check_linear_qkv_rope_fused(M, d, H, Hkv, bias, 15))
     for v in (13, 14):
         for (M, d, I) in [(333, 64, 128), (700, 768, 3072), (520, 256, 1152)]:
             c[f"linear_gu_swiglu_fused_v{v}_{M}x{d}x{I}"] = (lambda M=M, d=d, I=I, v=v: check_linear_gu_swiglu_fused(M, d, I, v))

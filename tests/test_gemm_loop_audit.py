@@ -25,6 +25,23 @@ def test_ring_gemm_k_loops_are_clean():
 
 
 @pytest.mark.skipif(os.environ.get("MANTIS_SKIP_BUILD_AUDIT") == "1", reason="MANTIS_SKIP_BUILD_AUDIT=1")
+def test_ring176_gemm_k_loops_are_clean():
+    """csrc/gemm176.hip (round 6): every instantiation of the 176 x 256 kernel carries exactly its 88 MFMAs per K-step and nothing the
+    schedule did not place there; no spills (the kernel runs one wave per SIMD on 176 AGPRs + ~150 VGPRs)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gemm_loop_audit as A
+    asm = A.compile_asm(os.path.join(ROOT, "mantis_amd", "csrc", "gemm176.hip"))
+    report, bad = A.audit(asm)
+    assert len(report) >= 5 and bad == 0, [(n, w, h[:4]) for n, w, h in report if h or "not found" in w]
+    for name, what, _ in report:
+        assert what.endswith("88 MFMAs"), (name, what)
+    text = open(asm).read()
+    import re
+    spills = [int(x) for x in re.findall(r"\.vgpr_spill_count:\s+(\d+)", text)] + [int(x) for x in re.findall(r"\.private_segment_fixed_size:\s+(\d+)", text)]
+    assert spills and max(spills) == 0, "the 176-row kernel spills"
+
+
+@pytest.mark.skipif(os.environ.get("MANTIS_SKIP_BUILD_AUDIT") == "1", reason="MANTIS_SKIP_BUILD_AUDIT=1")
 def test_fp8_ring_gemm_k_loops_are_clean():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import gemm_loop_audit as A

@@ -29,7 +29,7 @@ def compile_asm(src):
 def audit(asm_path):
     s = open(asm_path).read()
     report, bad = [], 0
-    for m in re.finditer(r"^(_Z\d+gemm_(?:nt_ring(?:16)?|fp8_ring)_kernel\w+):", s, re.M):
+    for m in re.finditer(r"^(_Z\d+gemm_(?:nt_ring(?:16|176)?|fp8_ring)_kernel\w+):", s, re.M):
         name = m.group(1)
         i, j = m.end(), s.index(".Lfunc_end", m.end())
         body = s[i:j].split("\n")
