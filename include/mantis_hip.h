@@ -115,10 +115,15 @@ int mantis_transpose(const void* in, void* out, int R, int C, int Rpad, int64_t 
  * them and runs the epilogue on all compute units -- no tickets, no spinning, nothing that can deadlock under CU masks.
  * Tile variants: 1 = 128x128 generic kernel, 2 = 256x256 generic kernel, 12 = 256x256 ring kernel with 8 waves x (128 x 64) of
  * 32x32x16 MFMAs, 13 = 256x256 ring16 kernel with 4 waves x (128 x 128) of 16x16x32 MFMAs, 14 = 256x256 ring16 kernel with 8 waves x
- * (128 x 64) of 16x16x32 MFMAs.  Automatic choice (variant 0): a fitted cost model picks the 128x128 kernel or a ring kernel
+ * (128 x 64) of 16x16x32 MFMAs, 15 = the 176x256 kernel (round 6, csrc/gemm176.hip: 4 waves x (176 x 64) of 16x16x32 MFMAs, A row-major only -- forward and
+ * dX layouts --, whole tiles without a K split, PERSISTENT workgroups that prefetch their next tile's first K-steps under the epilogue when a
+ * launch has more tiles than CUs; MANTIS_EUNSUPPORTED with flag 4096).  Automatic choice (variant 0): a fitted cost model picks the 128x128 kernel or a ring kernel
  * (mantis_gemm_pick_variant: 1 or 12 = "a ring kernel"); among the ring kernels, 14 for every K-major layout and for short per-CU K
  * walks, 13 for row-major (NT) operands with >= 400 K-steps per CU (rounds x K/64), unless the process was started with
- * MANTIS_GEMM_RING = 12 | 13 | 14 (forces that ring kernel wherever a ring kernel is chosen; A/B measurements).  The ring kernels address operands through 32-bit buffer descriptors: an
+ * MANTIS_GEMM_RING = 12 | 13 | 14 (forces that ring kernel wherever a ring kernel is chosen; A/B measurements); where a ring kernel is chosen, A is
+ * row-major and a predicted-time model (rounds x (K-steps x loop time + fixed cost) per tiling, for the launch's CU budget) favours it by >= 3 %,
+ * the 176x256 kernel: it turns the 352- / 528-tile grids of M = 5624 into whole rounds (MANTIS_GEMM_176 = 0 never | 1 model (default) | 2 always;
+ * MANTIS_GEMM_176P = 0: one tile per workgroup).  The ring kernels address operands through 32-bit buffer descriptors: an
  * operand of >= 4 GiB is routed to the generic kernel when the variant is auto and returns MANTIS_EUNSUPPORTED when a ring variant (or
  * the SwiGLU epilogue) was forced. */
 int mantis_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
@@ -126,7 +131,8 @@ int mantis_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, 
                         int64_t workspace_bytes, void* stream);
 /* bytes of caller-owned, 256-B aligned, ZERO-INITIALISED device workspace a launch of C[M,N] over K may need (0 = none; only the
  * ring kernel's deterministic split-K remainder round uses it; every launch leaves it zeroed-for-reuse, so one buffer per stream
- * serves all stream-ordered launches).  M = N = K = 0: the largest requirement of any shape on the current device (~64 MB). */
+ * serves all stream-ordered launches).  M = N = K = 0: the largest requirement of any shape on the current device (~128 MB on 256 CUs since
+ * round 5: 2 x #CU slabs of 256 KiB for the balanced remainder round; size buffers with this call, never with a constant). */
 int mantis_gemm_workspace_bytes(int M, int N, int K);
 /* CU budget of the GEMM tile scheduler (rounds of tiles, the K split of an incomplete last round, the tile variant).  PER CALL since round 5:
  * bits 16-27 of mantis_gemm_bf16_nt's / _sumsq's `flags` and of mantis_gemm_bf16_nt_fused's `variant` (0 = the default: the environment
@@ -136,14 +142,14 @@ int mantis_gemm_workspace_bytes(int M, int N, int K);
  * workgroup, so with C channels active plan for #CU - C.  Deterministic for a given budget; a different budget changes which tiles are
  * K-split, i.e. their fp32 summation order (results agree to bf16 rounding).  The split-K workspace size does not depend on it. */
 int mantis_gemm_cu_budget(int cus);
-/* Forward projections with a two-column epilogue fused in (16x16x32 ring kernels 13 / 14, NT layout).
+/* Forward projections with a two-column epilogue fused in (16x16x32 ring kernels 13 / 14 and the 176x256 kernel 15, NT layout).
  *   mode 1 (SwiGLU): B = [gate | up] weight [2 I, K], N = 2 I: C = A . B^T [M, 2 I] exactly as mantis_gemm_bf16_nt writes it AND
  *                    aux0 = silu(gate) * up [M, I] (bf16, row stride aux_ld) exactly as mantis_swiglu_fwd computes it (replaces
  *                    transformers LlamaMLP's act_fn(gate_proj(x)) * up_proj(x), modeling_llama.py:163-176, as ONE launch)
  *   mode 2 (RoPE):   q|k|v projection, heads of 128 columns, optional bias: columns [0, aux_n) leave with the rotary embedding applied
  *                    (aux0 = cos, aux1 = sin, bf16 [M, 64], row stride aux_ld), exactly as mantis_rope_apply(backward = 0) would
  *                    rotate them in a second pass (apply_rotary_pos_emb, modeling_llama.py:138-160)
- * variant: bits 0-3 0 = per-shape choice, 13 / 14 forced | 64 = in-kernel remainder reduction (flag 16384 of mantis_gemm_bf16_nt) | bits
+ * variant: bits 0-3 0 = per-shape choice, 13 / 14 / 15 forced | 64 = in-kernel remainder reduction (flag 16384 of mantis_gemm_bf16_nt) | bits
  * 16-27 CU budget (as in mantis_gemm_bf16_nt's flags).  MANTIS_EUNSUPPORTED for shapes outside the fused kernels' conditions (N % 256, I % 128,
  * aux_n % 128, 16-B alignment, operands < 4 GiB): the caller then issues the two launches. */
 int mantis_gemm_bf16_nt_fused(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,

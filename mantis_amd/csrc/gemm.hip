@@ -1380,8 +1380,8 @@ static int launch_gemm_ring(hipStream_t s, const bf16_t* A, const bf16_t* B, bf1
 // ---- the 176-row kernel: launcher and planner
 // (gemm176.hip)
 int mantis_launch_ring176(hipStream_t s, const bf16_t* A, const bf16_t* B, bf16_t* C, int M, int N, int K, long lda, long ldb, long ldc,
-                          const bf16_t* bias, const bf16_t* res, long ldr, int flags, int bkm, int kind, bf16_t* aux0, const bf16_t* aux1, long aux_ld,
-                          int aux_n);
+                          const bf16_t* bias, const bf16_t* res, long ldr, int flags, int bkm, int kind, int cus, bf16_t* aux0, const bf16_t* aux1,
+                          long aux_ld, int aux_n);
 // MANTIS_GEMM_176 (read once): 0 = never, 1 = where the planner predicts a gain (default), 2 = wherever the kernel applies (A/B measurements)
 static int ring176_mode() {
     static int v = -1;
@@ -1563,7 +1563,7 @@ int mantis_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, 
     // variant 1 = 128x128 generic kernel, 2 = 256x256 generic kernel, 12 / 13 = 256x256 ring kernels (default for well-quantised shapes)
     if (!ring && !big && variant != 1) return MANTIS_EINVAL;
     if (r176) {
-        return mantis_launch_ring176(GEMM_ARGS, bkm ? 1 : 0, 0, nullptr, nullptr, 0L, 0);
+        return mantis_launch_ring176(GEMM_ARGS, bkm ? 1 : 0, 0, plan_cus(flags_cus(flags)), nullptr, nullptr, 0L, 0);
     }
 #define RING_DISPATCH(AK, BK_, SW) (variant == 13 ? launch_gemm_ring<AK, BK_, SW, 4>(RING_ARGS) \
                                     : variant == 14 ? launch_gemm_ring<AK, BK_, SW, 8>(RING_ARGS) : launch_gemm_ring<AK, BK_, SW, 0>(RING_ARGS))
@@ -1652,7 +1652,8 @@ int mantis_gemm_bf16_nt_fused(const void* A, int64_t lda, const void* B, int64_t
                   (const bf16_t*)nullptr, 0L, flags, workspace, (long)workspace_bytes, (bf16_t*)aux0, (const bf16_t*)aux1, (long)aux_ld, aux_n
     if (variant == 15) {
         return mantis_launch_ring176(s, (const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C, M, N, K, (long)lda, (long)ldb, (long)ldc, (const bf16_t*)bias,
-                                     (const bf16_t*)nullptr, 0L, flags, 0, mode, (bf16_t*)aux0, (const bf16_t*)aux1, (long)aux_ld, aux_n);
+                                     (const bf16_t*)nullptr, 0L, flags, 0, mode, plan_cus(cus_bits >> EPI_CUS_SHIFT), (bf16_t*)aux0,
+                                     (const bf16_t*)aux1, (long)aux_ld, aux_n);
     }
     if (mode == PAIR_SWIGLU)
         return variant == 13 ? launch_gemm_ring<false, false, false, 4, PAIR_SWIGLU>(PAIR_ARGS)

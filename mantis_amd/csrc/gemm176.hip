@@ -21,36 +21,45 @@
 // five (a wave-uniform branch; the counted wait names only the uniform B pieces).  A is row-major (forward and dX: the M side is the
 // activation); B row-major (forward) or K-major (dX reads the weight as stored).  Epilogue: ring_epilogue<4, 4, 11> -- the ring16 code with a
 // short third pass (48 rows) -- plain / bias / activations / residual / accumulate / fused SwiGLU backward / the two-column forward fusions.
-template <bool BKM, bool SWIGLU = false, int PAIR = PAIR_NONE>
+template <bool BKM, bool SWIGLU = false, int PAIR = PAIR_NONE, bool PERSIST = true>
 __global__ __launch_bounds__(256) void gemm_nt_ring176_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C, int M, int N, int K, long lda, long ldb,
     long ldc, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res, long ldr, int flags, int tiles_m, int tiles_n,
     bf16_t* __restrict__ aux0, const bf16_t* __restrict__ aux1, long aux_ld, int aux_n) {
     static_assert(PAIR == PAIR_NONE || (!BKM && !SWIGLU), "the pair epilogues are forward (NT) fusions");
     constexpr int NBM = 11, NBN = 4, NMF = NBN * NBM, BMT = 176;
-    constexpr int B_SLOT = 32768, A_SLOT = 22528, B_RING = 3 * B_SLOT, A_OFF = B_RING, LDS_BYTES = B_RING + 2 * A_SLOT;
+    // LDS map: [B0 32K][B1 32K][A0 22K][A1 22K][B2 32K][spare 20K].  PERSIST: while the epilogue of a tile runs, steps 0 and 1 of the
+    // workgroup's NEXT tile land in B0 / A0 / B1 / A1, and the epilogue's four wave strips take [B2 | spare] = 52 KiB: 48-row passes (3 blocks,
+    // 4 x 12.75 KiB) instead of the ring16 kernels' 64-row ones.  Without PERSIST (one tile per workgroup) the strips lie at 0 as 64-row passes.
+    constexpr int B_SLOT = 32768, A_SLOT = 22528, A_OFF = 2 * B_SLOT, B2_OFF = A_OFF + 2 * A_SLOT, LDS_BYTES = 163840;
+    constexpr int PB = PERSIST ? 3 : 4, STRIP_OFF = PERSIST ? B2_OFF : 0;
+    static_assert(B2_OFF + B_SLOT <= LDS_BYTES && STRIP_OFF + 4 * PB * 16 * EPI_PITCH <= LDS_BYTES, "LDS map");
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wnh = wave >> 1, wno = (wave & 1) * 4;         // K-major B image: 128-column half, first 16-column block inside it
 
-    // workgroup -> tile: XCD-contiguous ranges of tile ids, groups of 8 tile rows walked column-major (as the ring16 kernels)
+    // (virtual) workgroup v -> tile: XCD-contiguous ranges of tile ids, groups of 8 tile rows walked column-major (as the ring16 kernels).
+    // PERSIST: workgroup b runs v = b, b + gridDim.x, ...: with a grid of #CU workgroups (a multiple of 8) every v of a workgroup lies on
+    // the same XCD's range, in the order the hardware would have dispatched them
     const int nk = (K + BK - 1) / BK;
-    const int bid = blockIdx.x, ntile = gridDim.x;
-    int tile_id;
-    {
-        const int q = ntile >> 3, r = ntile & 7, xcd = bid & 7;
-        tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int GROUP = 8;
-    const int per_group = GROUP * tiles_n;
-    const int g = tile_id / per_group;
-    const int first_m = g * GROUP;
-    const int gsz = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
-    const int in_g = tile_id - g * per_group;
-    const int m0 = (first_m + in_g % gsz) * BMT, n0 = (in_g / gsz) * 256;
+    const int ntile = tiles_m * tiles_n;
+    int m0, n0, tile_id;
+    auto tile_of = [&](int v, int& tm0, int& tn0, int& tid_) {
+        const int q = ntile >> 3, r = ntile & 7, xcd = v & 7;
+        tid_ = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+        const int GROUP = 8;
+        const int per_group = GROUP * tiles_n;
+        const int g = tid_ / per_group;
+        const int first_m = g * GROUP;
+        const int gsz = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
+        const int in_g = tid_ - g * per_group;
+        tm0 = (first_m + in_g % gsz) * BMT;
+        tn0 = (in_g / gsz) * 256;
+    };
+    int v = blockIdx.x;
+    tile_of(v, m0, n0, tile_id);
     const int pair_dist = PAIR == PAIR_SWIGLU ? (N >> 1) : 64;
-    auto pair_first = [&](int phi) { return PAIR == PAIR_SWIGLU ? (n0 >> 1) + phi : n0 + (phi >> 6) * 128 + (phi & 63); };
 
     f32x4 acc[NBN][NBM];
 
@@ -60,45 +69,50 @@ __global__ __launch_bounds__(256) void gemm_nt_ring176_kernel(
     constexpr unsigned OOB = 0xFFFFFFF0u;
     unsigned voA[6], voB[8];
     int kcA, kcB[8];
-    {
-        // A, row-major: piece wave + 4 j = rows 8 piece .. + 7; 16-B chunk swizzled with the row pair (slot = chunk ^ ((row >> 1) & 7));
-        // (4 piece + (rl >> 1)) & 7 does not depend on j
-        const int rl = lane >> 3, fz = (wave * 4 + (rl >> 1)) & 7, chunk = (lane & 7) ^ fz;
-        kcA = chunk * 8;
+    // per-lane DMA offsets of a tile (operands < 4 GiB: 32-bit arithmetic on the byte offsets)
+    auto lane_offsets = [&](int tm0, int tn0) {
+        {
+            // A, row-major: piece wave + 4 j = rows 8 piece .. + 7; 16-B chunk swizzled with the row pair (slot = chunk ^ ((row >> 1) & 7));
+            // (4 piece + (rl >> 1)) & 7 does not depend on j
+            const int rl = lane >> 3, fz = (wave * 4 + (rl >> 1)) & 7, chunk = (lane & 7) ^ fz;
+            kcA = chunk * 8;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            int grow = m0 + (wave + 4 * j) * 8 + rl;
-            grow = grow < M ? grow : M - 1;
-            voA[j] = (unsigned)(((long)grow * lda + chunk * 8) * 2);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        if constexpr (!BKM) {
-            // B, row-major: piece 8 wave + j of the 256-row slot
-            const int piece = 8 * wave + j, rl = lane >> 3, fz = (piece * 4 + (rl >> 1)) & 7, chunk = (lane & 7) ^ fz;
-            const int row = piece * 8 + rl;
-            kcB[j] = chunk * 8;
-            int grow = n0 + row;
-            if constexpr (PAIR != PAIR_NONE) {
-                // a wave's 64 rows = [32 first columns | 32 second columns] of its 32 features
-                constexpr int G = NBN * 8;
-                const int half = row >> 7, r = row & 127;
-                const int phi = half * 64 + (r / (2 * G)) * G + (r % G), second = (r / G) & 1;
-                grow = pair_first(phi) + second * pair_dist;
+            for (int j = 0; j < 6; ++j) {
+                int grow = tm0 + (wave + 4 * j) * 8 + rl;
+                grow = grow < M ? grow : M - 1;
+                voA[j] = (unsigned)grow * (unsigned)(lda * 2) + (unsigned)(chunk * 16);
             }
-            grow = grow < N ? grow : N - 1;
-            voB[j] = (unsigned)(((long)grow * ldb + chunk * 8) * 2);
-        } else {
-            // B, K-major: two [64 k][128 columns] images per slot; piece 4 wave + (j & 3) of half j >> 2: 4 k-rows x 256 B; LDS slot s of k-row
-            // kk holds the 16-B chunk s ^ ((kk & 3) << 2) ^ (((kk >> 3) & 1) << 1) (as the ring16 kernels)
-            const int half = j >> 2, piece = 4 * wave + (j & 3);
-            const int kk = piece * 4 + (lane >> 4), slot = lane & 15, cc = slot ^ ((kk & 3) << 2) ^ (((kk >> 3) & 1) << 1);
-            const long col = (long)n0 + half * 128 + cc * 8;
-            kcB[j] = kk;
-            voB[j] = (col + 8 <= ldb) ? (unsigned)(((long)kk * ldb + col) * 2) : OOB;
         }
-    }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if constexpr (!BKM) {
+                // B, row-major: piece 8 wave + j of the 256-row slot
+                const int piece = 8 * wave + j, rl = lane >> 3, fz = (piece * 4 + (rl >> 1)) & 7, chunk = (lane & 7) ^ fz;
+                const int row = piece * 8 + rl;
+                kcB[j] = chunk * 8;
+                int grow = tn0 + row;
+                if constexpr (PAIR != PAIR_NONE) {
+                    // a wave's 64 rows = [32 first columns | 32 second columns] of its 32 features
+                    constexpr int G = NBN * 8;
+                    const int half = row >> 7, r = row & 127;
+                    const int phi = half * 64 + (r / (2 * G)) * G + (r % G), second = (r / G) & 1;
+                    const int first = PAIR == PAIR_SWIGLU ? (tn0 >> 1) + phi : tn0 + (phi >> 6) * 128 + (phi & 63);
+                    grow = first + second * pair_dist;
+                }
+                grow = grow < N ? grow : N - 1;
+                voB[j] = (unsigned)grow * (unsigned)(ldb * 2) + (unsigned)(chunk * 16);
+            } else {
+                // B, K-major: two [64 k][128 columns] images per slot; piece 4 wave + (j & 3) of half j >> 2: 4 k-rows x 256 B; LDS slot s of
+                // k-row kk holds the 16-B chunk s ^ ((kk & 3) << 2) ^ (((kk >> 3) & 1) << 1) (as the ring16 kernels)
+                const int half = j >> 2, piece = 4 * wave + (j & 3);
+                const int kk = piece * 4 + (lane >> 4), slot = lane & 15, cc = slot ^ ((kk & 3) << 2) ^ (((kk >> 3) & 1) << 1);
+                const long col = (long)tn0 + half * 128 + cc * 8;
+                kcB[j] = kk;
+                voB[j] = (col + 8 <= ldb) ? (unsigned)kk * (unsigned)(ldb * 2) + (unsigned)(col * 2) : OOB;
+            }
+        }
+    };
+    lane_offsets(m0, n0);
     const unsigned soA1 = (unsigned)(BK * 2);
     const unsigned soB1 = BKM ? (unsigned)(BK * 2) * (unsigned)ldb : (unsigned)(BK * 2);
     // LDS destination of piece j inside a slot
@@ -117,11 +131,14 @@ __global__ __launch_bounds__(256) void gemm_nt_ring176_kernel(
         const unsigned vo = (kcA < krem) ? voA[j] : OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, d, 16, vo, soa, 0, DMA_AUX_A);
     };
-    // prologue: steps 0 and 1
-    static_for<0, 8>([&](auto jc) { issueB(jc, 0u, 0u, K); });
-    static_for<0, 6>([&](auto jc) { issueA(jc, 0u, 0u, K); });
-    static_for<0, 8>([&](auto jc) { issueB(jc, (unsigned)B_SLOT, soB1, K - BK); });
-    static_for<0, 6>([&](auto jc) { issueA(jc, (unsigned)A_SLOT, soA1, K - BK); });
+    // a tile's first two K-steps: B(0) -> B0, A(0) -> A0, B(1) -> B1, A(1) -> A1
+    auto prologue = [&]() {
+        static_for<0, 8>([&](auto jc) { issueB(jc, 0u, 0u, K); });
+        static_for<0, 6>([&](auto jc) { issueA(jc, 0u, 0u, K); });
+        static_for<0, 8>([&](auto jc) { issueB(jc, (unsigned)B_SLOT, soB1, K - BK); });
+        static_for<0, 6>([&](auto jc) { issueA(jc, (unsigned)A_SLOT, soA1, K - BK); });
+    };
+    prologue();
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < NBN; ++i)
@@ -178,57 +195,90 @@ __global__ __launch_bounds__(256) void gemm_nt_ring176_kernel(
             __builtin_amdgcn_sched_barrier(0);
         });
     };
+    auto b_next_slot = [](unsigned bb) { return bb == 0u ? (unsigned)B_SLOT : (bb == (unsigned)B_SLOT ? (unsigned)B2_OFF : 0u); };
 
     asm volatile("s_waitcnt vmcnt(13)" ::: "memory");          // step 0 landed (this wave's pieces: 8 + 6 or 5); step 1 may still be in flight
-    __builtin_amdgcn_s_barrier();
-    static_for<0, NOPS>([&](auto oc) { frag_op(oc, ic_<0>{}, ic_<0>{}, lds0 + A_OFF, lds0 + b_wave_off); });
-    unsigned bb = 0, ab = 0;                                     // slot offsets of step t in the B / A ring
-    unsigned soa = 2u * soA1, sob = 2u * soB1;                   // scalar K-step offsets of step t + 2
-    int krem = K - 2 * BK;
-    for (int t = 0; t < nk; ++t) {
-        unsigned bb1 = bb + B_SLOT; bb1 = bb1 >= (unsigned)B_RING ? 0u : bb1;
-        unsigned bb2 = bb1 + B_SLOT; bb2 = bb2 >= (unsigned)B_RING ? 0u : bb2;
-        const unsigned ab1 = (unsigned)A_SLOT - ab;
-        const unsigned a_base = lds0 + A_OFF + ab, b_base = lds0 + bb + b_wave_off;
-        const unsigned a_next = lds0 + A_OFF + ab1, b_next = lds0 + bb1 + b_wave_off;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // fragments (t, k-half 0)
-        __builtin_amdgcn_sched_barrier(0);
-        half_step(ic_<0>{}, ic_<1>{}, ic_<0>{}, a_base, b_base, bb2, sob, krem);
-        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");   // all but B(t+2) landed: step t+1 complete; step t's fragments all read
+    while (true) {
         __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        half_step(ic_<1>{}, ic_<0>{}, ic_<1>{}, a_next, b_next, ab, soa, krem);
-        bb = bb1;
-        ab = ab1;
-        soa += soA1;
-        sob += soB1;
-        krem -= BK;
+        static_for<0, NOPS>([&](auto oc) { frag_op(oc, ic_<0>{}, ic_<0>{}, lds0 + A_OFF, lds0 + b_wave_off); });
+        unsigned bb = 0, ab = 0;                                     // slot offsets of step t in the B / A ring
+        unsigned soa = 2u * soA1, sob = 2u * soB1;                   // scalar K-step offsets of step t + 2
+        int krem = K - 2 * BK;
+        for (int t = 0; t < nk; ++t) {
+            const unsigned bb1 = b_next_slot(bb), bb2 = b_next_slot(bb1);
+            const unsigned ab1 = (unsigned)A_SLOT - ab;
+            const unsigned a_base = lds0 + A_OFF + ab, b_base = lds0 + bb + b_wave_off;
+            const unsigned a_next = lds0 + A_OFF + ab1, b_next = lds0 + bb1 + b_wave_off;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // fragments (t, k-half 0)
+            __builtin_amdgcn_sched_barrier(0);
+            half_step(ic_<0>{}, ic_<1>{}, ic_<0>{}, a_base, b_base, bb2, sob, krem);
+            asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");   // all but B(t+2) landed: step t+1 complete; step t's fragments all read
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            half_step(ic_<1>{}, ic_<0>{}, ic_<1>{}, a_next, b_next, ab, soa, krem);
+            bb = bb1;
+            ab = ab1;
+            soa += soA1;
+            sob += soB1;
+            krem -= BK;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        __syncthreads();                                             // every wave's fragment reads done: the whole ring is free
+        const int cm0 = m0, cn0 = n0, ctile = tile_id;
+        bool more = false;
+        if constexpr (PERSIST) {
+            v += gridDim.x;
+            more = v < ntile;
+            if (more) {
+                // the next tile's first two K-steps fly while this tile's epilogue runs
+                tile_of(v, m0, n0, tile_id);
+                lane_offsets(m0, n0);
+                prologue();
+            }
+        }
+        const int Mlim = (cm0 + BMT) < M ? (cm0 + BMT) : M;          // rows of the short last pass beyond the tile belong to the next tile
+        ring_epilogue<4, NBN, NBM, BKM, SWIGLU, PAIR, false, PB>(acc, smem + STRIP_OFF, wave, tid, lane, wave, C, Mlim, N, ldc, bias, res, ldr, flags,
+                                                                 cm0, cn0, ctile, aux0, aux1, aux_ld, aux_n);
+        if (!more) break;
+#pragma unroll
+        for (int i = 0; i < NBN; ++i)
+#pragma unroll
+            for (int j = 0; j < NBM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // the DMA pieces were issued in front of the epilogue's own loads and stores (vmcnt retires in order): draining the queue costs the
+        // acknowledgement of the last stores, the pieces themselves landed microseconds ago
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-    __syncthreads();
-    const int Mlim = (m0 + BMT) < M ? (m0 + BMT) : M;             // rows of the short third pass beyond the tile belong to the next tile
-    ring_epilogue<4, NBN, NBM, BKM, SWIGLU, PAIR, false>(acc, smem, wave, tid, lane, wave, C, Mlim, N, ldc, bias, res, ldr, flags, m0, n0, tile_id,
-                                                         aux0, aux1, aux_ld, aux_n);
 }
 
+// MANTIS_GEMM_176P (read once): 1 = persistent workgroups with the next tile's first K-steps prefetched under the epilogue (default), 0 = one tile
+// per workgroup (A/B measurements; same results bit for bit)
+static int ring176_persist() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MANTIS_GEMM_176P"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v;
+}
 template <bool BKM, bool SWIGLU = false, int PAIR = PAIR_NONE>
 static int launch_gemm_ring176(hipStream_t s, const bf16_t* A, const bf16_t* B, bf16_t* C, int M, int N, int K, long lda, long ldb, long ldc,
-                               const bf16_t* bias, const bf16_t* res, long ldr, int flags, bf16_t* aux0 = nullptr, const bf16_t* aux1 = nullptr,
-                               long aux_ld = 0, int aux_n = 0) {
-    const int tiles_m = cdiv(M, 176), tiles_n = cdiv(N, 256);
-    MANTIS_LAUNCH((gemm_nt_ring176_kernel<BKM, SWIGLU, PAIR>), dim3(tiles_m * tiles_n), dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias, res,
-                       ldr, flags, tiles_m, tiles_n, aux0, aux1, aux_ld, aux_n);
+                               const bf16_t* bias, const bf16_t* res, long ldr, int flags, int cus, bf16_t* aux0 = nullptr,
+                               const bf16_t* aux1 = nullptr, long aux_ld = 0, int aux_n = 0) {
+    const int tiles_m = cdiv(M, 176), tiles_n = cdiv(N, 256), ntile = tiles_m * tiles_n;
+    if (ring176_persist() && ntile > cus) {
+        MANTIS_LAUNCH((gemm_nt_ring176_kernel<BKM, SWIGLU, PAIR, true>), dim3(cus), dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias, res, ldr,
+                           flags, tiles_m, tiles_n, aux0, aux1, aux_ld, aux_n);
+    } else {
+        MANTIS_LAUNCH((gemm_nt_ring176_kernel<BKM, SWIGLU, PAIR, false>), dim3(ntile), dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias, res,
+                           ldr, flags, tiles_m, tiles_n, aux0, aux1, aux_ld, aux_n);
+    }
     return mantis_check_launch();
 }
-
 // The one symbol gemm.hip links against (not part of the C-ABI: hidden visibility): kind = 0 plain epilogues (flags as mantis_gemm_bf16_nt), 1 / 2 the
 // two-column forward fusions (PAIR_SWIGLU / PAIR_ROPE); bkm = B given K-major; flags & EPI_SWIGLU_BWD selects the fused SwiGLU backward (B K-major).
 __attribute__((visibility("hidden"))) int mantis_launch_ring176(hipStream_t s, const bf16_t* A, const bf16_t* B, bf16_t* C, int M, int N, int K,
                                                                  long lda, long ldb, long ldc, const bf16_t* bias, const bf16_t* res, long ldr,
-                                                                 int flags, int bkm, int kind, bf16_t* aux0, const bf16_t* aux1, long aux_ld,
-                                                                 int aux_n) {
-#define R176_ARGS s, A, B, C, M, N, K, lda, ldb, ldc, bias, res, ldr, flags, aux0, aux1, aux_ld, aux_n
+                                                                 int flags, int bkm, int kind, int cus, bf16_t* aux0, const bf16_t* aux1,
+                                                                 long aux_ld, int aux_n) {
+#define R176_ARGS s, A, B, C, M, N, K, lda, ldb, ldc, bias, res, ldr, flags, cus, aux0, aux1, aux_ld, aux_n
     if (kind == PAIR_SWIGLU) return bkm ? MANTIS_EUNSUPPORTED : launch_gemm_ring176<false, false, PAIR_SWIGLU>(R176_ARGS);
     if (kind == PAIR_ROPE) return bkm ? MANTIS_EUNSUPPORTED : launch_gemm_ring176<false, false, PAIR_ROPE>(R176_ARGS);
     if (flags & EPI_SWIGLU_BWD) return bkm ? launch_gemm_ring176<true, true>(R176_ARGS) : MANTIS_EUNSUPPORTED;

@@ -92,7 +92,7 @@ __device__ __forceinline__ u32x4 epi_ld16(const bf16_t* p) {
 // of the result (row pitch 272 B); lane (rr = lane >> 3, cc = lane & 7) takes 8 consecutive columns of row it*8 + rr, applies bias /
 // activation / residual / accumulate / the fused SwiGLU backward on 16-B vectors and stores 16 B: every global instruction covers 8
 // whole 128-B lines.  Arithmetic and rounding order are those of gemm_epilogue (bit-identical).
-template <bool SWIGLU>
+template <bool SWIGLU, int NIT = 8>
 __device__ __forceinline__ void epi_readback64(const char* __restrict__ strip, bf16_t* __restrict__ C, int M, int N, long ldc,
                                                const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res, long ldr, int flags,
                                                int m_base, int n0w, int lane) {
@@ -102,7 +102,7 @@ __device__ __forceinline__ void epi_readback64(const char* __restrict__ strip, b
     const int rr = lane >> 3, cc = lane & 7;
     const int n = n0w + cc * 8;
 #pragma unroll 2
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         const int row = it * 8 + rr;
         const int m = m_base + row;
         const f32x4 lo = *reinterpret_cast<const f32x4*>(strip + row * EPI_PITCH + cc * 32);
@@ -307,31 +307,32 @@ __device__ __forceinline__ void epi_fast_finish(const EpiPre<G>& p, const char* 
 // global operands travel in groups of G iterations, one group ahead of the arithmetic (G = 8, a whole pass, for residual / accumulate;
 // G = 4 for the SwiGLU backward, which holds two operand sets and whose exp-heavy arithmetic covers the loads of the next half pass --
 // requesting a whole pass up front and then computing measured 4 % slower on dX(down), HBM bursts instead of a stream).
-template <int NBN, int NBM, bool BIAS, int ACT, int PRE, bool SS = false, bool NTS = false>
+template <int NBN, int NBM, bool BIAS, int ACT, int PRE, bool SS = false, bool NTS = false, int PB = 4>
 __device__ __forceinline__ void epi_fast_run(const f32x4 (&acc)[NBN][NBM], char* __restrict__ strip, bf16_t* __restrict__ C, int M, int N,
                                              long ldc, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res, long ldr, int mw0,
                                              int nw0, int lane, float* ss = nullptr) {
-    // NBM need not be a multiple of 4 (the 176-row tile: 11 blocks): the last pass then holds NBM % 4 blocks, i.e. 2 (NBM % 4) read-back
-    // iterations of 8 rows; group g of G iterations carries gvalid(g) <= G live ones (compile time)
-    constexpr int PN = NBN / 4, PM = (NBM + 3) / 4, NPASS = PM * PN;
-    constexpr int G = PRE == EPRE_SWIGLU ? 4 : 8, GPP = 8 / G, NG = NPASS * GPP;
+    // A pass holds PB 16-row blocks (4: the 64-row strips; 3: the persistent 176-row kernel's 48-row strips) and NBM need not be a multiple of
+    // PB (176 rows = 11 blocks): the last pass then holds the rest; a pass is 2 blocks read-back iterations of 8 rows, travelling in groups of
+    // G of which gv <= G are live (compile time)
+    constexpr int PN = NBN / 4, PM = (NBM + PB - 1) / PB, NPASS = PM * PN;
+    constexpr int G = PRE == EPRE_SWIGLU ? 4 : 8, GPP = (2 * PB + G - 1) / G, NG = NPASS * GPP;
     const int rr = lane >> 3, cc = lane & 7;
     char* wr = strip + (lane & 15) * EPI_PITCH + (4 * (lane >> 4)) * 4;
     EpiPre<G> cur, nxt;
-    constexpr int GV0 = (2 * (NBM < 4 ? NBM : 4)) < G ? (2 * (NBM < 4 ? NBM : 4)) : G;
+    constexpr int GV0 = (2 * (NBM < PB ? NBM : PB)) < G ? (2 * (NBM < PB ? NBM : PB)) : G;
     epi_fast_prefetch<PRE, G, GV0>(cur, C, M, N, ldc, res, ldr, mw0, 0, nw0 + cc * 8, rr);
     float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     static_for<0, NG>([&](auto gc) {
         constexpr int g = decltype(gc)::value, pass = g / GPP, sub = g % GPP;
         constexpr int pm = pass / PN, pn = pass % PN;
-        constexpr int blk = (NBM - 4 * pm) < 4 ? (NBM - 4 * pm) : 4;                 // 16-row blocks of this pass
+        constexpr int blk = (NBM - PB * pm) < PB ? (NBM - PB * pm) : PB;             // 16-row blocks of this pass
         constexpr int left = 2 * blk - sub * G, gv = left < 0 ? 0 : (left < G ? left : G);
         const int n = nw0 + pn * 64 + cc * 8;
         if constexpr (g + 1 < NG) {
             constexpr int p1 = (g + 1) / GPP, s1 = (g + 1) % GPP;
-            constexpr int blk1 = (NBM - 4 * (p1 / PN)) < 4 ? (NBM - 4 * (p1 / PN)) : 4;
+            constexpr int blk1 = (NBM - PB * (p1 / PN)) < PB ? (NBM - PB * (p1 / PN)) : PB;
             constexpr int left1 = 2 * blk1 - s1 * G, gv1 = left1 < 0 ? 0 : (left1 < G ? left1 : G);
-            epi_fast_prefetch<PRE, G, gv1>(nxt, C, M, N, ldc, res, ldr, mw0 + (p1 / PN) * 64, s1 * G, nw0 + (p1 % PN) * 64 + cc * 8, rr);
+            epi_fast_prefetch<PRE, G, gv1>(nxt, C, M, N, ldc, res, ldr, mw0 + (p1 / PN) * (PB * 16), s1 * G, nw0 + (p1 % PN) * 64 + cc * 8, rr);
         }
         if constexpr (sub == 0) {
             if constexpr (BIAS) {
@@ -346,9 +347,9 @@ __device__ __forceinline__ void epi_fast_run(const f32x4 (&acc)[NBN][NBM], char*
             for (int tm4 = 0; tm4 < blk; ++tm4)
 #pragma unroll
                 for (int tn4 = 0; tn4 < 4; ++tn4)
-                    *reinterpret_cast<f32x4*>(wr + tm4 * 16 * EPI_PITCH + tn4 * 16 * 4) = acc[pn * 4 + tn4][pm * 4 + tm4];
+                    *reinterpret_cast<f32x4*>(wr + tm4 * 16 * EPI_PITCH + tn4 * 16 * 4) = acc[pn * 4 + tn4][pm * PB + tm4];
         }
-        epi_fast_finish<BIAS, ACT, PRE, G, SS, NTS, gv>(cur, strip, C, M, N, ldc, bv, mw0 + pm * 64, sub * G, n, rr, cc, ss);
+        epi_fast_finish<BIAS, ACT, PRE, G, SS, NTS, gv>(cur, strip, C, M, N, ldc, bv, mw0 + pm * (PB * 16), sub * G, n, rr, cc, ss);
         if constexpr (PRE != EPRE_NONE && g + 1 < NG) cur = nxt;
     });
 }
@@ -378,7 +379,7 @@ __device__ __forceinline__ void mfma16(f32x4& c, const bf16x8& a, const bf16x8& 
 // KM: a K-major operand layout, i.e. a dX / dW launch whose plain result streams out.
 // (round 6: NWV waves per tile, NBN x NBM_ blocks per wave as explicit parameters -- the ring16 kernels are (4, 8, 8) and (8, 4, 8), their
 // finishing passes (., ., 4), the 176-row kernel (4, 4, 11): a last pass of NBM_ % 4 blocks, and the caller passes M clipped to its tile)
-template <int NWV, int NBN, int NBM_, bool KM, bool SWIGLU, int PAIR, bool FIN>
+template <int NWV, int NBN, int NBM_, bool KM, bool SWIGLU, int PAIR, bool FIN, int PB = 4>
 __device__ __forceinline__ void ring_epilogue(const f32x4 (&acc)[NBN][NBM_], char* __restrict__ smem, int wave_l, int tid_l, int lane,
                                                 int wn, bf16_t* __restrict__ C, int M, int N, long ldc, const bf16_t* __restrict__ bias,
                                                 const bf16_t* __restrict__ res, long ldr, int flags, int mw0, int n0, int tile_id,
@@ -386,8 +387,9 @@ __device__ __forceinline__ void ring_epilogue(const f32x4 (&acc)[NBN][NBM_], cha
     // epilogue: the wave tile goes through the wave-private strip in 64 x 64 passes.  Block (tn, tm): lane l holds row tm*16 + (l & 15),
     // columns tn*16 + 4*(l >> 4) .. + 3 -> one 16-B strip write per block (8 consecutive lanes = 8 rows of pitch 272 B: conflict-free)
     constexpr bool TWO = NBN == 8;                        // 128-column wave tiles: two strips per wave in the pair modes
-    constexpr int PM = (NBM_ + 3) / 4;                    // 64-row passes (the last one may hold fewer than 4 blocks)
-    char* strip = smem + wave_l * EPI_STRIP;
+    constexpr int PM = (NBM_ + PB - 1) / PB;              // passes of PB blocks (the last one may hold fewer)
+    constexpr int STRIP = PB * 16 * EPI_PITCH;            // a wave's strip: PB * 16 rows (PB = 4: EPI_STRIP)
+    char* strip = smem + wave_l * STRIP;
     const int nw0 = n0 + wn * (NBN * 16);
     const int pair_dist = PAIR == PAIR_SWIGLU ? (N >> 1) : 64;
     auto pair_first = [&](int phi) { return PAIR == PAIR_SWIGLU ? (n0 >> 1) + phi : n0 + (phi >> 6) * 128 + (phi & 63); };
@@ -398,26 +400,26 @@ __device__ __forceinline__ void ring_epilogue(const f32x4 (&acc)[NBN][NBM_], cha
         // 8 waves: one strip per wave (8 x 17 KiB): its 64 columns are [32 first | 32 second] -- the plain strip fill; per 64-row pass, lane
         //          (r16 = lane >> 2, fg = lane & 3) reads the first columns at fg*8 and the second ones at 32 + fg*8 of row it*16 + r16
         constexpr int G = NBN * 8;
-        char* sa = smem + (TWO ? 2 * wave_l : wave_l) * EPI_STRIP;
-        char* sb = TWO ? sa + EPI_STRIP : sa + 32 * 4;
+        char* sa = smem + (TWO ? 2 * wave_l : wave_l) * STRIP;
+        char* sb = TWO ? sa + STRIP : sa + 32 * 4;
         const int phi0 = wn * G;
         const int rr = TWO ? lane >> 3 : lane >> 2, cc = TWO ? lane & 7 : lane & 3;
         constexpr int RPI = TWO ? 8 : 16;                  // rows per read-back iteration
         const bool has_bias = flags & EPI_BIAS;
 #pragma unroll
         for (int pass = 0; pass < PM; ++pass) {
-            const int blk = (NBM_ - 4 * pass) < 4 ? (NBM_ - 4 * pass) : 4;      // (compile-time after unrolling)
+            const int blk = (NBM_ - PB * pass) < PB ? (NBM_ - PB * pass) : PB;      // (compile-time after unrolling)
 #pragma unroll
-            for (int tm4 = 0; tm4 < 4; ++tm4)
+            for (int tm4 = 0; tm4 < PB; ++tm4)
 #pragma unroll
                 for (int tn4 = 0; tn4 < 4; ++tn4) {
                     if (tm4 >= blk) continue;
                     const int off = (tm4 * 16 + (lane & 15)) * EPI_PITCH + (tn4 * 16 + 4 * (lane >> 4)) * 4;
                     if constexpr (TWO) {
-                        *reinterpret_cast<f32x4*>(sa + off) = acc[tn4][pass * 4 + tm4];
-                        *reinterpret_cast<f32x4*>(sb + off) = acc[4 + tn4][pass * 4 + tm4];
+                        *reinterpret_cast<f32x4*>(sa + off) = acc[tn4][pass * PB + tm4];
+                        *reinterpret_cast<f32x4*>(sb + off) = acc[4 + tn4][pass * PB + tm4];
                     } else {
-                        *reinterpret_cast<f32x4*>(sa + off) = acc[tn4][pass * 4 + tm4];      // blocks 0,1 = first, 2,3 = second columns
+                        *reinterpret_cast<f32x4*>(sa + off) = acc[tn4][pass * PB + tm4];      // blocks 0,1 = first, 2,3 = second columns
                     }
                 }
             const int phi = phi0 + cc * 8;
@@ -436,7 +438,7 @@ __device__ __forceinline__ void ring_epilogue(const f32x4 (&acc)[NBN][NBM_], cha
 #pragma unroll
                     for (int it = 0; it < 64 / RPI; ++it) {
                         if (it * RPI >= blk * 16) continue;
-                        int m = mw0 + pass * 64 + it * RPI + rr;
+                        int m = mw0 + pass * (PB * 16) + it * RPI + rr;
                         m = m < M ? m : M - 1;
                         vcs[it] = *reinterpret_cast<const u32x4*>(aux0 + (long)m * aux_ld + (phi & 63));
                         vss[it] = *reinterpret_cast<const u32x4*>(aux1 + (long)m * aux_ld + (phi & 63));
@@ -447,7 +449,7 @@ __device__ __forceinline__ void ring_epilogue(const f32x4 (&acc)[NBN][NBM_], cha
             for (int it = 0; it < 64 / RPI; ++it) {
                 if (it * RPI >= blk * 16) continue;
                 const int row = it * RPI + rr;
-                const int m = mw0 + pass * 64 + row;
+                const int m = mw0 + pass * (PB * 16) + row;
                 const f32x4 alo = *reinterpret_cast<const f32x4*>(sa + row * EPI_PITCH + cc * 32);
                 const f32x4 ahi = *reinterpret_cast<const f32x4*>(sa + row * EPI_PITCH + cc * 32 + 16);
                 const f32x4 blo = *reinterpret_cast<const f32x4*>(sb + row * EPI_PITCH + cc * 32);
@@ -511,17 +513,17 @@ __device__ __forceinline__ void ring_epilogue(const f32x4 (&acc)[NBN][NBM_], cha
         const bool vec_ok = !(ldc & 7) && !((uintptr_t)C & 15) && (!needs_res || (!(ldr & 7) && !((uintptr_t)res & 15))) &&
                             (!(flags & EPI_BIAS) || !((uintptr_t)bias & 15)) && (!(flags & EPI_SWIGLU_BWD) || !(N & 7));
         if (vec_ok && nw0 + NBN * 16 <= N) {
-#define EPI_FAST(B_, A_, P_, NT_) epi_fast_run<NBN, NBM_, B_, A_, P_, false, NT_>(acc, strip, C, M, N, ldc, bias, res, ldr, mw0, nw0, lane)
+#define EPI_FAST(B_, A_, P_, NT_) epi_fast_run<NBN, NBM_, B_, A_, P_, false, NT_, PB>(acc, strip, C, M, N, ldc, bias, res, ldr, mw0, nw0, lane)
             if constexpr (!SWIGLU && PAIR == PAIR_NONE) {
                 if (flags & EPI_SUMSQ) {
                     // weight-gradient launches of mantis_gemm_bf16_nt_sumsq: the squared norm of the stored tile rides along (the optimizer's
                     // global gradient norm then needs no pass of its own over these 16 GB).  Lane partials in a fixed order, DPP wave sum,
                     // waves summed in order by thread 0: deterministic.  The entry point guarantees the fast path for every wave.
                     float ss = 0.f;
-                    if (flags & EPI_ACCUM) epi_fast_run<NBN, NBM_, false, 0, EPRE_ACC, true, true>(acc, strip, C, M, N, ldc, bias, res, ldr, mw0, nw0, lane, &ss);
-                    else epi_fast_run<NBN, NBM_, false, 0, EPRE_NONE, true, true>(acc, strip, C, M, N, ldc, bias, res, ldr, mw0, nw0, lane, &ss);
+                    if (flags & EPI_ACCUM) epi_fast_run<NBN, NBM_, false, 0, EPRE_ACC, true, true, PB>(acc, strip, C, M, N, ldc, bias, res, ldr, mw0, nw0, lane, &ss);
+                    else epi_fast_run<NBN, NBM_, false, 0, EPRE_NONE, true, true, PB>(acc, strip, C, M, N, ldc, bias, res, ldr, mw0, nw0, lane, &ss);
                     ss = wave_sum(ss);
-                    float* red = reinterpret_cast<float*>(smem + NWV * EPI_STRIP);
+                    float* red = reinterpret_cast<float*>(smem + NWV * STRIP);
                     if (lane == 0) red[wave_l] = ss;
                     __syncthreads();
                     if (tid_l == 0) {
@@ -558,14 +560,14 @@ __device__ __forceinline__ void ring_epilogue(const f32x4 (&acc)[NBN][NBM_], cha
 #pragma unroll
         for (int pn = 0; pn < NBN / 4; ++pn) {
 #pragma unroll
-            for (int tm4 = 0; tm4 < 4; ++tm4)
+            for (int tm4 = 0; tm4 < PB; ++tm4)
 #pragma unroll
                 for (int tn4 = 0; tn4 < 4; ++tn4) {
-                    if (pm * 4 + tm4 >= NBM_) continue;       // the short last pass: rows past the tile are cut off by the caller's M
+                    if (pm * PB + tm4 >= NBM_) continue;      // the short last pass: rows past the tile are cut off by the caller's M
                     *reinterpret_cast<f32x4*>(strip + (tm4 * 16 + (lane & 15)) * EPI_PITCH + (tn4 * 16 + 4 * (lane >> 4)) * 4) =
-                        acc[pn * 4 + tn4][pm * 4 + tm4];
+                        acc[pn * 4 + tn4][pm * PB + tm4];
                 }
-            epi_readback64<SWIGLU>(strip, C, M, N, ldc, bias, res, ldr, flags, mw0 + pm * 64, nw0 + pn * 64, lane);
+            epi_readback64<SWIGLU, 2 * PB>(strip, C, M, N, ldc, bias, res, ldr, flags, mw0 + pm * (PB * 16), nw0 + pn * 64, lane);
         }
 }
 

@@ -88,6 +88,8 @@ def gemm_nt(a, b, bias=None, act=None, residual=None, out=None, accumulate=False
         _chk2d(out, "out")
     C = out
     ctx = _launch()
+    if cus is not None and not 0 <= int(cus) <= 4095:
+        raise ValueError(f"cus must be in [0, 4095] (0 = the library's default), got {cus}")
     flags = (1 if bias is not None else 0) | (GEMM_ACT[act] << 1) | (16 if residual is not None else 0) | (32 if accumulate else 0) \
         | (variant << 8) | (4096 if a_kmajor else 0) | (8192 if b_kmajor else 0) | ((ctx.gemm_cus if cus is None else cus) << CUS_SHIFT) \
         | (SK_INKERNEL if sk_inkernel else 0)

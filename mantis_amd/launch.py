@@ -21,7 +21,10 @@ class LaunchContext:
     __slots__ = ("timer", "dw_sumsq", "gemm_cus")
 
     def __init__(self, timer=None, dw_sumsq=None, gemm_cus=0):
-        self.timer, self.dw_sumsq, self.gemm_cus = timer, dw_sumsq, int(gemm_cus)
+        gemm_cus = int(gemm_cus)
+        if not 0 <= gemm_cus <= 4095:          # the budget travels in bits 16-27 of the GEMM flags word (round-5 advisor finding)
+            raise ValueError(f"gemm_cus must be in [0, 4095] (0 = the library's default), got {gemm_cus}")
+        self.timer, self.dw_sumsq, self.gemm_cus = timer, dw_sumsq, gemm_cus
 
     def __repr__(self):
         return (f"LaunchContext(timer={'on' if self.timer is not None else None}, dw_sumsq={'on' if self.dw_sumsq is not None else None}, "

@@ -84,6 +84,49 @@ def check_gemm_ring176_accumulate():
     return worst
 
 
+def check_gemm_ring176_persistent():
+    """The 176-row kernel runs PERSISTENT workgroups when a launch has more tiles than CUs: every workgroup walks several tiles, the next tile's
+    first two K-steps fly under the current tile's epilogue, whose strips are 48-row passes in another part of the LDS.  Same arithmetic in
+    the same order: a launch planned for 8 / 24 CUs (persistent, 6 ... 40 tiles per workgroup) must be BIT-identical to the one-tile-per-
+    workgroup launch of the same shape (<= 256 tiles: not persistent), for every epilogue kind, both B layouts and the fused forward forms."""
+    k = K()
+    worst = 0.0
+    M, N, K_ = 1409, 1032, 520                                   # 9 x 5 = 45 tiles, ragged everywhere
+    a, b = rnd(M, K_, seed=81), rnd(N, K_, seed=82, scale=0.1)
+    bias, res = rnd(N, seed=83), rnd(M, N, seed=84)
+    ad, bd, bkd = a.to(DEV), b.to(DEV), b.t().contiguous().to(DEV)
+    for kw, name in [(dict(), "plain"), (dict(bias=bias.to(DEV)), "bias"), (dict(residual=res.to(DEV)), "res"),
+                     (dict(bias=bias.to(DEV), act="gelu_pytorch_tanh"), "bias+tanh"), (dict(bias=bias.to(DEV), residual=res.to(DEV)), "bias+res")]:
+        for bkm in (False, True):
+            one = k.gemm_nt(ad, bkd if bkm else bd, b_kmajor=bkm, variant=15, **kw)
+            for cus in (8, 24):
+                per = k.gemm_nt(ad, bkd if bkm else bd, b_kmajor=bkm, variant=15, cus=cus, **kw)
+                assert torch.equal(one, per), f"persistent 176-row launch ({cus} CUs, {name}, bkm={bkm}) differs from the one-tile-per-workgroup launch"
+        ref = R.gemm_nt(a, b, bias=bias if "bias" in kw else None, act=kw.get("act"), residual=res if "residual" in kw else None)
+        worst = max(worst, close(one, ref, 1e-2, f"ring176 {name}"))
+    c0 = rnd(M, N, seed=85).to(DEV)
+    c1, c2 = c0.clone(), c0.clone()
+    k.gemm_nt(ad, bd, out=c1, accumulate=True, variant=15)
+    k.gemm_nt(ad, bd, out=c2, accumulate=True, variant=15, cus=8)
+    assert torch.equal(c1, c2), "persistent 176-row launch: accumulate differs"
+    # fused forward forms + SwiGLU backward through the caller's context
+    x, wq = rnd(700, 512, seed=86).to(DEV), rnd(1024, 512, seed=87, scale=0.1).to(DEV)
+    pos = torch.arange(700, dtype=torch.int64) % 977
+    inv = 1.0 / (500000.0 ** (torch.arange(0, 128, 2, dtype=torch.float32) / 128))
+    cd, sd = k.rope_table(pos.to(DEV), inv.to(DEV))
+    wg = rnd(2 * 768, 512, seed=88, scale=0.1).to(DEV)
+    dy, wdn, gu = rnd(700, 512, seed=89).to(DEV), rnd(512, 1024, seed=90, scale=0.1).to(DEV), rnd(700, 2048, seed=91).to(DEV)
+    q1 = k.linear_qkv_rope(x, wq, None, cd, sd, 6, 128, variant=15)
+    g1, a1 = k.linear_gu_swiglu(x, wg, variant=15)
+    d1 = k.linear_dx_swiglu(dy, wdn, gu, variant=15)
+    with k.launch_context(k.LaunchContext(gemm_cus=8)):
+        q2 = k.linear_qkv_rope(x, wq, None, cd, sd, 6, 128, variant=15)
+        g2, a2 = k.linear_gu_swiglu(x, wg, variant=15)
+        d2 = k.linear_dx_swiglu(dy, wdn, gu, variant=15)
+    assert torch.equal(q1, q2) and torch.equal(g1, g2) and torch.equal(a1, a2) and torch.equal(d1, d2), "persistent 176-row launch: fused epilogues differ"
+    return worst
+
+
 def check_gemm_ring176_planner():
     """The automatic choice takes the 176-row tile exactly where it turns the grid into whole rounds on this device (the M = 5624 forward / dX
     shapes with N = 4096 / 6144) and the result of the automatic launch is then bit-identical to the forced variant 15; shapes whose 256-row
@@ -2559,6 +2602,7 @@ def all_checks():
     c["gemm_ring176_accumulate"] = check_gemm_ring176_accumulate
     c["gemm_ring176_operand_over_2gib"] = lambda: check_gemm_operand_over_2gib(15, kmajor_a=False)
     c["gemm_ring176_planner"] = check_gemm_ring176_planner
+    c["gemm_ring176_persistent"] = check_gemm_ring176_persistent
     for (M, d, I) in [(333, 64, 128), (700, 768, 3072), (520, 256, 1152)]:
         c[f"linear_gu_swiglu_fused_v15_{M}x{d}x{I}"] = (lambda M=M, d=d, I=I: check_linear_gu_swiglu_fused(M, d, I, 15))
     for (M, d, H, Hkv, bias) in [(333, 64, 2, 1, False), (700, 512, 4, 2, True), (1000, 256, 6, 1, True)]:
