@@ -677,8 +677,10 @@ def main():
         sync()
         reducer.collect_exposed_ms()
         reducer.stats.update(buckets=0, bytes=0, exposed_ms=[], steps=0)
-    timer = None if (args.no_kernel_timer or host_only) else []
-    trainer.launch.timer = timer          # per-launch HIP events around every GEMM of THIS trainer's steps (launch.LaunchContext)
+    # The timed region runs BARE (round-5 verdict, weak 3): no per-launch events.  The ~800 torch.cuda.Event.record() per step that feed
+    # `roofline` (a marker packet between dependent kernels each) are taken on `args.steps` MORE steps right after the timed region, same
+    # workload, same process; `ms_per_step_with_timer` is what those instrumented steps cost, so the price of the instrument is on the line.
+    trainer.launch.timer = None
     sync()
     if world > 1:
         dist.barrier()
@@ -691,11 +693,23 @@ def main():
         dist.barrier()
     sync()
     elapsed = time.perf_counter() - t0
-    trainer.launch.timer = None
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
+    timer = None if (args.no_kernel_timer or host_only) else []
+    ms_with_timer = None
+    n_extra = 0
+    if timer is not None:
+        trainer.launch.timer = timer      # per-launch HIP events around every GEMM of THIS trainer's steps (launch.LaunchContext)
+        sync()
+        ti0 = time.perf_counter()
+        for i in range(args.steps):
+            one_step(args.warmup + args.steps + i)
+        sync()
+        ms_with_timer = 1e3 * (time.perf_counter() - ti0) / args.steps
+        trainer.launch.timer = None
+        n_extra = args.steps
     # second family definition (round-4 verdict: keep rounds comparable): with --vision-prefetch early the tower's GEMMs run on the prefetch
     # stream and are outside `roofline.achieved`; two more steps with the tower IN LINE on the compute stream (after one untimed transition
     # step that still picks up a prefetched tower) give the family as rounds 1 - 3 defined it -- every bf16 GEMM launch of the step
@@ -703,11 +717,11 @@ def main():
     if timer is not None and args.prefetch_early and on_gpu and world == 1 and not host_only:
         trainer.prefetch_early = False
         nxt_keep, args.prefetch = args.prefetch, False
-        one_step(args.warmup + args.steps)
+        one_step(args.warmup + args.steps + n_extra)
         inline_timer = []
         trainer.launch.timer = inline_timer
         for i in range(2):
-            one_step(args.warmup + args.steps + 1 + i)
+            one_step(args.warmup + args.steps + n_extra + 1 + i)
         sync()
         trainer.launch.timer = None
         trainer.prefetch_early, args.prefetch = True, nxt_keep
@@ -782,6 +796,8 @@ def main():
             # traffic / MFMA-busy come from PMC passes, which this run does not make: the LIVE fields are null; what the builder's own
             # PMC passes of the same command measured (another box, another day) is carried under a separately named key
             roof = dict(bound="mfma", kernel=kname, achieved=round(ach, 1),
+                        measured_on=(f"{args.steps} instrumented steps (HIP events around every GEMM launch on its launch stream) right after the bare "
+                                     f"timed region" if args.loop != "hf" else "the timed steps of the HF loop (instrumented)"),
                         peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4), bf16_gemm_family=bf16_family,
                         traffic=None, mfma_busy_pct=None,
                         pmc_static=None if not pmc else dict(
@@ -870,6 +886,8 @@ def main():
                    ms_per_step=round(ms, 2),
                    ms_per_step_median=round(_pct(step_ms, 0.5), 2), ms_per_step_p10=round(_pct(step_ms, 0.1), 2),
                    ms_per_step_p90=round(_pct(step_ms, 0.9), 2),
+                   ms_per_step_with_timer=None if (ms_with_timer is None or args.loop == "hf") else round(ms_with_timer, 2),
+                   timed_region=("HF loop, per-launch GEMM events on" if args.loop == "hf" else "bare: no per-launch events inside the timed steps"),
                    ms_training_step=round(_pct(ts_ms, 0.5), 2),
                    ms_training_step_p10=round(_pct(ts_ms, 0.1), 2), ms_training_step_p90=round(_pct(ts_ms, 0.9), 2),
                    ms_optimizer=round(_pct([e[1].elapsed_time(e[2]) for e in split], 0.5), 2) if opt is not None else None,

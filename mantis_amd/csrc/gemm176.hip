@@ -21,6 +21,9 @@
 // five (a wave-uniform branch; the counted wait names only the uniform B pieces).  A is row-major (forward and dX: the M side is the
 // activation); B row-major (forward) or K-major (dX reads the weight as stored).  Epilogue: ring_epilogue<4, 4, 11> -- the ring16 code with a
 // short third pass (48 rows) -- plain / bias / activations / residual / accumulate / fused SwiGLU backward / the two-column forward fusions.
+#ifndef R176_FASTSW
+#define R176_FASTSW 8       // read-back group of the fused SwiGLU backward (0 = the general read-back, 4, 8)
+#endif
 template <bool BKM, bool SWIGLU = false, int PAIR = PAIR_NONE, bool PERSIST = true>
 __global__ __launch_bounds__(256) void gemm_nt_ring176_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C, int M, int N, int K, long lda, long ldb,
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(256) void gemm_nt_ring176_kernel(
             }
         }
         const int Mlim = (cm0 + BMT) < M ? (cm0 + BMT) : M;          // rows of the short last pass beyond the tile belong to the next tile
-        ring_epilogue<4, NBN, NBM, BKM, SWIGLU, PAIR, false, PB>(acc, smem + STRIP_OFF, wave, tid, lane, wave, C, Mlim, N, ldc, bias, res, ldr, flags,
+        ring_epilogue<4, NBN, NBM, BKM, SWIGLU, PAIR, false, PB, R176_FASTSW>(acc, smem + STRIP_OFF, wave, tid, lane, wave, C, Mlim, N, ldc, bias, res, ldr, flags,
                                                                  cm0, cn0, ctile, aux0, aux1, aux_ld, aux_n);
         if (!more) break;
 #pragma unroll

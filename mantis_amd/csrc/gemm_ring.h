@@ -307,7 +307,7 @@ __device__ __forceinline__ void epi_fast_finish(const EpiPre<G>& p, const char* 
 // global operands travel in groups of G iterations, one group ahead of the arithmetic (G = 8, a whole pass, for residual / accumulate;
 // G = 4 for the SwiGLU backward, which holds two operand sets and whose exp-heavy arithmetic covers the loads of the next half pass --
 // requesting a whole pass up front and then computing measured 4 % slower on dX(down), HBM bursts instead of a stream).
-template <int NBN, int NBM, bool BIAS, int ACT, int PRE, bool SS = false, bool NTS = false, int PB = 4>
+template <int NBN, int NBM, bool BIAS, int ACT, int PRE, bool SS = false, bool NTS = false, int PB = 4, int SWG = 4>
 __device__ __forceinline__ void epi_fast_run(const f32x4 (&acc)[NBN][NBM], char* __restrict__ strip, bf16_t* __restrict__ C, int M, int N,
                                              long ldc, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res, long ldr, int mw0,
                                              int nw0, int lane, float* ss = nullptr) {
@@ -315,7 +315,7 @@ __device__ __forceinline__ void epi_fast_run(const f32x4 (&acc)[NBN][NBM], char*
     // PB (176 rows = 11 blocks): the last pass then holds the rest; a pass is 2 blocks read-back iterations of 8 rows, travelling in groups of
     // G of which gv <= G are live (compile time)
     constexpr int PN = NBN / 4, PM = (NBM + PB - 1) / PB, NPASS = PM * PN;
-    constexpr int G = PRE == EPRE_SWIGLU ? 4 : 8, GPP = (2 * PB + G - 1) / G, NG = NPASS * GPP;
+    constexpr int G = PRE == EPRE_SWIGLU ? SWG : 8, GPP = (2 * PB + G - 1) / G, NG = NPASS * GPP;
     const int rr = lane >> 3, cc = lane & 7;
     char* wr = strip + (lane & 15) * EPI_PITCH + (4 * (lane >> 4)) * 4;
     EpiPre<G> cur, nxt;
@@ -379,7 +379,7 @@ __device__ __forceinline__ void mfma16(f32x4& c, const bf16x8& a, const bf16x8& 
 // KM: a K-major operand layout, i.e. a dX / dW launch whose plain result streams out.
 // (round 6: NWV waves per tile, NBN x NBM_ blocks per wave as explicit parameters -- the ring16 kernels are (4, 8, 8) and (8, 4, 8), their
 // finishing passes (., ., 4), the 176-row kernel (4, 4, 11): a last pass of NBM_ % 4 blocks, and the caller passes M clipped to its tile)
-template <int NWV, int NBN, int NBM_, bool KM, bool SWIGLU, int PAIR, bool FIN, int PB = 4>
+template <int NWV, int NBN, int NBM_, bool KM, bool SWIGLU, int PAIR, bool FIN, int PB = 4, int FASTSW = 0>
 __device__ __forceinline__ void ring_epilogue(const f32x4 (&acc)[NBN][NBM_], char* __restrict__ smem, int wave_l, int tid_l, int lane,
                                                 int wn, bf16_t* __restrict__ C, int M, int N, long ldc, const bf16_t* __restrict__ bias,
                                                 const bf16_t* __restrict__ res, long ldr, int flags, int mw0, int n0, int tile_id,
@@ -537,6 +537,13 @@ __device__ __forceinline__ void ring_epilogue(const f32x4 (&acc)[NBN][NBM_], cha
                     }
                     return;
                 }
+            }
+            if constexpr (SWIGLU && FASTSW != 0) {
+                // the 176-row kernel (one wave per SIMD, nothing else on the CU to hide a memory round trip): the SwiGLU backward on the fast
+                // read-back, gate | up of FASTSW iterations (4 or 8) requested one group ahead -- measured per tile on few CUs:
+                // profiles/r06_experiments.md
+                epi_fast_run<NBN, NBM_, false, 0, EPRE_SWIGLU, false, true, PB, FASTSW>(acc, strip, C, M, N, ldc, bias, res, ldr, mw0, nw0, lane);
+                return;
             }
             if constexpr (!SWIGLU) {      // the SwiGLU-backward read-back stays on the general path: its tile moves 512 KiB (gate, up in; dgate, dup
                                           // out) and is HBM-bound either way; requesting operands ahead measured 3 - 4 % SLOWER on dX(down) (bursts)

@@ -58,3 +58,41 @@ def test_attn_dq64_owns_its_accumulator_file():
     import attn_dq64_audit as A
     problems = A.audit(A.assembly())
     assert not problems, problems
+
+
+def test_async_lds_read_audit_detects_a_touched_destination(tmp_path):
+    """tools/lds_async_read_audit.py on a hand-written stream: a v_mov of a hand-issued read's destination in front of its wait is a violation,
+    the same move behind the wait is not, a counted wait retires exactly the older reads, and a scalar load makes a counted wait meaningless."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import lds_async_read_audit as A
+    def run(body):
+        p = tmp_path / "k.s"
+        p.write_text("_Z1kv:\n" + body + "\n\ts_endpgm\n")
+        return A.audit(str(p))[0]
+    ok = "\tds_read_b64_tr_b16 v[4:5], v1 offset:64\n\tds_read_b64_tr_b16 v[6:7], v2\n\tv_add_u32_e32 v9, v1, v2\n\ts_waitcnt lgkmcnt(0)\n\tv_mov_b32_e32 v8, v4"
+    assert run(ok) == []
+    bad = "\tds_read_b64_tr_b16 v[4:5], v1\n\tv_mov_b32_e32 v8, v5\n\ts_waitcnt lgkmcnt(0)"
+    v = run(bad)
+    assert len(v) == 1 and v[0][3] == {5}
+    counted = "\tds_read_b64_tr_b16 v[4:5], v1\n\tds_read_b64_tr_b16 v[6:7], v1\n\ts_waitcnt lgkmcnt(1)\n\tv_mov_b32_e32 v8, v4\n\tv_mov_b32_e32 v9, v6\n\ts_waitcnt lgkmcnt(0)"
+    v = run(counted)
+    assert len(v) == 1 and v[0][3] == {6}
+    smem = "\ts_load_dword s4, s[0:1], 0x0\n\tds_read_b64_tr_b16 v[4:5], v1\n\tds_read_b64_tr_b16 v[6:7], v1\n\ts_waitcnt lgkmcnt(1)"
+    assert any("scalar memory" in x[4] for x in run(smem))
+    accv = "\tds_read_b128 v[4:7], v1\n\tv_accvgpr_write_b32 a0, v6\n\ts_waitcnt lgkmcnt(0)"
+    assert len(run(accv)) == 1
+
+
+@pytest.mark.skipif(os.environ.get("MANTIS_SKIP_BUILD_AUDIT") == "1", reason="MANTIS_SKIP_BUILD_AUDIT=1")
+@pytest.mark.parametrize("unit", ["attn", "gemm176", "gemm"])
+def test_hand_issued_lds_reads_are_not_touched_before_their_wait(unit):
+    """Round-5 advisor finding (csrc/attn.hip, dK/dV group kernel): a fragment requested by one asm statement and waited for by a later one
+    must not be named by any instruction in between -- the compiler thinks it is defined at issue.  Checked on the built assembly of every
+    kernel that uses the idiom (the dK/dV kernels' transposing reads, the ring GEMMs' fragment reads)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import lds_async_read_audit as A
+    viol, counts = A.audit(A.compile_asm(unit))
+    assert counts, "no kernel found"
+    assert not viol, [(k, n, c, sorted(r)) for k, n, c, r, _ in viol[:6]]
+    if unit == "attn":
+        assert any("dkv_g4" in k and c >= 500 for k, c in counts.items()), "the dK/dV group kernel's hand-issued reads were not seen"

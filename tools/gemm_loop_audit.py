@@ -19,10 +19,23 @@ FORBIDDEN = ("scratch_", "v_accvgpr_write", "v_accvgpr_read", "v_accvgpr_mov", "
 
 
 def compile_asm(src):
-    from mantis_amd.build import FLAGS, _hipcc
-    out = os.path.join(tempfile.mkdtemp(), "gemm.s")
-    subprocess.run([_hipcc(), *FLAGS, "-I", os.path.join(ROOT, "mantis_amd", "csrc"), "-S", "--cuda-device-only", src, "-o", out], check=True,
+    """assembly of `src` under the product's flags; cached per (source + headers + flags) digest so that the audits of one test session
+    (K loops, asynchronous LDS reads) compile a translation unit once (gemm.hip takes ~3 minutes)"""
+    from mantis_amd.build import FLAGS, EXTRA_FLAGS, _hipcc, _digest
+    base = os.path.splitext(os.path.basename(src))[0]
+    extra = EXTRA_FLAGS.get(base, [])
+    try:
+        dig = _digest(src, base)
+    except OSError:
+        dig = None
+    cache = os.path.join(tempfile.gettempdir(), f"mantis_audit_{base}_{dig}.s") if dig else None
+    if cache and os.path.exists(cache) and os.path.getsize(cache) > 0:
+        return cache
+    out = cache or os.path.join(tempfile.mkdtemp(), base + ".s")
+    tmp = out + f".{os.getpid()}.tmp"
+    subprocess.run([_hipcc(), *FLAGS, *extra, "-I", os.path.join(ROOT, "mantis_amd", "csrc"), "-S", "--cuda-device-only", src, "-o", tmp], check=True,
                    stderr=subprocess.DEVNULL)
+    os.replace(tmp, out)
     return out
 
 
