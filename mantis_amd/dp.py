@@ -34,6 +34,16 @@ import torch
 import torch.distributed as dist
 
 
+def rs_ag_chunk(n, rank, world):
+    """[a, b): the slice of an n-element bucket that `rank` owns between the reduce-scatter and the all-gather of MANTIS_DP_ALGO=rs_ag, or
+    None when the bucket cannot be cut into `world` equal chunks (RCCL's in-place tensor forms need n % world == 0: the bucket then takes the
+    plain all-reduce).  The chunks of the ranks tile [0, n) in rank order -- what reduce_scatter_tensor / all_gather_into_tensor assume."""
+    if world < 1 or n < world or n % world:
+        return None
+    c = n // world
+    return rank * c, (rank + 1) * c
+
+
 class GradReducer:
     def __init__(self, model, process_group=None, algo=None, gemm_cus=0):
         """gemm_cus: compute units the GEMM tile scheduler should plan for while this reducer's collectives run (every RCCL channel is a
@@ -129,11 +139,11 @@ class GradReducer:
         """Enqueue the mean over ranks of the flat bf16 slice `t`, in place.  Returns (handles, post) where post is host work to
         run after the handles complete (gloo only)."""
         if self._is_nccl():
-            n = t.numel()
-            if self.algo == "rs_ag" and n % self.world == 0 and n >= self.world:
+            ab = rs_ag_chunk(t.numel(), self.rank, self.world) if self.algo == "rs_ag" else None
+            if ab is not None:
                 # in-place reduce-scatter into this rank's chunk, then all-gather the chunks back: both phases are one
                 # direct exchange per peer on the fully connected node
-                chunk = t[self.rank * (n // self.world): (self.rank + 1) * (n // self.world)]
+                chunk = t[ab[0]: ab[1]]
                 h1 = dist.reduce_scatter_tensor(chunk, t, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
                 h2 = dist.all_gather_into_tensor(t, chunk, group=self.pg, async_op=True)
                 return [h1, h2], None

@@ -250,6 +250,10 @@ class LlavaEngine:
             return out
 
         # ================================================================================================ backward (row J)
+        cb = getattr(self, "_on_backward_start", None)
+        if cb is not None:               # MantisHipTrainer.prefetch_point == "backward": the next batch's tower is queued here
+            self._on_backward_start = None
+            cb()
         g = m.grads                      # dict name -> grad view (None if frozen)
         acc = not overwrite_grads
 

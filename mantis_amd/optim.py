@@ -118,22 +118,35 @@ class FusedAdamW(torch.optim.Optimizer):
 
     # ---- checkpoint / resume (train_mllava.py:281-294 resumes from the newest checkpoint-*; HF saves optimizer.state_dict() with torch.save)
     def _layout(self):
+        """[name, elements, offset in the flat state] per trainable parameter, in arena order.  The offset (round 6, advisor finding) pins the
+        placement rule the state was written under: names and sizes alone cannot tell two alignments apart."""
         m = self.model
-        return [[n, int(m._param(n).numel())] for n in self._names]
+        base = m.grad_arena.data_ptr() if getattr(m, "grad_arena", None) is not None else None
+        out = []
+        for n in self._names:
+            p = m._param(n)
+            g = getattr(p, "grad", None)
+            off = None
+            if base is not None and g is not None:
+                off = int((g.data_ptr() - base) // g.element_size())
+            out.append([n, int(p.numel())] if off is None else [n, int(p.numel()), off])
+        return out
 
     def state_dict(self):
-        """The flat state (references, no copies, except `master_hi`) + the step count + the hyper-parameters + the layout the arenas
-        belong to.  master_hi: the bf16 parameters in the gradient arena's layout (a copy: the checkpoint is self-contained);
-        master_lo: the masters' low 16 bits; exp_avg_sq AS STORED: its sign bit is a master's tie bit, its magnitude Adam's second moment."""
+        """The flat state + the step count + the hyper-parameters + the layout the arenas belong to.  `master_lo`, `exp_avg`, `exp_avg_sq` are
+        REFERENCES to the live device arrays (no copies); `master_hi` -- the bf16 parameters in the gradient arena's layout, which makes the
+        checkpoint self-contained -- is a copy, assembled on the HOST segment by segment (round 6: it used to be a second 16-GB device
+        array at every save).  exp_avg_sq is stored AS KEPT: its sign bit is a master's tie bit, its magnitude Adam's second moment --
+        `exp_avg_sq_is_signed` says so; consumers that want Adam's v call `second_moment()` or `export_fp32_state()`."""
         g = self.param_groups[0]
         group = {k: (list(v) if isinstance(v, tuple) else v) for k, v in g.items() if k != "params"}
         group["params"] = list(range(len(g["params"])))
         m = self.model
-        hi = torch.zeros(self.master_lo.numel(), dtype=m.arena.dtype, device=self.master_lo.device)
+        hi = torch.zeros(self.master_lo.numel(), dtype=m.arena.dtype, device="cpu")
         for p_off, g_off, cnt, _ in self._segments:
             hi[g_off:g_off + cnt].copy_(m.arena[p_off:p_off + cnt])
         return {"format": STATE_FORMAT, "step": int(self.step_count), "layout": self._layout(), "arena_align": ARENA_ALIGN,
-                "master_hi": hi, "master_lo": self.master_lo, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
+                "exp_avg_sq_is_signed": True, "master_hi": hi, "master_lo": self.master_lo, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
                 "param_groups": [group]}
 
     def export_fp32_state(self):
@@ -155,13 +168,23 @@ class FusedAdamW(torch.optim.Optimizer):
             raise ValueError(f"not a FusedAdamW state (format {sd.get('format')!r}, expected {STATE_FORMAT!r}); a torch.optim.AdamW state "
                              "holds per-parameter tensors and cannot be mapped onto the flat arenas")
         split = sd["format"] == STATE_FORMAT
+        if "arena_align" not in sd and ARENA_ALIGN != 128:
+            # a round-4 state carries no alignment: it was written under the then-default 128, which this process does not use
+            raise ValueError(f"FusedAdamW.load_state_dict: the checkpoint does not record its arena alignment (a round-4 state, written "
+                             f"with 128-element placement) and this process places parameters on {ARENA_ALIGN}-element boundaries "
+                             "(MANTIS_ARENA_ALIGN): refusing to load shifted offsets")
         if int(sd.get("arena_align", 128)) != ARENA_ALIGN:
             raise ValueError(f"FusedAdamW.load_state_dict: the checkpoint's flat state was laid out with parameters aligned to "
                              f"{sd.get('arena_align', 128)} elements, this process places them on {ARENA_ALIGN}-element boundaries "
                              "(MANTIS_ARENA_ALIGN): the offsets inside master / exp_avg / exp_avg_sq differ")
-        if [list(x) for x in sd["layout"]] != self._layout():
+        mine, theirs = self._layout(), [list(x) for x in sd["layout"]]
+        if [x[:2] for x in theirs] != [x[:2] for x in mine]:
             raise ValueError("FusedAdamW.load_state_dict: the checkpoint's parameter layout (names / sizes of the trainable parameters, in "
                              "arena order) differs from this model's")
+        bad = [(a[0], a[2], b[2]) for a, b in zip(theirs, mine) if len(a) > 2 and len(b) > 2 and a[2] != b[2]]
+        if bad:
+            raise ValueError(f"FusedAdamW.load_state_dict: same parameters, different offsets inside the flat state (first: {bad[0][0]} at "
+                             f"{bad[0][1]} in the checkpoint, {bad[0][2]} here): the arenas were laid out under another placement rule")
         keys = ("master_hi", "master_lo", "exp_avg", "exp_avg_sq") if split else ("master", "exp_avg", "exp_avg_sq")
         for k in keys:
             if tuple(sd[k].shape) != tuple(self.exp_avg.shape):
@@ -171,8 +194,18 @@ class FusedAdamW(torch.optim.Optimizer):
         m = self.model
         if split:
             self.master_lo.copy_(sd["master_lo"])
+            differ = 0
             for p_off, g_off, cnt, _ in self._segments:      # the upper halves ARE the parameters
-                m.arena[p_off:p_off + cnt].copy_(sd["master_hi"][g_off:g_off + cnt])
+                src = sd["master_hi"][g_off:g_off + cnt].to(device=m.arena.device, dtype=m.arena.dtype)
+                differ += int((m.arena[p_off:p_off + cnt] != src).sum())
+                m.arena[p_off:p_off + cnt].copy_(src)
+            if differ:
+                # the intended order is model weights first, optimizer state second, both of the same step: then nothing differs.  Warm-starting
+                # OTHER weights with an old optimizer state silently lost them until round 6 (advisor finding)
+                import warnings
+                warnings.warn(f"FusedAdamW.load_state_dict: {differ} trainable parameter elements differed from the checkpoint's masters and were "
+                              "overwritten by them (the masters' upper halves ARE the bf16 parameters).  To keep the model's current weights with "
+                              "old moments, load the state and then copy the weights in again (the optimizer re-snapshots its masters).")
         else:                                                # a round-4 checkpoint: split its fp32 masters
             self.exp_avg_sq.abs_()
             for p_off, g_off, cnt, _ in self._segments:

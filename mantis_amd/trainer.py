@@ -10,6 +10,8 @@ launched from inside the backward as each bucket's gradients complete.
 `MantisHipTrainer` is transformers-free; `as_hf_trainer()` returns a `transformers.Trainer` subclass whose
 `training_step` is this one, for users who keep the stock HF training loop (the reference already subclasses Trainer the
 same way in train_intern_vl_25.py:104-122)."""
+import os
+
 import torch
 
 from .launch import LaunchContext
@@ -96,9 +98,17 @@ class MantisHipTrainer:
             # early mode: the next batch's frozen tower is queued BEFORE this step's kernels, on `prefetch_stream` (meant to be a stream of
             # the lowest hardware-queue priority, hip_ops.priority_stream): its workgroups take the compute units this step's kernels
             # leave idle (incomplete tile rounds, epilogues) during the whole forward + backward
-            ev = torch.cuda.Event()
-            ev.record()
-            model.engine.prefetch_vision(next_inputs, after_event=ev, stream=getattr(self, "prefetch_stream", None), launch=self.launch)
+            eng, nxt_, launch_ = model.engine, next_inputs, self.launch
+
+            def queue_tower():
+                ev = torch.cuda.Event()
+                ev.record()
+                eng.prefetch_vision(nxt_, after_event=ev, stream=getattr(self, "prefetch_stream", None), launch=launch_)
+            # prefetch_point "backward" (experiment, MANTIS_PREFETCH_POINT): queued where the backward starts instead of at the top of the step
+            if getattr(self, "prefetch_point", os.environ.get("MANTIS_PREFETCH_POINT", "forward")) == "backward" and hasattr(eng, "vision_forward"):
+                eng._on_backward_start = queue_tower
+            else:
+                queue_tower()
             next_inputs = None
         fold = None
         if boundary and self.fold_norm_into is not None and not norm_now and (self.reducer is None or not self.reducer.active):
@@ -132,9 +142,11 @@ class _LookAhead:
     at a time (`get_batch_samples`, transformers >= 4.46) or one batch per iteration (older): either way the batch after the one in hand
     is the next entry of `recent`, or the look-ahead slot."""
 
-    def __init__(self, loader):
+    def __init__(self, source):
+        """source: a DataLoader (iterated here) or an iterator the loop already holds (kept as `source`, for identity checks)"""
         from collections import deque
-        self.it = iter(loader)
+        self.source = source
+        self.it = source if hasattr(source, "__next__") else iter(source)
         self.ahead = deque()
         self.recent = deque(maxlen=256)
 
@@ -160,23 +172,32 @@ class _LookAhead:
         return None
 
 
-class _LookAheadLoader:
-    """DataLoader stand-in whose iterators are `_LookAhead`s (everything else is the wrapped loader's); the trainer finds the live
-    iterator under `owner._mantis_iter`."""
-
-    def __init__(self, loader, owner):
-        self._mantis_loader, self._mantis_owner = loader, owner
+def _with_look_ahead(loader, owner):
+    """The loader ITSELF, its class swapped for a one-off subclass whose iterators are `_LookAhead`s (the trainer finds the live iterator
+    under `owner._mantis_iter`).  Round 5 wrapped the loader in a stand-in object instead: accelerate's `skip_first_batches` (mid-epoch resume)
+    then no longer recognised a DataLoaderShard / DataLoaderDispatcher, rebuilt a plain DataLoader from the forwarded attributes and the
+    shard's own behaviour (set_epoch, gradient_state registration, dispatcher mode) was lost for that epoch -- and `copy.copy(wrapper)`
+    recursed forever in `__getattr__` (advisor finding).  A subclass instance IS a DataLoaderShard for every isinstance check."""
+    base = type(loader)
+    if getattr(base, "_mantis_look_ahead", False):
+        loader._mantis_owner = owner
+        return loader
 
     def __iter__(self):
-        it = _LookAhead(self._mantis_loader)
-        self._mantis_owner._mantis_iter = it
+        it = _LookAhead(base.__iter__(self))
+        own = getattr(self, "_mantis_owner", None)
+        if own is not None:
+            own._mantis_iter = it
         return it
-
-    def __len__(self):
-        return len(self._mantis_loader)
-
-    def __getattr__(self, name):
-        return getattr(self._mantis_loader, name)
+    try:
+        cls = type("LookAhead" + base.__name__, (base,), {"__iter__": __iter__, "_mantis_look_ahead": True})
+        # through object's own slot: accelerate's DataLoaderAdapter shadows `__class__` with a read-only property (it poses as the DataLoader
+        # class it wraps), which a plain assignment would hit
+        object.__dict__["__class__"].__set__(loader, cls)
+        loader._mantis_owner = owner
+    except (TypeError, AttributeError):      # a loader type that cannot be re-classed: the iterator-level hook (get_batch_samples) still applies
+        pass
+    return loader
 
 
 def as_hf_trainer():
@@ -209,7 +230,19 @@ def as_hf_trainer():
                     pass
             if not self.mantis_prefetch:
                 return dl
-            return _LookAheadLoader(dl, self)
+            return _with_look_ahead(dl, self)
+
+        def get_batch_samples(self, epoch_iterator, num_batches, *args, **kwargs):
+            """transformers >= 4.46 draws every accumulation window through this method, with the iterator the loop ACTUALLY walks -- also the
+            one over the loader `accelerate.skip_first_batches` builds on a mid-epoch resume, which `get_train_dataloader` never sees.  An
+            iterator that is not a look-ahead yet becomes one here (iterator-level wrapping: the advisor's remedy for round 5's lost prefetch)."""
+            if self.mantis_prefetch and not isinstance(epoch_iterator, _LookAhead):
+                la = getattr(self, "_mantis_iter", None)
+                if la is None or getattr(la, "source", None) is not epoch_iterator:
+                    la = _LookAhead(epoch_iterator)
+                    self._mantis_iter = la
+                epoch_iterator = la
+            return super().get_batch_samples(epoch_iterator, num_batches, *args, **kwargs)
 
         def _fused(self):
             from .optim import FusedAdamW
@@ -264,6 +297,13 @@ def as_hf_trainer():
             it = getattr(self, "_mantis_iter", None)
             if self.mantis_prefetch and it is not None and hasattr(inner.engine, "prefetch_vision") and _on_gpu():
                 nxt = it.next_of(inputs)
+                if nxt is None and not any(r is inputs for r in it.recent) and not getattr(self, "_mantis_warned_no_lookahead", False):
+                    # the loop walks an iterator the look-ahead never saw (old transformers without get_batch_samples after a mid-epoch
+                    # resume): the tower runs in line for those steps -- same results, a few ms slower -- and that is said once
+                    import warnings
+                    warnings.warn("mantis_prefetch: this step's batch did not come through the look-ahead iterator; the next batch's vision "
+                                  "tower is not prefetched for now (results are unaffected)")
+                    self._mantis_warned_no_lookahead = True
                 if self.mantis_prefetch == "early" and not getattr(impl, "prefetch_early", False):
                     from . import hip_ops
                     impl.prefetch_early = True

@@ -161,7 +161,7 @@ class Idefics2Ref:
         am = torch.as_tensor(attention_mask)
         emb = F.embedding(ids, w["model.text_model.embed_tokens.weight"])
         if pixel_values is not None:
-            pv = torch.as_tensor(pixel_values).float()
+            pv = torch.as_tensor(pixel_values).float()       # (cast to the weights' dtype below, after the exact == 0 test on the fp32 pixels)
             B, M = pv.shape[:2]
             pv = pv.reshape(B * M, *pv.shape[2:])
             real = (pv == 0.0).sum(dim=(-1, -2, -3)) != pv[0].numel()
@@ -171,7 +171,7 @@ class Idefics2Ref:
             else:
                 pm = torch.as_tensor(pixel_attention_mask).bool().reshape(B * M, *pixel_attention_mask.shape[2:])[real]
             patch_mask = patch_mask_from_pixel_mask(pm, self.vc["patch_size"])
-            feats = self.vision(pv, patch_mask)
+            feats = self.vision(pv.to(self.w["lm_head.weight"].dtype), patch_mask)
             if record is not None:
                 record["vision_last_hidden_state"] = feats
             img = self.connector(feats, patch_mask.reshape(patch_mask.shape[0], -1), record)

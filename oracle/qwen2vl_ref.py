@@ -137,8 +137,8 @@ class Qwen2VLRef:
             y = layernorm(x, w[p + "norm1.weight"], w[p + "norm1.bias"], 1e-6)
             qkv = F.linear(y, w[p + "attn.qkv.weight"], w[p + "attn.qkv.bias"]).view(-1, 3, nh, hd)
             q, k, v = qkv[:, 0], qkv[:, 1], qkv[:, 2]
-            q = q * cos + rotate_half(q) * sin
-            k = k * cos + rotate_half(k) * sin
+            q = (q * cos + rotate_half(q) * sin).to(v.dtype)           # (HF rotates in fp32 and casts back: apply_rotary_pos_emb_vision)
+            k = (k * cos + rotate_half(k) * sin).to(v.dtype)
             outs, s = [], 0
             for n in lens:                                             # per-image attention (cu_seqlens)
                 sl = slice(s, s + n)
@@ -166,7 +166,7 @@ class Qwen2VLRef:
         B, L, _ = x.shape
         rp = tc["rope_parameters"]
         cos, sin = mrope_cos_sin(position_ids, hd, rp["rope_theta"], rp["mrope_section"])
-        cos, sin = cos[:, None], sin[:, None]
+        cos, sin = cos[:, None].to(x.dtype), sin[:, None].to(x.dtype)      # (HF's rotary module returns the tables in the activations' dtype)
         pre = "model.language_model."
         for i in range(tc["num_hidden_layers"] if n_layers is None else n_layers):
             p = f"{pre}layers.{i}."
@@ -195,7 +195,8 @@ class Qwen2VLRef:
         emb = F.embedding(ids, w["model.language_model.embed_tokens.weight"])
         B, T = ids.shape
         if pixel_values is not None:
-            img = self.vision(torch.as_tensor(pixel_values).float(), image_grid_thw, record, n_vit_layers)
+            # (pixels in the weights' dtype: fp32 for the parity oracle, bf16 for tests/golden/make_bf16_envelope.py)
+            img = self.vision(torch.as_tensor(pixel_values).to(self.w["lm_head.weight"].dtype), image_grid_thw, record, n_vit_layers)
             if record is not None:
                 record["vision_merged"] = img
             sel = ids == cfg["image_token_id"]

@@ -361,3 +361,109 @@ def test_grad_reducer_refuses_a_shared_hardware_queue():
     out = q.get(timeout=120)
     p.join(30)
     assert out == dict(raised=True, warned=True, ok=True, regrouped=True, warns_by_default=True, subgroup_untouched=True), out
+
+
+def test_rs_ag_chunks_tile_the_bucket_in_rank_order():
+    """MANTIS_DP_ALGO=rs_ag index arithmetic (mantis_amd/dp.py:rs_ag_chunk): for every divisible size the ranks' chunks tile [0, n) in rank
+    order with equal lengths; sizes that do not divide (or are smaller than the world) are refused, i.e. take the plain all-reduce."""
+    from mantis_amd.dp import rs_ag_chunk
+    for world in (1, 2, 3, 4, 8):
+        for n in (world, 8 * world, 1024 * world, 58_720_256 * world // world * world):
+            cuts = [rs_ag_chunk(n, r, world) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+            assert len({b - a for a, b in cuts}) == 1
+        for n in (0, world - 1, world + 1 if world > 1 else 0, 1000 * world + 1 if world > 1 else 0):
+            if world > 1 or n == 0:
+                assert rs_ag_chunk(n, 0, world) is None or n % world == 0 and n >= world
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+def _rs_ag_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mantis_amd import dp
+        # RCCL's tensor collectives restated over gloo (fp32 staging: gloo has neither AVG nor bf16 sums), with the SAME in-place
+        # contract -- output = this rank's chunk of the input, input = the whole bucket: what is tested is the reducer's chunk arithmetic
+        # and call pattern, not the transport
+        calls = []
+
+        def reduce_scatter_tensor(output, input, op=None, group=None, async_op=False):
+            assert op == dist.ReduceOp.AVG and async_op
+            n, w = input.numel(), dist.get_world_size()
+            assert output.numel() * w == n and output.data_ptr() == input.data_ptr() + rank * output.numel() * input.element_size(), "not the in-place chunk"
+            st = input.float()
+            dist.all_reduce(st, op=dist.ReduceOp.SUM)
+            c = n // w
+            output.copy_((st[rank * c:(rank + 1) * c] / w).to(output.dtype))
+            calls.append(("rs", n))
+            return _Done()
+
+        def all_gather_into_tensor(output, input, group=None, async_op=False):
+            assert async_op and output.numel() == input.numel() * dist.get_world_size()
+            parts = [torch.empty(input.numel(), dtype=torch.float32) for _ in range(dist.get_world_size())]
+            dist.all_gather(parts, input.float())
+            output.copy_(torch.cat(parts).to(output.dtype))
+            calls.append(("ag", output.numel()))
+            return _Done()
+
+        def all_reduce_avg(t, op=None, group=None, async_op=False):
+            if op != dist.ReduceOp.AVG:
+                return real_all_reduce(t, op=op, group=group, async_op=async_op)
+            st = t.float()
+            real_all_reduce(st, op=dist.ReduceOp.SUM)
+            t.copy_((st / dist.get_world_size()).to(t.dtype))
+            calls.append(("ar", t.numel()))
+            return _Done()
+
+        real_all_reduce = dist.all_reduce
+        dist.reduce_scatter_tensor, dist.all_gather_into_tensor, dist.all_reduce = reduce_scatter_tensor, all_gather_into_tensor, all_reduce_avg
+
+        class M:                                               # the reducer only asks the model for its buckets
+            def __init__(self):
+                g = torch.Generator().manual_seed(100 + rank)
+                self.b = {"even": torch.randn(4096, generator=g).to(torch.bfloat16), "odd": torch.randn(4097, generator=g).to(torch.bfloat16),
+                          "tiny": torch.randn(1, generator=g).to(torch.bfloat16)}
+
+            def grad_buckets(self):
+                return self.b
+        m = M()
+        mine = {k: v.float().clone() for k, v in m.b.items()}
+        red = dp.GradReducer(m, algo="rs_ag")
+        red._nccl = True                                       # take the RCCL branch (gloo has no stream to probe: `active` is decided by world)
+        red.begin()
+        for k in ("even", "odd", "tiny"):
+            red.bucket_ready(k)
+        red.finish()
+        q.put((rank, {k: v.float().numpy() for k, v in m.b.items()}, {k: v.numpy() for k, v in mine.items()}, calls))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rs_ag_branch_reduces_to_the_mean_with_mocked_rccl_collectives():
+    """The `rs_ag` branch of GradReducer._reduce_mean has never run on more than one rank (no multi-GPU box): here it runs on 2 ranks with
+    RCCL's in-place tensor collectives restated over gloo.  A divisible bucket takes reduce-scatter + all-gather on the rank's own chunk and
+    ends as the mean on both ranks; a bucket whose size does not divide by the world takes the plain all-reduce."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rs_ag_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for k in ("even", "odd", "tiny"):
+        mean = (res[0][2][k] + res[1][2][k]) / 2
+        for r in range(2):
+            got = res[r][1][k]
+            assert np.allclose(got, mean, rtol=1e-2, atol=1e-2), (k, r)
+        assert np.array_equal(res[0][1][k], res[1][1][k]), f"ranks disagree on {k}"
+    for r in range(2):
+        assert res[r][3] == [("rs", 4096), ("ag", 4096), ("ar", 4097), ("ar", 1)], res[r][3]
