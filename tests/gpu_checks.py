@@ -1449,6 +1449,7 @@ def check_llava_full_width_vs_oracle():
     assert abs(float(loss) - float(oloss)) <= 5e-3 * abs(float(oloss)), (float(loss), float(oloss))
     rows, worst_c, worst_r = [], 1.0, 0.0
     grads = {}
+    env = Hh.bf16_envelope("oracle_bf16:llava_full_width")
     for n in names:
         g = model._param(n).grad.detach().float().cpu()
         og = oracle.w[n].grad
@@ -1466,7 +1467,8 @@ def check_llava_full_width_vs_oracle():
                 fh.write(f"| {n} | {'x'.join(map(str, sh))} | {c:.6f} | {r:.4f} | {on:.3e} |\n")
             fh.write(f"\nloss {float(loss):.5f} vs oracle {float(oloss):.5f}; worst cosine {worst_c:.6f}, worst rel-L2 {worst_r:.4f}\n")
     for n, sh, c, r, on in rows:
-        assert c >= 0.999 and r <= 0.04, (n, c, r)          # measured: worst 0.99968 / 0.026 (q and k projections of layer 1); SURVEY 8c's 2e-2 holds for all others
+        cbar, rbar = Hh.envelope_bars(env, n)                # SURVEY 8c's 0.999 / 2e-2, or 1.5 x the reference's own bf16 deviation on this tensor
+        assert c >= cbar and r <= rbar, (n, c, r, cbar, rbar)  # (round 5 measured: worst 0.99968 / 0.026, q and k projections of layer 1)
     # ---- the clip norm and the optimizer step
     tp = {n: torch.nn.Parameter(before[n].clone()) for n in names}
     for n in names:
@@ -1528,7 +1530,9 @@ def check_idefics2_full_width_vs_oracle():
     rec = {}
     out = model.engine.step_from_batch(batch, compute_grads=True, overwrite_grads=True, need_logits=True, record=rec)
     torch.cuda.synchronize()
-    rep = Hh.check_idefics2_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-3, grad_cos=0.999, grad_rel=0.05)     # measured 0.99931 / 0.037 (round 5; rounds 3 - 4: bars 0.997 / 0.08)
+    # per-tensor bars: SURVEY 8c's 0.999 / 2e-2 or 1.5 x the reference's own bf16 deviation at this geometry (round 5 measured 0.99931 / 0.037 at
+    # worst; the oracle in bf16 sits at 0.99900 / 0.049 on the same tensors: tests/golden/bf16_envelope.json)
+    rep = Hh.check_idefics2_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-3, envelope=Hh.bf16_envelope("oracle_bf16:idefics2_full_width"))
     worst = min(c for c, _ in rep.values())
     print(f"    idefics2 full width vs oracle: worst gradient cosine {worst:.5f}, worst rel {max(r for _, r in rep.values()):.4f}", flush=True)
     return 1.0 - worst
@@ -1556,7 +1560,8 @@ def check_qwen2vl_full_width_vs_oracle():
     rec = {}
     out = model.engine.step_from_batch(batch, compute_grads=True, overwrite_grads=True, need_logits=True, record=rec)
     torch.cuda.synchronize()
-    rep = Hh.check_qwen2vl_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-3, grad_cos=0.999, grad_rel=0.04)      # measured 0.99959 / 0.029 (round 5; rounds 3 - 4: bars 0.997 / 0.08)
+    # per-tensor bars from the reference's own bf16 deviation (round 5 measured 0.99959 / 0.029 at worst; the oracle in bf16: 0.99931 / 0.037)
+    rep = Hh.check_qwen2vl_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-3, envelope=Hh.bf16_envelope("oracle_bf16:qwen2vl_full_width"))
     worst = min(c for c, _ in rep.values())
     print(f"    qwen2-vl full width vs oracle: worst gradient cosine {worst:.5f}, worst rel {max(r for _, r in rep.values()):.4f}", flush=True)
     return 1.0 - worst

@@ -87,7 +87,35 @@ def write_grad_parity(path):
 GRAD_COS, GRAD_REL = 0.999, 2e-2
 
 
-def check_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-3, grad_cos=GRAD_COS, grad_rel=GRAD_REL):
+# Round 6 (verdict item 5): the exceptions above are no longer "measured + margin".  tests/golden/bf16_envelope.json records how far the REFERENCE'S
+# OWN bf16 run sits from its fp32 run, per tensor: transformers' Qwen2VLForConditionalGeneration (the class the reference resolves to) on the
+# tiny goldens + 24 random inputs, and the pinned oracle classes in bf16 at the full-width geometries of the `*_full_width_vs_oracle` checks
+# (tests/golden/make_bf16_envelope.py).  A tensor's bar is then max(SURVEY's 2e-2, 1.5 x the reference's own bf16 deviation) and
+# min(0.999, 1 - 1.5 x (1 - its cosine)): the product may be as far from fp32 as 1.5 x what the reference's own training arithmetic is.
+ENVELOPE_FACTOR = 1.5
+_ENVELOPE = None
+
+
+def bf16_envelope(case):
+    """{tensor: (cosine, rel-L2)} of the reference's bf16 run against its fp32 run for `case` (a key of tests/golden/bf16_envelope.json)"""
+    global _ENVELOPE
+    if _ENVELOPE is None:
+        import json
+        with open(os.path.join(G, "bf16_envelope.json")) as f:
+            _ENVELOPE = json.load(f)
+    return {k: (float(v[0]), float(v[1])) for k, v in _ENVELOPE[case].items() if not k.startswith("__")}
+
+
+def envelope_bars(envelope, name, grad_cos=GRAD_COS, grad_rel=GRAD_REL):
+    """(cosine bar, rel-L2 bar) of tensor `name`: SURVEY 8c's bars, relaxed to ENVELOPE_FACTOR x the reference's own bf16 deviation where that is
+    larger; a tensor the envelope does not know keeps SURVEY's bars."""
+    if not envelope or name not in envelope:
+        return grad_cos, grad_rel
+    c, r = envelope[name]
+    return min(grad_cos, 1.0 - ENVELOPE_FACTOR * (1.0 - c)), max(grad_rel, ENVELOPE_FACTOR * r)
+
+
+def check_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-3, grad_cos=GRAD_COS, grad_rel=GRAD_REL, envelope=None):
     """bf16 product path vs fp32 oracle on identical (bf16-rounded) weights.  Tolerances: SURVEY.md section 8c."""
     orec = {}
     oracle.zero_grad()
@@ -122,7 +150,8 @@ def check_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-3, grad_c
         if np.linalg.norm(og.numpy()) < 1e-12:
             assert np.linalg.norm(g) < 1e-6, name
             continue
-        assert c >= grad_cos and r <= grad_rel, (name, c, r)
+        cbar, rbar = envelope_bars(envelope, name, grad_cos, grad_rel)
+        assert c >= cbar and r <= rbar, (name, c, r, cbar, rbar)
     _note_report(report)
     return report
 
@@ -298,7 +327,7 @@ def idefics2_batch(z):
     return b
 
 
-def check_idefics2_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-3, grad_cos=GRAD_COS, grad_rel=GRAD_REL):
+def check_idefics2_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-3, grad_cos=GRAD_COS, grad_rel=GRAD_REL, envelope=None):
     """bf16 product path vs the fp32 Idefics2 oracle on identical (bf16-rounded) weights."""
     orec = {}
     oracle.zero_grad()
@@ -330,7 +359,8 @@ def check_idefics2_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-
         if np.linalg.norm(og.numpy()) < 1e-12:
             assert np.linalg.norm(g) < 1e-6, name
             continue
-        assert c >= grad_cos and r <= grad_rel, (name, c, r)
+        cbar, rbar = envelope_bars(envelope, name, grad_cos, grad_rel)
+        assert c >= cbar and r <= rbar, (name, c, r, cbar, rbar)
     _note_report(report)
     return report
 
@@ -360,11 +390,14 @@ def qwen2vl_batch(z):
 
 
 def check_qwen2vl_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-3, grad_cos=GRAD_COS, grad_rel=GRAD_REL, act_rel=3e-2,
-                                      grad_cos_1d=None, grad_rel_1d=None, kbias_cos=0.998, kbias_rel=6e-2):
+                                      grad_cos_1d=None, grad_rel_1d=None, kbias_cos=0.998, kbias_rel=6e-2, envelope=None):
     """bf16 product path vs the fp32 Qwen2-VL oracle on identical (bf16-rounded) weights.  grad_cos_1d / grad_rel_1d: separate bar for
     the 1-D parameters (biases, norm weights; default: the matrices' bar); kbias_cos / kbias_rel: the KEY bias, whose gradient is a
     near-cancelling sum (a constant added to every key only shifts the scores of a query uniformly, up to RoPE) and therefore mostly rounding
-    noise of dS -- bf16 measured 0.99898 / 0.045 at worst (profiles/r05_grad_parity.md); with an fp8 1-D bar given, FP8_COS_KBIAS applies."""
+    noise of dS -- bf16 measured 0.99898 / 0.045 at worst (profiles/r05_grad_parity.md); the REFERENCE'S OWN bf16 run (transformers' class, 4
+    goldens + 24 random inputs of the golden geometry) deviates from its fp32 run by up to 0.99843 / 0.063 on this tensor
+    (tests/golden/bf16_envelope.json, `reference_bf16:qwen2vl_tiny_random24_worst`): the default bars 0.998 / 6e-2 lie inside 1.5 x that.
+    With an fp8 1-D bar given, FP8_COS_KBIAS applies.  envelope: per-tensor bars from the reference's bf16 deviation (envelope_bars)."""
     orec = {}
     oracle.zero_grad()
     pv = z["pixel_values"] if "pixel_values" in z.files else None
@@ -403,6 +436,9 @@ def check_qwen2vl_step_against_oracle(model, oracle, z, out, rec, loss_rtol=5e-3
         if one_d and name.endswith("k_proj.bias"):                 # the near-cancelling key-bias gradient
             cbar = min(kbias_cos, FP8_COS_KBIAS) if grad_cos_1d is not None else kbias_cos
             rbar = max(rbar, kbias_rel)
+        if envelope is not None:                                   # bars from the reference's own bf16 deviation (see envelope_bars)
+            cbar, rbar = envelope_bars(envelope, name, cbar if not (one_d and name.endswith("k_proj.bias")) else GRAD_COS,
+                                       rbar if not (one_d and name.endswith("k_proj.bias")) else GRAD_REL)
         assert c >= cbar and r <= rbar, (name, c, r, cbar, rbar)
     _note_report(report)
     return report
