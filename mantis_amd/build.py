@@ -12,11 +12,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libmantis_hip.so")
-SOURCES = ["pack", "norm", "act", "rope", "ce", "vit", "gemm", "gemm176", "gemm_fp8", "attn", "attn_fwd64", "attn_dq64", "optim"]
+SOURCES = ["pack", "norm", "act", "rope", "ce", "vit", "gemm", "gemm176", "gemm_fp8", "attn", "attn_fwd64", "optim"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"]
 # attn_fwd64: the hand-placed instruction stream wants one VALU instruction per source operation (no v_pk_* packing of f32 pairs)
-# attn_dq64: its inline-asm MFMAs own the accumulator file by register number -- the compiler must not park VGPR spills there
-EXTRA_FLAGS = {"attn_fwd64": ["-fno-slp-vectorize"], "attn_dq64": ["-mllvm", "-amdgpu-spill-vgpr-to-agpr=0"]}
+EXTRA_FLAGS = {"attn_fwd64": ["-fno-slp-vectorize"]}
 HEADERS = ["common.h", "attn_common.h", "gemm_ring.h"]
 
 

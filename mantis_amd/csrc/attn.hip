@@ -1402,36 +1402,13 @@ static int launch_fwd(bool causal, dim3 grid, hipStream_t s, const bf16_t* Q, co
     return mantis_check_launch();
 }
 
-// attn_dq64.hip: the hd-128 dQ with 64 query rows per wave (one workgroup per CU, accumulators and Q / dO fragments in hand-owned AGPRs)
-int mantis_attn_dq64_launch(bool causal, int B, hipStream_t s, const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* dO,
-                            const float* LSE, float* Dsum, bf16_t* dQ, int L, int Lk, int H, int Hkv, long ldq, long ldk,
-                            long ldv, long ldo, long lddq, float scale, const bf16_t* Ofwd, long ldout, const int* kstart);
-
-// MANTIS_ATTN_DQ64 = 1 / 0 (read once): the 64-row dQ kernel for every length / never; default ATTN_DQ64_DEFAULT (2 = from 1024 query rows on)
-#ifndef ATTN_DQ64_DEFAULT
-#define ATTN_DQ64_DEFAULT 0
-#endif
-static int attn_dq64_mode() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("MANTIS_ATTN_DQ64");
-        v = (e && e[0] == '0') ? 0 : (e && e[0] == '1') ? 1 : ATTN_DQ64_DEFAULT;
-    }
-    return v;
-}
-
+// (round 6: the opt-in 64-query-rows-per-wave dQ kernel of rounds 4 - 5, csrc/attn_dq64.hip, is gone: correct, but 266 vs 233 us against this
+// file's attn_bwd_dq_kernel in every measurement of two rounds -- a 512-register kernel runs one workgroup per CU and nothing overlaps its
+// prologue, profiles/r05_attn_anatomy.md -- and a kernel off the default path earns nothing.)
 template <int HD>
 static void launch_dq(bool causal, hipStream_t s, const bf16_t* Q, const bf16_t* K, const bf16_t* V, const bf16_t* dO, const int* kmask,
                       const float* LSE, float* Dsum, bf16_t* dQ, int B, int L, int Lk, int H, int Hkv, long ldq, long ldk, long ldv,
                       long ldo, long lddq, float scale, const bf16_t* Ofwd, long ldout, const int* kstart) {
-    if constexpr (HD == 128) {
-        const int mode = attn_dq64_mode();
-        if (kmask == nullptr && (mode == 1 || (mode == 2 && L >= 1024))) {      // batches with a key-padding mask keep attn_bwd_dq_kernel
-            mantis_attn_dq64_launch(causal, B, s, Q, K, V, dO, LSE, Dsum, dQ, L, Lk, H, Hkv, ldq, ldk, ldv, ldo, lddq, scale, Ofwd, ldout,
-                                    kstart);
-            return;
-        }
-    }
     const dim3 gq(cdiv(L, 128) * H * B);
     if (causal)
         MANTIS_LAUNCH((attn_bwd_dq_kernel<HD, true>), gq, dim3(256), 0, s, Q, K, V, dO, kmask, LSE, Dsum, dQ, L, Lk, H, Hkv, ldq, ldk, ldv,

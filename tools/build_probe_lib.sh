@@ -8,7 +8,6 @@ python -m mantis_amd.build >/dev/null 2>&1
 mkdir -p tools/_bin
 extra=""
 [ "$src" = attn_fwd64 ] && extra="-fno-slp-vectorize"
-[ "$src" = attn_dq64 ] && extra="-mllvm -amdgpu-spill-vgpr-to-agpr=0"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast $extra "$@" -c mantis_amd/csrc/$src.hip -o tools/_bin/${src}_${out}.o
 objs=$(ls mantis_amd/csrc/_obj/*.o | grep -v "/${src}\.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/_bin/libmantis_${out}.so $objs tools/_bin/${src}_${out}.o
