@@ -25,7 +25,7 @@ import os
 import re
 from collections import defaultdict
 
-GEMM_FAMILY = ("gemm_nt_ring_kernel", "gemm_nt_ring16_kernel", "gemm_nt_kernel")
+GEMM_FAMILY = ("gemm_nt_ring_kernel", "gemm_nt_ring16_kernel", "gemm_nt_ring176_kernel", "gemm_nt_kernel")
 GEMM_FINISH = ("gemm_ring16_finish_kernel",)       # round 5: K-split finishing pass -- its bytes belong to the family, its launches do not count
 ATTN_FAMILY = ("attn_fwd_kernel", "attn_fwd64_kernel", "attn_bwd")
 
