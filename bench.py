@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 FLOP_PER_SAMPLE = 1.351e14      # SURVEY.md section 8d (ViT fwd x1, projector + LLM fwd+bwd x3, causal attention at 1/2)
 PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_FP8_TFLOPS = 5000.0        # MI355X dense fp8 MFMA (MX-scaled K = 64 / 128 forms; MI355X_MICROARCH.md)
-PMC_JSON = os.path.join(ROOT, "profiles", "r05_pmc_step.json")   # tools/pmc_step_report.py output (offline PMC passes, tracked)
+PMC_JSON = os.path.join(ROOT, "profiles", "r06_pmc_step.json")   # tools/pmc_step_report.py output (offline PMC passes, tracked)
 PMC_JSON_QWEN_FP8 = os.path.join(ROOT, "profiles", "r02_pmc_qwen2vl_fp8.json")   # same, for `--config qwen2_vl_7b --precision fp8`
 
 
@@ -405,7 +405,7 @@ def run_hf_loop(args, model, batches, B, Event, sync, vmode):
             timed = self.state.global_step >= W
             impl = getattr(self, "_mantis_impl", None)
             if impl is not None:
-                impl.launch.timer = state["timer"] if (timed and not args.no_kernel_timer) else None
+                impl.launch.timer = None          # bare, like the native loop's timed region: `roofline` comes from the native loop's instrumented steps
             loss = super().training_step(model_, inputs, num_items_in_batch)
             if timed and state["cur"] is not None:
                 state["cur"][1].record()
@@ -745,7 +745,7 @@ def main():
         opt = None
         gc.collect()
         torch.cuda.empty_cache()
-        elapsed, split, losses, timer, timed_batches, hf_trainer = run_hf_loop(args, model, batches, B, Event, sync, vmode)
+        elapsed, split, losses, _hf_timer, timed_batches, hf_trainer = run_hf_loop(args, model, batches, B, Event, sync, vmode)
         opt = hf_trainer._fused()
         fold = opt is not None
     dp_devices = None
@@ -808,7 +808,8 @@ def main():
             # PMC passes of the same command measured (another box, another day) is carried under a separately named key
             roof = dict(bound="mfma", kernel=kname, achieved=round(ach, 1),
                         measured_on=(f"{args.steps} instrumented steps (HIP events around every GEMM launch on its launch stream) right after the bare "
-                                     f"timed region" if args.loop != "hf" else "the timed steps of the HF loop (instrumented)"),
+                                     f"timed region" + (" of the NATIVE loop, which runs first in this process (the HF loop's timed steps are bare too)"
+                                                        if args.loop == "hf" else "")),
                         peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4), bf16_gemm_family=bf16_family,
                         traffic=None, mfma_busy_pct=None,
                         pmc_static=None if not pmc else dict(
@@ -913,7 +914,7 @@ def main():
                    ms_per_step_median=round(_pct(step_ms, 0.5), 2), ms_per_step_p10=round(_pct(step_ms, 0.1), 2),
                    ms_per_step_p90=round(_pct(step_ms, 0.9), 2),
                    ms_per_step_with_timer=None if (ms_with_timer is None or args.loop == "hf") else round(ms_with_timer, 2),
-                   timed_region=("HF loop, per-launch GEMM events on" if args.loop == "hf" else "bare: no per-launch events inside the timed steps"),
+                   timed_region="bare: no per-launch events inside the timed steps",
                    ms_training_step=round(_pct(ts_ms, 0.5), 2),
                    ms_training_step_p10=round(_pct(ts_ms, 0.1), 2), ms_training_step_p90=round(_pct(ts_ms, 0.9), 2),
                    ms_optimizer=round(_pct([e[1].elapsed_time(e[2]) for e in split], 0.5), 2) if opt is not None else None,
