@@ -14,13 +14,18 @@
 // LDS: a K-step is A 22 KiB (176 rows x 128 B) + B 32 KiB, which does not divide the ring16 kernels' ten 16-KiB slabs, and 3 steps (162 KiB) do not
 // fit 160 KiB -- so TWO rings with the same 2.5-step schedule: B in three 32-KiB slots (issued in the first half of a step, 1.5 steps of lead),
 // A in two 22-KiB slots (issued behind the mid-step barrier that frees the slot of the step being computed, one step of lead): 140 KiB.
-//   half 0 of step t: MFMAs (t, k 0-31);  shadows: fragments (t, k 32-63), DMA B(t+2) -> B slot (t+2) % 3
+//   half 0 of step t: MFMAs (t, k 0-31);  shadows: fragments (t, k 32-63), DMA B(t+2) -> the B slot step t-1 used (three slots in turn)
 //   lgkmcnt(0), vmcnt(8) [all but B(t+2)], s_barrier: step t read by every wave, step t+1 landed
 //   half 1 of step t: MFMAs (t, k 32-63); shadows: fragments (t+1, k 0-31), DMA A(t+2) -> A slot t % 2
 // DMA pieces (1 KiB = 8 rows x 128 B): B 32 = 8 per wave (wave w loads the 64 B rows it reads); A 22: piece w + 4 j, waves 0,1 six, waves 2,3
 // five (a wave-uniform branch; the counted wait names only the uniform B pieces).  A is row-major (forward and dX: the M side is the
-// activation); B row-major (forward) or K-major (dX reads the weight as stored).  Epilogue: ring_epilogue<4, 4, 11> -- the ring16 code with a
-// short third pass (48 rows) -- plain / bias / activations / residual / accumulate / fused SwiGLU backward / the two-column forward fusions.
+// activation); B row-major (forward) or K-major (dX reads the weight as stored).  Epilogue: ring_epilogue<4, 4, 11> (gemm_ring.h) -- the ring16 code
+// with a short last pass -- plain / bias / activations / residual / accumulate / fused SwiGLU backward (fast read-back: gate | up requested a group
+// ahead) / the two-column forward fusions.
+// PERSIST (launches with more tiles than CUs): #CU workgroups walk their tiles in the hardware's dispatch order; behind the K loop's last barrier
+// the NEXT tile's first two K-steps are issued and fly under the epilogue, whose strips are 48-row passes in [B slot 2 | spare] (see the LDS map
+// below).  Same arithmetic in the same order as one tile per workgroup: bit-identical (check gemm_ring176_persistent).  Measured:
+// profiles/r06_experiments.md 1 - 3.
 #ifndef R176_FASTSW
 #define R176_FASTSW 8       // read-back group of the fused SwiGLU backward (0 = the general read-back, 4, 8)
 #endif
