@@ -786,8 +786,8 @@ def main():
                     json.dump([dict(tag=list(x[5]) if len(x) > 5 else None, us=round(x[3].elapsed_time(x[4]) * 1e3, 1))
                                for x in all_gemms[-per:]], fh)
             gf = (pmc or {}).get("gemm_family") or {}
-            kname, peak = ("gemm_nt_ring16_kernel + gemm_nt_ring_kernel + gemm_nt_kernel (bf16 MFMA GEMM family: every launch of "
-                           "mantis_gemm_bf16_nt / _fused, csrc/gemm.hip)"), PEAK_BF16_TFLOPS
+            kname, peak = ("gemm_nt_ring176_kernel + gemm_nt_ring16_kernel + gemm_nt_ring_kernel + gemm_nt_kernel (bf16 MFMA GEMM family: every "
+                           "launch of mantis_gemm_bf16_nt / _fused / _sumsq, csrc/gemm.hip + csrc/gemm176.hip)"), PEAK_BF16_TFLOPS
             bf16_family = None
             family = all_gemms
             if precision != "bf16":
