@@ -165,6 +165,19 @@ int mantis_gemm_bf16_nt_fused(const void* A, int64_t lda, const void* B, int64_t
  * residual; otherwise MANTIS_EUNSUPPORTED (-2) and the caller runs mantis_gemm_bf16_nt followed by mantis_sumsq. */
 int mantis_gemm_bf16_nt_sumsq(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K, int flags,
                               float* tile_sumsq, void* workspace, int64_t workspace_bytes, void* stream);
+/* Two weight-gradient GEMMs in ONE launch (round 6): C1[M1,N1] (+)= A1^T . B1 and C2[M2,N2] (+)= A2^T . B2 with A given [K, M], B given [K, N] (the
+ * TN form of mantis_gemm_bf16_nt_sumsq: dW = dY^T . X reads both activations as stored) for two problems that share K.  Replaces two launches
+ * whose 256 x 256 grids each end in a K-split remainder round + finishing pass by one grid of whole tiles -- dW(down_proj) 4096 x 14336 (896 tiles)
+ * + dW(q|k|v) 6144 x 4096 (384 tiles) of a Llama-3-8B / Mistral-7B decoder layer = 1280 tiles = 5.0 rounds on 256 CUs -- in one XCD-contiguous
+ * tile order over the union; no workspace.  flags: 32 accumulate | bits 16-27 CU budget.  ts1 / ts2: per-tile sums of squares of what was stored
+ * (cdiv(M,256) * cdiv(N,256) floats each, as mantis_gemm_bf16_nt_sumsq) or both NULL.  Results: the 8-wave ring16 kernel's whole-tile
+ * arithmetic (= variant 14 of mantis_gemm_bf16_nt on a shape without a K-split remainder, bit for bit); against a K-split launch of the same
+ * shape the remainder tiles' fp32 summation order differs (bf16 rounding).  MANTIS_EUNSUPPORTED: N % 256, unaligned or >= 4 GiB operands.
+ * mantis_gemm_tn_pair_wins: 1 when the cost model predicts the paired launch >= 3 % ahead of two launches for `cus` CUs (<= 0: default). */
+int mantis_gemm_bf16_tn_pair(const void* A1, int64_t lda1, const void* B1, int64_t ldb1, void* C1, int64_t ldc1, int M1, int N1, float* ts1,
+                             const void* A2, int64_t lda2, const void* B2, int64_t ldb2, void* C2, int64_t ldc2, int M2, int N2, float* ts2,
+                             int K, int flags, void* stream);
+int mantis_gemm_tn_pair_wins(int M1, int N1, int M2, int N2, int K, int cus);
 /* tile family the auto heuristic (flags bits 8-11 == 0) picks: 12 = a 256x256 ring kernel (which of 12 / 13 / 14: see above), 1 = the 128x128 generic kernel */
 int mantis_gemm_pick_variant(int M, int N, int K);
 /* the same for a launch planned for `cus` compute units (cus <= 0: the default budget) */

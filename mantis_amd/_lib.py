@@ -44,6 +44,8 @@ SIGNATURES = {
     "mantis_gemm_cu_budget": [I],
     "mantis_gemm_pick_variant": [I, I, I],
     "mantis_gemm_pick_variant_cus": [I, I, I, I],
+    "mantis_gemm_bf16_tn_pair": [P, L, P, L, P, L, I, I, P, P, L, P, L, P, L, I, I, P, I, I, P],
+    "mantis_gemm_tn_pair_wins": [I, I, I, I, I, I],
     "mantis_gemm_remainder_plan": [I, I, I, I, P, I],
     "mantis_fp8_quantize_ws_floats": [],
     "mantis_fp8_quantize": [P, L, I, L, I, P, L, P, L, P, P, P, I, P],

@@ -735,12 +735,24 @@ __host__ __device__ __forceinline__ int sk_bound(int c, int units, int T, int nk
     return (int)a;
 }
 
-template <int NW, bool AKM, bool BKM, bool SWIGLU = false, int PAIR = PAIR_NONE>
+// Two problems in ONE grid (round 6b): two weight-gradient GEMMs of a decoder layer that share K (the token count) and are independent of each
+// other -- dW(down_proj) 4096 x 14336 = 896 tiles (3.5 rounds on 256 CUs) and dW(q|k|v) 6144 x 4096 = 384 tiles (1.5 rounds), each with a K-split
+// remainder round and a finishing pass -- are 1280 tiles = 5.0 rounds together: whole tiles only, no slabs, no finishing kernels.  The grid's tile
+// order is the XCD-contiguous one over the union; a workgroup whose tile lies behind the first problem's takes the second problem's operands
+// (a wave-uniform switch of kernel arguments in front of everything else).  RingGroup2 carries the second problem; the plain kernels take the
+// empty NoGroup.
+struct NoGroup {};
+struct RingGroup2 {
+    const bf16_t* A; const bf16_t* B; bf16_t* C; bf16_t* aux0;
+    long lda, ldb, ldc;
+    int M, N, tiles_m, tiles_n, tiles1;      // tiles1: tiles of the first problem
+};
+template <int NW, bool AKM, bool BKM, bool SWIGLU = false, int PAIR = PAIR_NONE, class GRP = NoGroup>
 __global__ __launch_bounds__(NW * 64) void gemm_nt_ring16_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, bf16_t* __restrict__ C, int M, int N, int K, long lda, long ldb,
     long ldc, const bf16_t* __restrict__ bias, const bf16_t* __restrict__ res, long ldr, int flags, int tiles_m, int tiles_n,
     int full, int S, float* __restrict__ sk_slabs, unsigned int* __restrict__ sk_cnt, bf16_t* __restrict__ aux0,
-    const bf16_t* __restrict__ aux1, long aux_ld, int aux_n, SkPlan plan) {
+    const bf16_t* __restrict__ aux1, long aux_ld, int aux_n, SkPlan plan, GRP grp) {
     static_assert(NW == 4 || NW == 8, "4 waves of 128 x 128 or 8 waves of 128 x 64");
     static_assert(PAIR == PAIR_NONE || (!AKM && !BKM && !SWIGLU), "the pair epilogues are forward (NT) fusions");
 #ifdef RING16_STAMPS
@@ -813,6 +825,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_ring16_kernel(
             sk_slab = U + tl - 1;
         }
         tile_id = full + tl;
+    }
+    if constexpr (std::is_same<GRP, RingGroup2>::value) {
+        if (tile_id >= grp.tiles1) {         // the second problem of a grouped launch (whole tiles only: bid < full always)
+            tile_id -= grp.tiles1;
+            A = grp.A; B = grp.B; C = grp.C; aux0 = grp.aux0;
+            lda = grp.lda; ldb = grp.ldb; ldc = grp.ldc;
+            M = grp.M; N = grp.N; tiles_m = grp.tiles_m; tiles_n = grp.tiles_n;
+        }
     }
     const int GROUP = 8;
     const int per_group = GROUP * tiles_n;
@@ -1355,7 +1375,7 @@ static int launch_gemm_ring(hipStream_t s, const bf16_t* A, const bf16_t* B, bf1
         const int grid16 = plan.units ? full + plan.units + plan.nspan : grid;
         const int S16 = plan.units ? rem : S;                  // balanced plan: the kernels take the number of remainder tiles here
         MANTIS_LAUNCH((gemm_nt_ring16_kernel<R16, AKM, BKM, SWIGLU, PAIR>), dim3(grid16), dim3(R16 * 64), 0, s, A, B, C, M, N, K, lda, ldb, ldc,
-                           bias, res, ldr, flags, tiles_m, tiles_n, full, S16, slabs, finish ? nullptr : cnt, aux0, aux1, aux_ld, aux_n, plan);
+                           bias, res, ldr, flags, tiles_m, tiles_n, full, S16, slabs, finish ? nullptr : cnt, aux0, aux1, aux_ld, aux_n, plan, NoGroup{});
         if (finish) {
             // one wave per workgroup, except for the sum of squares (all R16 waves of a tile half in one block: fixed-order reduction)
 #define FIN_ARGS 0, s, C, M, N, ldc, bias, res, ldr, flags, tiles_m, tiles_n, full, S16, slabs, aux0, aux1, aux_ld, aux_n, plan.units, nk
@@ -1617,6 +1637,74 @@ int mantis_gemm_bf16_nt_sumsq(const void* A, int64_t lda, const void* B, int64_t
     return SS_DISPATCH(false, false);
 #undef SS_DISPATCH
 #undef SS_ARGS
+}
+
+// ---- two weight-gradient GEMMs in one grid (see RingGroup2 at the kernel)
+// predicted launch time (us) of C[M,N] over K on the 256 x 256 ring kernels for `cus` CUs, the cost model of gemm_pick_variant
+static double ring256_us(int M, int N, int K, int cus) {
+    const int nk = cdiv(K, BK);
+    const long t = (long)cdiv(M, 256) * cdiv(N, 256);
+    const int S = ring_split(t, nk, cus);
+    const long rem = t % cus;
+    const int sub = rem ? (int)((S * rem + cus - 1) / cus) : 0;
+    return 1.45 * ((double)(t / cus) * (nk + 5.0) + (rem ? sub * ((double)nk / S + 5.0) + (S > 1 ? 8.0 + 1.7 * S : 0.0) : 0.0));
+}
+static bool tn_pair_wins(int M1, int N1, int M2, int N2, int K, int cus_req) {
+    static int mode = -1;              // MANTIS_GEMM_PAIR (read once): 0 never, 1 where the model predicts a gain (default), 2 always
+    if (mode < 0) { const char* e = getenv("MANTIS_GEMM_PAIR"); mode = (e && e[0] >= '0' && e[0] <= '2' && e[1] == 0) ? e[0] - '0' : 1; }
+    if (mode == 0 || default_ring_variant()) return false;
+    if (mode == 2) return true;
+    const int cus = plan_cus(cus_req), nk = cdiv(K, BK);
+    const long t = (long)cdiv(M1, 256) * cdiv(N1, 256) + (long)cdiv(M2, 256) * cdiv(N2, 256);
+    const double both = 1.45 * (double)((t + cus - 1) / cus) * (nk + 5.0);
+    return both < 0.97 * (ring256_us(M1, N1, K, cus) + ring256_us(M2, N2, K, cus));
+}
+static int tn_operand_ok(const void* A, int64_t lda, const void* B, int64_t ldb, const void* C, int64_t ldc, int M, int N, int K) {
+    if (M <= 0 || N <= 0) return MANTIS_EINVAL;
+    if (N % 256 || ldc % 8 || ldc < N || lda % 8 || ldb % 8 || lda < M || ldb < N || (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15)) return MANTIS_EUNSUPPORTED;
+    const long lim = (1L << 32) - (1L << 16);
+    if ((long)K * lda * 2 >= lim || (long)K * ldb * 2 >= lim) return MANTIS_EUNSUPPORTED;
+    return 0;
+}
+
+// 1 when mantis_gemm_bf16_tn_pair would run C1[M1,N1] and C2[M2,N2] (both over K, both operands K-major) as ONE grid and the cost model
+// predicts that to beat two launches by >= 3 % for `cus` CUs (<= 0: the default budget) -- e.g. dW(down_proj) + dW(q|k|v) of a Llama-3-8B /
+// Mistral-7B layer: 896 + 384 tiles = 5.0 rounds on 256 CUs; 0 otherwise.  A pure query.
+int mantis_gemm_tn_pair_wins(int M1, int N1, int M2, int N2, int K, int cus) {
+    if (M1 <= 0 || N1 <= 0 || M2 <= 0 || N2 <= 0 || K <= 0 || N1 % 256 || N2 % 256) return 0;
+    return tn_pair_wins(M1, N1, M2, N2, K, cus > 0 ? cus : 0) ? 1 : 0;
+}
+// Two weight-gradient GEMMs in ONE launch: C1 (+)= A1^T-view . B1 and C2 (+)= A2^T-view . B2, i.e. mantis_gemm_bf16_nt_sumsq's TN form
+// (A given [K, M], B given [K, N]; flags: 32 accumulate | bits 16-27 CU budget) for two problems that share K.  ts1 / ts2: per 256 x 256 tile
+// sums of squares of what was stored (cdiv(M,256) * cdiv(N,256) floats each), or both NULL for none.  Whole tiles of the 8-wave ring16 kernel
+// in one XCD-contiguous order over the union of the two grids: no K split, no workspace.  Each result is bit-identical to the one
+// mantis_gemm_bf16_nt(_sumsq) writes with variant 14 for a shape WITHOUT a K-split remainder (same kernel code, whole tiles); against a
+// K-split launch of the same shape the fp32 summation order of the remainder tiles differs (bf16 rounding).  MANTIS_EUNSUPPORTED: N % 256, unaligned
+// operands, >= 4 GiB operands.
+int mantis_gemm_bf16_tn_pair(const void* A1, int64_t lda1, const void* B1, int64_t ldb1, void* C1, int64_t ldc1, int M1, int N1, float* ts1,
+                             const void* A2, int64_t lda2, const void* B2, int64_t ldb2, void* C2, int64_t ldc2, int M2, int N2, float* ts2,
+                             int K, int flags, void* stream) {
+    if (K <= 0 || (ts1 == nullptr) != (ts2 == nullptr)) return MANTIS_EINVAL;
+    if (flags & ~(EPI_ACCUM | EPI_CUS_MASK)) return MANTIS_EUNSUPPORTED;
+    int rc = tn_operand_ok(A1, lda1, B1, ldb1, C1, ldc1, M1, N1, K);
+    if (rc == 0) rc = tn_operand_ok(A2, lda2, B2, ldb2, C2, ldc2, M2, N2, K);
+    if (rc != 0) return rc;
+    RingGroup2 g;
+    g.A = (const bf16_t*)A2; g.B = (const bf16_t*)B2; g.C = (bf16_t*)C2; g.aux0 = (bf16_t*)ts2;
+    g.lda = (long)lda2; g.ldb = (long)ldb2; g.ldc = (long)ldc2;
+    g.M = M2; g.N = N2; g.tiles_m = cdiv(M2, 256); g.tiles_n = cdiv(N2, 256);
+    const int tm1 = cdiv(M1, 256), tn1 = cdiv(N1, 256);
+    g.tiles1 = tm1 * tn1;
+    const int total = g.tiles1 + g.tiles_m * g.tiles_n;
+    SkPlan plan;
+    plan.units = 0;
+    plan.nspan = 0;
+    const int f = (flags & EPI_ACCUM) | EPI_A_KMAJOR | EPI_B_KMAJOR | (ts1 ? EPI_SUMSQ : 0);
+    MANTIS_LAUNCH((gemm_nt_ring16_kernel<8, true, true, false, PAIR_NONE, RingGroup2>), dim3(total), dim3(512), 0, (hipStream_t)stream,
+                       (const bf16_t*)A1, (const bf16_t*)B1, (bf16_t*)C1, M1, N1, K, (long)lda1, (long)ldb1, (long)ldc1, (const bf16_t*)nullptr,
+                       (const bf16_t*)nullptr, 0L, f, tm1, tn1, total, 1, (float*)nullptr, (unsigned int*)nullptr, (bf16_t*)ts1,
+                       (const bf16_t*)nullptr, 0L, 0, plan, g);
+    return mantis_check_launch();
 }
 
 // Forward projections with a two-column epilogue fused in (ring16 kernels, NT layout, see PAIR_* at the kernel):

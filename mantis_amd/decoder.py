@@ -158,6 +158,11 @@ def decoder_backward(K, lm, grads, grads_layers, tc, ctx, hctx, plan, B, L, kmas
         if on_bucket_ready is not None:
             off_path(lambda: on_bucket_ready(key))
 
+    # Round 6: on a single stream without bucket hooks (no gradient exchange to start early) dW(down_proj) waits for the layer's dW(q|k|v) and the
+    # two run as ONE grid where the library predicts a gain (hip_ops.linear_dw_pair: 896 + 384 tiles = 5.0 whole rounds on 256 CUs for the
+    # Llama-3-8B / Mistral-7B geometry instead of two launches with a K-split remainder round and a finishing pass each).  Its operands -- the
+    # layer's incoming gradient and the SwiGLU output -- are held until then (+ one [rows, d] and one [rows, I] buffer of lifetime).
+    pair_dw = None
     for i in reversed(range(tc.num_hidden_layers)):
         lw = lm["layers"][i]
         lg_ = grads_layers[i]
@@ -166,7 +171,14 @@ def decoder_backward(K, lm, grads, grads_layers, tc, ctx, hctx, plan, B, L, kmas
             _, entry = layer_forward(K, lw, tc, entry[0], B, L, cos, sin, kmask, kstart, scale)
         x_in, rstd1, qkv, o, lse, x_mid, rstd2, gu, n1, n2, a = entry
         del entry
-        if lg_["down"] is not None:
+        if pair_dw is None:
+            pair_dw = bool(side is None and on_bucket_ready is None and lg_["down"] is not None and lg_["qkv"] is not None and
+                           hasattr(K, "dw_pair_wins") and
+                           K.dw_pair_wins(lg_["down"].shape[0], lg_["down"].shape[1], lg_["qkv"].shape[0], lg_["qkv"].shape[1], dx.shape[0]))
+        held = None
+        if pair_dw and lg_["down"] is not None and lg_["qkv"] is not None:
+            held = (dx, a)                                   # dW(down) runs with dW(q|k|v) below
+        elif lg_["down"] is not None:
             off_path(lambda dx=dx, a=a: K.linear_dw(dx, a, lg_["down"], acc), dx, a)
         bucket(("layer", i, "down"))
         dgu = K.linear_dx_swiglu(dx, lw["down"], gu)     # dact = dx . W_down and the SwiGLU backward in one launch
@@ -184,7 +196,10 @@ def decoder_backward(K, lm, grads, grads_layers, tc, ctx, hctx, plan, B, L, kmas
         dqkv = K.attn_bwd(qkv, o, do, lse, B, L, H, Hkv, hd, kmask, scale, True, kstart=kstart, qend=qend)
         del do, o
         K.rope_apply_(dqkv, cos, sin, H + Hkv, hd, backward=True)
-        if lg_["qkv"] is not None:
+        if held is not None:
+            K.linear_dw_pair(held[0], held[1], lg_["down"], dqkv, n1, lg_["qkv"], acc)
+            held = None
+        elif lg_["qkv"] is not None:
             off_path(lambda dqkv=dqkv, n1=n1: K.linear_dw(dqkv, n1, lg_["qkv"], acc), dqkv, n1)
         if lg_.get("qkv_b") is not None:
             K.colsum(dqkv, lg_["qkv_b"], acc)

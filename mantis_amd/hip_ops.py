@@ -384,6 +384,60 @@ def linear_dw(dy, x, grad_w, accumulate):
     gemm_nt(a, x, out=grad_w, accumulate=accumulate, a_kmajor=True, b_kmajor=True)
 
 
+def dw_pair_wins(out1, in1, out2, in2, tokens):
+    """True when linear_dw_pair(...) would run the two weight-gradient GEMMs grad[out1, in1] and grad[out2, in2] over `tokens` rows as ONE grid
+    and the library's cost model predicts a gain over two launches for this context's CU budget (csrc/gemm.hip: tn_pair_wins)."""
+    return bool(_L.mantis_gemm_tn_pair_wins(int(out1), int(in1), int(out2), int(in2), int(tokens), _launch().gemm_cus))
+
+
+def linear_dw_pair(dy1, x1, grad_w1, dy2, x2, grad_w2, accumulate):
+    """grad_w1 (+)= dy1^T @ x1 and grad_w2 (+)= dy2^T @ x2 in ONE launch (mantis_gemm_bf16_tn_pair: the two grids' tiles in one whole-round
+    grid -- dW(down_proj) + dW(q|k|v) of a decoder layer are 896 + 384 = 1280 tiles = 5.0 rounds on 256 CUs instead of two launches with a
+    K-split remainder round and a finishing pass each).  With a sum-of-squares collector in the LaunchContext both results leave their tile
+    partials, as linear_dw does.  Falls back to two linear_dw calls for shapes outside the paired kernel's conditions."""
+    ctx = _launch()
+    a1, a2 = dy1[:, : grad_w1.shape[0]], dy2[:, : grad_w2.shape[0]]
+    Kd = a1.shape[0]
+    ok = (a2.shape[0] == Kd and x1.shape[0] == Kd and x2.shape[0] == Kd and grad_w1.is_contiguous() and grad_w2.is_contiguous()
+          and grad_w1.shape[1] % 256 == 0 and grad_w2.shape[1] % 256 == 0)
+    if not ok:
+        linear_dw(dy1, x1, grad_w1, accumulate)
+        linear_dw(dy2, x2, grad_w2, accumulate)
+        return
+    (M1, N1), (M2, N2) = grad_w1.shape, grad_w2.shape
+    col = ctx.dw_sumsq
+    s1 = s2 = None
+    if col is not None:
+        t1, t2 = ((M1 + 255) // 256) * (N1 // 256), ((M2 + 255) // 256) * (N2 // 256)
+        s1 = col.take(grad_w1, t1)
+        s2 = col.take(grad_w2, t2) if s1 is not None else None
+        if s1 is not None and s2 is None:
+            col.give_back(grad_w1, t1)
+            s1 = None
+    prof = ctx.timer
+    if prof is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = _L.mantis_gemm_bf16_tn_pair(_p(a1), a1.stride(0), _p(x1), x1.stride(0), _p(grad_w1), grad_w1.stride(0), M1, N1, s1,
+                                     _p(a2), a2.stride(0), _p(x2), x2.stride(0), _p(grad_w2), grad_w2.stride(0), M2, N2, s2,
+                                     Kd, (32 if accumulate else 0) | (ctx.gemm_cus << CUS_SHIFT), _stream())
+    if rc == -2:
+        if s1 is not None:
+            col.give_back(grad_w2, ((M2 + 255) // 256) * (N2 // 256))
+            col.give_back(grad_w1, ((M1 + 255) // 256) * (N1 // 256))
+        linear_dw(dy1, x1, grad_w1, accumulate)
+        linear_dw(dy2, x2, grad_w2, accumulate)
+        return
+    _lib.check(rc, f"gemm_tn_pair {M1}x{N1} + {M2}x{N2} K={Kd}")
+    if prof is not None:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        fl = 2.0 * Kd * (M1 * N1 + M2 * N2)
+        by = 2.0 * (Kd * (M1 + N1 + M2 + N2) + (M1 * N1 + M2 * N2) * (1 + bool(accumulate)))
+        prof.append(("gemm_nt_kernel", fl, by, e0, e1, (M1 + M2, N1 if N1 == N2 else 0, Kd, "TN", f"pair {M1}x{N1}+{M2}x{N2}" + ("+sumsq" if s1 is not None else "")
+                                                        + ("+acc" if accumulate else "")), _stream()))
+
+
 def sum_f32(x, out, accumulate=False):
     _lib.check(_L.mantis_sum_f32(_p(x), x.numel(), _p(out), int(accumulate), _stream()), "sum_f32")
 

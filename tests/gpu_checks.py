@@ -2496,6 +2496,83 @@ def check_gemm_sumsq():
     return worst
 
 
+def check_gemm_tn_pair():
+    """mantis_gemm_bf16_tn_pair (round 6): two weight-gradient GEMMs that share K in ONE grid of whole 256 x 256 tiles.  (a) shapes whose own
+    grids need no K split: both results BIT-identical to mantis_gemm_bf16_nt with variant 14 (the same kernel code on the same tiles), with and
+    without accumulation, ragged M, A as a column window (lda > M); (b) the decoder layer's pair at full size -- dW(down_proj) 4096 x 14336 and
+    dW(q|k|v) 6144 x 4096 over 5624 rows, 1280 tiles = 5.0 rounds: every row against the oracle, within 2e-3 of the K-split launches it replaces,
+    reproducible bit for bit; (c) the tile sums of squares equal the float64 sum of squares of what was stored; (d) the planner takes the pair for
+    (b) on a 256-CU device and not for two grids that are whole rounds already; N % 256 != 0 falls back to two launches (same results)."""
+    import ctypes
+    k = K()
+    L = k._L
+    worst = 0.0
+
+    def pair(a1, x1, g1, a2, x2, g2, acc, sumsq):
+        M1, N1, M2, N2, Kd = g1.shape[0], g1.shape[1], g2.shape[0], g2.shape[1], a1.shape[0]
+        t1 = torch.full((((M1 + 255) // 256) * (N1 // 256),), float("nan"), dtype=torch.float32, device=DEV) if sumsq else None
+        t2 = torch.full((((M2 + 255) // 256) * (N2 // 256),), float("nan"), dtype=torch.float32, device=DEV) if sumsq else None
+        p = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+        rc = L.mantis_gemm_bf16_tn_pair(p(a1), a1.stride(0), p(x1), x1.stride(0), p(g1), g1.stride(0), M1, N1, p(t1),
+                                        p(a2), a2.stride(0), p(x2), x2.stride(0), p(g2), g2.stride(0), M2, N2, p(t2), Kd, 32 if acc else 0,
+                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+        return t1, t2
+    # (a) no K split in either own grid: bitwise against variant 14
+    for (M1, N1, M2, N2, Kd) in [(512, 512, 1024, 256, 264), (300, 512, 520, 256, 1000), (2048, 2048, 4096, 4096, 136)]:
+        wide = rnd(Kd, (M1 + 47) // 8 * 8, seed=91, scale=0.5).to(DEV)          # lda > M, lda % 8 == 0
+        a1, x1 = wide[:, :M1], rnd(Kd, N1, seed=92, scale=0.5).to(DEV)
+        a2, x2 = rnd(Kd, (M2 + 7) // 8 * 8, seed=93, scale=0.5).to(DEV)[:, :M2], rnd(Kd, N2, seed=94, scale=0.5).to(DEV)
+        for acc in (False, True):
+            c1 = rnd(M1, N1, seed=95).to(DEV) if acc else torch.empty(M1, N1, dtype=BF, device=DEV)
+            c2 = rnd(M2, N2, seed=96).to(DEV) if acc else torch.empty(M2, N2, dtype=BF, device=DEV)
+            r1, r2 = c1.clone(), c2.clone()
+            k.gemm_nt(a1, x1, out=r1, accumulate=acc, a_kmajor=True, b_kmajor=True, variant=14)
+            k.gemm_nt(a2, x2, out=r2, accumulate=acc, a_kmajor=True, b_kmajor=True, variant=14)
+            for sumsq in (False, True):
+                g1, g2 = c1.clone(), c2.clone()
+                t1, t2 = pair(a1, x1, g1, a2, x2, g2, acc, sumsq)
+                assert torch.equal(g1, r1) and torch.equal(g2, r2), f"paired launch differs from variant 14 ({M1}x{N1} + {M2}x{N2} K={Kd} acc={acc})"
+                if sumsq:
+                    for t, r in ((t1, r1), (t2, r2)):
+                        assert torch.isfinite(t).all()
+                        want = float(r.double().pow(2).sum())
+                        assert abs(float(t.double().sum()) - want) <= 1e-5 * want
+    # (b) - (d) the decoder layer's pair at full size
+    Kd, d, I, QKV = 5624, 4096, 14336, 6144
+    dx, a = rnd(Kd, d, seed=101, scale=0.5).to(DEV), rnd(Kd, I, seed=102, scale=0.5).to(DEV)
+    dqkv, n1 = rnd(Kd, QKV, seed=103, scale=0.5).to(DEV), rnd(Kd, d, seed=104, scale=0.5).to(DEV)
+    gd, gq = torch.empty(d, I, dtype=BF, device=DEV), torch.empty(QKV, d, dtype=BF, device=DEV)
+    t1, t2 = pair(dx, a, gd, dqkv, n1, gq, False, True)
+    gd2, gq2 = torch.empty_like(gd), torch.empty_like(gq)
+    pair(dx, a, gd2, dqkv, n1, gq2, False, True)
+    assert torch.equal(gd, gd2) and torch.equal(gq, gq2), "paired launch not reproducible"
+    sep_d = k.gemm_nt(dx, a, a_kmajor=True, b_kmajor=True)
+    sep_q = k.gemm_nt(dqkv, n1, a_kmajor=True, b_kmajor=True)
+    close(gd, sep_d, 2e-3, "paired dW(down) vs its own launch")
+    close(gq, sep_q, 2e-3, "paired dW(q|k|v) vs its own launch")
+    for g, (aa, xx) in ((gd, (dx, a)), (gq, (dqkv, n1))):
+        ref = aa.float().t() @ xx.float()
+        worst = max(worst, close(g, ref, 1e-2, "paired dW vs fp32"))
+        err = (g.float() - ref).norm(dim=1) / (ref.norm(dim=1) + 1e-30)
+        assert float(err.max()) < 2e-2, float(err.max())
+    for t, g in ((t1, gd), (t2, gq)):
+        want = float(g.double().pow(2).sum())
+        assert abs(float(t.double().sum()) - want) <= 1e-5 * want
+    if k.num_cus() == 256 and not os.environ.get("MANTIS_GEMM_PAIR") and not os.environ.get("MANTIS_GEMM_RING"):
+        assert k.dw_pair_wins(d, I, QKV, d, Kd), "the planner did not pair dW(down) + dW(q|k|v)"
+        assert not k.dw_pair_wins(4096, 4096, 28672, 4096, Kd), "the planner paired two grids that are whole rounds already"
+    # the wrapper: same results as the raw entry; a shape outside its conditions falls back to two launches
+    g1, g2 = torch.empty_like(gd), torch.empty_like(gq)
+    k.linear_dw_pair(dx, a, g1, dqkv, n1, g2, False)
+    assert torch.equal(g1, gd) and torch.equal(g2, gq)
+    xs, gs = rnd(Kd, 264, seed=105).to(DEV), torch.empty(d, 264, dtype=BF, device=DEV)
+    k.linear_dw_pair(dx, xs, gs, dqkv, n1, g2, False)
+    assert torch.equal(gs, k.gemm_nt(dx, xs, a_kmajor=True, b_kmajor=True)) and torch.equal(g2, sep_q)
+    return worst
+
+
 def check_norm_fold_step():
     """The gradient norm folded into the weight-gradient GEMMs (MantisHipTrainer(fold_norm_into=opt), single rank): same gradients bit for
     bit, clip_grad_norm_ value equal to the separate pass to 1e-5, parameters after the optimizer step equal to the unfolded run to one
@@ -2744,6 +2821,7 @@ def all_checks():
                                  (d, I, M, True, True)]:             # dW of down_proj (TN)
         c[f"fullsize_gemm_{m}x{n}x{k_}_{int(akm)}{int(bkm)}"] = (lambda m=m, n=n, k_=k_, akm=akm, bkm=bkm: check_gemm_fullsize(m, n, k_, akm, bkm))
     c["gemm_sumsq"] = check_gemm_sumsq
+    c["gemm_tn_pair"] = check_gemm_tn_pair
     c["norm_fold_step"] = check_norm_fold_step
     c["fullsize_gemm_down_fwd_residual_v13"] = check_gemm_fullsize_down_fwd
     c["gemm_cu_budget"] = check_gemm_cu_budget
