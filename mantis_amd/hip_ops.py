@@ -434,7 +434,8 @@ def linear_dw_pair(dy1, x1, grad_w1, dy2, x2, grad_w2, accumulate):
         e1.record()
         fl = 2.0 * Kd * (M1 * N1 + M2 * N2)
         by = 2.0 * (Kd * (M1 + N1 + M2 + N2) + (M1 * N1 + M2 * N2) * (1 + bool(accumulate)))
-        prof.append(("gemm_nt_kernel", fl, by, e0, e1, (M1 + M2, N1 if N1 == N2 else 0, Kd, "TN", f"pair {M1}x{N1}+{M2}x{N2}" + ("+sumsq" if s1 is not None else "")
+        # one table row for the launch: the first problem's shape, the second named in the epilogue column (FLOPs and bytes are the pair's)
+        prof.append(("gemm_nt_kernel", fl, by, e0, e1, (M1, N1, Kd, "TN", f"paired with {M2}x{N2}x{Kd}" + ("+sumsq" if s1 is not None else "")
                                                         + ("+acc" if accumulate else "")), _stream()))
 
 
