@@ -108,6 +108,9 @@ int mantis_transpose(const void* in, void* out, int R, int C, int Rpad, int64_t 
  *        | bits 8-11 tile variant (0 = auto) | 4096 A is K-major ([K,M], row stride lda) | 8192 B is K-major ([K,N]):
  *        dX = dY.W uses B K-major (the weight as stored), dW = dY^T.X uses both K-major -- no transposed copies.
  *        | bits 16-27 CU budget this launch is planned for (0 = default; see mantis_gemm_cu_budget)
+ *        | 32768 the launch shares the GPU with long-running kernels of other queues (RCCL collectives of a data-parallel step): the 176-row
+ *          kernel then runs one tile per workgroup instead of persistent workgroups (same results; a persistent workgroup that waits for a
+ *          CU someone else holds walks its whole static tile list late).  mantis_gemm_bf16_nt_fused: bit 7 (128) of `variant`.
  *        | 16384 remainder tiles of a ring16 launch reduced by their last arriver inside the GEMM kernel instead of by the finishing
  *          kernel (round-4 behaviour; same results bit for bit; tests / A-B measurements; process default: MANTIS_GEMM_SK_FINISH=0).
  * Remainder rounds: tiles of an incomplete last round of 256x256 tiles are split along K (deterministic); the ring16 kernels' split

@@ -1727,6 +1727,7 @@ int mantis_gemm_bf16_nt_fused(const void* A, int64_t lda, const void* B, int64_t
     const long lim = (1L << 32) - (1L << 16);
     if ((long)M * lda * 2 >= lim || (long)N * ldb * 2 >= lim) return MANTIS_EUNSUPPORTED;
     const bool inkernel = variant & 64;          // bit 6 of `variant`: see EPI_SK_INKERNEL
+    const bool shared = variant & 128;           // bit 7 of `variant`: see EPI_SHARED_GPU
     const int cus_bits = variant & EPI_CUS_MASK; // bits 16-27 of `variant`: the CU budget, as in mantis_gemm_bf16_nt's flags
     variant &= 15;
     if (variant == 0) {
@@ -1735,7 +1736,7 @@ int mantis_gemm_bf16_nt_fused(const void* A, int64_t lda, const void* B, int64_t
     }
     if (variant < 13 || variant > 15) return MANTIS_EUNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
-    const int flags = (bias ? EPI_BIAS : 0) | (inkernel ? EPI_SK_INKERNEL : 0) | cus_bits;
+    const int flags = (bias ? EPI_BIAS : 0) | (inkernel ? EPI_SK_INKERNEL : 0) | (shared ? EPI_SHARED_GPU : 0) | cus_bits;
 #define PAIR_ARGS s, (const bf16_t*)A, (const bf16_t*)B, (bf16_t*)C, M, N, K, (long)lda, (long)ldb, (long)ldc, (const bf16_t*)bias, \
                   (const bf16_t*)nullptr, 0L, flags, workspace, (long)workspace_bytes, (bf16_t*)aux0, (const bf16_t*)aux1, (long)aux_ld, aux_n
     if (variant == 15) {

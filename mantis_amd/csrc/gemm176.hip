@@ -271,7 +271,7 @@ static int launch_gemm_ring176(hipStream_t s, const bf16_t* A, const bf16_t* B, 
                                const bf16_t* bias, const bf16_t* res, long ldr, int flags, int cus, bf16_t* aux0 = nullptr,
                                const bf16_t* aux1 = nullptr, long aux_ld = 0, int aux_n = 0) {
     const int tiles_m = cdiv(M, 176), tiles_n = cdiv(N, 256), ntile = tiles_m * tiles_n;
-    if (ring176_persist() && ntile > cus) {
+    if (ring176_persist() && ntile > cus && !(flags & EPI_SHARED_GPU)) {
         MANTIS_LAUNCH((gemm_nt_ring176_kernel<BKM, SWIGLU, PAIR, true>), dim3(cus), dim3(256), 0, s, A, B, C, M, N, K, lda, ldb, ldc, bias, res, ldr,
                            flags, tiles_m, tiles_n, aux0, aux1, aux_ld, aux_n);
     } else {

@@ -19,6 +19,9 @@
 #define EPI_B_KMAJOR 8192                   // B given as [K, N]
 #define EPI_CUS_SHIFT 16                    // bits 16-27: CU budget this launch is planned for (0 = the default: MANTIS_GEMM_CUS or the whole device)
 #define EPI_CUS_MASK (0xFFF << EPI_CUS_SHIFT)
+#define EPI_SHARED_GPU 32768                 // the launch shares the GPU with long-running kernels of other queues (RCCL collectives under data parallelism): the
+                                            // 176-row kernel then runs one tile per workgroup -- a persistent workgroup that has to wait for a CU someone else
+                                            // holds would walk its whole static tile list late (the hardware's own dispatch degrades gracefully instead)
 #define EPI_SK_INKERNEL 16384                // ring16 kernels: remainder tiles reduced by their last arriver inside the GEMM kernel (round 4) instead of by
                                             // gemm_ring16_finish_kernel -- same results bit for bit; tests and A/B measurements
 

@@ -17,6 +17,7 @@ GEMM_ACT = {None: 0, "gelu": 1, "gelu_pytorch_tanh": 2, "quick_gelu": 3}
 # the caller's LaunchContext (mantis_amd/launch.py), installed by the engine for the duration of one step -- no module-level switches.
 CUS_SHIFT = 16               # bits 16-27 of the GEMM entry points' flags: the CU budget of that launch (include/mantis_hip.h)
 SK_INKERNEL = 16384          # flag: K-split remainder tiles reduced inside the GEMM kernel (round 4) instead of by the finishing kernel
+SHARED_GPU = 32768           # flag: RCCL collectives hold CUs beside this launch (LaunchContext.shared_gpu): no persistent GEMM workgroups
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -92,7 +93,7 @@ def gemm_nt(a, b, bias=None, act=None, residual=None, out=None, accumulate=False
         raise ValueError(f"cus must be in [0, 4095] (0 = the library's default), got {cus}")
     flags = (1 if bias is not None else 0) | (GEMM_ACT[act] << 1) | (16 if residual is not None else 0) | (32 if accumulate else 0) \
         | (variant << 8) | (4096 if a_kmajor else 0) | (8192 if b_kmajor else 0) | ((ctx.gemm_cus if cus is None else cus) << CUS_SHIFT) \
-        | (SK_INKERNEL if sk_inkernel else 0)
+        | (SK_INKERNEL if sk_inkernel else 0) | (SHARED_GPU if ctx.shared_gpu else 0)
     prof = ctx.timer
     if prof is not None:
         e0 = torch.cuda.Event(enable_timing=True)
@@ -285,7 +286,8 @@ def _gemm_fused(a, b, out, mode, aux0, aux1, aux_ld, aux_n, bias, variant, extra
         e0.record()
     wsp, wsn = _gemm_workspace()
     rc = _L.mantis_gemm_bf16_nt_fused(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, _p(bias), mode, _p(aux0),
-                                      _p(aux1), aux_ld, aux_n, variant | (_launch().gemm_cus << CUS_SHIFT), wsp, wsn, _stream())
+                                      _p(aux1), aux_ld, aux_n, variant | (_launch().gemm_cus << CUS_SHIFT) | (128 if _launch().shared_gpu else 0),
+                                      wsp, wsn, _stream())
     if rc == -2:
         return False
     _lib.check(rc, f"gemm_fused mode={mode} M={M} N={N} K={K}")
@@ -340,7 +342,8 @@ def linear_dx_swiglu(dy, w_down, gu, variant=0, sk_inkernel=False):
         e0.record()
     wsp, wsn = _gemm_workspace()
     rc = _L.mantis_gemm_bf16_nt(_p(dy), dy.stride(0), _p(w_down), w_down.stride(0), _p(dgu), dgu.stride(0), M, I, d, None, _p(gu),
-                                gu.stride(0), 64 | 8192 | (variant << 8) | (_launch().gemm_cus << CUS_SHIFT) | (SK_INKERNEL if sk_inkernel else 0), wsp, wsn,
+                                gu.stride(0), 64 | 8192 | (variant << 8) | (_launch().gemm_cus << CUS_SHIFT) | (SK_INKERNEL if sk_inkernel else 0)
+                                | (SHARED_GPU if _launch().shared_gpu else 0), wsp, wsn,
                                 _stream())
     _lib.check(rc, f"gemm+swiglu_bwd M={M} I={I} d={d}")
     if prof is not None:

@@ -16,11 +16,14 @@ class LaunchContext:
                  GEMM launch (bench.py's roofline, tools/gemm_step_replay.py)
     dw_sumsq:    None, or the optimizer's collector (`optim.FusedAdamW.begin_fold()`): every weight-gradient GEMM then also leaves the
                  sum of squares of what it stored (mantis_gemm_bf16_nt_sumsq)
+    shared_gpu:  True when long-running kernels of other queues (RCCL collectives) hold compute units beside the step's kernels: the GEMM
+                 entry points get flag 32768 (one tile per workgroup in the 176-row kernel); MantisHipTrainer sets it with an active reducer
     gemm_cus:    compute units the GEMM tile scheduler plans for (0 = the library's default: MANTIS_GEMM_CUS or the whole device);
                  with C RCCL channels active a data-parallel trainer plans for #CU - C"""
-    __slots__ = ("timer", "dw_sumsq", "gemm_cus")
+    __slots__ = ("timer", "dw_sumsq", "gemm_cus", "shared_gpu")
 
-    def __init__(self, timer=None, dw_sumsq=None, gemm_cus=0):
+    def __init__(self, timer=None, dw_sumsq=None, gemm_cus=0, shared_gpu=False):
+        self.shared_gpu = bool(shared_gpu)       # collectives of another queue run beside the step's kernels: no persistent GEMM workgroups
         gemm_cus = int(gemm_cus)
         if not 0 <= gemm_cus <= 4095:          # the budget travels in bits 16-27 of the GEMM flags word (round-5 advisor finding)
             raise ValueError(f"gemm_cus must be in [0, 4095] (0 = the library's default), got {gemm_cus}")

@@ -33,7 +33,8 @@ class MantisHipTrainer:
         # launch options of THIS trainer's steps (per-launch timers: bench.py sets `launch.timer`; the folded gradient norm's collector;
         # the GEMM scheduler's CU budget = what the reducer's RCCL channels leave): handed to the engine with every call, never a
         # process-wide switch -- two trainers / models in one process do not see each other's
-        self.launch = LaunchContext(gemm_cus=getattr(reducer, "gemm_cus", 0) or 0)
+        # an ACTIVE reducer's collectives hold compute units beside the backward's kernels: the GEMMs then run without persistent workgroups
+        self.launch = LaunchContext(gemm_cus=getattr(reducer, "gemm_cus", 0) or 0, shared_gpu=bool(getattr(reducer, "active", False)))
 
     def _prepare_inputs(self, inputs):
         # HF:trainer.py:2203-2235 moves tensors to the device; here the engine does the H2D itself (non_blocking) because

@@ -85,3 +85,27 @@ def test_two_trainers_keep_their_own_options(monkeypatch):
     seen.clear()
     m1.engine.step_from_batch(batch, compute_grads=False)
     assert seen and all(c.timer is None and c.gemm_cus == 0 for c in seen)
+
+
+def test_an_active_reducer_switches_persistent_gemm_workgroups_off():
+    """Round 6: a persistent GEMM workgroup that has to wait for a compute unit an RCCL channel holds would walk its whole static tile list late;
+    with an ACTIVE gradient reducer the trainer's launches therefore carry `shared_gpu` (flag 32768: one tile per workgroup in the 176-row
+    kernel, same results).  No reducer / an inactive one (world size 1): persistent."""
+    from mantis_amd.launch import LaunchContext
+    from mantis_amd.trainer import MantisHipTrainer
+    assert LaunchContext().shared_gpu is False and LaunchContext(shared_gpu=1).shared_gpu is True
+    model, _, _ = Hh.build_product_model("siglip", "cpu")
+
+    class Red:
+        gemm_cus = 240
+
+        def __init__(self, active):
+            self.active = active
+    assert MantisHipTrainer(model, 1).launch.shared_gpu is False
+    assert MantisHipTrainer(model, 1, reducer=Red(False)).launch.shared_gpu is False
+    tr = MantisHipTrainer(model, 1, reducer=Red(True))
+    assert tr.launch.shared_gpu is True and tr.launch.gemm_cus == 240
+    with pytest.raises(ValueError):
+        LaunchContext(gemm_cus=-1)
+    with pytest.raises(ValueError):
+        LaunchContext(gemm_cus=4096)
