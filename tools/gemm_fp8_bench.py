@@ -26,12 +26,13 @@ def timeit(fn, n=20, warm=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--variants", default="1,2")
+    ap.add_argument("--tokens", type=int, default=4096)
     args = ap.parse_args()
     import __graft_entry__
     __graft_entry__.build()
     from mantis_amd import hip_ops as K
     dev = "cuda"
-    T, d, I, QKV = 4096, 3584, 18944, 4608
+    T, d, I, QKV = args.tokens, 3584, 18944, 4608
     shapes = [("qkv fwd", T, QKV, d), ("o fwd / dX", T, d, d), ("gate|up fwd", T, 2 * I, d), ("down fwd", T, d, I),
               ("dX gate|up", T, d, 2 * I), ("dX down", T, I, d), ("dW qkv", QKV, d, T), ("dW o", d, d, T), ("dW gate|up", 2 * I, d, T),
               ("dW down", d, I, T), ("square 8192", 8192, 8192, 8192)]
