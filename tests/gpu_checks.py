@@ -2678,6 +2678,69 @@ def check_dp_rccl_world1():
     return 0.0
 
 
+DP_WORLD2_CASES = {"llava": ("siglip_b1_img2_adjacent", "siglip_b1_img4"), "idefics2": ("idefics2_b1_img2", "idefics2_b1_navit"),
+                   "qwen2vl": ("qwen2vl_b1_img2", "qwen2vl_b1_img1_tall"), "qwen2vl_fp8": ("qwen2vl_b1_img2", "qwen2vl_b1_img1_tall")}
+
+
+def check_dp_world2_on_gpu(family):
+    """TWO ranks on the box's one MI355X (tests/dp_world2_gpu_worker.py; transport gloo, because RCCL refuses two ranks on one device): the
+    product's N > 1 path end to end on the real kernels, each rank on its OWN golden batch (different lengths and image counts) --
+    `GradReducer` signalled per bucket from inside the HIP backward of the family's layer loop (bf16 or fp8), gradient norm of the REDUCED
+    gradient, clip + FusedAdamW on both ranks.  Both ranks must end with BIT-IDENTICAL gradients and parameters (replicas stay replicas),
+    every bucket of the arena must have been exchanged exactly once, the gradient must be the mean of the two per-batch gradients this
+    process computes on the same kernels, and each rank's loss its own batch's loss."""
+    import socket
+    import subprocess
+    import sys
+    import tempfile
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import dp_world2_gpu_worker as W
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases = DP_WORLD2_CASES[family]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    with tempfile.TemporaryDirectory() as td:
+        outs = [os.path.join(td, f"r{r}.pt") for r in range(2)]
+        procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "dp_world2_gpu_worker.py"), str(r), "2", str(port), family,
+                                   cases[r], outs[r]], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                 for r in range(2)]
+        logs = []
+        for p in procs:
+            try:
+                logs.append(p.communicate(timeout=600)[0])
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    q.kill()
+                raise AssertionError("data-parallel workers hung")
+        for r, p in enumerate(procs):
+            assert p.returncode == 0, f"rank {r} failed:\n{logs[r][-1500:]}"
+        res = [torch.load(o) for o in outs]
+    r0, r1 = res
+    assert torch.equal(r0["grads"], r1["grads"]), "ranks disagree on the reduced gradients"
+    assert torch.equal(r0["params"], r1["params"]), "ranks disagree on the parameters after the optimizer step"
+    assert r0["grad_norm"] == r1["grad_norm"] and r0["grad_norm"] > 0
+    # single-process reference on the same kernels: per-batch gradients, averaged in fp32
+    m, make_batch = W.build(family, DEV)
+    nb = len(m.grad_buckets())
+    acc, losses = None, []
+    for r in range(2):
+        m._ensure_grad_arena()
+        out = m.engine.step_from_batch(make_batch(Hh.load_case(cases[r])), compute_grads=True, overwrite_grads=True)
+        torch.cuda.synchronize()
+        losses.append(float(out["loss"]))
+        g = m.grad_arena.detach().float().cpu()
+        acc = g.clone() if acc is None else acc + g
+    ref = acc / 2
+    for r, rr in enumerate(res):
+        assert abs(rr["loss"] - losses[r]) <= 1e-6 * max(1.0, abs(losses[r])), (r, rr["loss"], losses[r])
+        assert rr["buckets"] == nb and rr["bytes"] >= ref.numel() * 2, (rr["buckets"], nb, rr["bytes"], ref.numel() * 2)
+    norm_ref = float(ref.double().norm())
+    assert abs(r0["grad_norm"] - norm_ref) <= 2e-2 * norm_ref, (r0["grad_norm"], norm_ref)      # the norm of the REDUCED gradient
+    return close(r0["grads"], ref, 1e-2, f"2-rank reduced gradient vs the mean of the per-batch gradients ({family})")
+
+
 def all_checks():
     """name -> thunk, in dependency order (cheap and fundamental first)."""
     c = {}
@@ -2809,6 +2872,8 @@ def all_checks():
     c["packed_fullsize_vs_batched"] = check_packed_fullsize_vs_batched
     c["norm_overlap"] = check_norm_overlap
     c["dp_rccl_world1"] = check_dp_rccl_world1
+    for fam in DP_WORLD2_CASES:
+        c["dp_world2_on_gpu_" + fam] = (lambda fam=fam: check_dp_world2_on_gpu(fam))
     # cfg2 (BASELINE.json configs[1]) shapes, every row against the oracle
     c["fullsize_attn_causal"] = lambda: check_attn_fullsize(False)
     c["fullsize_attn_causal_rightpad"] = lambda: check_attn_fullsize(True)
