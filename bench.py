@@ -706,6 +706,12 @@ def main():
     n_extra = 0
     if timer is not None:
         trainer.launch.timer = timer      # per-launch HIP events around every GEMM of THIS trainer's steps (launch.LaunchContext)
+        # the fp8 layer loop runs its weight-gradient GEMMs on a lowest-priority side stream (decoder_fp8.decoder_backward), where a launch's
+        # event-to-event time is mostly waiting for compute units: the instrumented steps keep every launch on the compute stream (same
+        # kernels, bit-identical results), so that `roofline.achieved` divides by launch DURATIONS; the timed region above ran as the product does
+        dw_env = os.environ.get("MANTIS_DW_STREAM")
+        if precision != "bf16":
+            os.environ["MANTIS_DW_STREAM"] = "0"
         sync()
         ti0 = time.perf_counter()
         for i in range(args.steps):
@@ -729,6 +735,11 @@ def main():
         sync()
         trainer.launch.timer = None
         trainer.prefetch_early, args.prefetch = True, nxt_keep
+    if timer is not None and precision != "bf16":
+        if dw_env is None:
+            os.environ.pop("MANTIS_DW_STREAM", None)
+        else:
+            os.environ["MANTIS_DW_STREAM"] = dw_env
     native_loop = None
     if args.loop == "hf":
         if world != 1 or not on_gpu or opt is None:
@@ -809,7 +820,10 @@ def main():
             roof = dict(bound="mfma", kernel=kname, achieved=round(ach, 1),
                         measured_on=(f"{args.steps} instrumented steps (HIP events around every GEMM launch on its launch stream) right after the bare "
                                      f"timed region" + (" of the NATIVE loop, which runs first in this process (the HF loop's timed steps are bare too)"
-                                                        if args.loop == "hf" else "")),
+                                                        if args.loop == "hf" else "") +
+                                     ("; the fp8 loop's weight-gradient GEMMs, on a lowest-priority side stream in the timed region, are kept on the "
+                                      "compute stream for these steps (same kernels, bit-identical): launch durations, not queueing"
+                                      if precision != "bf16" else "")),
                         peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4), bf16_gemm_family=bf16_family,
                         traffic=None, mfma_busy_pct=None,
                         pmc_static=None if not pmc else dict(

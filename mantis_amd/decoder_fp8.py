@@ -119,6 +119,28 @@ def decoder_backward(K, lm, w8, grads, grads_layers, tc, ctx, hctx, plan, B, L, 
     saved, cos, sin, scale = ctx["saved"], ctx["cos"], ctx["sin"], ctx["scale"]
     dx = D.head_backward(K, lm, grads, hctx, plan, B, L, acc, on_bucket_ready)
     rw = w8.rowwise
+    # The weight-gradient GEMMs are off the critical path (nothing in the backward reads a dW).  The fp8 GEMM has no K split for the tiles of an
+    # incomplete last round (Qwen2-7B: N = 3584 = 14 tiles of 256 -- 448-tile grids = 1.75 rounds on 256 CUs on five of the twelve shapes), so
+    # on a side stream (hip_ops.side_stream) the dW launches queue behind the quantiser that made their operands, and their workgroups take
+    # the compute units the dX chain's launches leave idle (one 160-KiB workgroup per CU either way).  Bucket hooks follow them onto that
+    # stream, as in decoder.decoder_backward; the caller's stream joins at the end.  Bit-identical.  Default: the lowest-priority queue on a
+    # single GPU (same box, Qwen2-VL-7B step: 332.7 -> 327.9 ms; a plain stream 328.7), the calling stream under data parallelism (the
+    # bucket exchanges then start exactly where they are signalled); MANTIS_DW_STREAM = 0 | 1 | low overrides either.
+    side = K.side_stream(default="low" if on_bucket_ready is None else "0")
+
+    def off_path(fn, *inputs):
+        if side is None:
+            fn()
+        else:
+            side.run(fn, *inputs)
+
+    def dw(dyq, xq, grad):
+        if grad is not None:
+            off_path(lambda: _dw(K, dyq, xq, grad, acc), dyq.qt, dyq.col_dequant, dyq.state, xq.qt, xq.col_dequant, xq.state)
+
+    def bucket(key):
+        if on_bucket_ready is not None:
+            off_path(lambda: on_bucket_ready(key))
     parts_dx = K.amax_parts_buffer(dx.device) if PRODUCER_AMAX and not rw else None
     parts_mid = K.amax_parts_buffer(dx.device) if PRODUCER_AMAX and not rw else None
     dx_amax = None                     # the top layer's dx comes from the loss head (no producer-side amax); below: rmsnorm_bwd's
@@ -131,9 +153,8 @@ def decoder_backward(K, lm, w8, grads, grads_layers, tc, ctx, hctx, plan, B, L, 
         x_in, rstd1, qkv, o, lse, x_mid, rstd2, gu, n1q, oq, n2q, aq = entry
         del entry
         dxq = _quant(K, dx, E5M2, lg_["down"] is not None, dx_amax, rw)
-        _dw(K, dxq, aq, lg_["down"], acc)
-        if on_bucket_ready is not None:
-            on_bucket_ready(("layer", i, "down"))
+        dw(dxq, aq, lg_["down"])
+        bucket(("layer", i, "down"))
         wd = w8.get(K, i, "down")
         # dact = dx . W_down, the SwiGLU backward and max |dgu| in ONE launch (the [M, I] activation gradient never goes to HBM, the
         # quantiser's amax pass over the 2I-wide gradient is skipped)
@@ -144,22 +165,21 @@ def decoder_backward(K, lm, w8, grads, grads_layers, tc, ctx, hctx, plan, B, L, 
         del aq, gu, dxq
         dguq = _quant(K, dgu, E5M2, lg_["gu"] is not None, dgu_amax, rw)
         del dgu
-        _dw(K, dguq, n2q, lg_["gu"], acc)
-        if on_bucket_ready is not None:
-            on_bucket_ready(("layer", i, "gu"))
+        dw(dguq, n2q, lg_["gu"])
+        bucket(("layer", i, "gu"))
         dn2 = _dx(K, dguq, w8.get(K, i, "gu"))
         del dguq, n2q
         dx_mid = K.rmsnorm_bwd(dn2, x_mid, lw["ln2"], rstd2, dx, lg_["ln2"], acc, amax_parts=parts_mid)
         del dn2, dx
         dmq = _quant(K, dx_mid, E5M2, lg_["o"] is not None, parts_mid, rw)
-        _dw(K, dmq, oq, lg_["o"], acc)
+        dw(dmq, oq, lg_["o"])
         do = _dx(K, dmq, w8.get(K, i, "o"))
         del dmq, oq
         dqkv = K.attn_bwd(qkv, o, do, lse, B, L, H, Hkv, hd, kmask, scale, True, kstart=kstart, qend=qend)
         del do, o
         K.rope_apply_(dqkv, cos, sin, H + Hkv, hd, backward=True)
         dqq = _quant(K, dqkv, E5M2, lg_["qkv"] is not None, None, rw)
-        _dw(K, dqq, n1q, lg_["qkv"], acc)
+        dw(dqq, n1q, lg_["qkv"])
         if lg_.get("qkv_b") is not None:
             K.colsum(dqkv, lg_["qkv_b"], acc)
         dn1 = _dx(K, dqq, w8.get(K, i, "qkv"))
@@ -167,8 +187,9 @@ def decoder_backward(K, lm, w8, grads, grads_layers, tc, ctx, hctx, plan, B, L, 
         dx = K.rmsnorm_bwd(dn1, x_in, lw["ln1"], rstd1, dx_mid, lg_["ln1"], acc, amax_parts=parts_dx)
         dx_amax = parts_dx
         del dn1, dx_mid, x_in
-        if on_bucket_ready is not None:
-            on_bucket_ready(("layer", i, "attn"))
+        bucket(("layer", i, "attn"))
+    if side is not None:
+        side.join()
     return dx
 
 

@@ -857,16 +857,17 @@ def priority_stream(level):
 _SIDE = {}
 
 
-def side_stream():
+def side_stream(default="0"):
     """The process' side stream for the current device when MANTIS_DW_STREAM is 1 (a plain stream) or "low" (a stream on the
-    lowest-priority hardware queue), else None (everything on the current stream)."""
-    mode = _os.environ.get("MANTIS_DW_STREAM", "0")
+    lowest-priority hardware queue), else None (everything on the current stream).  `default`: the mode when the variable is unset (the
+    fp8 layer loop asks for "low" on a single GPU, decoder_fp8.decoder_backward; MANTIS_DW_STREAM=0 switches it off)."""
+    mode = _os.environ.get("MANTIS_DW_STREAM") or default
     if mode not in ("1", "low"):
         return None
-    dev = torch.cuda.current_device()
-    s = _SIDE.get(dev)
+    key = (torch.cuda.current_device(), mode)
+    s = _SIDE.get(key)
     if s is None:
-        s = _SIDE[dev] = SideStream("low" if mode == "low" else None)
+        s = _SIDE[key] = SideStream("low" if mode == "low" else None)
     return s
 
 

@@ -164,7 +164,7 @@ def linear_dx(dy, w, k=None):
     return (_f(dy)[:, :n] @ _f(w)).to(dy.dtype)
 
 
-def side_stream():
+def side_stream(default="0"):
     return None
 
 

@@ -1251,6 +1251,42 @@ def check_dw_side_stream():
     return 0.0
 
 
+def check_fp8_dw_side_stream():
+    """The fp8 layer loop's weight-gradient GEMMs on a side stream (decoder_fp8.decoder_backward: the lowest-priority queue by default on a
+    single GPU, MANTIS_DW_STREAM = 0 | 1 | low): loss and every gradient BIT-IDENTICAL to the single-stream step over two accumulating
+    micro-batches, with hooks (which also pin the default back to the calling stream) seeing every bucket once, in every mode."""
+    import os
+    old = os.environ.get("MANTIS_DW_STREAM")
+    z = Hh.load_case("qwen2vl_b2_rightpad")
+    res = []
+    try:
+        for flag, hooks in (("0", False), (None, False), ("1", False), ("low", True), ("0", True), (None, True)):
+            if flag is None:
+                os.environ.pop("MANTIS_DW_STREAM", None)
+            else:
+                os.environ["MANTIS_DW_STREAM"] = flag
+            model = Hh.build_qwen2vl_product(DEV).set_precision("fp8")
+            seen, losses = [], []
+            for i in range(2):
+                model._ensure_grad_arena()
+                out = model.engine.step_from_batch(Hh.qwen2vl_batch(z), grad_scale=0.5, loss_scale=0.5, compute_grads=True,
+                                                   overwrite_grads=(i == 0), on_bucket_ready=seen.append if hooks else None)
+                losses.append(out["loss"].clone())
+            torch.cuda.synchronize()
+            res.append((torch.stack(losses).cpu(), model.grad_arena.clone().cpu(), [str(k) for k in seen]))
+            if hooks:
+                assert len(seen) > 4
+    finally:
+        if old is None:
+            os.environ.pop("MANTIS_DW_STREAM", None)
+        else:
+            os.environ["MANTIS_DW_STREAM"] = old
+    for r in res[1:]:
+        assert torch.equal(res[0][0], r[0]) and torch.equal(res[0][1], r[1]), "side-stream dW GEMMs changed the fp8 step's result"
+    assert res[3][2] == res[4][2] == res[5][2]
+    return 0.0
+
+
 def check_navit_prepare():
     """Device-side NaViT image preparation (padding-image flags, pixel mask -> patch mask, bucketised position ids) bit-exact vs the oracle's
     restatement of modeling_idefics2.py:1636-1658 / :190-210: no mask, rectangular masks of every aspect, all-zero padding images, a
@@ -2904,6 +2940,7 @@ def all_checks():
     for a in ATTN_CROSS_CASES:
         c["attn_cross_" + "_".join(map(str, a))] = (lambda a=a: check_attn_cross(*a))
     c["dw_side_stream_bitwise"] = check_dw_side_stream
+    c["fp8_dw_side_stream_bitwise"] = check_fp8_dw_side_stream
     c["navit_prepare"] = check_navit_prepare
     c["llava_full_width_vs_oracle"] = check_llava_full_width_vs_oracle
     c["llava_clip_full_width_vs_oracle"] = check_llava_clip_full_width_vs_oracle
