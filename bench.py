@@ -38,7 +38,7 @@ FLOP_PER_SAMPLE = 1.351e14      # SURVEY.md section 8d (ViT fwd x1, projector + 
 PEAK_BF16_TFLOPS = 2500.0       # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_FP8_TFLOPS = 5000.0        # MI355X dense fp8 MFMA (MX-scaled K = 64 / 128 forms; MI355X_MICROARCH.md)
 PMC_JSON = os.path.join(ROOT, "profiles", "r06_pmc_step.json")   # tools/pmc_step_report.py output (offline PMC passes, tracked)
-PMC_JSON_QWEN_FP8 = os.path.join(ROOT, "profiles", "r02_pmc_qwen2vl_fp8.json")   # same, for `--config qwen2_vl_7b --precision fp8`
+PMC_JSON_QWEN_FP8 = os.path.join(ROOT, "profiles", "r06_pmc_qwen2vl_fp8.json")   # same, for `--config qwen2_vl_7b --precision fp8`
 
 
 def synthetic_batch(cfg, B, T, n_img, img_hw, rank, step=0):
