@@ -109,3 +109,37 @@ def test_an_active_reducer_switches_persistent_gemm_workgroups_off():
         LaunchContext(gemm_cus=-1)
     with pytest.raises(ValueError):
         LaunchContext(gemm_cus=4096)
+
+
+def test_side_stream_mode_selection(monkeypatch):
+    """hip_ops.side_stream: MANTIS_DW_STREAM = 0 | 1 | low decides; unset, the caller's default does (the fp8 layer loop asks for "low" on a
+    single GPU and for the calling stream when bucket hooks are installed, decoder_fp8.decoder_backward).  One stream object per (device, mode)."""
+    from mantis_amd import hip_ops as K
+    made = []
+
+    class Fake:
+        def __init__(self, priority=None):
+            self.priority = priority
+            made.append(priority)
+    monkeypatch.setattr(K, "SideStream", Fake)
+    monkeypatch.setattr(K, "_SIDE", {})
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    monkeypatch.delenv("MANTIS_DW_STREAM", raising=False)
+    assert K.side_stream() is None and K.side_stream(default="0") is None
+    low = K.side_stream(default="low")
+    assert low is not None and low.priority == "low" and K.side_stream(default="low") is low
+    monkeypatch.setenv("MANTIS_DW_STREAM", "0")
+    assert K.side_stream(default="low") is None                     # the variable overrides the default
+    monkeypatch.setenv("MANTIS_DW_STREAM", "1")
+    plain = K.side_stream(default="low")
+    assert plain is not None and plain.priority is None and plain is not low
+    monkeypatch.setenv("MANTIS_DW_STREAM", "low")
+    assert K.side_stream() is low
+    assert made == ["low", None]
+
+
+def test_fp8_backward_asks_for_the_low_priority_stream_only_without_bucket_hooks():
+    import inspect
+    from mantis_amd import decoder_fp8
+    src = inspect.getsource(decoder_fp8.decoder_backward)
+    assert 'K.side_stream(default="low" if on_bucket_ready is None else "0")' in src
